@@ -1,0 +1,62 @@
+"""In-tree build of the HIP C-ABI library: hipcc --offload-arch=gfx950 csrc/*.hip -> csrc/libsga_hip.so.
+
+Cross-compiles without a GPU (used by __graft_entry__.build()).  Objects are rebuilt only when their
+source (or a header) is newer; the .so travels to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB = os.path.join(CSRC, 'libsga_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast',
+         '-Wno-unused-result', '-I', CSRC]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def _compile(src, obj, extra):
+    cmd = [HIPCC] + FLAGS + extra + ['-c', src, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+    return src
+
+
+def build_lib(verbose: bool = True, extra_flags=()) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h')))
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = s[:-4] + '.o'
+        objs.append(o)
+        if _newer([s] + hdrs, o):
+            jobs.append((s, o))
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for done in ex.map(lambda so: _compile(so[0], so[1], list(extra_flags)), jobs):
+                if verbose:
+                    print('[sga build] compiled', os.path.basename(done), flush=True)
+    if jobs or _newer(objs, LIB):
+        r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+        if verbose:
+            print('[sga build] linked', LIB, flush=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_lib(extra_flags=sys.argv[1:])

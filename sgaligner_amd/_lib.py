@@ -1,0 +1,57 @@
+"""ctypes binding of the C-ABI HIP library (include/sgaligner_hip.h).
+
+There is NO fallback: if csrc/libsga_hip.so is missing or fails to load, every product op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsga_hip.so')
+_lib = None
+
+P = c_void_p
+I = c_int
+F = c_float
+
+# name -> (restype, argtypes).  Mirrors include/sgaligner_hip.h one to one.
+SIGNATURES = {
+    'sga_version': (I, []),
+    'sga_last_error': (c_char_p, []),
+    'sga_device_cus': (I, []),
+    'sga_pointnet_fwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+}
+
+
+class SgaLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SgaLibraryError(
+                f'HIP library not built: {LIB_PATH} is missing. Run `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `python -m sgaligner_amd._build`). sgaligner_amd has no CPU fallback.')
+        try:
+            l = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise SgaLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:
+                raise SgaLibraryError(f'{LIB_PATH} does not export {name}; rebuild the library') from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().sga_last_error()
+        raise RuntimeError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')

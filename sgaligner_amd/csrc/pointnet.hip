@@ -1,0 +1,211 @@
+// Per-object PointNet set-abstraction encoder, forward.
+//
+// Replaces reference src/aligner/networks/pointnet.py:120-175 (PointNetfeat.forward with
+// global_feat=True, input_transform=False, feature_transform=False):
+//     y[t,c] = max_p relu(W3 relu(W2 relu(W1 x[t,p] + b1) + b2) + b3)[c]
+// (the three BatchNorm calls at :141-142,154-155,158-159 discard their result and do not enter y).
+//
+// CDNA4 design (exact fp32, v_mfma_f32_32x32x2_f32):
+//   * one WAVE owns one object and walks its points 32 at a time; the whole 3->64->128->C3 chain for
+//     a 32-point tile stays in that wave's registers:
+//       layer 1  VALU: lane (h = lane>>5, pt = lane&31) computes the 32 of 64 channels its half feeds
+//                to the MFMA K-steps (k = 8q + 4h + r);
+//       layer 2  H2^T[ch, pt] = W2 * H1^T : A = W2 slice (LDS), B = H1 (registers).  The C layout
+//                (lane = pt, reg r = channel (r&3)+8(r>>2)+4h) IS the A-operand layout of
+//       layer 3  Z3[pt, ch]   = H2 * W3^T : A = H2 (registers, straight from layer 2's accumulators),
+//                B = W3 slice (LDS).  C layout: lane = channel, regs = points -> the max-pool over
+//                points is an in-lane max over 16 registers + one cross-half exchange per object.
+//     No activation ever touches LDS or HBM; bias add and ReLU commute with the max where needed.
+//   * W2 (32 KiB) and W3 (128 KiB) are re-laid out once per workgroup into LDS in exact per-lane
+//     operand order ([block][k-group][lane][4]) so every ds_read_b128 is lane-linear (conflict free)
+//     and feeds 4 MFMAs.  That fills the CU's 160 KiB LDS: one persistent 8-wave workgroup per CU.
+//   * HBM traffic is the points once (12 B/point) + T*C3*(4+4) B out: the kernel is MFMA-bound
+//     (82 304 FLOP/point at C3 = 256).
+#include "sga_common.h"
+
+namespace {
+
+constexpr int PN_WAVES = 8;
+constexpr int PN_THREADS = PN_WAVES * 64;
+
+template <int C3, bool WITH_ARGMAX>
+__global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
+    const float* __restrict__ x,   // [T, P, 3]
+    const float* __restrict__ w1,  // [64, 3]
+    const float* __restrict__ b1,  // [64]
+    const float* __restrict__ w2,  // [128, 64]
+    const float* __restrict__ b2,  // [128]
+    const float* __restrict__ w3,  // [C3, 128]
+    const float* __restrict__ b3,  // [C3]
+    float* __restrict__ y,         // [T, C3]
+    int* __restrict__ argmax,      // [T, C3] or nullptr
+    int T, int P) {
+    constexpr int NB3 = C3 / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w2s = lds;             // [4 cb][8 q][64 lane][4]        = 8192 floats
+    float* w3s = lds + 8192;      // [NB3 cb][4 kb][4 g][64 lane][4] = C3*128 floats
+
+    const int tid = threadIdx.x;
+    // ---- stage weights into LDS in operand order (once per persistent workgroup)
+    for (int d = tid; d < 2048; d += PN_THREADS) {          // W2: 2048 float4 slots
+        const int ln = d & 63, q = (d >> 6) & 7, cb = d >> 9;
+        const int row = cb * 32 + (ln & 31), k = 8 * q + 4 * (ln >> 5);
+        *reinterpret_cast<f32x4*>(w2s + d * 4) = *reinterpret_cast<const f32x4*>(w2 + row * 64 + k);
+    }
+    for (int d = tid; d < C3 * 32; d += PN_THREADS) {       // W3: C3*128/4 float4 slots
+        const int ln = d & 63, g = (d >> 6) & 3, kb = (d >> 8) & 3, cb = d >> 10;
+        const int row = cb * 32 + (ln & 31), k = kb * 32 + 8 * g + 4 * (ln >> 5);
+        *reinterpret_cast<f32x4*>(w3s + d * 4) = *reinterpret_cast<const f32x4*>(w3 + row * 128 + k);
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, pt = lane & 31;
+    const int n_tiles = (P + 31) >> 5;
+
+    for (int t = blockIdx.x * PN_WAVES + wave; t < T; t += gridDim.x * PN_WAVES) {
+        const float* xt = x + (size_t)t * P * 3;
+        float best[NB3];
+        int bidx[NB3];
+#pragma unroll
+        for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
+
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int p0 = tile * 32;
+            // Opaque per-tile copies of the lane ids: the weight reads below are loop-invariant, and
+            // without this LICM hoists ~900 registers of them out of the tile loop (-> scratch spills).
+            int lane_o = lane, h_o = h;
+            asm volatile("" : "+v"(lane_o), "+v"(h_o));
+            const int pi = min(p0 + pt, P - 1);          // ragged tail: replicate the last point
+            const float x0 = xt[pi * 3 + 0], x1 = xt[pi * 3 + 1], x2 = xt[pi * 3 + 2];
+
+            // ---- layer 1 (VALU): channels k = 8q + 4h + r
+            float h1[32];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = 8 * q + 4 * h_o;
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w1 + k * 3);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w1 + k * 3 + 4);
+                const f32x4 wc = *reinterpret_cast<const f32x4*>(w1 + k * 3 + 8);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + k);
+                h1[q * 4 + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
+                h1[q * 4 + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
+                h1[q * 4 + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
+                h1[q * 4 + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
+            }
+
+            // ---- layer 2 (MFMA): H2^T = W2 * H1^T, accumulators start at the bias
+            float h2[64];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * g + 4 * h_o);
+                    acc[g * 4 + 0] = bb[0]; acc[g * 4 + 1] = bb[1]; acc[g * 4 + 2] = bb[2]; acc[g * 4 + 3] = bb[3];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w2s + ((cb * 8 + q) * 64 + lane_o) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], h1[q * 4 + r], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h2[cb * 16 + r] = fmaxf(acc[r], 0.f);
+            }
+
+            // ---- layer 3 (MFMA): Z3 = H2 * W3^T, running max over points
+#pragma unroll
+            for (int cb = 0; cb < NB3; ++cb) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(w3s + (((cb * 4 + kb) * 4 + g) * 64 + lane_o) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h2[kb * 16 + g * 4 + r], wv[r], acc, 0, 0, 0);
+                    }
+                }
+                if (WITH_ARGMAX) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {        // ascending point order, strict > keeps the first max
+                        const bool gt = acc[r] > best[cb];
+                        best[cb] = gt ? acc[r] : best[cb];
+                        bidx[cb] = gt ? (p0 + mfma32_row(r, h)) : bidx[cb];
+                    }
+                } else {
+                    float m = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                    best[cb] = fmaxf(best[cb], m);
+                }
+            }
+        }
+
+        // ---- combine the two lane halves (they hold disjoint point rows), bias + ReLU, store
+#pragma unroll
+        for (int cb = 0; cb < NB3; ++cb) {
+            const float ov = __shfl_xor(best[cb], 32, 64);
+            float v = best[cb];
+            int bi = bidx[cb];
+            if (WITH_ARGMAX) {
+                const int oi = __shfl_xor(bidx[cb], 32, 64);
+                const bool take = (ov > v) || (ov == v && oi < bi);
+                v = take ? ov : v;
+                bi = take ? oi : bi;
+                bi = min(bi, P - 1);
+            } else {
+                v = fmaxf(v, ov);
+            }
+            if (h == 0) {
+                const int c = cb * 32 + pt;
+                y[(size_t)t * C3 + c] = fmaxf(v + b3[c], 0.f);
+                if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
+            }
+        }
+    }
+}
+
+template <int C3>
+int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+               const float* w3, const float* b3, float* y, int* argmax, int T, int P, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)(8192 + C3 * 128) * sizeof(float);
+    int grid = (T + PN_WAVES - 1) / PN_WAVES;
+    const int ncu = sga_num_cus();
+    if (grid > ncu) grid = ncu;
+    if (argmax) {
+        auto k = pointnet_fwd_kernel<C3, true>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+    } else {
+        auto k = pointnet_fwd_kernel<C3, false>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+    }
+    SGA_CHECK_LAUNCH("sga_pointnet_fwd");
+    return SGA_OK;
+}
+
+}  // namespace
+
+extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, float* y,
+                                int32_t* argmax, int T, int P, int C3, void* stream) {
+    SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_fwd: need T >= 0 and P >= 1 (got T=%d P=%d)", T, P);
+    SGA_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && y, "sga_pointnet_fwd: null pointer");
+    if (T == 0) return SGA_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (C3) {
+        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s);
+        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s);
+        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s);
+        default:
+            sga_set_error("sga_pointnet_fwd: out_size C3=%d unsupported (64, 128 or 256: W3 must fit the 160 KiB LDS)", C3);
+            return SGA_ERR_ARG;
+    }
+}
