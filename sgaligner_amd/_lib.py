@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsga_hip.so')
@@ -22,6 +22,18 @@ SIGNATURES = {
     'sga_last_error': (c_char_p, []),
     'sga_device_cus': (I, []),
     'sga_pointnet_fwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    'sga_gemm': (I, [I, I, I, I, I, P, c_long, I, P, c_long, P, c_long, P, I, P]),
+    'sga_colsum': (I, [P, c_long, I, I, P, I, P]),
+    'sga_cast_f64_f32': (I, [P, P, c_size_t, P]),
+    'sga_loss_gather': (I, [P, I, I, P, I, P, I, P, P]),
+    'sga_loss_scatter': (I, [P, P, P, P, I, I, I, P, P]),
+    'sga_loss_neg_sums': (I, [P, I, I, I, I, F, F, P, P]),
+    'sga_loss_neg_grad': (I, [P, I, I, I, I, F, F, P, P, P]),
+    'sga_loss_anchor_fwd': (I, [P, P, I, I, P, F, F, F, P, P]),
+    'sga_loss_anchor_bwd': (I, [P, P, I, I, P, F, F, F, P, P, P, P]),
+    'sga_fusion_fwd': (I, [P, I, P, P, I, I, P]),
+    'sga_fusion_bwd_workspace_bytes': (c_size_t, [I]),
+    'sga_fusion_bwd': (I, [P, I, P, P, P, P, I, I, P, c_size_t, P]),
 }
 
 

@@ -1,0 +1,533 @@
+// Dense node-similarity + contrastive (ICL) / alignment (IAL) loss, forward and backward, without
+// ever materialising an anchors x negatives matrix.
+//
+// Replaces reference src/aligner/losses.py: calculate_prob_dist :5-15, ICLLoss.forward :43-58,
+// IALLoss.forward :68-97 (and their autograd).  For each embedding table k (modalities + 'joint')
+// with L2-normalised rows and index sets e1i/e2i (A anchors each), e1j (J1), e2j (J2):
+//     X1 = E[e1i], X2 = E[e2i], N1 = E[e1j], N2 = E[e2j]            (packed row blocks of Z_k)
+//     s11 = sum exp(X1 N1^T/t)  s12 = sum exp(X1 N2^T/t)  s22 = sum exp(X2 N2^T/t)  s21 = sum exp(X2 N1^T/t)
+//     S = X1 X2^T ;  qA[i,j] = g(exp(S[i,j]/t); s11, s12) ;  qB[i,j] = g(exp(S[j,i]/t); s22, s21)
+//     g(d; sa, sb) = 1 / (1 + 1/(d/(sa+1e-9)+1e-9) + 1/(d/(sb+1e-9)+1e-9) + 1e-9)
+//     ICL_k  = sum_ij -log(a qA + (1-a) qB)                         (t = 0.1; the mean's 1/A^2 is applied by the host)
+//     IALa_m = sum_ij exp(qoA)(qoA - log qmA), IALb_m likewise with qB   (t = 1; qo from table m, qm from 'joint')
+//
+// Kernel set (all exact fp32 on v_mfma_f32_32x32x2_f32, fp64 only for the global scalar sums):
+//   gather      E, idx            -> Z (normalised, K padded to a multiple of 8), row norms
+//   sweep<sum>  Z                 -> the 4x2 global sums per table           (anchors x negatives, pass 1)
+//   anchor<fwd> Z (all tables)    -> ICL / IALa / IALb sums                  (anchors x anchors,  pass 2)
+//   anchor<bwd> Z, upstream coefs -> dL/dS stash (transposed) + dL/d(sums)   (anchors x anchors)
+//   (sga_gemm)  stash, Z          -> dZ anchor rows
+//   sweep<grad> Z, dL/d(sums)     -> dZ += coefficient-weighted negatives    (owner-stationary, two sweeps)
+//   scatter     dZ, Z, norms, idx -> dE (normalisation Jacobian + index_add)
+// S tiles are produced in the orientation "lane = owner row, registers = other rows", which is also
+// the MFMA A-operand layout, so the gradient GEMM (coefficients x other rows) chains straight from the
+// accumulators with no LDS transpose and each owner row is accumulated by exactly one wave.
+#include "mfma_tiles.h"
+
+namespace {
+
+constexpr int CT_THREADS = 256;
+constexpr int CT_MAXT = 9;            // modalities (<= 8) + joint
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float QEPS = 1e-9f;
+
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+struct GV { float q, dd, dsa, dsb; };
+
+// g and its derivatives wrt d, sa, sb; a = 1/(sa+eps), b = 1/(sb+eps)
+__device__ __forceinline__ GV g_full(float d, float a, float b) {
+    const float u = fmaf(d, a, QEPS), v = fmaf(d, b, QEPS);
+    const float ru = frcp(u), rv = frcp(v);
+    const float q = frcp(1.f + ru + rv + QEPS);
+    const float q2 = q * q, ru2 = ru * ru, rv2 = rv * rv;
+    GV o;
+    o.q = q;
+    o.dd = q2 * (a * ru2 + b * rv2);
+    o.dsa = -q2 * d * a * a * ru2;
+    o.dsb = -q2 * d * b * b * rv2;
+    return o;
+}
+__device__ __forceinline__ float g_val(float d, float a, float b) {
+    const float ru = frcp(fmaf(d, a, QEPS)), rv = frcp(fmaf(d, b, QEPS));
+    return frcp(1.f + ru + rv + QEPS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather + normalise:  Z[r, :] = E[idx[r], :] / max(||.||, 1e-12), zero padded to Dp; nrm[r] = ||.||
+// (F.normalize(emb, dim=1) then emb[data_dict[...]]: losses.py:44-48, :73-79, :84-87)
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_normalize_kernel(const float* __restrict__ E, int D, const int* __restrict__ idx, int R,
+                                        float* __restrict__ Z, int Dp, float* __restrict__ nrm) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
+        const float* x = E + (size_t)idx[r] * D;
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) { const float v = x[d]; ss += v * v; }
+        ss = wave_sum(ss);
+        const float n = sqrtf(ss);
+        const float inv = 1.f / fmaxf(n, 1e-12f);
+        float* z = Z + (size_t)r * Dp;
+        for (int d = lane; d < Dp; d += 64) z[d] = d < D ? x[d] * inv : 0.f;
+        if (lane == 0) nrm[r] = n;
+    }
+}
+
+// dE[idx[r], :] += J_normalize^T dZ[r, :]
+__global__ void scatter_normalize_bwd_kernel(const float* __restrict__ dZ, const float* __restrict__ Z,
+                                             const float* __restrict__ nrm, const int* __restrict__ idx, int R, int D,
+                                             int Dp, float* __restrict__ dE) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
+        const float* g = dZ + (size_t)r * Dp;
+        const float* z = Z + (size_t)r * Dp;
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += g[d] * z[d];
+        dot = wave_sum(dot);
+        const float n = nrm[r];
+        const bool clamped = n < 1e-12f;
+        const float inv = 1.f / fmaxf(n, 1e-12f);
+        if (clamped) dot = 0.f;
+        float* o = dE + (size_t)idx[r] * D;
+        for (int d = lane; d < D; d += 64) atomicAdd(o + d, (g[d] - z[d] * dot) * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// owner-stationary sweeps over (owner rows) x (other rows): pass-1 sums and the negatives' gradient
+// ------------------------------------------------------------------------------------------------
+struct SweepSeg { int row0, n, fam; };                 // other rows [row0, row0+n), sum family 0..3
+struct SweepGroup { int own0, nown, blk0, nseg; SweepSeg seg[2]; };
+struct SweepArgs {
+    const float* Z; int Dp; int ngroups; SweepGroup grp[4];
+    float k0, k1;                   // log2(e)/tau for the two temperatures
+    float it0, it1;                 // 1/tau
+    double* sums;                   // [8]  (fam*2 + temp)            (SUM mode: output)
+    const double* gs;               // [8]  dL/d(sums)                (GRAD mode: input)
+    float* dZ;                      // [R][Dp]                        (GRAD mode: atomic accumulate)
+    int col0;                       // first gradient column of this pass (GRAD, Dp > NCT*32)
+};
+
+template <int NJT, int NCT, bool GRAD>
+__global__ __launch_bounds__(CT_THREADS) void sweep_kernel(SweepArgs a) {
+    constexpr int OT = NJT * 32;                      // other rows per step
+    constexpr int GW = NCT * 32;                      // gradient columns per pass
+    constexpr int S_FLOATS = (128 + OT) * SGA_LDS_STRIDE;
+    constexpr int G_FLOATS = GRAD ? OT * GW : 0;
+    __shared__ __attribute__((aligned(16))) float lds[S_FLOATS > G_FLOATS ? S_FLOATS : G_FLOATS];
+    float* own_s = lds;
+    float* oth_s = lds + 128 * SGA_LDS_STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
+    const SweepGroup& grp = a.grp[g];
+    const int own0 = grp.own0 + ((int)blockIdx.x - grp.blk0) * 128;
+    const int own_end = grp.own0 + grp.nown;
+    const int my_i = own0 + wave * 32 + (lane & 31);
+
+    f32x16 gacc[GRAD ? NCT : 1];
+    if (GRAD) zero_acc<GRAD ? NCT : 1>(gacc);
+    double dsum[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        if (sg >= grp.nseg) break;
+        const SweepSeg seg = grp.seg[sg];
+        float c0 = 0.f, c1 = 0.f;
+        if (GRAD) { c0 = (float)(a.gs[seg.fam * 2 + 0] * (double)a.it0); c1 = (float)(a.gs[seg.fam * 2 + 1] * (double)a.it1); }
+        const int ntile = (seg.n + OT - 1) / OT;
+        for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y) {
+            const int j0 = seg.row0 + jt * OT, j_end = seg.row0 + seg.n;
+            f32x16 sacc[NJT];
+            zero_acc<NJT>(sacc);
+            for (int k0 = 0; k0 < a.Dp; k0 += SGA_KC) {
+                __syncthreads();
+                lds_load_rows<128, CT_THREADS>(own_s, a.Z, a.Dp, own0, own_end, k0, a.Dp, tid);
+                lds_load_rows<OT, CT_THREADS>(oth_s, a.Z, a.Dp, j0, j_end, k0, a.Dp, tid);
+                __syncthreads();
+                mfma_chunk<NJT>(sacc, oth_s, own_s + (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE, lane);
+            }
+            if (!GRAD) {
+                float p0 = 0.f, p1 = 0.f;
+                const bool iv = my_i < own_end;
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = iv && (j0 + t * 32 + mfma32_row(r, h) < j_end);
+                        const float e0 = fexp2(sacc[t][r] * a.k0), e1 = fexp2(sacc[t][r] * a.k1);
+                        p0 += ok ? e0 : 0.f;
+                        p1 += ok ? e1 : 0.f;
+                    }
+                dsum[sg][0] += (double)p0;
+                dsum[sg][1] += (double)p1;
+            } else {
+                // coefficient dL/d(dot) = sum_temp dL/ds * exp(dot/tau)/tau, in place (A-operand layout)
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sacc[t][r] = c0 * fexp2(sacc[t][r] * a.k0) + c1 * fexp2(sacc[t][r] * a.k1);
+                __syncthreads();
+                // stage the other rows' gradient columns [OT][GW] (zero beyond valid rows / Dp)
+                for (int e = tid; e < OT * (GW / 4); e += CT_THREADS) {
+                    const int r = e / (GW / 4), c = (e % (GW / 4)) * 4;
+                    const int gr = j0 + r, gc = a.col0 + c;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (gr < j_end && gc < a.Dp) v = *reinterpret_cast<const f32x4*>(a.Z + (size_t)gr * a.Dp + gc);
+                    *reinterpret_cast<f32x4*>(lds + r * GW + c) = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const float av = sacc[t][s];
+                        const float* brow = lds + (t * 32 + mfma32_row(s, h)) * GW + (lane & 31);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            gacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[ct * 32], gacc[ct], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    if (!GRAD) {
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const double v = wave_sum_d(dsum[sg][tt]);
+                if (lane == 0 && sg < grp.nseg && v != 0.0) atomicAdd(a.sums + grp.seg[sg].fam * 2 + tt, v);
+            }
+    } else {
+        // gacc[ct][r] = dOwner[wave*32 + row(r,h)][col0 + ct*32 + (lane&31)]
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int d = a.col0 + ct * 32 + (lane & 31);
+            if (d < a.Dp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = own0 + wave * 32 + mfma32_row(r, h);
+                    if (i < own_end) atomicAdd(a.dZ + (size_t)i * a.Dp + d, gacc[ct][r]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// anchors x anchors: loss terms (fwd) and dL/dS + dL/d(sums) (bwd), all tables in one pass
+// ------------------------------------------------------------------------------------------------
+struct AnchorArgs {
+    int NT, A;
+    const float* Z[CT_MAXT]; int Dp[CT_MAXT];
+    const double* sums;            // [NT][8]
+    float alpha, kc, ki, itc, iti; // ICL alpha; log2e/tau and 1/tau for ICL (c) and IAL (i)
+    double* out;                   // fwd: [NT] icl sums, [M] iala, [M] ialb
+    const float* coef;             // bwd: upstream dL/d(out) in the same order
+    float* M1[CT_MAXT];            // bwd: stash, M1[k][j*A + i] = dL/dS_k[i,j]
+    double* gs;                    // bwd: [NT][8] dL/d(sums)
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
+    constexpr int NJT = 2, OT = 64;
+    __shared__ __attribute__((aligned(16))) float own1[128 * SGA_LDS_STRIDE];   // X1 rows of block I
+    __shared__ __attribute__((aligned(16))) float own2[128 * SGA_LDS_STRIDE];   // X2 rows of block I
+    __shared__ __attribute__((aligned(16))) float oth1[OT * SGA_LDS_STRIDE];    // X2 rows of block J  (for P)
+    __shared__ __attribute__((aligned(16))) float oth2[OT * SGA_LDS_STRIDE];    // X1 rows of block J  (for Q)
+    __shared__ float inv_s[CT_MAXT * 8];                                        // 1/(sum + 1e-9)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int A = a.A, NT = a.NT, M = NT > 1 ? NT - 1 : 0;
+    for (int e = tid; e < NT * 8; e += CT_THREADS) inv_s[e] = (float)(1.0 / (a.sums[e] + 1e-9));
+    const int i0 = blockIdx.x * 128, j0 = blockIdx.y * OT;
+    const int my_i = i0 + wave * 32 + (lane & 31);
+    const bool iv = my_i < A;
+
+    f32x16 xJ[NJT], gJ[NJT];
+    zero_acc<NJT>(xJ);
+    zero_acc<NJT>(gJ);
+
+    for (int it = 0; it < NT; ++it) {
+        const int k = (NT > 1) ? (it == 0 ? NT - 1 : it - 1) : 0;       // joint first, then the modalities
+        const bool is_joint = NT > 1 && it == 0;
+        const float* Z = a.Z[k];
+        const int Dp = a.Dp[k];
+        f32x16 P[NJT], Q[NJT];
+        zero_acc<NJT>(P);
+        zero_acc<NJT>(Q);
+        for (int k0 = 0; k0 < Dp; k0 += SGA_KC) {
+            __syncthreads();
+            lds_load_rows<128, CT_THREADS>(own1, Z, Dp, i0, A, k0, Dp, tid);
+            lds_load_rows<128, CT_THREADS>(own2, Z, Dp, A + i0, 2 * A, k0, Dp, tid);
+            lds_load_rows<OT, CT_THREADS>(oth1, Z, Dp, A + j0, 2 * A, k0, Dp, tid);
+            lds_load_rows<OT, CT_THREADS>(oth2, Z, Dp, j0, A, k0, Dp, tid);
+            __syncthreads();
+            const int ro = (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE;
+            mfma_chunk<NJT>(P, oth1, own1 + ro, lane);      // P[i,j] = X1[i].X2[j] = S[i,j]
+            mfma_chunk<NJT>(Q, oth2, own2 + ro, lane);      // Q[i,j] = X2[i].X1[j] = S[j,i]
+        }
+        if (is_joint) {
+#pragma unroll
+            for (int t = 0; t < NJT; ++t) xJ[t] = P[t];
+        }
+        const float* is = inv_s + k * 8;                    // [fam*2 + temp]
+        const float a11c = is[0], a12c = is[2], a22c = is[4], a21c = is[6];
+        const float a11i = is[1], a12i = is[3], a22i = is[5], a21i = is[7];
+        const float* js = inv_s + (NT - 1) * 8;
+        const float j11 = js[1], j12 = js[3], j22 = js[5], j21 = js[7];
+
+        if (!BWD) {
+            float icl = 0.f, la = 0.f, lb = 0.f;
+#pragma unroll
+            for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = iv && (j0 + t * 32 + mfma32_row(r, h) < A);
+                    const float x = P[t][r], y = Q[t][r];
+                    const float qa = g_val(fexp2(x * a.kc), a11c, a12c);
+                    const float qb = g_val(fexp2(y * a.kc), a22c, a21c);
+                    const float term = -flog(a.alpha * qa + (1.f - a.alpha) * qb);
+                    icl += ok ? term : 0.f;
+                    if (M > 0 && !is_joint) {
+                        const float dm = fexp2(x * a.ki), dj = fexp2(xJ[t][r] * a.ki);
+                        const float qoa = g_val(dm, a11i, a12i), qma = g_val(dj, j11, j12);
+                        const float qob = g_val(dm, a22i, a21i), qmb = g_val(dj, j22, j21);
+                        const float ta = __expf(qoa) * (qoa - flog(qma));
+                        const float tb = __expf(qob) * (qob - flog(qmb));
+                        la += ok ? ta : 0.f;
+                        lb += ok ? tb : 0.f;
+                    }
+                }
+            icl = wave_sum(icl);
+            if (lane == 0) atomicAdd(a.out + k, (double)icl);
+            if (M > 0 && !is_joint) {
+                la = wave_sum(la);
+                lb = wave_sum(lb);
+                if (lane == 0) { atomicAdd(a.out + NT + k, (double)la); atomicAdd(a.out + NT + M + k, (double)lb); }
+            }
+        } else {
+            const float c = a.coef[k];
+            const float ca = (M > 0 && !is_joint) ? a.coef[NT + k] : 0.f;
+            const float cb = (M > 0 && !is_joint) ? a.coef[NT + M + k] : 0.f;
+            float gs_c[4] = {0.f, 0.f, 0.f, 0.f};          // this table, ICL temperature
+            float gs_i[4] = {0.f, 0.f, 0.f, 0.f};          // this table, IAL temperature
+            float gs_j[4] = {0.f, 0.f, 0.f, 0.f};          // joint table, IAL temperature
+#pragma unroll
+            for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = iv && (j0 + t * 32 + mfma32_row(r, h) < A);
+                    const float x = P[t][r], y = Q[t][r];
+                    const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
+                    const GV Ax = g_full(dx, a11c, a12c), Bx = g_full(dx, a22c, a21c);
+                    const float qAy = g_val(dy, a11c, a12c), qBy = g_val(dy, a22c, a21c);
+                    const float z_ij = a.alpha * Ax.q + (1.f - a.alpha) * qBy;
+                    const float z_ji = a.alpha * qAy + (1.f - a.alpha) * Bx.q;
+                    const float wA = ok ? -c * a.alpha * frcp(z_ij) : 0.f;
+                    const float wB = ok ? -c * (1.f - a.alpha) * frcp(z_ji) : 0.f;
+                    float gx = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
+                    gs_c[0] += wA * Ax.dsa; gs_c[1] += wA * Ax.dsb; gs_c[2] += wB * Bx.dsa; gs_c[3] += wB * Bx.dsb;
+                    if (M > 0 && !is_joint) {
+                        const float dm = fexp2(x * a.ki), dj = fexp2(xJ[t][r] * a.ki);
+                        const GV OA = g_full(dm, a11i, a12i), OB = g_full(dm, a22i, a21i);
+                        const GV MA = g_full(dj, j11, j12), MB = g_full(dj, j22, j21);
+                        const float eA = ok ? __expf(OA.q) : 0.f, eB = ok ? __expf(OB.q) : 0.f;
+                        const float tA = ca * eA * (OA.q - flog(MA.q) + 1.f), uA = -ca * eA * frcp(MA.q);
+                        const float tB = cb * eB * (OB.q - flog(MB.q) + 1.f), uB = -cb * eB * frcp(MB.q);
+                        gx += (tA * OA.dd + tB * OB.dd) * dm * a.iti;
+                        gJ[t][r] += (uA * MA.dd + uB * MB.dd) * dj * a.iti;
+                        gs_i[0] += tA * OA.dsa; gs_i[1] += tA * OA.dsb; gs_i[2] += tB * OB.dsa; gs_i[3] += tB * OB.dsb;
+                        gs_j[0] += uA * MA.dsa; gs_j[1] += uA * MA.dsb; gs_j[2] += uB * MB.dsa; gs_j[3] += uB * MB.dsb;
+                    }
+                    P[t][r] = gx;
+                }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float vc = wave_sum(gs_c[f]);
+                if (lane == 0 && vc != 0.f) atomicAdd(a.gs + k * 8 + f * 2 + 0, (double)vc);
+                if (M > 0 && !is_joint) {
+                    const float vi = wave_sum(gs_i[f]), vj = wave_sum(gs_j[f]);
+                    if (lane == 0 && vi != 0.f) atomicAdd(a.gs + k * 8 + f * 2 + 1, (double)vi);
+                    if (lane == 0 && vj != 0.f) atomicAdd(a.gs + (NT - 1) * 8 + f * 2 + 1, (double)vj);
+                }
+            }
+            if (is_joint) {
+#pragma unroll
+                for (int t = 0; t < NJT; ++t) gJ[t] = P[t];
+            } else if (iv) {
+                float* m1 = a.M1[k];
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = j0 + t * 32 + mfma32_row(r, h);
+                        if (j < A) m1[(size_t)j * A + my_i] = P[t][r];
+                    }
+            }
+        }
+    }
+    if (BWD && NT > 1 && iv) {
+        float* m1 = a.M1[NT - 1];
+#pragma unroll
+        for (int t = 0; t < NJT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + t * 32 + mfma32_row(r, h);
+                if (j < A) m1[(size_t)j * A + my_i] = gJ[t][r];
+            }
+    }
+}
+
+int rows_grid(int R) {
+    int g = (R + 3) / 4;
+    const int cap = sga_num_cus() * 8;
+    return g > cap ? cap : (g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int sga_loss_gather(const float* E, int T, int D, const int32_t* idx, int R, float* Z, int Dp, float* nrm,
+                               void* stream) {
+    SGA_CHECK_ARG(E && idx && Z && nrm && D >= 1 && Dp >= D && Dp % 8 == 0 && R >= 0, "sga_loss_gather: bad argument (Dp must be a multiple of 8 >= D)");
+    (void)T;
+    if (R == 0) return SGA_OK;
+    hipLaunchKernelGGL(gather_normalize_kernel, dim3(rows_grid(R)), dim3(256), 0, static_cast<hipStream_t>(stream), E, D, idx, R, Z, Dp, nrm);
+    SGA_CHECK_LAUNCH("sga_loss_gather");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_scatter(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int R, int D,
+                                int Dp, float* dE, void* stream) {
+    SGA_CHECK_ARG(dZ && Z && nrm && idx && dE && D >= 1 && Dp >= D, "sga_loss_scatter: bad argument");
+    if (R == 0) return SGA_OK;
+    hipLaunchKernelGGL(scatter_normalize_bwd_kernel, dim3(rows_grid(R)), dim3(256), 0, static_cast<hipStream_t>(stream), dZ, Z, nrm, idx, R, D, Dp, dE);
+    SGA_CHECK_LAUNCH("sga_loss_scatter");
+    return SGA_OK;
+}
+
+static void fill_groups(SweepArgs& a, int A, int J1, int J2, bool grad) {
+    const int x1 = 0, x2 = A, n1 = 2 * A, n2 = 2 * A + J1;
+    int blk = 0, g = 0;
+    auto add = [&](int own0, int nown, SweepSeg s0, SweepSeg s1) {
+        if (nown <= 0) return;
+        SweepGroup& G = a.grp[g++];
+        G.own0 = own0; G.nown = nown; G.blk0 = blk; G.nseg = 2; G.seg[0] = s0; G.seg[1] = s1;
+        blk += (nown + 127) / 128;
+    };
+    add(x1, A, SweepSeg{n1, J1, 0}, SweepSeg{n2, J2, 1});       // s11, s12
+    add(x2, A, SweepSeg{n2, J2, 2}, SweepSeg{n1, J1, 3});       // s22, s21
+    if (grad) {
+        add(n1, J1, SweepSeg{x1, A, 0}, SweepSeg{x2, A, 3});
+        add(n2, J2, SweepSeg{x1, A, 1}, SweepSeg{x2, A, 2});
+    }
+    a.ngroups = g;
+}
+
+static int total_blocks(const SweepArgs& a) {
+    int n = 0;
+    for (int g = 0; g < a.ngroups; ++g) n += (a.grp[g].nown + 127) / 128;
+    return n;
+}
+
+extern "C" int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8,
+                                 void* stream) {
+    SGA_CHECK_ARG(Z && sums8 && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0 && tau0 > 0 && tau1 > 0, "sga_loss_neg_sums: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(sums8, 0, 8 * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_neg_sums: memset failed"); return SGA_ERR_HIP; }
+    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    SweepArgs a{};
+    a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
+    a.sums = sums8; a.gs = nullptr; a.dZ = nullptr; a.col0 = 0;
+    fill_groups(a, A, J1, J2, false);
+    const int nblk = total_blocks(a);
+    const int jt = ((J1 > J2 ? J1 : J2) + 127) / 128;
+    int gy = (8 * sga_num_cus() + nblk - 1) / nblk;
+    if (gy > jt) gy = jt;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL((sweep_kernel<4, 1, false>), dim3(nblk, gy), dim3(CT_THREADS), 0, s, a);
+    SGA_CHECK_LAUNCH("sga_loss_neg_sums");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1,
+                                 const double* gs8, float* dZ, void* stream) {
+    SGA_CHECK_ARG(Z && gs8 && dZ && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_neg_grad: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    SweepArgs a{};
+    a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
+    a.sums = nullptr; a.gs = gs8; a.dZ = dZ;
+    fill_groups(a, A, J1, J2, true);
+    const int nblk = total_blocks(a);
+    int mx = A > J1 ? A : J1;
+    if (J2 > mx) mx = J2;
+    int gy = (6 * sga_num_cus() + nblk - 1) / nblk;
+    if (Dp <= 128) {
+        const int jt = (mx + 127) / 128;
+        if (gy > jt) gy = jt;
+        if (gy < 1) gy = 1;
+        a.col0 = 0;
+        hipLaunchKernelGGL((sweep_kernel<4, 4, true>), dim3(nblk, gy), dim3(CT_THREADS), 0, s, a);
+    } else {
+        const int jt = (mx + 63) / 64;
+        if (gy > jt) gy = jt;
+        if (gy < 1) gy = 1;
+        for (int col0 = 0; col0 < Dp; col0 += 256) {
+            a.col0 = col0;
+            hipLaunchKernelGGL((sweep_kernel<2, 8, true>), dim3(nblk, gy), dim3(CT_THREADS), 0, s, a);
+        }
+    }
+    SGA_CHECK_LAUNCH("sga_loss_neg_grad");
+    return SGA_OK;
+}
+
+static int fill_anchor(AnchorArgs& a, const float* const* Z, const int* Dp, int NT, int A, const double* sums,
+                       float alpha, float tau_icl, float tau_ial) {
+    if (NT < 1 || NT > CT_MAXT) { sga_set_error("sga_loss_anchor: NT=%d outside [1,%d]", NT, CT_MAXT); return SGA_ERR_ARG; }
+    a.NT = NT; a.A = A; a.sums = sums; a.alpha = alpha;
+    a.kc = LOG2E / tau_icl; a.ki = LOG2E / tau_ial; a.itc = 1.f / tau_icl; a.iti = 1.f / tau_ial;
+    for (int k = 0; k < NT; ++k) {
+        if (!Z[k] || Dp[k] % 8) { sga_set_error("sga_loss_anchor: table %d null or Dp %% 8 != 0", k); return SGA_ERR_ARG; }
+        a.Z[k] = Z[k]; a.Dp[k] = Dp[k];
+    }
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
+                                   float alpha, float tau_icl, float tau_ial, double* out, void* stream) {
+    SGA_CHECK_ARG(Z && Dp && sums && out && A >= 0, "sga_loss_anchor_fwd: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = NT > 1 ? NT - 1 : 0;
+    if (hipMemsetAsync(out, 0, (NT + 2 * M) * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_anchor_fwd: memset failed"); return SGA_ERR_HIP; }
+    if (A == 0) return SGA_OK;
+    AnchorArgs a{};
+    int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial);
+    if (rc) return rc;
+    a.out = out;
+    hipLaunchKernelGGL(anchor_kernel<false>, dim3((A + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    SGA_CHECK_LAUNCH("sga_loss_anchor_fwd");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
+                                   float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
+                                   double* gs, void* stream) {
+    SGA_CHECK_ARG(Z && Dp && sums && coef && M1 && gs && A >= 0, "sga_loss_anchor_bwd: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(gs, 0, NT * 8 * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_anchor_bwd: memset failed"); return SGA_ERR_HIP; }
+    if (A == 0) return SGA_OK;
+    AnchorArgs a{};
+    int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial);
+    if (rc) return rc;
+    a.coef = coef; a.gs = gs;
+    for (int k = 0; k < NT; ++k) { SGA_CHECK_ARG(M1[k], "sga_loss_anchor_bwd: null stash %d", k); a.M1[k] = M1[k]; }
+    hipLaunchKernelGGL(anchor_kernel<true>, dim3((A + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    SGA_CHECK_LAUNCH("sga_loss_anchor_bwd");
+    return SGA_OK;
+}

@@ -1,0 +1,182 @@
+// Generic exact-fp32 MFMA GEMM used by the small dense layers of the path and by the loss backward.
+//
+//   C[M,N] (+)= opA(A)[M,K] * opB(B)[K,N] (+ bias[N])
+//
+// Replaces, on the reference path: nn.Linear forward/backward for object_embedding /
+// structure_embedding / meta_embedding_rel / meta_embedding_attr (src/aligner/sg_aligner.py:112,116,
+// 119,122; the .float() casts of the f64 bag-of-words inputs at :73-74 are folded into the A loader),
+// and the dS * E products of the contrastive-loss backward (autograd of src/aligner/losses.py:6-8).
+//
+// v_mfma_f32_32x32x2_f32, 128x128 block tile, 4 waves; a wave owns 32 output columns (so C stores are
+// 128-byte coalesced) and walks four 32-row tiles; K is staged through LDS in chunks of 32 with
+// conflict-free ds_read_b128 operand reads (mfma_tiles.h).  Optional split-K (atomic fp32 adds) for
+// the weight-gradient shape (M,N small, K = number of objects).
+#include "mfma_tiles.h"
+
+namespace {
+
+constexpr int GM_THREADS = 256;
+
+// Stage a [128][SGA_KC] operand tile: element (row, k) of op(X).
+//   kmajor == 0 : X is [rows][K]   (k contiguous)     -> X[row*ld + k]
+//   kmajor == 1 : X is [K][rows]   (row contiguous)   -> X[k*ld + row]
+template <typename TIn>
+__device__ __forceinline__ void stage_tile(float* __restrict__ tile, const TIn* __restrict__ X, long ld, int kmajor,
+                                           int row0, int nrows, int k0, int kend, int tid, bool vec_ok) {
+    if (!kmajor) {
+        if (vec_ok && sizeof(TIn) == 4) {
+            constexpr int V = SGA_KC / 4;
+            for (int e = tid; e < 128 * V; e += GM_THREADS) {
+                const int r = e / V, c = (e % V) * 4;
+                const int gr = row0 + r, gk = k0 + c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gr < nrows) {
+                    if (gk + 3 < kend) {
+                        v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + (size_t)gr * ld + gk);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (gk + j < kend) v[j] = (float)X[(size_t)gr * ld + gk + j];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(tile + r * SGA_LDS_STRIDE + c) = v;
+            }
+        } else {
+            for (int e = tid; e < 128 * SGA_KC; e += GM_THREADS) {
+                const int r = e / SGA_KC, c = e % SGA_KC;
+                const int gr = row0 + r, gk = k0 + c;
+                tile[r * SGA_LDS_STRIDE + c] = (gr < nrows && gk < kend) ? (float)X[(size_t)gr * ld + gk] : 0.f;
+            }
+        }
+    } else {
+        for (int e = tid; e < 128 * SGA_KC; e += GM_THREADS) {
+            const int r = e % 128, c = e / 128;
+            const int gr = row0 + r, gk = k0 + c;
+            tile[r * SGA_LDS_STRIDE + c] = (gr < nrows && gk < kend) ? (float)X[(size_t)gk * ld + gr] : 0.f;
+        }
+    }
+}
+
+template <typename TA>
+__global__ __launch_bounds__(GM_THREADS) void gemm_kernel(const TA* __restrict__ A, long lda, int transA,
+                                                          const float* __restrict__ B, long ldb, int transB,
+                                                          float* __restrict__ C, long ldc,
+                                                          const float* __restrict__ bias, int M, int N, int K,
+                                                          int accumulate, int k_per_split, int use_atomic,
+                                                          int a_vec_ok, int b_vec_ok) {
+    __shared__ __attribute__((aligned(16))) float As[128 * SGA_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[128 * SGA_LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    f32x16 acc[4];
+    zero_acc<4>(acc);
+    for (int k0 = kbeg; k0 < kend; k0 += SGA_KC) {
+        __syncthreads();
+        stage_tile<TA>(As, A, lda, transA, m0, M, k0, kend, tid, a_vec_ok);
+        stage_tile<float>(Bs, B, ldb, !transB, n0, N, k0, kend, tid, b_vec_ok);
+        __syncthreads();
+        // MFMA "A" rows = output rows m (4 tiles), MFMA "B" row = this wave's output column n
+        mfma_chunk<4>(acc, As, Bs + (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE, lane);
+    }
+    const int n = n0 + wave * 32 + (lane & 31);
+    if (n >= N) return;
+    const float bv = (bias && blockIdx.z == 0) ? bias[n] : 0.f;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + t * 32 + mfma32_row(r, h);
+            if (m < M) {
+                float* p = C + (size_t)m * ldc + n;
+                const float v = acc[t][r] + bv;
+                if (use_atomic) atomicAdd(p, v);
+                else *p = accumulate ? (*p + v) : v;
+            }
+        }
+    }
+}
+
+// column sums: out[n] (+)= sum_m X[m*ld + n]   (bias gradients)
+__global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rw = threadIdx.x >> 6;                 // 4 row-walkers per block
+    float s = 0.f;
+    if (n < N)
+        for (int m = blockIdx.y * 4 + rw; m < M; m += gridDim.y * 4) s += X[(size_t)m * ld + n];
+    __shared__ float red[4][64];
+    red[rw][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rw == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
+}  // namespace
+
+extern "C" int sga_cast_f64_f32(const double* in, float* out, size_t n, void* stream) {
+    SGA_CHECK_ARG(in && out, "sga_cast_f64_f32: null pointer");
+    if (n == 0) return SGA_OK;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, n);
+    SGA_CHECK_LAUNCH("sga_cast_f64_f32");
+    return SGA_OK;
+}
+
+extern "C" int sga_gemm(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64,
+                        const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
+                        void* stream) {
+    SGA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sga_gemm: negative size");
+    SGA_CHECK_ARG(A && B && C, "sga_gemm: null pointer");
+    if (M == 0 || N == 0) return SGA_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int gx = (M + 127) / 128, gy = (N + 127) / 128;
+    // split K when the output grid cannot fill the chip (weight-gradient shape)
+    int splits = 1;
+    const int ncu = sga_num_cus();
+    if (gx * gy < ncu && K >= 4096) {
+        splits = min((2 * ncu) / (gx * gy), (K + 1023) / 1024);
+        if (splits < 1) splits = 1;
+    }
+    int kper = ((K + splits - 1) / splits + SGA_KC - 1) / SGA_KC * SGA_KC;
+    if (kper < SGA_KC) kper = SGA_KC;
+    splits = K > 0 ? (K + kper - 1) / kper : 1;
+    const int use_atomic = splits > 1;
+    if (use_atomic && !accumulate) {
+        if (ldc == N) {
+            if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s) != hipSuccess) { sga_set_error("sga_gemm: memset failed"); return SGA_ERR_HIP; }
+        } else {
+            if (hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) { sga_set_error("sga_gemm: memset2d failed"); return SGA_ERR_HIP; }
+        }
+    }
+    const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
+    const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
+    dim3 grid(gx, gy, splits);
+    if (a_is_f64)
+        hipLaunchKernelGGL(gemm_kernel<double>, grid, dim3(GM_THREADS), 0, s, static_cast<const double*>(A), lda, transA, B, ldb,
+                           transB, C, ldc, bias, M, N, K, accumulate, kper, use_atomic, 0, (int)b_al);
+    else
+        hipLaunchKernelGGL(gemm_kernel<float>, grid, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, transA, B, ldb,
+                           transB, C, ldc, bias, M, N, K, accumulate, kper, use_atomic, (int)a_al, (int)b_al);
+    SGA_CHECK_LAUNCH("sga_gemm");
+    return SGA_OK;
+}
+
+extern "C" int sga_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream) {
+    SGA_CHECK_ARG(X && out && M >= 0 && N >= 0, "sga_colsum: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0) return SGA_OK;
+    if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) { sga_set_error("sga_colsum: memset failed"); return SGA_ERR_HIP; }
+    if (M == 0) return SGA_OK;
+    int gy = (M + 255) / 256;
+    if (gy > 512) gy = 512;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, s, X, ld, M, N, out);
+    SGA_CHECK_LAUNCH("sga_colsum");
+    return SGA_OK;
+}

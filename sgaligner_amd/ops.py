@@ -43,3 +43,223 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
                                      T, P, C3, _stream())
     _lib.check(rc, 'sga_pointnet_fwd')
     return y, am
+
+
+# ------------------------------------------------------------------------------------------ GEMM / Linear
+def gemm(a, b, trans_a: bool, trans_b: bool, m: int, n: int, k: int, bias=None, out=None, accumulate=False):
+    """out[m,n] (+)= op(a)[m,k] @ op(b)[k,n] (+ bias).  a may be float64 (converted in the loader)."""
+    dev = b.device
+    if out is None:
+        out = torch.empty((m, n), device=dev, dtype=torch.float32)
+    lda = a.stride(0)
+    ldb = b.stride(0)
+    rc = _lib.lib().sga_gemm(int(trans_a), int(trans_b), m, n, k, _p(a), lda, int(a.dtype == torch.float64), _p(b), ldb,
+                             _p(out), out.stride(0), _p(bias), int(accumulate), _stream())
+    _lib.check(rc, 'sga_gemm')
+    return out
+
+
+def colsum(x, out=None):
+    m, n = x.shape
+    if out is None:
+        out = torch.empty((n,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().sga_colsum(_p(x), x.stride(0), m, n, _p(out), 0, _stream()), 'sga_colsum')
+    return out
+
+
+def cast_f32(x):
+    if x.dtype == torch.float32:
+        return x
+    if x.dtype != torch.float64:
+        raise RuntimeError(f'sgaligner_amd: unsupported feature dtype {x.dtype}')
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().sga_cast_f64_f32(_p(x), _p(out), x.numel(), _stream()), 'sga_cast_f64_f32')
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b  (nn.Linear; reference sg_aligner.py:112,116,119,122).  x may be float64."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        if not x.is_cuda:
+            raise RuntimeError('sgaligner_amd.LinearFn: HIP device tensor required; there is no CPU path')
+        x = x.contiguous()
+        _req(weight, 'weight'); _req(bias, 'bias')
+        t, k = x.shape
+        y = gemm(x, weight, False, True, t, weight.shape[0], k, bias=bias)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        t, k = x.shape
+        n = weight.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm(gy, weight, False, False, t, k, n)                 # dX = dY W
+        if ctx.needs_input_grad[1]:
+            gw = gemm(gy, cast_f32(x), True, False, n, k, t)             # dW = dY^T X
+        if ctx.needs_input_grad[2]:
+            gb = colsum(gy)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias):
+    return LinearFn.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------ Fusion
+import ctypes as _ct
+
+
+def _ptr_array(tensors):
+    arr = (_ct.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+class FusionFn(torch.autograd.Function):
+    """MultiModalFusion.forward (reference sg_aligner.py:30-35)."""
+
+    @staticmethod
+    def forward(ctx, weight, *embs):
+        m = len(embs)
+        embs = [_req(e.contiguous(), f'embs[{i}]') for i, e in enumerate(embs)]
+        w = _req(weight.contiguous(), 'fusion.weight')
+        t, d = embs[0].shape
+        for e in embs:
+            if tuple(e.shape) != (t, d):
+                raise RuntimeError('sgaligner_amd.FusionFn: all modality tables must share one shape')
+        joint = torch.empty((t, m * d), device=w.device, dtype=torch.float32)
+        arr = _ptr_array(embs)
+        _lib.check(_lib.lib().sga_fusion_fwd(arr, m, _p(w), _p(joint), t, d, _stream()), 'sga_fusion_fwd')
+        ctx.save_for_backward(w, *embs)
+        return joint
+
+    @staticmethod
+    def backward(ctx, gj):
+        w, *embs = ctx.saved_tensors
+        m = len(embs)
+        t, d = embs[0].shape
+        gj = gj.contiguous()
+        gembs = [torch.empty_like(e) for e in embs]
+        gw = torch.empty_like(w)
+        nb = _lib.lib().sga_fusion_bwd_workspace_bytes(m)
+        ws = torch.empty((nb,), device=w.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().sga_fusion_bwd(_ptr_array(embs), m, _p(w), _p(gj), _ptr_array(gembs), _p(gw), t, d,
+                                             _p(ws), nb, _stream()), 'sga_fusion_bwd')
+        return (gw, *gembs)
+
+
+def fusion(weight, embs):
+    return FusionFn.apply(weight, *embs)
+
+
+# ------------------------------------------------------------------------------------------ contrastive loss
+import numpy as _np
+
+
+class IndexSets:
+    """Device copy of the four host index arrays of a batch (reference scan3r.py:142-173 keeps them as
+    numpy int32 on the host): packed [e1i | e2i | e1j | e2j], converted once per batch."""
+
+    def __init__(self, data_dict, device):
+        arrs = [_np.ascontiguousarray(_np.asarray(data_dict[k]).astype(_np.int32)) for k in ('e1i', 'e2i', 'e1j', 'e2j')]
+        if arrs[0].shape != arrs[1].shape:
+            raise RuntimeError('sgaligner_amd: e1i and e2i must have the same length')
+        self.A, self.J1, self.J2 = int(arrs[0].shape[0]), int(arrs[2].shape[0]), int(arrs[3].shape[0])
+        self.R = 2 * self.A + self.J1 + self.J2
+        self.idx = torch.from_numpy(_np.concatenate(arrs)).to(device)
+
+    @staticmethod
+    def of(data_dict, device):
+        c = data_dict.get('_sga_index_sets') if isinstance(data_dict, dict) else None
+        if c is None or c.idx.device != torch.device(device):
+            c = IndexSets(data_dict, device)
+            if isinstance(data_dict, dict):
+                data_dict['_sga_index_sets'] = c
+        return c
+
+
+TAU_ICL = 0.1      # losses.py:39 (ctor argument ignored by the reference)
+TAU_IAL = 1.0      # losses.py:63
+ALPHA = 0.5        # losses.py:36,60 defaults
+
+
+class ContrastiveTermsFn(torch.autograd.Function):
+    """Raw loss sums for NT tables (modalities..., joint):
+        out[k]         = sum_ij -log(a qA + (1-a) qB)          k < NT     (ICL, tau 0.1)
+        out[NT+m]      = sum_ij exp(qoA)(qoA - log qmA)        m < NT-1   (IAL a, tau 1, qm from the last table)
+        out[NT+M+m]    = same with the B direction
+    (reference losses.py:5-15,43-58,68-97).  NT == 1 -> ICL only."""
+
+    @staticmethod
+    def forward(ctx, index_sets, alpha, *tables):
+        L = _lib.lib()
+        nt = len(tables)
+        m = nt - 1 if nt > 1 else 0
+        tables = [_req(t.contiguous(), f'table[{i}]') for i, t in enumerate(tables)]
+        dev = tables[0].device
+        s = index_sets
+        T = tables[0].shape[0]
+        zs, nrms, dps = [], [], []
+        sums = torch.empty((nt, 8), device=dev, dtype=torch.float64)
+        st = _stream()
+        for k, e in enumerate(tables):
+            d = e.shape[1]
+            dp = (d + 7) // 8 * 8
+            z = torch.empty((s.R, dp), device=dev, dtype=torch.float32)
+            nrm = torch.empty((s.R,), device=dev, dtype=torch.float32)
+            _lib.check(L.sga_loss_gather(_p(e), T, d, _p(s.idx), s.R, _p(z), dp, _p(nrm), st), 'sga_loss_gather')
+            _lib.check(L.sga_loss_neg_sums(_p(z), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, sums[k].data_ptr(), st),
+                       'sga_loss_neg_sums')
+            zs.append(z); nrms.append(nrm); dps.append(dp)
+        out = torch.empty((nt + 2 * m,), device=dev, dtype=torch.float64)
+        zarr = _ptr_array(zs)
+        dparr = (_ct.c_int * nt)(*dps)
+        _lib.check(L.sga_loss_anchor_fwd(zarr, dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), st),
+                   'sga_loss_anchor_fwd')
+        ctx.s, ctx.alpha, ctx.dps, ctx.nt = s, float(alpha), dps, nt
+        ctx.shapes = [tuple(t.shape) for t in tables]
+        ctx.save_for_backward(sums, *zs, *nrms)
+        return out.float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        s, nt, dps = ctx.s, ctx.nt, ctx.dps
+        sums, *rest = ctx.saved_tensors
+        zs, nrms = rest[:nt], rest[nt:]
+        dev = sums.device
+        st = _stream()
+        coef = gout.contiguous().float()
+        A = s.A
+        m1 = [torch.empty((A, A), device=dev, dtype=torch.float32) for _ in range(nt)]
+        gs = torch.empty((nt, 8), device=dev, dtype=torch.float64)
+        dparr = (_ct.c_int * nt)(*dps)
+        _lib.check(L.sga_loss_anchor_bwd(_ptr_array(zs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
+                                         _ptr_array(m1), _p(gs), st), 'sga_loss_anchor_bwd')
+        grads = []
+        for k in range(nt):
+            z, dp = zs[k], dps[k]
+            dz = torch.zeros((s.R, dp), device=dev, dtype=torch.float32)
+            if A > 0:
+                # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]
+                gemm(m1[k], z[A:2 * A], True, False, A, dp, A, out=dz[0:A])
+                gemm(m1[k], z[0:A], False, False, A, dp, A, out=dz[A:2 * A])
+            m1[k] = None
+            _lib.check(L.sga_loss_neg_grad(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), st),
+                       'sga_loss_neg_grad')
+            t, d = ctx.shapes[k]
+            de = torch.zeros((t, d), device=dev, dtype=torch.float32)
+            _lib.check(L.sga_loss_scatter(_p(dz), _p(z), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
+            grads.append(de)
+        return (None, None, *grads)
+
+
+def contrastive_terms(tables, data_dict, alpha=ALPHA):
+    s = IndexSets.of(data_dict, tables[0].device)
+    return ContrastiveTermsFn.apply(s, alpha, *tables), s

@@ -1,0 +1,86 @@
+"""GPU parity: contrastive loss kernels (through the C-ABI) vs reference golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _overall(out, dd, mods, lv_ial, lv_icl):
+    """OverallLoss arithmetic on top of ops.contrastive_terms (same wiring as sgaligner_amd.aligner.losses)."""
+    from sgaligner_amd import ops
+    tabs = [out[m] for m in mods] + ([out['joint']] if len(mods) > 1 else [])
+    sums, s = ops.contrastive_terms(tabs, dd)
+    nt, m = len(tabs), len(mods) if len(mods) > 1 else 0
+    a2 = float(s.A) ** 2
+    icl = sums[:nt] / a2
+    if m == 0:
+        return {'loss': icl[0], 'icl_loss_unimodal': icl[0]}
+    ial = 0.1 * (0.5 * sums[nt:nt + m] + 0.5 * sums[nt + m:nt + 2 * m])
+    tot_ial = (torch.exp(-lv_ial) * ial + lv_ial).sum() * 0.1
+    icl_uni = (torch.exp(-lv_icl) * icl[:m] + lv_icl).sum()
+    return {'loss': tot_ial + icl_uni + icl[m], 'ial_loss': tot_ial, 'icl_loss_unimodal': icl_uni,
+            'icl_loss_multimodal': icl[m]}
+
+
+@pytest.mark.parametrize('tag', ['b1', 'b2', 'b4'])
+def test_loss_golden(tag):
+    g = load_golden('losses_' + tag)
+    mods = [str(s) for s in g['modules']]
+    out = {k: torch.from_numpy(g['emb_' + k]).cuda().requires_grad_(True) for k in mods + ['joint']}
+    dd = {k: g[k] for k in ('e1i', 'e2i', 'e1j', 'e2j')}
+    lv_ial = torch.from_numpy(g['lv_ial']).cuda().requires_grad_(True)
+    lv_icl = torch.from_numpy(g['lv_icl']).cuda().requires_grad_(True)
+    res = _overall(out, dd, mods, lv_ial, lv_icl)
+    res['loss'].backward()
+    torch.cuda.synchronize()
+    assert abs(res['loss'].item() - float(g['loss'])) < 1e-3 * max(1, abs(float(g['loss'])))
+    assert abs(res['ial_loss'].item() - float(g['ial'])) < 1e-4 * max(1, abs(float(g['ial'])))
+    assert abs(res['icl_loss_unimodal'].item() - float(g['icl_uni'])) < 1e-4 * max(1, abs(float(g['icl_uni'])))
+    assert abs(res['icl_loss_multimodal'].item() - float(g['icl_multi'])) < 1e-4
+    assert np.abs(lv_ial.grad.cpu().numpy() - g['g_lv_ial']).max() < 1e-4
+    assert np.abs(lv_icl.grad.cpu().numpy() - g['g_lv_icl']).max() < 1e-4
+    for k in mods + ['joint']:
+        err = np.abs(out[k].grad.cpu().numpy() - g['g_' + k]).max()
+        assert err < 1e-4, (k, err)
+
+
+def test_loss_single_module_golden():
+    g = load_golden('losses_m1')
+    emb = torch.from_numpy(g['emb_point']).cuda().requires_grad_(True)
+    dd = {k: g[k] for k in ('e1i', 'e2i', 'e1j', 'e2j')}
+    res = _overall({'point': emb}, dd, ['point'], None, None)
+    res['loss'].backward()
+    assert abs(res['loss'].item() - float(g['loss'])) < 1e-4
+    assert np.abs(emb.grad.cpu().numpy() - g['g_point']).max() < 1e-4
+
+
+@pytest.mark.parametrize('B,N,mods', [(3, 40, ['point', 'gat', 'rel']), (6, 64, ['point', 'rel']), (2, 150, ['point'])])
+def test_loss_vs_oracle_fp64(B, N, mods):
+    """multi-tile sizes (A, J not multiples of the 128/64 tiles) against the fp64 oracle"""
+    from oracle import sga_oracle as O
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(B, N, 8, seed=B * 100 + N, ragged=True, anchors='val')
+    T = int(dd['tot_obj_count'].sum())
+    torch.manual_seed(B + N)
+    m = len(mods)
+    out64 = {k: torch.randn(T, 100, dtype=torch.float64).requires_grad_(True) for k in mods}
+    if m > 1:
+        out64['joint'] = (0.5 * torch.randn(T, 100 * m, dtype=torch.float64)).requires_grad_(True)
+    lv1 = (0.2 * torch.randn(m, dtype=torch.float64)).requires_grad_(True)
+    lv2 = (0.2 * torch.randn(m, dtype=torch.float64)).requires_grad_(True)
+    ref = O.overall_loss(out64, dd, mods, lv1, lv2)
+    ref['loss'].backward()
+    out = {k: v.detach().float().cuda().requires_grad_(True) for k, v in out64.items()}
+    l1 = lv1.detach().float().cuda().requires_grad_(True)
+    l2 = lv2.detach().float().cuda().requires_grad_(True)
+    res = _overall(out, dd, mods, l1, l2)
+    res['loss'].backward()
+    torch.cuda.synchronize()
+    assert abs(res['loss'].item() - ref['loss'].item()) < 1e-3 * max(1, abs(ref['loss'].item()))
+    for k in out:
+        gref = out64[k].grad
+        err = (out[k].grad.cpu().double() - gref).abs().max().item()
+        assert err < 1e-3 * max(1e-3, gref.abs().max().item()) + 1e-6, (k, err, gref.abs().max().item())
