@@ -14,8 +14,8 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libsga_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast',
-         '-Wno-unused-result', '-I', CSRC]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-munsafe-fp-atomics',
+         '-Wno-unused-result', '-Wno-unused-value', '-I', CSRC]
 
 
 def _newer(src_list, target):

@@ -209,3 +209,249 @@ extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1
             return SGA_ERR_ARG;
     }
 }
+
+// =================================================================================================
+// Backward (sparse through the max-pool).
+//
+// Autograd of pointnet.py:140-161: only the arg-max point of each (object, channel) carries gradient,
+// so per object the backward touches <= C3 "winner rows" r (row r = channel r, point argmax[t,r]):
+//   g_r   = gy[t,r] * (y[t,r] > 0)                         x_r = x[t, argmax[t,r]]
+//   H1    = relu(W1 x_r + b1) [C3,64]   Z2 = W2 H1 + b2 [C3,128]   (recomputed, never stored)
+//   gb3[r] += g_r ;  gW3[r,:] += g_r relu(Z2)[r,:]         (row r of W3 only sees winner row r)
+//   dZ2   = g_r W3[r,:] * (Z2 > 0)      gW2 += dZ2^T H1    gb2 += colsum(dZ2)
+//   dZ1   = (dZ2 W2) * (H1 > 0)         gW1 += dZ1^T X     gb1 += colsum(dZ1)
+// One wave owns one 32-row tile of the object.  Reductions over rows need the rows on the MFMA K
+// dimension, reductions over channels need the channels there, so layer 2 is recomputed in both
+// accumulator orientations (lane=row / lane=channel) instead of transposing through LDS; gW3 rows are
+// private to (wave, lane) and accumulate in registers across objects, gW2 accumulates in LDS.
+// =================================================================================================
+namespace {
+
+constexpr int PB_WAVES = 8;
+constexpr int PB_THREADS = PB_WAVES * 64;
+
+// PH == 0: gW1, gb1 (lane = row orientation, dH1 = dZ2 W2).   PH == 1: gW3, gb3, gW2, gb2 (lane = channel).
+// Two launches keep each phase at ~160 live registers; fused they spilled >130 VGPRs to scratch.
+template <int PH>
+__global__ __launch_bounds__(PB_THREADS) void pointnet_bwd_kernel(
+    const float* __restrict__ x, const int* __restrict__ argmax, const float* __restrict__ y,
+    const float* __restrict__ gy, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+    float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
+    float* __restrict__ gw3, float* __restrict__ gb3, int T, int P) {
+    constexpr int C3 = 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w2s = lds;               // operand order [4 cb][8 q][64 lane][4]
+    float* w2r = lds + 8192;        // row-major [128][64]
+    float* gw2s = lds + 16384;      // accumulator [128][64]
+    const int tid = threadIdx.x;
+    for (int d = tid; d < 2048; d += PB_THREADS) {
+        const int ln = d & 63, q = (d >> 6) & 7, cb = d >> 9;
+        const int row = cb * 32 + (ln & 31), k = 8 * q + 4 * (ln >> 5);
+        *reinterpret_cast<f32x4*>(w2s + d * 4) = *reinterpret_cast<const f32x4*>(w2 + row * 64 + k);
+        *reinterpret_cast<f32x4*>(w2r + d * 4) = *reinterpret_cast<const f32x4*>(w2 + d * 4);
+        *reinterpret_cast<f32x4*>(gw2s + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    // persistent per-lane accumulators
+    float gw3a[64];                 // [cb][s] : gW3[wave*32 + row(s,h)][cb*32 + l31]
+#pragma unroll
+    for (int i = 0; i < 64; ++i) gw3a[i] = 0.f;
+    float gb3a = 0.f, gb2a[4] = {0.f, 0.f, 0.f, 0.f};
+    float gw1a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb1a[2] = {0.f, 0.f};
+
+    for (int t = blockIdx.x; t < T; t += gridDim.x) {
+        int lane_o = lane, h_o = h;
+        asm volatile("" : "+v"(lane_o), "+v"(h_o));          // keep weight reads inside the loop (see fwd):
+        const int l31_o = lane_o & 31;                       // every weight address below goes through these
+        const int c = wave * 32 + l31_o;                     // this lane's winner row (lane = row layouts)
+        const int p = min(max(argmax[(size_t)t * C3 + c], 0), P - 1);
+        const float* xp = x + ((size_t)t * P + p) * 3;
+        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+        const float yv = y[(size_t)t * C3 + c];
+        const float g = yv > 0.f ? gy[(size_t)t * C3 + c] : 0.f;
+        if (PH == 1 && h == 0) gb3a += g;
+
+        // ---- H1 in "lane = row" layout (k = 8q + 4h + r), as in the forward
+        float h1[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 8 * q + 4 * h_o;
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(w1 + k * 3);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w1 + k * 3 + 4);
+            const f32x4 wc = *reinterpret_cast<const f32x4*>(w1 + k * 3 + 8);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + k);
+            h1[q * 4 + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
+            h1[q * 4 + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
+            h1[q * 4 + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
+            h1[q * 4 + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
+        }
+
+        // ======== orientation 1: lane = row, regs = ch2  ->  dZ2 -> dH1 = dZ2 W2
+        f32x16 dh1[2];
+        if (PH == 0) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh1[kt][r] = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * gq + 4 * h_o);
+                acc[gq * 4 + 0] = bb[0]; acc[gq * 4 + 1] = bb[1]; acc[gq * 4 + 2] = bb[2]; acc[gq * 4 + 3] = bb[3];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w2s + ((cb * 8 + q) * 64 + lane_o) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], h1[q * 4 + r], acc, 0, 0, 0);
+            }
+            // dZ2[row][ch2] = g * W3[c][ch2] * (Z2 > 0), ch2 = cb*32 + 8gq + 4h + r
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 w3v = *reinterpret_cast<const f32x4*>(w3 + (size_t)c * 128 + cb * 32 + 8 * gq + 4 * h_o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[gq * 4 + r] = (acc[gq * 4 + r] > 0.f ? g : 0.f) * w3v[r];
+            }
+            // dH1[row][k1] += sum_ch2 dZ2[row][ch2] W2[ch2][k1]   (A = dZ2 regs, B = W2 rows from LDS)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float* wrow = w2r + (cb * 32 + mfma32_row(s, h_o)) * 64 + l31_o;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    dh1[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s], wrow[kt * 32], dh1[kt], 0, 0, 0);
+            }
+        }
+
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- H1 again in "lane = k1, regs = rows" layout (x of row(s,h) fetched by lane shuffle);
+        //      dZ1 = dH1 * (H1 > 0); gW1 / gb1 partial sums
+        f32x16 h1c[2];
+        {
+            const float wa0 = w1[l31_o * 3 + 0], wb0 = w1[l31_o * 3 + 1], wc0 = w1[l31_o * 3 + 2], bb0 = b1[l31_o];
+            const float wa1 = w1[(32 + l31_o) * 3 + 0], wb1 = w1[(32 + l31_o) * 3 + 1], wc1 = w1[(32 + l31_o) * 3 + 2], bb1 = b1[32 + l31_o];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int src = mfma32_row(s, h);
+                const float sx0 = __shfl(x0, src, 64), sx1 = __shfl(x1, src, 64), sx2 = __shfl(x2, src, 64);
+                const float hv0 = fmaxf(fmaf(wc0, sx2, fmaf(wb0, sx1, fmaf(wa0, sx0, bb0))), 0.f);
+                const float hv1 = fmaxf(fmaf(wc1, sx2, fmaf(wb1, sx1, fmaf(wa1, sx0, bb1))), 0.f);
+                h1c[0][s] = hv0;
+                h1c[1][s] = hv1;
+                if (PH != 0) continue;
+                const float dz0 = hv0 > 0.f ? dh1[0][s] : 0.f;
+                const float dz1 = hv1 > 0.f ? dh1[1][s] : 0.f;
+                gw1a[0][0] = fmaf(dz0, sx0, gw1a[0][0]); gw1a[0][1] = fmaf(dz0, sx1, gw1a[0][1]); gw1a[0][2] = fmaf(dz0, sx2, gw1a[0][2]);
+                gw1a[1][0] = fmaf(dz1, sx0, gw1a[1][0]); gw1a[1][1] = fmaf(dz1, sx1, gw1a[1][1]); gw1a[1][2] = fmaf(dz1, sx2, gw1a[1][2]);
+                gb1a[0] += dz0;
+                gb1a[1] += dz1;
+            }
+        }
+
+        // ======== orientation 2: lane = ch2, regs = rows  ->  gW3, gb2, gW2 += dZ2^T H1
+        if (PH == 1)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc;
+            const float bv = b2[cb * 32 + l31_o];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bv;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w2s + ((cb * 8 + q) * 64 + lane_o) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[q * 4 + r], wv[r], acc, 0, 0, 0);
+            }
+            float colsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int cr = wave * 32 + mfma32_row(s, h_o);
+                const float z = acc[s];
+                const float gsv = __shfl(g, mfma32_row(s, h), 64);
+                gw3a[cb * 16 + s] = fmaf(gsv, fmaxf(z, 0.f), gw3a[cb * 16 + s]);
+                const float w3e = w3[(size_t)cr * 128 + cb * 32 + l31_o];      // unconditional load: a select here
+                const float dz = (z > 0.f ? gsv : 0.f) * w3e;                   // would be turned into 64 branches
+                acc[s] = dz;
+                colsum += dz;
+            }
+            gb2a[cb] += colsum;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s], h1c[kt][s], o, 0, 0, 0);
+                // o[r] = gW2[ch2 = cb*32 + row(r,h)][k1 = kt*32 + l31]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(gw2s + (cb * 32 + mfma32_row(r, h)) * 64 + kt * 32 + l31, o[r]);
+            }
+        }
+    }
+
+    // ---- flush the per-workgroup partials
+    if (PH == 1) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int cr = wave * 32 + mfma32_row(s, h);
+            atomicAdd(gw3 + (size_t)cr * 128 + cb * 32 + l31, gw3a[cb * 16 + s]);
+        }
+        const float v = gb2a[cb] + __shfl_xor(gb2a[cb], 32, 64);
+        if (h == 0) atomicAdd(gb2 + cb * 32 + l31, v);
+    }
+    if (h == 0) atomicAdd(gb3 + wave * 32 + l31, gb3a);
+    __syncthreads();
+    for (int d = tid; d < 8192; d += PB_THREADS) atomicAdd(gw2 + d, gw2s[d]);
+    } else {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int k1 = kt * 32 + l31;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = gw1a[kt][d] + __shfl_xor(gw1a[kt][d], 32, 64);
+            if (h == 0) atomicAdd(gw1 + k1 * 3 + d, v);
+        }
+        const float vb = gb1a[kt] + __shfl_xor(gb1a[kt], 32, 64);
+        if (h == 0) atomicAdd(gb1 + k1, vb);
+    }
+    }
+}
+
+}  // namespace
+
+extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy,
+                                const float* w1, const float* b1, const float* w2, const float* b2,
+                                const float* w3, float* gw1, float* gb1, float* gw2, float* gb2, float* gw3,
+                                float* gb3, int T, int P, int C3, void* stream) {
+    SGA_CHECK_ARG(C3 == 256, "sga_pointnet_bwd: out_size C3=%d unsupported (256 only)", C3);
+    SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_bwd: bad sizes");
+    SGA_CHECK_ARG(x && argmax && y && gy && w1 && b1 && w2 && b2 && w3 && gw1 && gb1 && gw2 && gb2 && gw3 && gb3,
+                  "sga_pointnet_bwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipMemsetAsync(gw1, 0, 64 * 3 * sizeof(float), s);
+    hipMemsetAsync(gb1, 0, 64 * sizeof(float), s);
+    hipMemsetAsync(gw2, 0, 128 * 64 * sizeof(float), s);
+    hipMemsetAsync(gb2, 0, 128 * sizeof(float), s);
+    hipMemsetAsync(gw3, 0, 256 * 128 * sizeof(float), s);
+    hipMemsetAsync(gb3, 0, 256 * sizeof(float), s);
+    if (T == 0) return SGA_OK;
+    const size_t lds_bytes = 3 * 8192 * sizeof(float);
+    int grid = T < sga_num_cus() ? T : sga_num_cus();
+    hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(pointnet_bwd_kernel<1>, dim3(grid), dim3(PB_THREADS), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3,
+                       gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    hipLaunchKernelGGL(pointnet_bwd_kernel<0>, dim3(grid), dim3(PB_THREADS), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3,
+                       gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    SGA_CHECK_LAUNCH("sga_pointnet_bwd");
+    return SGA_OK;
+}

@@ -45,6 +45,40 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     return y, am
 
 
+class PointNetFn(torch.autograd.Function):
+    """PointNetfeat.forward (reference pointnet.py:120-175) with the sparse max-pool backward."""
+
+    @staticmethod
+    def forward(ctx, x_tp3, w1, b1, w2, b2, w3, b3):
+        x = _req(x_tp3.contiguous(), 'tot_obj_pts')
+        ws = [_req(w1.reshape(w1.shape[0], -1).contiguous(), 'conv1.weight'), _req(b1.contiguous(), 'conv1.bias'),
+              _req(w2.reshape(w2.shape[0], -1).contiguous(), 'conv2.weight'), _req(b2.contiguous(), 'conv2.bias'),
+              _req(w3.reshape(w3.shape[0], -1).contiguous(), 'conv3.weight'), _req(b3.contiguous(), 'conv3.bias')]
+        need = any(ctx.needs_input_grad[1:])
+        y, am = pointnet_forward(x, *ws, want_argmax=need)
+        if need:
+            ctx.save_for_backward(x, am, y, *ws)
+            ctx.wshapes = (tuple(w1.shape), tuple(w2.shape), tuple(w3.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, am, y, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
+        T, P, _ = x.shape
+        C3 = w3.shape[0]
+        gy = gy.contiguous()
+        g = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        rc = _lib.lib().sga_pointnet_bwd(_p(x), _p(am), _p(y), _p(gy), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3),
+                                         _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]), T, P, C3, _stream())
+        _lib.check(rc, 'sga_pointnet_bwd')
+        s1, s2, s3 = ctx.wshapes
+        return None, g[0].reshape(s1), g[1], g[2].reshape(s2), g[3], g[4].reshape(s3), g[5]
+
+
+def pointnet(x_tp3, w1, b1, w2, b2, w3, b3):
+    return PointNetFn.apply(x_tp3, w1, b1, w2, b2, w3, b3)
+
+
 # ------------------------------------------------------------------------------------------ GEMM / Linear
 def gemm(a, b, trans_a: bool, trans_b: bool, m: int, n: int, k: int, bias=None, out=None, accumulate=False):
     """out[m,n] (+)= op(a)[m,k] @ op(b)[k,n] (+ bias).  a may be float64 (converted in the loader)."""

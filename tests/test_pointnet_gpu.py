@@ -47,3 +47,43 @@ def test_pointnet_fwd_oracle(T, P):
     assert am.min() >= 0 and am.max() < P
     agree = (am == io) | (yo <= 0)
     assert agree.float().mean() > 0.999
+
+
+@pytest.mark.parametrize('tag', ['small', 'ragged'])
+def test_pointnet_bwd_golden(tag):
+    from sgaligner_amd import ops
+    g = load_golden('pointnet_' + tag)
+    x = _dev(g['x'].transpose(0, 2, 1))
+    w = [_dev(g[k]).requires_grad_(True) for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')]
+    y = ops.pointnet(x, *w)
+    (y * _dev(g['cot'])).sum().backward()
+    torch.cuda.synchronize()
+    assert np.abs(y.detach().cpu().numpy() - g['y']).max() < 2e-5
+    for t, k in zip(w, ('gw1', 'gb1', 'gw2', 'gb2', 'gw3', 'gb3')):
+        ref = g[k]
+        err = np.abs(t.grad.cpu().numpy() - ref).max()
+        assert err < 1e-4 * max(1.0, np.abs(ref).max()), (k, err, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('T,P', [(1, 5), (300, 64), (40, 512), (1000, 33)])
+def test_pointnet_bwd_oracle(T, P):
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    torch.manual_seed(T + P)
+    p = O.init_params(['point'])
+    ws = [p['object_encoder.conv1.weight'].reshape(64, 3), torch.randn(64) * 0.1,
+          p['object_encoder.conv2.weight'].reshape(128, 64), torch.randn(128) * 0.1,
+          p['object_encoder.conv3.weight'].reshape(256, 128), torch.randn(256) * 0.1]
+    x = torch.randn(T, P, 3)
+    cot = torch.randn(T, 256)
+    wr = [w.clone().double().requires_grad_(True) for w in ws]
+    yo = O.pointnet_feat(x.double().permute(0, 2, 1), *wr)
+    (yo * cot.double()).sum().backward()
+    wd = [w.clone().contiguous().cuda().requires_grad_(True) for w in ws]
+    y = ops.pointnet(x.cuda(), *wd)
+    (y * cot.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for a, b, name in zip(wd, wr, ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')):
+        ref = b.grad
+        err = (a.grad.cpu().double() - ref).abs().max().item()
+        assert err < 2e-4 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
