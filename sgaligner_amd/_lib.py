@@ -23,6 +23,10 @@ SIGNATURES = {
     'sga_device_cus': (I, []),
     'sga_pointnet_fwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
     'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, P]),
+    'sga_gat_attn_fwd': (I, [P, P, P, P, P, P, P, I, I, P, P]),
+    'sga_gat_attn_bwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
+    'sga_elu_fwd': (I, [P, P, c_size_t, P]),
+    'sga_elu_bwd': (I, [P, P, P, c_size_t, P]),
     'sga_gemm': (I, [I, I, I, I, I, P, c_long, I, P, c_long, P, c_long, P, I, P]),
     'sga_colsum': (I, [P, c_long, I, I, P, I, P]),
     'sga_cast_f64_f32': (I, [P, P, c_size_t, P]),

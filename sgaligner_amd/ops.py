@@ -297,3 +297,111 @@ class ContrastiveTermsFn(torch.autograd.Function):
 def contrastive_terms(tables, data_dict, alpha=ALPHA):
     s = IndexSets.of(data_dict, tables[0].device)
     return ContrastiveTermsFn.apply(s, alpha, *tables), s
+
+
+# ------------------------------------------------------------------------------------------ GAT
+class GraphBatch:
+    """Device-side CSR-style description of the 2B scene graphs of a batch: node/edge offsets in the
+    src,ref,src,ref... order of reference sg_aligner.py:86-110, plus the int64 [sum E, 2] edge list
+    (graph-local node ids, column 0 = source j, column 1 = target i) exactly as collated."""
+
+    def __init__(self, node_counts, edge_counts, edges):
+        nc = _np.asarray(node_counts, dtype=_np.int64).reshape(-1)
+        ec = _np.asarray(edge_counts, dtype=_np.int64).reshape(-1)
+        if nc.shape != ec.shape:
+            raise RuntimeError('sgaligner_amd: graph_per_obj_count and graph_per_edge_count disagree')
+        self.G = int(nc.shape[0])
+        self.nmax = int(nc.max()) if self.G else 0
+        self.T = int(nc.sum())
+        self.E = int(ec.sum())
+        dev = edges.device
+        if edges.dtype != torch.int64:
+            edges = edges.to(torch.int64)
+        self.edges = edges.contiguous()
+        if self.edges.shape[0] < self.E:
+            raise RuntimeError('sgaligner_amd: edge list shorter than graph_per_edge_count says')
+        self.node_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(nc)]).astype(_np.int32)).to(dev)
+        self.edge_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(ec)]).astype(_np.int32)).to(dev)
+
+    @staticmethod
+    def of(data_dict):
+        c = data_dict.get('_sga_graph_batch')
+        if c is None or c.edges.device != data_dict['edges'].device:
+            c = GraphBatch(data_dict['graph_per_obj_count'], data_dict['graph_per_edge_count'], data_dict['edges'])
+            data_dict['_sga_graph_batch'] = c
+        return c
+
+
+def _attn_fwd(h, att_s, att_d, bias, gb):
+    out = torch.empty_like(h)
+    _lib.check(_lib.lib().sga_gat_attn_fwd(_p(h), _p(att_s), _p(att_d), _p(bias), _p(gb.edges), _p(gb.node_off),
+                                           _p(gb.edge_off), gb.G, gb.nmax, _p(out), _stream()), 'sga_gat_attn_fwd')
+    return out
+
+
+def _attn_bwd(h, d_o, att_s, att_d, gb):
+    dh = torch.empty_like(h)
+    das = torch.empty_like(att_s)
+    dad = torch.empty_like(att_d)
+    _lib.check(_lib.lib().sga_gat_attn_bwd(_p(h), _p(d_o), _p(att_s), _p(att_d), _p(gb.edges), _p(gb.node_off),
+                                           _p(gb.edge_off), gb.G, gb.nmax, _p(dh), _p(das), _p(dad), _stream()),
+               'sga_gat_attn_bwd')
+    return dh, das, dad
+
+
+def _elu(x):
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().sga_elu_fwd(_p(x), _p(y), x.numel(), _stream()), 'sga_elu_fwd')
+    return y
+
+
+class MultiGATFn(torch.autograd.Function):
+    """MultiGAT.forward over ALL graphs of a batch (reference gat.py:40-48 x sg_aligner.py:86-110):
+    GATConv(3->128, h=2), ELU, GATConv(256->128, h=2)."""
+
+    @staticmethod
+    def forward(ctx, gb, x, w0, as0, ad0, b0, w1, as1, ad1, b1):
+        if not x.is_cuda:
+            raise RuntimeError('sgaligner_amd.MultiGATFn: HIP device tensor required; there is no CPU path')
+        x32 = cast_f32(x.contiguous())
+        ps = [_req(t.contiguous(), n) for t, n in ((w0, 'gat0.lin'), (as0.reshape(-1), 'gat0.att_src'), (ad0.reshape(-1), 'gat0.att_dst'),
+                                                   (b0, 'gat0.bias'), (w1, 'gat1.lin'), (as1.reshape(-1), 'gat1.att_src'),
+                                                   (ad1.reshape(-1), 'gat1.att_dst'), (b1, 'gat1.bias'))]
+        w0, as0f, ad0f, b0, w1, as1f, ad1f, b1 = ps
+        t = x32.shape[0]
+        if t != gb.T:
+            raise RuntimeError(f'sgaligner_amd: tot_rel_pose has {t} rows but the graphs hold {gb.T} nodes')
+        if w0.shape[0] != 256 or w1.shape != (256, 256):
+            raise RuntimeError('sgaligner_amd: the HIP GAT path implements hidden_units=[F,128,128], heads=[2,2]')
+        h0 = gemm(x32, w0, False, True, t, 256, x32.shape[1])
+        o0 = _attn_fwd(h0, as0f, ad0f, b0, gb)
+        x1 = _elu(o0)
+        h1 = gemm(x1, w1, False, True, t, 256, 256)
+        o1 = _attn_fwd(h1, as1f, ad1f, b1, gb)
+        ctx.gb = gb
+        ctx.att_shapes = (tuple(as0.shape), tuple(as1.shape))
+        ctx.save_for_backward(x32, h0, o0, x1, h1, w0, as0f, ad0f, w1, as1f, ad1f)
+        return o1
+
+    @staticmethod
+    def backward(ctx, d_o1):
+        x32, h0, o0, x1, h1, w0, as0, ad0, w1, as1, ad1 = ctx.saved_tensors
+        gb = ctx.gb
+        t = x32.shape[0]
+        d_o1 = d_o1.contiguous()
+        dh1, das1, dad1 = _attn_bwd(h1, d_o1, as1, ad1, gb)
+        db1 = colsum(d_o1)
+        dw1 = gemm(dh1, x1, True, False, 256, 256, t)
+        dx1 = gemm(dh1, w1, False, False, t, 256, 256)
+        d_o0 = torch.empty_like(o0)
+        _lib.check(_lib.lib().sga_elu_bwd(_p(o0), _p(dx1), _p(d_o0), o0.numel(), _stream()), 'sga_elu_bwd')
+        dh0, das0, dad0 = _attn_bwd(h0, d_o0, as0, ad0, gb)
+        db0 = colsum(d_o0)
+        dw0 = gemm(dh0, x32, True, False, 256, x32.shape[1], t)
+        s0, s1 = ctx.att_shapes
+        return (None, None, dw0, das0.reshape(s0), dad0.reshape(s0), db0, dw1, das1.reshape(s1), dad1.reshape(s1), db1)
+
+
+def multi_gat(gb, x, layer0, layer1):
+    """layer = (lin_weight, att_src, att_dst, bias)."""
+    return MultiGATFn.apply(gb, x, *layer0, *layer1)

@@ -1,0 +1,70 @@
+"""GPU parity: batched GAT structure encoder (C-ABI) vs the oracle's PyG-2.2.0 restatement (GAT-UNPINNED)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs(seed, sizes, extra_dups=True):
+    rng = np.random.default_rng(seed)
+    edges, ecnt = [], []
+    for n in sizes:
+        ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing='ij')
+        m = ii != jj
+        e = np.stack([ii[m], jj[m]], 1)
+        if extra_dups and n > 2:
+            keep = rng.random(e.shape[0]) > 0.3                       # not complete
+            e = e[keep]
+            dup = e[rng.integers(0, e.shape[0], size=max(1, n // 2))]  # duplicate edges
+            loops = np.stack([np.arange(n // 2)] * 2, 1)               # explicit self loops in the input
+            e = np.concatenate([e, dup, loops])
+        edges.append(e)
+        ecnt.append(e.shape[0])
+    return np.concatenate(edges).astype(np.int64), np.asarray(ecnt)
+
+
+@pytest.mark.parametrize('sizes,dups', [([5, 7], True), ([64, 64, 33, 1, 2, 128], False), ([9, 17, 100, 3], True)])
+def test_multigat_fwd_bwd(sizes, dups):
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    torch.manual_seed(len(sizes))
+    edges, ecnt = _graphs(sum(sizes), sizes, dups)
+    T = sum(sizes)
+    x = torch.randn(T, 3, dtype=torch.float64)
+    p = O.init_params(['point', 'gat'], dtype=torch.float64, seed=3)
+    layers = O._gat_layers(p)
+    for l in layers:
+        l['bias'] = torch.randn_like(l['bias']) * 0.1
+        for k in l:
+            l[k] = l[k].clone().requires_grad_(True)
+    cot = torch.randn(T, 256, dtype=torch.float64)
+    outs, so, se = [], 0, 0
+    et = torch.from_numpy(edges)
+    for n, ne in zip(sizes, ecnt):
+        outs.append(O.multi_gat(x[so:so + n], et[se:se + ne].t(), layers))
+        so += n
+        se += ne
+    ref = torch.cat(outs)
+    (ref * cot).sum().backward()
+
+    gb = ops.GraphBatch(np.asarray(sizes), ecnt, et.cuda())
+    dl = [[l[k].detach().float().cuda().requires_grad_(True) for k in ('lin_w', 'att_src', 'att_dst', 'bias')] for l in layers]
+    out = ops.multi_gat(gb, x.cuda(), dl[0], dl[1])
+    (out * cot.float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max() < 1e-4
+    for li in range(2):
+        for t, k in zip(dl[li], ('lin_w', 'att_src', 'att_dst', 'bias')):
+            gref = layers[li][k].grad
+            err = (t.grad.cpu().double() - gref).abs().max().item()
+            assert err < 1e-3 * max(1.0, gref.abs().max().item()), (li, k, err, gref.abs().max().item())
+
+
+def test_gat_too_many_nodes_fails_loudly():
+    from sgaligner_amd import ops
+    edges, ecnt = _graphs(0, [130], False)
+    gb = ops.GraphBatch(np.asarray([130]), ecnt, torch.from_numpy(edges).cuda())
+    h = torch.randn(130, 256, device='cuda')
+    with pytest.raises(RuntimeError, match='at most 128'):
+        ops._attn_fwd(h, torch.randn(256, device='cuda'), torch.randn(256, device='cuda'), torch.zeros(256, device='cuda'), gb)
