@@ -1,0 +1,87 @@
+"""Contrastive (ICL) + alignment (IAL) losses -- drop-in for reference src/aligner/losses.py
+(CustomMultiLossLayer :17-34, ICLLoss :36-58, IALLoss :60-97, OverallLoss :99-152) on the tiled HIP
+loss kernels (csrc/contrastive.hip).  The heavy op is ops.contrastive_terms, which returns the raw
+double-summed terms; what remains here is the reference's scalar arithmetic on 1-element tensors."""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class CustomMultiLossLayer(nn.Module):
+    def __init__(self, loss_num, device=None):
+        super().__init__()
+        self.loss_num = loss_num
+        self.log_vars = nn.Parameter(torch.zeros(self.loss_num, ), requires_grad=True)
+
+    def forward(self, loss_list):
+        assert len(loss_list) == self.loss_num
+        precision = torch.exp(-self.log_vars)
+        loss = 0
+        for i in range(self.loss_num):
+            loss += precision[i] * loss_list[i] + self.log_vars[i]
+        return loss
+
+
+class ICLLoss(nn.Module):
+    def __init__(self, device, temperature=0.05, alpha=0.5):
+        super().__init__()
+        self.temp = 0.1                 # the reference ignores the ctor argument (losses.py:39)
+        self.alpha = alpha
+        self.device = device
+
+    def forward(self, emb, data_dict):
+        sums, s = ops.contrastive_terms([emb], data_dict, alpha=self.alpha)
+        return sums[0] / float(s.A * s.A)                         # .mean() over the A x A matrix (:57)
+
+
+class IALLoss(nn.Module):
+    def __init__(self, device, temperature=0.05, alpha=0.5):
+        super().__init__()
+        self.temp = 1.0                 # losses.py:63
+        self.alpha = alpha
+        self.device = device
+        self.zoom = 0.1
+
+    def forward(self, src_emb, ref_emb, data_dict):
+        """src_emb: modality table (gives qo), ref_emb: joint table (gives qm) -- call order of losses.py:122."""
+        sums, _ = ops.contrastive_terms([src_emb, ref_emb], data_dict)
+        return self.zoom * (self.alpha * sums[2] + (1 - self.alpha) * sums[3])
+
+
+class OverallLoss(nn.Module):
+    def __init__(self, ial_loss_layer, icl_loss_layer, device, metadata):
+        super().__init__()
+        self.zoom = metadata['zoom']
+        self.device = device
+        self.modules = metadata['modules']
+        self.weight_align_loss = metadata['wt_align_loss']            # stored, unused (as in the reference)
+        self.weight_contrastive_loss = metadata['wt_contrastive_loss']
+        self.align_loss = IALLoss(device)
+        self.contrastive_loss = ICLLoss(self.device)
+        self.align_multi_loss_layer = ial_loss_layer
+        self.contrastive_multi_loss_layer = icl_loss_layer
+
+    def forward(self, output_dict, data_dict):
+        mods = list(self.modules)
+        m = len(mods)
+        if m > 1:
+            # one fused pass over all M+1 tables: every similarity tile is computed once and shared by
+            # ICL_m, ICL_joint and IAL_m (the reference recomputes the joint table's q's M times)
+            tabs = [output_dict[k] for k in mods] + [output_dict['joint']]
+            sums, s = ops.contrastive_terms(tabs, data_dict, alpha=self.contrastive_loss.alpha)
+            nt = m + 1
+            a2 = float(s.A * s.A)
+            icl = sums[:nt] / a2
+            al = self.align_loss
+            ial = al.zoom * (al.alpha * sums[nt:nt + m] + (1 - al.alpha) * sums[nt + m:nt + 2 * m])
+            total_align_loss = self.align_multi_loss_layer([ial[i] for i in range(m)]) * self.zoom
+            icl_uni = self.contrastive_multi_loss_layer([icl[i] for i in range(m)])
+            icl_multi = icl[m]
+            loss = total_align_loss + icl_uni + icl_multi
+        else:
+            total_align_loss = 0.0
+            icl_multi = 0.0
+            icl_uni = self.contrastive_loss(output_dict[mods[0]], data_dict)
+            loss = icl_uni
+        return {'loss': loss, 'icl_loss_unimodal': icl_uni, 'icl_loss_multimodal': icl_multi, 'ial_loss': total_align_loss}

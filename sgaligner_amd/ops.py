@@ -405,3 +405,28 @@ class MultiGATFn(torch.autograd.Function):
 def multi_gat(gb, x, layer0, layer1):
     """layer = (lin_weight, att_src, att_dst, bias)."""
     return MultiGATFn.apply(gb, x, *layer0, *layer1)
+
+
+# ------------------------------------------------------------------------------------------ similarity + ranking
+def simrank(emb, pair_counts, q_pair, q_idx, q_tgt, k: int):
+    """For each query object: rank of its target and the k nearest other objects of its pair.
+    emb [T,D] fp32 (un-normalised: the kernel applies emb/||emb|| as inference_align_reg.py:126 does);
+    pair_counts [B] objects per pair; q_* host int arrays (global object indices; q_tgt may be None).
+    Returns (rank [Q] int32, topk_idx [Q,k] int32 pair-local, topk_sim [Q,k] fp32) on the device."""
+    emb = _req(emb.contiguous(), 'embedding')
+    dev = emb.device
+    T, D = emb.shape
+    pc = _np.asarray(pair_counts, dtype=_np.int64).reshape(-1)
+    pair_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(pc)]).astype(_np.int32)).to(dev)
+    Q = int(len(q_idx))
+    f = lambda a: torch.from_numpy(_np.ascontiguousarray(_np.asarray(a, dtype=_np.int32))).to(dev)
+    qp, qi = f(q_pair), f(q_idx)
+    qt = f(q_tgt) if q_tgt is not None else None
+    rank = torch.empty((max(Q, 1),), device=dev, dtype=torch.int32)
+    tk = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.int32)
+    ts = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.float32)
+    nb = _lib.lib().sga_simrank_workspace_bytes(T)
+    ws = torch.empty((nb,), device=dev, dtype=torch.uint8)
+    _lib.check(_lib.lib().sga_simrank(_p(emb), T, D, _p(pair_off), len(pc), int(pc.max()) if len(pc) else 0, _p(qp), _p(qi),
+                                      _p(qt), Q, k, _p(rank), _p(tk), _p(ts), _p(ws), nb, _stream()), 'sga_simrank')
+    return rank[:Q], tk[:Q, :k], ts[:Q, :k]
