@@ -1,0 +1,104 @@
+/* sgaligner_hip.h -- C ABI of libsga_hip.so (sgaligner_amd/csrc), the MI355X (gfx950) implementation of
+ * SGAligner's node-embedding + matching hot path.
+ *
+ * The reference (sayands/sgaligner) is pure Python and has no FFI; each entry point below states the
+ * reference code it replaces (paths relative to the reference repository root).  A reference-side caller
+ * binds these with ctypes (INTEGRATION.md shows the stub); sgaligner_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - plain device pointers + sizes; the library never allocates, frees or retains memory;
+ *   - all matrices row-major fp32 unless stated, base pointers 16-byte aligned;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 on success, non-zero on failure with the message available from sga_last_error()
+ *     (thread-local); argument errors are detected before any launch.
+ */
+#ifndef SGALIGNER_HIP_H
+#define SGALIGNER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int sga_version(void);                 /* 100 * major + minor */
+const char* sga_last_error(void);
+int sga_device_cus(void);
+
+/* ---- PointNet object encoder ------------------------------------------------------------------------
+ * replaces PointNetfeat.forward, src/aligner/networks/pointnet.py:120-175 (called sg_aligner.py:115):
+ *   y[t,c] = max_p relu(W3 relu(W2 relu(W1 x[t,p] + b1) + b2) + b3)[c]      (BN outputs are discarded there)
+ * x [T,P,3] (data_dict['tot_obj_pts'] layout), w1 [64,3], w2 [128,64], w3 [C3,128], y [T,C3],
+ * argmax [T,C3] int32 (first arg-max point per channel; NULL to skip).  C3 in {64,128,256}. */
+int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
+                     void* stream);
+/* autograd of the above wrt the six parameters (sparse through the max-pool); gy [T,C3]; C3 == 256. */
+int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy, const float* w1,
+                     const float* b1, const float* w2, const float* b2, const float* w3, float* gw1, float* gb1,
+                     float* gw2, float* gb2, float* gw3, float* gb3, int T, int P, int C3, void* stream);
+
+/* ---- dense layers -----------------------------------------------------------------------------------
+ * C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]);  transX = 0: X stored [rows][K]..., see gemm.hip.
+ * replaces nn.Linear fwd/bwd of object_embedding / structure_embedding / meta_embedding_rel / _attr
+ * (src/aligner/sg_aligner.py:112,116,119,122) and the dS*E products of the loss backward.
+ * a_is_f64 != 0: A is float64 (the collated bag-of-words features, scan3r.py:196-197) converted on load. */
+int sga_gemm(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64, const float* B,
+             long ldb, float* C, long ldc, const float* bias, int accumulate, void* stream);
+int sga_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream);   /* bias grads */
+int sga_cast_f64_f32(const double* in, float* out, size_t n, void* stream);                        /* .float(), sg_aligner.py:73-75 */
+
+/* ---- modality fusion --------------------------------------------------------------------------------
+ * replaces MultiModalFusion.forward, src/aligner/sg_aligner.py:30-35:
+ *   joint[t, m*D:(m+1)*D] = softmax(weight)[m] * embs[m][t,:] / max(||embs[m][t,:]||, 1e-12)
+ * embs: host array of M device pointers [T,D]; weight [M] (the [M,1] parameter); joint [T,M*D]. */
+int sga_fusion_fwd(const float* const* embs, int M, const float* weight, float* joint, int T, int D, void* stream);
+size_t sga_fusion_bwd_workspace_bytes(int M);
+int sga_fusion_bwd(const float* const* embs, int M, const float* weight, const float* gjoint, float* const* gembs,
+                   float* gweight, int T, int D, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- GAT structure encoder --------------------------------------------------------------------------
+ * replaces torch_geometric.nn.GATConv (2.2.0, un-vendored) as used by src/aligner/networks/gat.py:36-37,44,
+ * for ALL graphs of a batch in one launch (sg_aligner.py:86-110 issues 2B sequential calls):
+ * H [T,256] = x W^T (2 heads x 128), att_src/att_dst/bias [256]; edges [sumE,2] int64 graph-local (col 0 source,
+ * col 1 target); node_off/edge_off [G+1] int32 prefix sums; nmax = max nodes per graph (<= 128).
+ * out[i] = sum_j softmax_j(leaky_relu(a_s[j]+a_d[i], 0.2)) H[j] + bias, self loops normalised as PyG does. */
+int sga_gat_attn_fwd(const float* H, const float* att_src, const float* att_dst, const float* bias,
+                     const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G, int nmax,
+                     float* out, void* stream);
+int sga_gat_attn_bwd(const float* H, const float* dO, const float* att_src, const float* att_dst, const int64_t* edges,
+                     const int32_t* node_off, const int32_t* edge_off, int G, int nmax, float* dH, float* d_att_src,
+                     float* d_att_dst, void* stream);
+int sga_elu_fwd(const float* x, float* y, size_t n, void* stream);                    /* F.elu, gat.py:45-46 */
+int sga_elu_bwd(const float* x, const float* gy, float* gx, size_t n, void* stream);
+
+/* ---- contrastive (ICL) / alignment (IAL) loss ---------------------------------------------------------
+ * replace src/aligner/losses.py: calculate_prob_dist :5-15, ICLLoss.forward :43-58, IALLoss.forward :68-97.
+ * Per table: Z [R,Dp] = packed, L2-normalised rows [e1i (A) | e2i (A) | e1j (J1) | e2j (J2)], Dp = D padded to 8. */
+int sga_loss_gather(const float* E, int T, int D, const int32_t* idx, int R, float* Z, int Dp, float* nrm, void* stream);
+int sga_loss_scatter(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int R, int D, int Dp,
+                     float* dE, void* stream);                                  /* dE += J_normalize^T dZ (atomic) */
+/* the four global sums of losses.py:10-11 at two temperatures: sums8[fam*2+temp], fam = s11,s12,s22,s21 */
+int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, void* stream);
+/* dZ += d(sums)/dZ weighted by gs8 = dL/d(sums8) (owner-stationary sweeps, atomic accumulate) */
+int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
+                      float* dZ, void* stream);
+/* anchors x anchors terms for NT tables (modalities..., joint): out = [NT icl sums | M iala | M ialb], M = NT-1 */
+int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums, float alpha,
+                        float tau_icl, float tau_ial, double* out, void* stream);
+/* given coef = dL/d(out): M1[k][j*A+i] = dL/dS_k[i,j] and gs[k][8] = dL/d(sums) */
+int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums, float alpha,
+                        float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, void* stream);
+
+/* ---- per-pair similarity + ranking --------------------------------------------------------------------
+ * replaces eval_step's emb/||emb||, sim = 1 - emb emb^T, argsort (src/inference/sgaligner/inference_align_reg.py:
+ * 125-128) fused with the rank look-ups of utils/alignment.py:3-25,27-41,59-70.  For query object q_idx[q] of pair
+ * q_pair[q]: rank[q] = 1-based rank of q_tgt[q] among the pair's other objects; topk_*[q,:K] nearest others. */
+size_t sga_simrank_workspace_bytes(int T);
+int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, int B, int max_pair_objects,
+                const int32_t* q_pair, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
+                int32_t* topk_idx, float* topk_sim, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGALIGNER_HIP_H */

@@ -218,6 +218,8 @@ class IndexSets:
         return c
 
 
+KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel with HIP events on the launch stream
+
 TAU_ICL = 0.1      # losses.py:39 (ctor argument ignored by the reference)
 TAU_IAL = 1.0      # losses.py:63
 ALPHA = 0.5        # losses.py:36,60 defaults
@@ -285,8 +287,15 @@ class ContrastiveTermsFn(torch.autograd.Function):
                 gemm(m1[k], z[A:2 * A], True, False, A, dp, A, out=dz[0:A])
                 gemm(m1[k], z[0:A], False, False, A, dp, A, out=dz[A:2 * A])
             m1[k] = None
+            ev = None
+            if KERNEL_EVENTS is not None and dp <= 128:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _lib.check(L.sga_loss_neg_grad(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), st),
                        'sga_loss_neg_grad')
+            if ev is not None:
+                ev[1].record()
+                KERNEL_EVENTS.setdefault('sweep_kernel<4,4,grad>', []).append(ev + ((A, s.J1, s.J2, dp),))
             t, d = ctx.shapes[k]
             de = torch.zeros((t, d), device=dev, dtype=torch.float32)
             _lib.check(L.sga_loss_scatter(_p(dz), _p(z), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')

@@ -1,0 +1,82 @@
+"""Engine hooks for the path: `train_step / val_step / test_step / eval_step` with the reference's
+signatures (src/engine/epoch_based_trainer.py:56-60, src/engine/single_tester.py:52-63,
+src/trainers/trainval_sgaligner.py:71-79, src/inference/sgaligner/inference_align_reg.py:74-76,98-143),
+so the reference's EpochBasedTrainer / SingleTester loops can call them unchanged.
+Multi-GPU: one process per GPU, pairs sharded, tables all-gathered for the batch-global loss."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import dist as sdist
+from .aligner.losses import CustomMultiLossLayer, OverallLoss
+from .aligner.sg_aligner import MultiModalEncoder
+from .utils import alignment
+
+
+class AlignerSteps:
+    def __init__(self, modules, rel_dim=41, attr_dim=164, zoom=0.1, device='cuda', seed=42):
+        if not torch.cuda.is_available() and str(device).startswith('cuda'):
+            raise RuntimeError('sgaligner_amd.AlignerSteps: no HIP device; the product path has no CPU fallback')
+        self.modules = list(modules)
+        self.device = torch.device(device)
+        torch.manual_seed(seed)                                   # identical replicas on every rank
+        self.model = MultiModalEncoder(modules=self.modules, rel_dim=rel_dim, attr_dim=attr_dim).to(self.device)
+        m = len(self.modules)
+        self.multi_loss_layer_icl = CustomMultiLossLayer(loss_num=m, device=self.device).to(self.device)
+        self.multi_loss_layer_ial = CustomMultiLossLayer(loss_num=m, device=self.device).to(self.device)
+        meta = {'zoom': zoom, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': self.modules}
+        self.loss_func = OverallLoss(self.multi_loss_layer_ial, self.multi_loss_layer_icl, self.device, meta)
+        self.params = list(self.model.parameters())
+        if m > 1:
+            self.params += list(self.multi_loss_layer_ial.parameters()) + list(self.multi_loss_layer_icl.parameters())
+
+    # -- reference hook names ---------------------------------------------------------------------
+    def train_step(self, epoch, iteration, data_dict):
+        output_dict = self.model(data_dict)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            loss_dict = self._global_loss(output_dict, data_dict)
+        else:
+            loss_dict = self.loss_func(output_dict, data_dict)
+        return output_dict, loss_dict
+
+    val_step = train_step
+
+    def test_step(self, iteration, data_dict):
+        return self.model(data_dict)
+
+    def eval_step(self, iteration, data_dict, output_dict, all_k=(1, 2, 3, 4, 5), reg_k=0):
+        emb = output_dict['joint'] if len(self.modules) > 1 else output_dict[self.modules[0]]
+        return alignment.evaluate_batch(emb.detach(), data_dict, all_k=all_k, reg_k=reg_k)
+
+    # -- fwd + loss + bwd (what bench.py times) ---------------------------------------------------
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def forward_backward(self, data_dict):
+        self.zero_grad()
+        output_dict, loss_dict = self.train_step(0, 0, data_dict)
+        loss_dict['loss'].backward()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            # log_vars see the full (replicated) loss on every rank; everything else sees only this rank's rows
+            w = dist.get_world_size()
+            for p in list(self.multi_loss_layer_ial.parameters()) + list(self.multi_loss_layer_icl.parameters()):
+                if p.grad is not None:
+                    p.grad /= w
+            sdist.allreduce_grads(self.params)
+        return output_dict, loss_dict
+
+    # -- batch-global loss across ranks -------------------------------------------------------------
+    def _global_loss(self, output_dict, data_dict):
+        """All-gather the tables and index sets; every rank evaluates the batch-global loss (a replica:
+        identical value on every rank) and back-propagates only into its own rows -- so the table
+        gradient needs no reduction, and the parameter gradients are summed by allreduce_grads."""
+        world = dist.get_world_size()
+        t_local = int(data_dict['tot_obj_pts'].shape[0])
+        rows = [None] * world
+        dist.all_gather_object(rows, t_local)
+        gathered = sdist.gather_tables(output_dict, rows, reduce_grad=False)
+        gdd = sdist.gather_index_sets(data_dict, rows)
+        return self.loss_func(gathered, gdd)

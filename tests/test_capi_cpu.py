@@ -1,0 +1,118 @@
+"""CPU: the C-ABI library loads and exports exactly what include/sgaligner_hip.h declares; the ctypes
+binding covers every symbol; product ops fail loudly without a HIP device (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'sgaligner_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(sga_\w+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sgaligner_amd import _build, _lib
+    _build.build_lib(verbose=False)
+    assert os.path.exists(_lib.LIB_PATH)
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(l, s), f'{s} declared in include/sgaligner_hip.h but not exported'
+    assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
+    assert _lib.lib().sga_version() >= 100
+
+
+def test_argument_errors_reported_without_gpu():
+    from sgaligner_amd import _lib
+    l = _lib.lib()
+    rc = l.sga_pointnet_fwd(None, None, None, None, None, None, None, None, None, 4, 0, 256, None)
+    assert rc != 0 and b'P >= 1' in l.sga_last_error()
+    rc = l.sga_loss_gather(None, 1, 100, None, 1, None, 100, None, None)
+    assert rc != 0 and b'multiple of 8' in l.sga_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    from sgaligner_amd import ops
+    from sgaligner_amd.aligner.sg_aligner import MultiModalEncoder
+    from sgaligner_amd.synthetic import make_batch
+    x = torch.randn(4, 8, 3)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.pointnet_forward(ops._req(x, 'x'), None, None, None, None, None, None, False)
+    model = MultiModalEncoder(modules=['point', 'gat', 'rel'], rel_dim=41, attr_dim=164)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        model(make_batch(1, 4, 8))
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.randn(3, 5), torch.randn(2, 5), torch.randn(2))
+
+
+def test_nothing_in_the_product_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'sgaligner_amd')):
+        for f in files:
+            if f.endswith('.py') and re.search(r'^\s*(from|import)\s+oracle', open(os.path.join(dirpath, f)).read(), flags=re.M):
+                bad.append(f)
+    assert not bad, bad
+
+
+def test_state_dict_contract():
+    """state_dict keys/shapes a released reference checkpoint carries, strict-loadable."""
+    from conftest import load_golden
+    from sgaligner_amd.aligner.sg_aligner import MultiModalEncoder
+    g = load_golden('full_multimodal_gat_unpinned')
+    model = MultiModalEncoder(modules=['point', 'gat', 'rel', 'attr'], rel_dim=41, attr_dim=164)
+    sd = model.state_dict()
+    assert set(sd) == set(str(s) for s in g['sd_keys'])
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(g['sd__' + k].shape), k
+    model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('sd__')}, strict=True)
+    conv1 = model.object_encoder.conv1
+    assert float(conv1.bias.detach().abs().max()) >= 0.0 and model.object_encoder.bn1.weight.shape == (64,)
+    # init statistics of a fresh model: conv bias 0, BN weight 1, xavier_normal std (pointnet.py:116-118)
+    fresh = MultiModalEncoder(modules=['point'], rel_dim=41, attr_dim=164)
+    assert float(fresh.object_encoder.conv2.bias.abs().max()) == 0.0
+    assert float((fresh.object_encoder.bn2.weight - 1).abs().max()) == 0.0
+    std = float(fresh.object_encoder.conv3.weight.std())
+    assert abs(std - (2.0 / (128 + 256)) ** 0.5) < 0.01
+
+
+def test_alignment_rank_list_api_matches_reference_golden():
+    from conftest import load_golden
+    from sgaligner_amd.utils import alignment
+    g = load_golden('alignment_handmade')
+    sim = torch.from_numpy(g['sim'])
+    rl = torch.argsort(sim, dim=1, stable=True)
+    assert np.allclose(alignment.compute_mean_reciprocal_rank(rl, g['e1i'], g['e2i'], []), g['mrr'])
+    assert [alignment.compute_hits_k(rl, g['e1i'], g['e2i'], k)[0] for k in (1, 2, 3, 4, 5)] == [int(v) for v in g['hits']]
+    sg = alignment.compute_sgar(sim, rl, g['e1i'], g['e2i'], ['2', '50', '100'])
+    assert [sg[m] for m in ('2', '50', '100')] == [float(v) for v in g['sgar']]
+    ns = int(g['src_count'])
+    assert alignment.compute_node_corrs(rl, ns, 3) == [tuple(int(x) for x in c) for c in g['node_corrs']]
+    assert abs(alignment.compute_alignment_score(rl, ns, sim.shape[0] - ns) - float(g['align_score'])) < 1e-12
+
+
+def test_synthetic_batch_schema():
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(3, (6, 5), 16, seed=1, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    assert dd['tot_obj_pts'].shape == (T, 16, 3) and dd['tot_obj_pts'].dtype == torch.float32
+    assert dd['tot_rel_pose'].dtype == torch.float64 and dd['edges'].dtype == torch.int64
+    assert dd['e1i'].dtype == np.int32 and len(dd['e1i']) == len(dd['e2i']) == int(dd['e1i_count'].sum())
+    allidx = np.concatenate([dd['e1i'], dd['e1j'], dd['e2i'], dd['e2j']])
+    assert sorted(allidx.tolist()) == list(range(T))          # the four sets partition the objects (scan3r.py:102-107)
+    off = 0
+    for (ns, nr), na in zip(dd['graph_per_obj_count'], dd['e1i_count']):
+        assert (dd['e1i'] >= off).sum() >= na
+        off += ns + nr
+    gb = ops.GraphBatch.of(dd)
+    assert gb.G == 6 and gb.T == T and int(gb.edge_off[-1]) == dd['edges'].shape[0]
+    s = ops.IndexSets.of(dd, 'cpu')
+    assert s.R == T and s.idx.dtype == torch.int32
