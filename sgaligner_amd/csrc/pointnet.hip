@@ -230,10 +230,11 @@ namespace {
 constexpr int PB_WAVES = 8;
 constexpr int PB_THREADS = PB_WAVES * 64;
 
-// PH == 0: gW1, gb1 (lane = row orientation, dH1 = dZ2 W2).   PH == 1: gW3, gb3, gW2, gb2 (lane = channel).
-// Two launches keep each phase at ~160 live registers; fused they spilled >130 VGPRs to scratch.
-template <int PH>
-__global__ __launch_bounds__(PB_THREADS) void pointnet_bwd_kernel(
+// PH == 0: gW1, gb1 (lane = row orientation, dH1 = dZ2 W2).  PH == 1: gW3, gb3, gb2.  PH == 2: gW2 (lane = channel).
+// Three launches keep every phase's accumulators in registers (fused they spilled >130 VGPRs to scratch,
+// and accumulating gW2 through LDS atomics instead cost more than the MFMA work itself).
+template <int PH, int NW>
+__global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
     const float* __restrict__ x, const int* __restrict__ argmax, const float* __restrict__ y,
     const float* __restrict__ gy, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(PB_THREADS) void pointnet_bwd_kernel(
     float* w2r = lds + 8192;        // row-major [128][64]
     float* gw2s = lds + 16384;      // accumulator [128][64]
     const int tid = threadIdx.x;
-    for (int d = tid; d < 2048; d += PB_THREADS) {
+    for (int d = tid; d < 2048; d += NW * 64) {
         const int ln = d & 63, q = (d >> 6) & 7, cb = d >> 9;
         const int row = cb * 32 + (ln & 31), k = 8 * q + 4 * (ln >> 5);
         *reinterpret_cast<f32x4*>(w2s + d * 4) = *reinterpret_cast<const f32x4*>(w2 + row * 64 + k);
@@ -254,15 +255,22 @@ __global__ __launch_bounds__(PB_THREADS) void pointnet_bwd_kernel(
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int lane = tid & 63, wave0 = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    static_assert(PH == 2 || NW == 8, "row-tile-private accumulators need one tile per wave");
     // persistent per-lane accumulators
-    float gw3a[64];                 // [cb][s] : gW3[wave*32 + row(s,h)][cb*32 + l31]
+    float gw3a[PH == 1 ? 64 : 1];   // [cb][s] : gW3[wave*32 + row(s,h)][cb*32 + l31]
 #pragma unroll
-    for (int i = 0; i < 64; ++i) gw3a[i] = 0.f;
+    for (int i = 0; i < (PH == 1 ? 64 : 1); ++i) gw3a[i] = 0.f;
+    f32x16 gw2a[PH == 2 ? 8 : 1];   // [cb][kt] : gW2[cb*32 + row(r,h)][kt*32 + l31]
+#pragma unroll
+    for (int i = 0; i < (PH == 2 ? 8 : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gw2a[i][r] = 0.f;
     float gb3a = 0.f, gb2a[4] = {0.f, 0.f, 0.f, 0.f};
     float gw1a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb1a[2] = {0.f, 0.f};
 
-    for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    for (int t = blockIdx.x; t < T; t += gridDim.x)
+    for (int wave = wave0; wave < 8; wave += NW) {       // wave = winner-row tile of this object
         int lane_o = lane, h_o = h;
         asm volatile("" : "+v"(lane_o), "+v"(h_o));          // keep weight reads inside the loop (see fwd):
         const int l31_o = lane_o & 31;                       // every weight address below goes through these
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(PB_THREADS) void pointnet_bwd_kernel(
         }
 
         // ======== orientation 2: lane = ch2, regs = rows  ->  gW3, gb2, gW2 += dZ2^T H1
-        if (PH == 1)
+        if (PH >= 1)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             __builtin_amdgcn_sched_barrier(0);
@@ -375,28 +383,25 @@ __global__ __launch_bounds__(PB_THREADS) void pointnet_bwd_kernel(
                 const int cr = wave * 32 + mfma32_row(s, h_o);
                 const float z = acc[s];
                 const float gsv = __shfl(g, mfma32_row(s, h), 64);
-                gw3a[cb * 16 + s] = fmaf(gsv, fmaxf(z, 0.f), gw3a[cb * 16 + s]);
+                if (PH == 1) gw3a[cb * 16 + s] = fmaf(gsv, fmaxf(z, 0.f), gw3a[cb * 16 + s]);
                 const float w3e = w3[(size_t)cr * 128 + cb * 32 + l31_o];      // unconditional load: a select here
                 const float dz = (z > 0.f ? gsv : 0.f) * w3e;                   // would be turned into 64 branches
                 acc[s] = dz;
                 colsum += dz;
             }
-            gb2a[cb] += colsum;
+            if (PH == 1) gb2a[cb] += colsum;
+            if (PH == 2) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                f32x16 o;
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s], h1c[kt][s], o, 0, 0, 0);
-                // o[r] = gW2[ch2 = cb*32 + row(r,h)][k1 = kt*32 + l31]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(gw2s + (cb * 32 + mfma32_row(r, h)) * 64 + kt * 32 + l31, o[r]);
+                    for (int s = 0; s < 16; ++s)
+                        gw2a[cb * 2 + kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s], h1c[kt][s], gw2a[cb * 2 + kt], 0, 0, 0);
             }
         }
     }
 
     // ---- flush the per-workgroup partials
+    const int wave = wave0;
     if (PH == 1) {
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
@@ -409,8 +414,15 @@ __global__ __launch_bounds__(PB_THREADS) void pointnet_bwd_kernel(
         if (h == 0) atomicAdd(gb2 + cb * 32 + l31, v);
     }
     if (h == 0) atomicAdd(gb3 + wave * 32 + l31, gb3a);
-    __syncthreads();
-    for (int d = tid; d < 8192; d += PB_THREADS) atomicAdd(gw2 + d, gw2s[d]);
+    } else if (PH == 2) {
+        // gw2a[cb*2+kt][r] = gW2[cb*32 + row(r,h)][kt*32 + l31]: combine the 8 waves in LDS, then one atomic per element
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(gw2s + ((i >> 1) * 32 + mfma32_row(r, h)) * 64 + (i & 1) * 32 + l31, gw2a[PH == 2 ? i : 0][r]);
+        __syncthreads();
+        for (int d = tid; d < 8192; d += NW * 64) atomicAdd(gw2 + d, gw2s[d]);
     } else {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -446,12 +458,15 @@ extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const flo
     if (T == 0) return SGA_OK;
     const size_t lds_bytes = 3 * 8192 * sizeof(float);
     int grid = T < sga_num_cus() ? T : sga_num_cus();
-    hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(pointnet_bwd_kernel<1>, dim3(grid), dim3(PB_THREADS), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3,
-                       gw1, gb1, gw2, gb2, gw3, gb3, T, P);
-    hipLaunchKernelGGL(pointnet_bwd_kernel<0>, dim3(grid), dim3(PB_THREADS), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3,
-                       gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    auto k0 = pointnet_bwd_kernel<0, 8>;
+    auto k1 = pointnet_bwd_kernel<1, 8>;
+    auto k2 = pointnet_bwd_kernel<2, 4>;     // 4 waves -> one wave per SIMD, the full 512-register file for the 8 gW2 tiles
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(k2, dim3(grid), dim3(256), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    hipLaunchKernelGGL(k1, dim3(grid), dim3(512), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    hipLaunchKernelGGL(k0, dim3(grid), dim3(512), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
     SGA_CHECK_LAUNCH("sga_pointnet_bwd");
     return SGA_OK;
 }
