@@ -114,9 +114,7 @@ template <int NJT, int NCT, bool GRAD>
 __global__ __launch_bounds__(CT_THREADS) void sweep_kernel(SweepArgs a) {
     constexpr int OT = NJT * 32;                      // other rows per step
     constexpr int GW = NCT * 32;                      // gradient columns per pass
-    constexpr int S_FLOATS = (128 + OT) * SGA_LDS_STRIDE;
-    constexpr int G_FLOATS = GRAD ? OT * GW : 0;
-    __shared__ __attribute__((aligned(16))) float lds[S_FLOATS > G_FLOATS ? S_FLOATS : G_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // max(S chunks, gradient tile): sweep_lds_bytes()
     float* own_s = lds;
     float* oth_s = lds + 128 * SGA_LDS_STRIDE;
 
@@ -217,6 +215,148 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_kernel(SweepArgs a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path of the sweeps for Dp <= 128 (emb_dim = 100 -> Dp = 104): the wave's 32 owner rows live in
+// registers for the whole sweep (NQ float4 per lane = the MFMA B operand of every S tile), and each
+// 128-row "other" tile is staged ONCE into LDS as full rows and serves both the S tiles (ds_read_b128
+// along k) and the gradient GEMM (ds_read_b32 along the columns): one global->LDS pass and two barriers
+// per tile instead of one per 32-wide K chunk and a second staging for the gradient.
+// ------------------------------------------------------------------------------------------------
+template <int NQ, bool GRAD>
+__global__ __launch_bounds__(CT_THREADS) void sweep_fast_kernel(SweepArgs a) {
+    constexpr int DP = NQ * 8;
+    constexpr int STR = DP + 4;                         // (DP+4)/4 odd -> conflict-free ds_read_b128 over 16 rows
+    constexpr int NJT = 4, OT = 128, NCT = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [OT][STR] + 32 floats of slack
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
+    const SweepGroup& grp = a.grp[g];
+    const int own0 = grp.own0 + ((int)blockIdx.x - grp.blk0) * 128;
+    const int own_end = grp.own0 + grp.nown;
+    const int my_i = own0 + wave * 32 + (lane & 31);
+
+    // owner rows -> registers (zero for rows past the group's end)
+    f32x4 own[NQ];
+    {
+        const float* src = a.Z + (size_t)(my_i < own_end ? my_i : own0) * DP + 4 * h;
+        const float msk = my_i < own_end ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * q);
+            own[q] = v * msk;
+        }
+    }
+    f32x16 gacc[GRAD ? NCT : 1];
+    if (GRAD) zero_acc<GRAD ? NCT : 1>(gacc);
+    double dsum[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        if (sg >= grp.nseg) break;
+        const SweepSeg seg = grp.seg[sg];
+        float c0 = 0.f, c1 = 0.f;
+        if (GRAD) { c0 = (float)(a.gs[seg.fam * 2 + 0] * (double)a.it0); c1 = (float)(a.gs[seg.fam * 2 + 1] * (double)a.it1); }
+        const int ntile = (seg.n + OT - 1) / OT;
+        for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y) {
+            const int j0 = seg.row0 + jt * OT, j_end = seg.row0 + seg.n;
+            __syncthreads();                              // previous tile fully consumed
+            for (int e = tid; e < OT * (DP / 4); e += CT_THREADS) {
+                const int r = e / (DP / 4), c = (e % (DP / 4)) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (j0 + r < j_end) v = *reinterpret_cast<const f32x4*>(a.Z + (size_t)(j0 + r) * DP + c);
+                *reinterpret_cast<f32x4*>(lds + r * STR + c) = v;
+            }
+            __syncthreads();
+            // ---- S tiles: lane = owner row, registers = other rows
+            f32x16 sacc[NJT];
+            zero_acc<NJT>(sacc);
+            const float* ap = lds + (lane & 31) * STR + 4 * h;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int t = 0; t < NJT; ++t) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + t * 32 * STR + 8 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], own[q][r], sacc[t], 0, 0, 0);
+                }
+            }
+            if (!GRAD) {
+                float p0 = 0.f, p1 = 0.f;
+                const bool iv = my_i < own_end;
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = iv && (j0 + t * 32 + mfma32_row(r, h) < j_end);
+                        const float e0 = fexp2(sacc[t][r] * a.k0), e1 = fexp2(sacc[t][r] * a.k1);
+                        p0 += ok ? e0 : 0.f;
+                        p1 += ok ? e1 : 0.f;
+                    }
+                dsum[sg][0] += (double)p0;
+                dsum[sg][1] += (double)p1;
+            } else {
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sacc[t][r] = c0 * fexp2(sacc[t][r] * a.k0) + c1 * fexp2(sacc[t][r] * a.k1);
+                // ---- gradient GEMM straight from the accumulators (rows past j_end are zero in LDS)
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const float av = sacc[t][s];
+                        const float* brow = lds + (t * 32 + mfma32_row(s, h)) * STR + (lane & 31);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            gacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[ct * 32], gacc[ct], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    if (!GRAD) {
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const double v = wave_sum_d(dsum[sg][tt]);
+                if (lane == 0 && sg < grp.nseg && v != 0.0) atomicAdd(a.sums + grp.seg[sg].fam * 2 + tt, v);
+            }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int d = ct * 32 + (lane & 31);
+            if (d < DP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = own0 + wave * 32 + mfma32_row(r, h);
+                    if (i < own_end) atomicAdd(a.dZ + (size_t)i * DP + d, gacc[ct][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int NJT, int NCT, bool GRAD>
+static void launch_sweep(const SweepArgs& a, int nblk, int gy, hipStream_t s) {
+    const size_t sf = (size_t)(128 + NJT * 32) * SGA_LDS_STRIDE, gf = GRAD ? (size_t)NJT * 32 * NCT * 32 : 0;
+    const size_t lds = (sf > gf ? sf : gf) * sizeof(float);
+    auto k = sweep_kernel<NJT, NCT, GRAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(nblk, gy), dim3(CT_THREADS), lds, s, a);
+}
+
+template <int NQ, bool GRAD>
+static void launch_sweep_fast(const SweepArgs& a, int nblk, int gy, hipStream_t s) {
+    const size_t lds = (size_t)(128 * (NQ * 8 + 4) + 32) * sizeof(float);
+    auto k = sweep_fast_kernel<NQ, GRAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(nblk, gy), dim3(CT_THREADS), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,7 +590,9 @@ extern "C" int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, 
     int gy = (8 * sga_num_cus() + nblk - 1) / nblk;
     if (gy > jt) gy = jt;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL((sweep_kernel<4, 1, false>), dim3(nblk, gy), dim3(CT_THREADS), 0, s, a);
+    if (Dp == 104) launch_sweep_fast<13, false>(a, nblk, gy, s);
+    else if (Dp == 128) launch_sweep_fast<16, false>(a, nblk, gy, s);
+    else launch_sweep<4, 1, false>(a, nblk, gy, s);
     SGA_CHECK_LAUNCH("sga_loss_neg_sums");
     return SGA_OK;
 }
@@ -473,14 +615,16 @@ extern "C" int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, 
         if (gy > jt) gy = jt;
         if (gy < 1) gy = 1;
         a.col0 = 0;
-        hipLaunchKernelGGL((sweep_kernel<4, 4, true>), dim3(nblk, gy), dim3(CT_THREADS), 0, s, a);
+        if (Dp == 104) launch_sweep_fast<13, true>(a, nblk, gy, s);
+        else if (Dp == 128) launch_sweep_fast<16, true>(a, nblk, gy, s);
+        else launch_sweep<4, 4, true>(a, nblk, gy, s);
     } else {
         const int jt = (mx + 63) / 64;
         if (gy > jt) gy = jt;
         if (gy < 1) gy = 1;
-        for (int col0 = 0; col0 < Dp; col0 += 256) {
+        for (int col0 = 0; col0 < Dp; col0 += 320) {       // 10 column tiles per pass: one pass for the 300-d joint table
             a.col0 = col0;
-            hipLaunchKernelGGL((sweep_kernel<2, 8, true>), dim3(nblk, gy), dim3(CT_THREADS), 0, s, a);
+            launch_sweep<2, 10, true>(a, nblk, gy, s);
         }
     }
     SGA_CHECK_LAUNCH("sga_loss_neg_grad");
