@@ -89,6 +89,21 @@ int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, con
 int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums, float alpha,
                         float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, void* stream);
 
+/* fused variants for the normal pipeline, where the last table is the fusion of the M others: every joint
+ * similarity is S_J = sum_m beta_m S_m (beta_m = w_m^2 / sum w^2, w = softmax(fusion.weight), sg_aligner.py:32-34
+ * + losses.py:44,73), so the 300-d table is never multiplied.  Z[m] [R+32, 104] (Dp must be 104, 32 readable rows of
+ * slack), beta [M] device.  sums/gs [(M+1)][8] with the joint in row M; gamma[m] += dL/dbeta_m through the negatives. */
+int sga_loss_multi_sums(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                        double* sums, void* stream);
+int sga_loss_multi_grad(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                        const double* gs, float* const* dZ, double* gamma, void* stream);
+/* ZJ[r, m*104+d] = sqrt(beta_m) Z_m[r,d] for the anchor rows (operand of the anchors x anchors kernels), and its adjoint */
+int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream);
+int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows, float* const* dZ,
+                        double* gamma2, void* stream);
+/* *poison = NaN if any row norm is below F.normalize's eps (the identity above would not hold): fail loudly */
+int sga_loss_check_norms(const float* nrm, int n, float* poison, void* stream);
+
 /* ---- per-pair similarity + ranking --------------------------------------------------------------------
  * replaces eval_step's emb/||emb||, sim = 1 - emb emb^T, argsort (src/inference/sgaligner/inference_align_reg.py:
  * 125-128) fused with the rank look-ups of utils/alignment.py:3-25,27-41,59-70.  For query object q_idx[q] of pair

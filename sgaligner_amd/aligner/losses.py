@@ -8,6 +8,9 @@ from torch import nn
 from .. import ops
 
 
+FUSED_JOINT = True     # tests flip this to cross-check the fused path against the independent-table path
+
+
 class CustomMultiLossLayer(nn.Module):
     def __init__(self, loss_num, device=None):
         super().__init__()
@@ -68,8 +71,14 @@ class OverallLoss(nn.Module):
         if m > 1:
             # one fused pass over all M+1 tables: every similarity tile is computed once and shared by
             # ICL_m, ICL_joint and IAL_m (the reference recomputes the joint table's q's M times)
-            tabs = [output_dict[k] for k in mods] + [output_dict['joint']]
-            sums, s = ops.contrastive_terms(tabs, data_dict, alpha=self.contrastive_loss.alpha)
+            tabs = [output_dict[k] for k in mods]
+            src = getattr(output_dict['joint'], '_sga_fusion', None)
+            fused = (src is not None and FUSED_JOINT and 2 <= m <= 4 and len(src[1]) == m
+                     and all(a is b for a, b in zip(src[1], tabs)) and all(t.shape[1] <= 104 for t in tabs))
+            if fused:      # the joint table IS the fusion of these tables: never multiply the 100*M-d table
+                sums, s = ops.fused_contrastive_terms(tabs, src[0], data_dict, alpha=self.contrastive_loss.alpha)
+            else:          # arbitrary joint table: treat it as an independent (M+1)-th table
+                sums, s = ops.contrastive_terms(tabs + [output_dict['joint']], data_dict, alpha=self.contrastive_loss.alpha)
             nt = m + 1
             a2 = float(s.A * s.A)
             icl = sums[:nt] / a2

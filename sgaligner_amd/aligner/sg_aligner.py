@@ -44,7 +44,11 @@ class MultiModalFusion(nn.Module):
         assert len(embs) == self.modal_num
         if any(e is None for e in embs):
             raise NotImplementedError('sgaligner_amd MultiModalFusion: None entries are not supported')
-        return ops.fusion(self.weight, list(embs))
+        joint = ops.fusion(self.weight, list(embs))
+        # provenance tag: lets OverallLoss derive the joint similarities from the modality tiles
+        # (S_joint = sum_m beta_m S_m) instead of sweeping the 100*M-d table (ops.FusedContrastiveFn)
+        joint._sga_fusion = (self.weight, tuple(embs))
+        return joint
 
 
 class MultiModalEncoder(nn.Module):

@@ -360,6 +360,257 @@ static void launch_sweep_fast(const SweepArgs& a, int nblk, int gy, hipStream_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused multi-table sweeps ("joint = fusion of these tables" case, the normal pipeline).
+//
+// The joint row is cat_m(w_m zhat_m)/||.|| (sg_aligner.py:32-34 followed by F.normalize in losses.py:44,
+// 73), so with beta_m = w_m^2 / sum_k w_k^2 every joint similarity is  S_J = sum_m beta_m S_m : the 300-d
+// table never has to be multiplied.  One launch computes the M modality S tiles of an
+// (owner block, other tile) pair, derives S_J, and
+//   SUM  mode: accumulates the 4x2 global sums of all M+1 tables;
+//   GRAD mode: forms c_m = dL/dS_m + beta_m dL/dS_J, chains the M gradient GEMMs from the accumulators,
+//              and accumulates Gamma_m = sum dL/dS_J * S_m  (= dL/dbeta_m through the negatives).
+// vs. the per-table path this removes the joint table's S and gradient GEMMs (~half of all loss FLOPs).
+// Geometry: 4 waves, one per SIMD (the M owner-row operands + M gradient tiles need ~410 registers, so
+// the kernel takes the whole 512-entry file); 32-row other tiles for all M tables are streamed into a
+// double-buffered LDS ring by global_load_lds DMA (no VGPR round trip) one step ahead of the MFMAs.
+// Requires Dp == 104 (emb_dim 100) and 32 readable rows past the end of every Z buffer.
+// ------------------------------------------------------------------------------------------------
+struct MultiArgs {
+    int M; const float* Z[4]; int ngroups; SweepGroup grp[4];
+    float k0, k1, it0, it1;
+    const float* beta;              // [M]
+    double* sums;                   // [(M+1)][8]            SUM out
+    const double* gs;               // [(M+1)][8]            GRAD in (joint = row M)
+    float* dZ[4];                   // GRAD out, atomic accumulate
+    double* gamma;                  // [M]                   GRAD out
+};
+
+template <int M, int G0, int NG, bool GRAD>
+__global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
+    constexpr int DP = 104, NQ = 13, OT = 32, NCT = 4;
+    constexpr int TILE_F = OT * DP;                     // 3328 floats = 13 KiB per table
+    constexpr int BUF_F = M * TILE_F;
+    constexpr int NCHUNK = M * 13;                      // 1 KiB DMA pieces per step
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][M][OT][DP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
+    const SweepGroup& grp = a.grp[g];
+    const int own0 = grp.own0 + ((int)blockIdx.x - grp.blk0) * 128;
+    const int own_end = grp.own0 + grp.nown;
+    const int my_i = own0 + wave * 32 + (lane & 31);
+    const bool iv = my_i < own_end;
+
+    f32x4 own[M][NQ];
+    float beta[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const float* src = a.Z[m] + (size_t)(iv ? my_i : own0) * DP + 4 * h;
+        const float msk = iv ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 8 * q) * msk;
+        beta[m] = a.beta[m];
+    }
+    f32x16 gacc[GRAD ? NG : 1][NCT];
+    if (GRAD) {
+#pragma unroll
+        for (int m = 0; m < NG; ++m) zero_acc<NCT>(gacc[m]);
+    }
+    float gam[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) gam[m] = 0.f;
+
+    auto issue = [&](int j0, float* buf) {             // DMA the M [32][104] tiles starting at row j0
+        for (int c = wave; c < NCHUNK; c += 4) {
+            const int m = c / 13, cc = c - m * 13;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(a.Z[m] + (size_t)j0 * DP + cc * 256 + lane * 4),
+                (__attribute__((address_space(3))) void*)(buf + m * TILE_F + cc * 256), 16, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        if (sg >= grp.nseg) break;
+        const SweepSeg seg = grp.seg[sg];
+        const int ntile = (seg.n + OT - 1) / OT;
+        const int j_end = seg.row0 + seg.n;
+        float c0[M + 1], c1[M + 1];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) {
+            c0[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
+            c1[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
+        }
+        double dsum[M + 1][2];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
+
+        __syncthreads();                                   // ring free (previous segment fully consumed)
+        if ((int)blockIdx.y < ntile) issue(seg.row0 + blockIdx.y * OT, lds);
+        int it = 0;
+        for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y, ++it) {
+            float* buf = lds + (it & 1) * BUF_F;
+            const int j0 = seg.row0 + jt * OT;
+            __syncthreads();                               // tile `it` landed (vmcnt drained) / other buffer free
+            if (jt + (int)gridDim.y < ntile) issue(seg.row0 + (jt + gridDim.y) * OT, lds + ((it + 1) & 1) * BUF_F);
+
+            // ---- S tiles of the M tables: lane = owner row, registers = other rows
+            f32x16 sacc[M];
+            zero_acc<M>(sacc);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float* ap = buf + m * TILE_F + (lane & 31) * DP + 4 * h;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], own[m][q][r], sacc[m], 0, 0, 0);
+                }
+            }
+            // ---- joint similarity, sums / coefficients
+            if (!GRAD) {
+                float p0[M + 1], p1[M + 1];
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = iv && (j0 + mfma32_row(r, h) < j_end);
+                    float sj = 0.f;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const float sv = sacc[m][r];
+                        sj = fmaf(beta[m], sv, sj);
+                        p0[m] += ok ? fexp2(sv * a.k0) : 0.f;
+                        p1[m] += ok ? fexp2(sv * a.k1) : 0.f;
+                    }
+                    p0[M] += ok ? fexp2(sj * a.k0) : 0.f;
+                    p1[M] += ok ? fexp2(sj * a.k1) : 0.f;
+                }
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = iv && (j0 + mfma32_row(r, h) < j_end);
+                    float sj = 0.f;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][r], sj);
+                    const float cj = ok ? c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1) : 0.f;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const float sv = sacc[m][r];
+                        if (G0 == 0 && g < 2) gam[m] = fmaf(cj, sv, gam[m]);       // each pair once (anchor-owner sweep)
+                        sacc[m][r] = ok ? fmaf(beta[m], cj, c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1)) : 0.f;
+                    }
+                }
+                // ---- gradient GEMMs chained from the accumulators, B operand prefetched one step ahead
+#pragma unroll
+                for (int mm = 0; mm < NG; ++mm) {
+                    const int m = G0 + mm;
+                    const float* bb = buf + m * TILE_F + (lane & 31);
+                    float bc[NCT], bn[NCT];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) bc[ct] = bb[mfma32_row(0, h) * DP + ct * 32];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        if (s + 1 < 16) {
+#pragma unroll
+                            for (int ct = 0; ct < NCT; ++ct) bn[ct] = bb[mfma32_row(s + 1, h) * DP + ct * 32];
+                        }
+                        const float av = sacc[m][s];
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) gacc[mm][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[ct], gacc[mm][ct], 0, 0, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) bc[ct] = bn[ct];
+                    }
+                }
+            }
+        }
+        if (!GRAD) {
+#pragma unroll
+            for (int m = 0; m <= M; ++m)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const double v = wave_sum_d(dsum[m][tt]);
+                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + m * 8 + seg.fam * 2 + tt, v);
+                }
+        }
+    }
+    if (GRAD) {
+#pragma unroll
+        for (int mm = 0; mm < NG; ++mm) {
+            float* dz = a.dZ[G0 + mm];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int d = ct * 32 + (lane & 31);
+                if (d < DP) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = own0 + wave * 32 + mfma32_row(r, h);
+                        if (i < own_end) atomicAdd(dz + (size_t)i * DP + d, gacc[mm][ct][r]);
+                    }
+                }
+            }
+        }
+        if (G0 == 0 && g < 2) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float v = wave_sum(gam[m]);
+                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + m, (double)v);
+            }
+        }
+    }
+}
+
+template <int M, int G0, int NG, bool GRAD>
+static void launch_sweep_multi(const MultiArgs& a, int nblk, int gy, hipStream_t s) {
+    const size_t lds = (size_t)2 * M * 32 * 104 * sizeof(float);
+    auto k = sweep_multi_kernel<M, G0, NG, GRAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(nblk, gy), dim3(CT_THREADS), lds, s, a);
+}
+
+// joint operand rows for the anchors x anchors kernels: ZJ[r, m*104 + d] = sqrt(beta_m) Z_m[r, d]
+__global__ void build_joint_kernel(MultiArgs a, float* __restrict__ ZJ, int rows) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb)
+        for (int m = 0; m < a.M; ++m) {
+            const float sb = sqrtf(a.beta[m]);
+            for (int d = lane; d < 104; d += 64) ZJ[(size_t)r * (a.M * 104) + m * 104 + d] = sb * a.Z[m][(size_t)r * 104 + d];
+        }
+}
+
+// fold dL/dZJ back: dZ_m[r,:] += sqrt(beta_m) dZJ[r, block m];  gamma2[m] += <dZJ[r, block m], Z_m[r,:]>
+__global__ void fold_joint_kernel(MultiArgs a, const float* __restrict__ dZJ, int rows, double* __restrict__ gamma2) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m >= a.M) break;
+            const float sb = sqrtf(a.beta[m]);
+            for (int d = lane; d < 104; d += 64) {
+                const float gj = dZJ[(size_t)r * (a.M * 104) + m * 104 + d];
+                acc[m] = fmaf(gj, a.Z[m][(size_t)r * 104 + d], acc[m]);
+                a.dZ[m][(size_t)r * 104 + d] += sb * gj;
+            }
+        }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float v = wave_sum(acc[m]);
+        if (lane == 0 && m < a.M && v != 0.f) atomicAdd(gamma2 + m, (double)v);
+    }
+}
+
+// poison = NaN if any row of any table took F.normalize's eps branch (then S_J != sum beta_m S_m)
+__global__ void check_norms_kernel(const float* __restrict__ nrm, int n, float* __restrict__ poison) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (!(nrm[i] >= 1e-12f)) *poison = __builtin_nanf("");
+}
+
+// ------------------------------------------------------------------------------------------------
 // anchors x anchors: loss terms (fwd) and dL/dS + dL/d(sums) (bwd), all tables in one pass
 // ------------------------------------------------------------------------------------------------
 struct AnchorArgs {
@@ -673,5 +924,97 @@ extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT,
     for (int k = 0; k < NT; ++k) { SGA_CHECK_ARG(M1[k], "sga_loss_anchor_bwd: null stash %d", k); a.M1[k] = M1[k]; }
     hipLaunchKernelGGL(anchor_kernel<true>, dim3((A + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     SGA_CHECK_LAUNCH("sga_loss_anchor_bwd");
+    return SGA_OK;
+}
+
+// ---- fused multi-table entry points (joint table == fusion of the M tables) ----------------------------
+static int fill_multi(MultiArgs& a, const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
+                      float tau1, bool grad) {
+    if (M < 2 || M > 4) { sga_set_error("sga_loss_multi: M=%d outside [2,4]", M); return SGA_ERR_ARG; }
+    a.M = M;
+    for (int m = 0; m < M; ++m) { if (!Z[m]) { sga_set_error("sga_loss_multi: null table"); return SGA_ERR_ARG; } a.Z[m] = Z[m]; }
+    a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
+    SweepArgs tmp{};
+    fill_groups(tmp, A, J1, J2, grad);
+    a.ngroups = tmp.ngroups;
+    for (int g = 0; g < 4; ++g) a.grp[g] = tmp.grp[g];
+    return SGA_OK;
+}
+static int multi_blocks(const MultiArgs& a) { int n = 0; for (int g = 0; g < a.ngroups; ++g) n += (a.grp[g].nown + 127) / 128; return n; }
+
+extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
+                                   float tau1, double* sums, void* stream) {
+    SGA_CHECK_ARG(Z && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(sums, 0, (size_t)(M + 1) * 8 * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_multi_sums: memset failed"); return SGA_ERR_HIP; }
+    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    MultiArgs a{};
+    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false);
+    if (rc) return rc;
+    a.sums = sums;
+    const int nblk = multi_blocks(a);
+    const int jt = ((J1 > J2 ? J1 : J2) + 31) / 32;
+    int gy = (4 * sga_num_cus() + nblk - 1) / nblk;
+    if (gy > jt) gy = jt;
+    if (gy < 1) gy = 1;
+    if (M == 2) launch_sweep_multi<2, 0, 2, false>(a, nblk, gy, s);
+    else if (M == 3) launch_sweep_multi<3, 0, 3, false>(a, nblk, gy, s);
+    else launch_sweep_multi<4, 0, 2, false>(a, nblk, gy, s);
+    SGA_CHECK_LAUNCH("sga_loss_multi_sums");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
+                                   float tau1, const double* gs, float* const* dZ, double* gamma, void* stream) {
+    SGA_CHECK_ARG(Z && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    MultiArgs a{};
+    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, true);
+    if (rc) return rc;
+    a.gs = gs; a.gamma = gamma;
+    for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }
+    const int nblk = multi_blocks(a);
+    int mx = A > J1 ? A : J1;
+    if (J2 > mx) mx = J2;
+    const int jt = (mx + 31) / 32;
+    int gy = (4 * sga_num_cus() + nblk - 1) / nblk;
+    if (gy > jt) gy = jt;
+    if (gy < 1) gy = 1;
+    if (M == 2) launch_sweep_multi<2, 0, 2, true>(a, nblk, gy, s);
+    else if (M == 3) launch_sweep_multi<3, 0, 3, true>(a, nblk, gy, s);
+    else { launch_sweep_multi<4, 0, 2, true>(a, nblk, gy, s); launch_sweep_multi<4, 2, 2, true>(a, nblk, gy, s); }
+    SGA_CHECK_LAUNCH("sga_loss_multi_grad");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream) {
+    SGA_CHECK_ARG(Z && beta && ZJ && M >= 2 && M <= 4 && rows >= 0, "sga_loss_build_joint: bad argument");
+    if (rows == 0) return SGA_OK;
+    MultiArgs a{};
+    a.M = M; a.beta = beta;
+    for (int m = 0; m < M; ++m) a.Z[m] = Z[m];
+    hipLaunchKernelGGL(build_joint_kernel, dim3(rows_grid(rows)), dim3(256), 0, static_cast<hipStream_t>(stream), a, ZJ, rows);
+    SGA_CHECK_LAUNCH("sga_loss_build_joint");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows,
+                                   float* const* dZ, double* gamma2, void* stream) {
+    SGA_CHECK_ARG(Z && beta && dZJ && dZ && gamma2 && M >= 2 && M <= 4 && rows >= 0, "sga_loss_fold_joint: bad argument");
+    if (rows == 0) return SGA_OK;
+    MultiArgs a{};
+    a.M = M; a.beta = beta;
+    for (int m = 0; m < M; ++m) { a.Z[m] = Z[m]; a.dZ[m] = dZ[m]; }
+    hipLaunchKernelGGL(fold_joint_kernel, dim3(rows_grid(rows)), dim3(256), 0, static_cast<hipStream_t>(stream), a, dZJ, rows, gamma2);
+    SGA_CHECK_LAUNCH("sga_loss_fold_joint");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_check_norms(const float* nrm, int n, float* poison, void* stream) {
+    SGA_CHECK_ARG(nrm && poison && n >= 0, "sga_loss_check_norms: bad argument");
+    if (n == 0) return SGA_OK;
+    hipLaunchKernelGGL(check_norms_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), nrm, n, poison);
+    SGA_CHECK_LAUNCH("sga_loss_check_norms");
     return SGA_OK;
 }

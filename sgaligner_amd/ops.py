@@ -439,3 +439,104 @@ def simrank(emb, pair_counts, q_pair, q_idx, q_tgt, k: int):
     _lib.check(_lib.lib().sga_simrank(_p(emb), T, D, _p(pair_off), len(pc), int(pc.max()) if len(pc) else 0, _p(qp), _p(qi),
                                       _p(qt), Q, k, _p(rank), _p(tk), _p(ts), _p(ws), nb, _stream()), 'sga_simrank')
     return rank[:Q], tk[:Q, :k], ts[:Q, :k]
+
+
+class FusedContrastiveFn(torch.autograd.Function):
+    """Same outputs as ContrastiveTermsFn for tables (E_1..E_M, joint) when joint == MultiModalFusion(E_1..E_M):
+    the joint similarities are derived from the modality tiles (S_J = sum_m beta_m S_m), so the 300-d table is
+    never swept.  Inputs: beta [M] (= softmax(w)^2 / sum, differentiable), the M modality tables."""
+
+    @staticmethod
+    def forward(ctx, index_sets, alpha, beta, *tables):
+        L = _lib.lib()
+        M = len(tables)
+        nt = M + 1
+        tables = [_req(t.contiguous(), f'table[{i}]') for i, t in enumerate(tables)]
+        beta = _req(beta.contiguous(), 'beta')
+        dev = tables[0].device
+        s = index_sets
+        T = tables[0].shape[0]
+        st = _stream()
+        dp = 104
+        zs, nrms = [], []
+        poison = torch.zeros((1,), device=dev, dtype=torch.float32)
+        for k, e in enumerate(tables):
+            d = e.shape[1]
+            if d > dp:
+                raise RuntimeError('sgaligner_amd: the fused loss path needs emb_dim <= 104')
+            z = torch.empty((s.R + 32, dp), device=dev, dtype=torch.float32)
+            z[s.R:].zero_()
+            nrm = torch.empty((s.R,), device=dev, dtype=torch.float32)
+            _lib.check(L.sga_loss_gather(_p(e), T, d, _p(s.idx), s.R, _p(z), dp, _p(nrm), st), 'sga_loss_gather')
+            _lib.check(L.sga_loss_check_norms(_p(nrm), s.R, _p(poison), st), 'sga_loss_check_norms')
+            zs.append(z); nrms.append(nrm)
+        zarr = _ptr_array(zs)
+        sums = torch.empty((nt, 8), device=dev, dtype=torch.float64)
+        _lib.check(L.sga_loss_multi_sums(zarr, M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), st), 'sga_loss_multi_sums')
+        zj = torch.empty((2 * s.A, M * dp), device=dev, dtype=torch.float32)
+        _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')
+        out = torch.empty((nt + 2 * M,), device=dev, dtype=torch.float64)
+        dps = [dp] * M + [M * dp]
+        _lib.check(L.sga_loss_anchor_fwd(_ptr_array(zs + [zj]), (_ct.c_int * nt)(*dps), nt, s.A, _p(sums), float(alpha),
+                                         TAU_ICL, TAU_IAL, _p(out), st), 'sga_loss_anchor_fwd')
+        ctx.s, ctx.alpha, ctx.M = s, float(alpha), M
+        ctx.shapes = [tuple(t.shape) for t in tables]
+        ctx.save_for_backward(sums, beta, zj, *zs, *nrms)
+        return out.float() + poison
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        s, M = ctx.s, ctx.M
+        nt = M + 1
+        sums, beta, zj, *rest = ctx.saved_tensors
+        zs, nrms = rest[:M], rest[M:]
+        dev = sums.device
+        st = _stream()
+        dp = 104
+        A = s.A
+        coef = gout.contiguous().float()
+        m1 = [torch.empty((A, A), device=dev, dtype=torch.float32) for _ in range(nt)]
+        gs = torch.empty((nt, 8), device=dev, dtype=torch.float64)
+        dps = [dp] * M + [M * dp]
+        _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
+                                         TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gs), st), 'sga_loss_anchor_bwd')
+        dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for _ in range(M)]
+        gam = torch.zeros((2, M), device=dev, dtype=torch.float64)      # [0]: via negatives, [1]: via the anchor rows of ZJ
+        if A > 0:
+            for k in range(M):
+                gemm(m1[k], zs[k][A:2 * A], True, False, A, dp, A, out=dzs[k][0:A])
+                gemm(m1[k], zs[k][0:A], False, False, A, dp, A, out=dzs[k][A:2 * A])
+                m1[k] = None
+            dzj = torch.empty((2 * A, M * dp), device=dev, dtype=torch.float32)
+            gemm(m1[M], zj[A:2 * A], True, False, A, M * dp, A, out=dzj[0:A])
+            gemm(m1[M], zj[0:A], False, False, A, M * dp, A, out=dzj[A:2 * A])
+            m1[M] = None
+            _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), gam[1].data_ptr(), st),
+                       'sga_loss_fold_joint')
+        ev = None
+        if KERNEL_EVENTS is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        _lib.check(L.sga_loss_multi_grad(_ptr_array(zs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
+                                         gam[0].data_ptr(), st), 'sga_loss_multi_grad')
+        if ev is not None:
+            ev[1].record()
+            KERNEL_EVENTS.setdefault(f'sweep_multi_kernel<{M},grad>', []).append(ev + ((A, s.J1, s.J2, M),))
+        grads = []
+        for k in range(M):
+            t, d = ctx.shapes[k]
+            de = torch.zeros((t, d), device=dev, dtype=torch.float32)
+            _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
+            grads.append(de)
+        # d/dbeta_m: through the negatives (gamma) + through sqrt(beta_m) in the anchor rows of ZJ
+        gbeta = (gam[0] + gam[1] / (2.0 * torch.sqrt(beta.double()))).float()
+        return (None, None, gbeta, *grads)
+
+
+def fused_contrastive_terms(tables, fusion_weight, data_dict, alpha=ALPHA):
+    """tables: the M modality tables the joint table was fused from; fusion_weight: the [M,1] parameter."""
+    s = IndexSets.of(data_dict, tables[0].device)
+    w = torch.softmax(fusion_weight.reshape(-1), dim=0)                # sg_aligner.py:32
+    beta = (w * w) / (w * w).sum()
+    return FusedContrastiveFn.apply(s, alpha, beta, *tables), s

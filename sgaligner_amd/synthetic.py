@@ -15,7 +15,7 @@ import torch
 def make_batch(n_pairs: int, n_obj, n_pts: int, seed: int = 42, device='cpu', rel_dim: int = 41,
                attr_dim: int = 164, ragged: bool = False, anchors: str = 'train', gen_device=None) -> dict:
     """n_obj: int N (both scenes) or (N_src, N_ref).  ragged=True varies the per-pair object counts.
-    anchors='train' -> A = int(0.3*N_common) (min 2, scan3r.py:89-91); 'val' -> all common objects."""
+    anchors='train' -> A = int(0.3*N) per pair (min 2, capped at the common objects); 'val' -> all common objects."""
     gen_device = gen_device or 'cpu'
     g = torch.Generator(device=gen_device).manual_seed(seed)
     rng = np.random.default_rng(seed)
@@ -56,8 +56,10 @@ def make_batch(n_pairs: int, n_obj, n_pts: int, seed: int = 42, device='cpu', re
         pts[off + ns:off + ns + nr] = p_ref - center
         pose[off:off + ns] = (c_src[0:1] - c_src).double()
         pose[off + ns:off + ns + nr] = (c_ref[0:1] - c_ref).double()
-        a = ncom if anchors == 'val' else (2 if int(0.3 * ncom) < 1 else int(0.3 * ncom))
-        a = min(a, ncom) if ncom >= 2 else ncom
+        # A = int(0.3*N) anchors per pair (configs[1]: 19, configs[2]: 38), the first A of the
+        # common objects (train-time truncation of scan3r.py:89-91, min 2); 'val' = every common object
+        a = ncom if anchors == 'val' else max(2, int(0.3 * min(ns, nr)))
+        a = min(a, ncom)
         e1i += list(range(off, off + a))
         e2i += list(range(off + ns, off + ns + a))
         e1j += list(range(off + a, off + ns))

@@ -78,5 +78,7 @@ class AlignerSteps:
         rows = [None] * world
         dist.all_gather_object(rows, t_local)
         gathered = sdist.gather_tables(output_dict, rows, reduce_grad=False)
+        if 'joint' in gathered:          # the gathered joint is the fusion of the gathered tables (replicated weight)
+            gathered['joint']._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
         gdd = sdist.gather_index_sets(data_dict, rows)
         return self.loss_func(gathered, gdd)
