@@ -99,7 +99,7 @@ __global__ void scatter_normalize_bwd_kernel(const float* __restrict__ dZ, const
 // owner-stationary sweeps over (owner rows) x (other rows): pass-1 sums and the negatives' gradient
 // ------------------------------------------------------------------------------------------------
 struct SweepSeg { int row0, n, fam; };                 // other rows [row0, row0+n), sum family 0..3
-struct SweepGroup { int own0, nown, blk0, nseg; SweepSeg seg[2]; };
+struct SweepGroup { int own0, nown, blk0, nseg; SweepSeg seg[2]; int nsplit; };   // nsplit: multi kernel only
 struct SweepArgs {
     const float* Z; int Dp; int ngroups; SweepGroup grp[4];
     float k0, k1;                   // log2(e)/tau for the two temperatures
@@ -398,7 +398,9 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
     const SweepGroup& grp = a.grp[g];
-    const int own0 = grp.own0 + ((int)blockIdx.x - grp.blk0) * 128;
+    const int wg_in_grp = (int)blockIdx.x - grp.blk0;
+    const int nsplit = grp.nsplit, split = wg_in_grp % nsplit;          // the group's other tiles are dealt round-robin to nsplit workgroups
+    const int own0 = grp.own0 + (wg_in_grp / nsplit) * 128;
     const int own_end = grp.own0 + grp.nown;
     const int my_i = own0 + wave * 32 + (lane & 31);
     const bool iv = my_i < own_end;
@@ -448,25 +450,35 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
         for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
 
         __syncthreads();                                   // ring free (previous segment fully consumed)
-        if ((int)blockIdx.y < ntile) issue(seg.row0 + blockIdx.y * OT, lds);
+        if (split < ntile) issue(seg.row0 + split * OT, lds);
         int it = 0;
-        for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y, ++it) {
+        for (int jt = split; jt < ntile; jt += nsplit, ++it) {
             float* buf = lds + (it & 1) * BUF_F;
             const int j0 = seg.row0 + jt * OT;
             __syncthreads();                               // tile `it` landed (vmcnt drained) / other buffer free
-            if (jt + (int)gridDim.y < ntile) issue(seg.row0 + (jt + gridDim.y) * OT, lds + ((it + 1) & 1) * BUF_F);
+            if (jt + nsplit < ntile) issue(seg.row0 + (jt + nsplit) * OT, lds + ((it + 1) & 1) * BUF_F);
 
             // ---- S tiles of the M tables: lane = owner row, registers = other rows
             f32x16 sacc[M];
             zero_acc<M>(sacc);
+            {   // one wave per SIMD: nobody else hides the LDS latency, so the A operand is read one K-group ahead
+                // into the OTHER of two register quads (no copy: a copy lets the compiler fold the buffers back together)
+                const float* ap = buf + (lane & 31) * DP + 4 * h;
+                f32x4 avA = *reinterpret_cast<const f32x4*>(ap), avB = avA;
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // the prologue read
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const float* ap = buf + m * TILE_F + (lane & 31) * DP + 4 * h;
+                for (int gq = 0; gq < M * NQ; ++gq) {
+                    const int m = gq / NQ, q = gq % NQ;
+                    const int nm = (gq + 1) / NQ, nq = (gq + 1) % NQ;
+                    if (gq + 1 < M * NQ) {
+                        if (gq & 1) avA = *reinterpret_cast<const f32x4*>(ap + nm * TILE_F + 8 * nq);
+                        else avB = *reinterpret_cast<const f32x4*>(ap + nm * TILE_F + 8 * nq);
+                    }
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], own[m][q][r], sacc[m], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r)
+                        sacc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32((gq & 1) ? avB[r] : avA[r], own[m][q][r], sacc[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // next group's ds_read first ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // ... then this group's 4 MFMAs
                 }
             }
             // ---- joint similarity, sums / coefficients
@@ -491,40 +503,51 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
+                // dL/dS_J for this tile (kept in VGPRs), then per table: c_m = dL/dS_m + beta_m dL/dS_J -> gradient GEMM.
+                // Only cj and ONE table's coefficients are live at a time: the MFMA A operand must be a VGPR and the
+                // M owner operands already take 156 of the 256.
+                float cj[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const bool ok = iv && (j0 + mfma32_row(r, h) < j_end);
                     float sj = 0.f;
 #pragma unroll
                     for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][r], sj);
-                    const float cj = ok ? c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1) : 0.f;
-#pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        const float sv = sacc[m][r];
-                        if (G0 == 0 && g < 2) gam[m] = fmaf(cj, sv, gam[m]);       // each pair once (anchor-owner sweep)
-                        sacc[m][r] = ok ? fmaf(beta[m], cj, c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1)) : 0.f;
-                    }
+                    cj[r] = ok ? c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1) : 0.f;
                 }
-                // ---- gradient GEMMs chained from the accumulators, B operand prefetched one step ahead
+                if (G0 == 0 && g < 2) {                         // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gam[m] = fmaf(cj[r], sacc[m][r], gam[m]);
+                }
 #pragma unroll
                 for (int mm = 0; mm < NG; ++mm) {
                     const int m = G0 + mm;
+                    float cm[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = iv && (j0 + mfma32_row(r, h) < j_end);
+                        const float sv = sacc[m][r];
+                        cm[r] = ok ? fmaf(beta[m], cj[r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1)) : 0.f;
+                    }
                     const float* bb = buf + m * TILE_F + (lane & 31);
                     float bc[NCT], bn[NCT];
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) bc[ct] = bb[mfma32_row(0, h) * DP + ct * 32];
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
-                        if (s + 1 < 16) {
 #pragma unroll
-                            for (int ct = 0; ct < NCT; ++ct) bn[ct] = bb[mfma32_row(s + 1, h) * DP + ct * 32];
-                        }
-                        const float av = sacc[m][s];
+                        for (int ct = 0; ct < NCT; ++ct) bn[ct] = bb[mfma32_row(s + 1 < 16 ? s + 1 : s, h) * DP + ct * 32];
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) gacc[mm][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[ct], gacc[mm][ct], 0, 0, 0);
+                        for (int ct = 0; ct < NCT; ++ct)
+                            gacc[mm][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(cm[s], bc[ct], gacc[mm][ct], 0, 0, 0);
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) bc[ct] = bn[ct];
+                        __builtin_amdgcn_sched_group_barrier(0x100, NCT, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -565,11 +588,11 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
 }
 
 template <int M, int G0, int NG, bool GRAD>
-static void launch_sweep_multi(const MultiArgs& a, int nblk, int gy, hipStream_t s) {
+static void launch_sweep_multi(const MultiArgs& a, int nwg, hipStream_t s) {
     const size_t lds = (size_t)2 * M * 32 * 104 * sizeof(float);
     auto k = sweep_multi_kernel<M, G0, NG, GRAD>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(nblk, gy), dim3(CT_THREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(CT_THREADS), lds, s, a);
 }
 
 // joint operand rows for the anchors x anchors kernels: ZJ[r, m*104 + d] = sqrt(beta_m) Z_m[r, d]
@@ -940,7 +963,22 @@ static int fill_multi(MultiArgs& a, const float* const* Z, int M, const float* b
     for (int g = 0; g < 4; ++g) a.grp[g] = tmp.grp[g];
     return SGA_OK;
 }
-static int multi_blocks(const MultiArgs& a) { int n = 0; for (int g = 0; g < a.ngroups; ++g) n += (a.grp[g].nown + 127) / 128; return n; }
+// Split every group's other-tile list so that all workgroups run ~`target` 32-row steps: uniform work units keep
+// the 256 CUs busy to the end (anchor-owner blocks see 2.4x more other rows than negative-owner blocks).
+static int plan_multi(MultiArgs& a, int target_steps) {
+    int nwg = 0;
+    for (int g = 0; g < a.ngroups; ++g) {
+        SweepGroup& G = a.grp[g];
+        int steps = 0;
+        for (int sg = 0; sg < G.nseg; ++sg) steps += (G.seg[sg].n + 31) / 32;
+        int ns = (steps + target_steps - 1) / target_steps;
+        if (ns < 1) ns = 1;
+        G.nsplit = ns;
+        G.blk0 = nwg;
+        nwg += ((G.nown + 127) / 128) * ns;
+    }
+    return nwg;
+}
 
 extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
                                    float tau1, double* sums, void* stream) {
@@ -952,14 +990,10 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* be
     int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false);
     if (rc) return rc;
     a.sums = sums;
-    const int nblk = multi_blocks(a);
-    const int jt = ((J1 > J2 ? J1 : J2) + 31) / 32;
-    int gy = (4 * sga_num_cus() + nblk - 1) / nblk;
-    if (gy > jt) gy = jt;
-    if (gy < 1) gy = 1;
-    if (M == 2) launch_sweep_multi<2, 0, 2, false>(a, nblk, gy, s);
-    else if (M == 3) launch_sweep_multi<3, 0, 3, false>(a, nblk, gy, s);
-    else launch_sweep_multi<4, 0, 2, false>(a, nblk, gy, s);
+    const int nwg = plan_multi(a, 160);
+    if (M == 2) launch_sweep_multi<2, 0, 2, false>(a, nwg, s);
+    else if (M == 3) launch_sweep_multi<3, 0, 3, false>(a, nwg, s);
+    else launch_sweep_multi<4, 0, 2, false>(a, nwg, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums");
     return SGA_OK;
 }
@@ -974,16 +1008,10 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* be
     if (rc) return rc;
     a.gs = gs; a.gamma = gamma;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }
-    const int nblk = multi_blocks(a);
-    int mx = A > J1 ? A : J1;
-    if (J2 > mx) mx = J2;
-    const int jt = (mx + 31) / 32;
-    int gy = (4 * sga_num_cus() + nblk - 1) / nblk;
-    if (gy > jt) gy = jt;
-    if (gy < 1) gy = 1;
-    if (M == 2) launch_sweep_multi<2, 0, 2, true>(a, nblk, gy, s);
-    else if (M == 3) launch_sweep_multi<3, 0, 3, true>(a, nblk, gy, s);
-    else { launch_sweep_multi<4, 0, 2, true>(a, nblk, gy, s); launch_sweep_multi<4, 2, 2, true>(a, nblk, gy, s); }
+    const int nwg = plan_multi(a, 160);
+    if (M == 2) launch_sweep_multi<2, 0, 2, true>(a, nwg, s);
+    else if (M == 3) launch_sweep_multi<3, 0, 3, true>(a, nwg, s);
+    else { launch_sweep_multi<4, 0, 2, true>(a, nwg, s); launch_sweep_multi<4, 2, 2, true>(a, nwg, s); }
     SGA_CHECK_LAUNCH("sga_loss_multi_grad");
     return SGA_OK;
 }
