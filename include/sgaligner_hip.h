@@ -77,6 +77,9 @@ int sga_elu_bwd(const float* x, const float* gy, float* gx, size_t n, void* stre
 int sga_loss_gather(const float* E, int T, int D, const int32_t* idx, int R, float* Z, int Dp, float* nrm, void* stream);
 int sga_loss_scatter(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int R, int D, int Dp,
                      float* dE, void* stream);                                  /* dE += J_normalize^T dZ (atomic) */
+/* Scalar-accumulator buffers (sums8, sums, out, gs, gamma below) hold (1 + sga_loss_slots()) * n doubles: the first n
+ * are the result, the rest per-wave partial slots (one shared set of addresses would serialise the fp64 atomics). */
+int sga_loss_slots(void);
 /* the four global sums of losses.py:10-11 at two temperatures: sums8[fam*2+temp], fam = s11,s12,s22,s21 */
 int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, void* stream);
 /* dZ += d(sums)/dZ weighted by gs8 = dL/d(sums8) (owner-stationary sweeps, atomic accumulate) */

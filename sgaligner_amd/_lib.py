@@ -43,6 +43,7 @@ SIGNATURES = {
     'sga_loss_build_joint': (I, [P, I, P, I, P, P]),
     'sga_loss_fold_joint': (I, [P, I, P, P, I, P, P, P]),
     'sga_loss_check_norms': (I, [P, I, P, P]),
+    'sga_loss_slots': (I, []),
     'sga_fusion_fwd': (I, [P, I, P, P, I, I, P]),
     'sga_fusion_bwd_workspace_bytes': (c_size_t, [I]),
     'sga_fusion_bwd': (I, [P, I, P, P, P, P, I, I, P, c_size_t, P]),

@@ -35,6 +35,29 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
+// Global scalar accumulators (loss sums, dL/d(sums), Gamma) are hit by every wave of every workgroup; a single
+// set of addresses serialises in L2 (measured: ~10 of the 15 ms of the anchors backward).  Each accumulator therefore
+// has SGA_SLOTS copies, a wave adds to copy (wave id mod SGA_SLOTS), and reduce_slots_kernel folds them into copy 0's
+// final location.  Buffers passed to the C ABI hold (1 + SGA_SLOTS) * n doubles: [result n | slots].
+constexpr int SGA_SLOTS = 128;
+__device__ __forceinline__ int my_slot() {
+    return (int)((blockIdx.x * gridDim.y + blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)) % SGA_SLOTS;
+}
+__global__ void reduce_slots_kernel(double* __restrict__ buf, int n) {      // buf[0..n) = sum_s buf[n + s*n + i]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = 0.0;
+    for (int sl = 0; sl < SGA_SLOTS; ++sl) v += buf[n + (size_t)sl * n + i];
+    buf[i] = v;
+}
+static int zero_slots(double* buf, int n, hipStream_t s, const char* who) {
+    if (hipMemsetAsync(buf, 0, (size_t)(1 + SGA_SLOTS) * n * sizeof(double), s) != hipSuccess) { sga_set_error("%s: memset failed", who); return SGA_ERR_HIP; }
+    return SGA_OK;
+}
+static void fold_slots(double* buf, int n, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3((n + 63) / 64), dim3(64), 0, s, buf, n);
+}
+
 struct GV { float q, dd, dsa, dsb; };
 
 // g and its derivatives wrt d, sa, sb; a = 1/(sa+eps), b = 1/(sb+eps)
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_kernel(SweepArgs a) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const double v = wave_sum_d(dsum[sg][tt]);
-                if (lane == 0 && sg < grp.nseg && v != 0.0) atomicAdd(a.sums + grp.seg[sg].fam * 2 + tt, v);
+                if (lane == 0 && sg < grp.nseg && v != 0.0) atomicAdd(a.sums + 8 + my_slot() * 8 + grp.seg[sg].fam * 2 + tt, v);
             }
     } else {
         // gacc[ct][r] = dOwner[wave*32 + row(r,h)][col0 + ct*32 + (lane&31)]
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_fast_kernel(SweepArgs a) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const double v = wave_sum_d(dsum[sg][tt]);
-                if (lane == 0 && sg < grp.nseg && v != 0.0) atomicAdd(a.sums + grp.seg[sg].fam * 2 + tt, v);
+                if (lane == 0 && sg < grp.nseg && v != 0.0) atomicAdd(a.sums + 8 + my_slot() * 8 + grp.seg[sg].fam * 2 + tt, v);
             }
     } else {
 #pragma unroll
@@ -557,7 +580,7 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const double v = wave_sum_d(dsum[m][tt]);
-                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + m * 8 + seg.fam * 2 + tt, v);
+                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + (M + 1) * 8 * (1 + my_slot()) + m * 8 + seg.fam * 2 + tt, v);
                 }
         }
     }
@@ -581,7 +604,7 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const float v = wave_sum(gam[m]);
-                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + m, (double)v);
+                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + m, (double)v);
             }
         }
     }
@@ -658,6 +681,8 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int A = a.A, NT = a.NT, M = NT > 1 ? NT - 1 : 0;
+    double* const out_s = BWD ? nullptr : a.out + (NT + 2 * M) * (1 + my_slot());
+    double* const gs_s = BWD ? a.gs + NT * 8 * (1 + my_slot()) : nullptr;
     for (int e = tid; e < NT * 8; e += CT_THREADS) inv_s[e] = (float)(1.0 / (a.sums[e] + 1e-9));
     const int i0 = blockIdx.x * 128, j0 = blockIdx.y * OT;
     const int my_i = i0 + wave * 32 + (lane & 31);
@@ -719,11 +744,11 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
                     }
                 }
             icl = wave_sum(icl);
-            if (lane == 0) atomicAdd(a.out + k, (double)icl);
+            if (lane == 0) atomicAdd(out_s + k, (double)icl);
             if (M > 0 && !is_joint) {
                 la = wave_sum(la);
                 lb = wave_sum(lb);
-                if (lane == 0) { atomicAdd(a.out + NT + k, (double)la); atomicAdd(a.out + NT + M + k, (double)lb); }
+                if (lane == 0) { atomicAdd(out_s + NT + k, (double)la); atomicAdd(out_s + NT + M + k, (double)lb); }
             }
         } else {
             const float c = a.coef[k];
@@ -764,11 +789,11 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const float vc = wave_sum(gs_c[f]);
-                if (lane == 0 && vc != 0.f) atomicAdd(a.gs + k * 8 + f * 2 + 0, (double)vc);
+                if (lane == 0 && vc != 0.f) atomicAdd(gs_s + k * 8 + f * 2 + 0, (double)vc);
                 if (M > 0 && !is_joint) {
                     const float vi = wave_sum(gs_i[f]), vj = wave_sum(gs_j[f]);
-                    if (lane == 0 && vi != 0.f) atomicAdd(a.gs + k * 8 + f * 2 + 1, (double)vi);
-                    if (lane == 0 && vj != 0.f) atomicAdd(a.gs + (NT - 1) * 8 + f * 2 + 1, (double)vj);
+                    if (lane == 0 && vi != 0.f) atomicAdd(gs_s + k * 8 + f * 2 + 1, (double)vi);
+                    if (lane == 0 && vj != 0.f) atomicAdd(gs_s + (NT - 1) * 8 + f * 2 + 1, (double)vj);
                 }
             }
             if (is_joint) {
@@ -853,7 +878,7 @@ extern "C" int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, 
                                  void* stream) {
     SGA_CHECK_ARG(Z && sums8 && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0 && tau0 > 0 && tau1 > 0, "sga_loss_neg_sums: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sums8, 0, 8 * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_neg_sums: memset failed"); return SGA_ERR_HIP; }
+    if (int rc = zero_slots(sums8, 8, s, "sga_loss_neg_sums")) return rc;
     if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
     SweepArgs a{};
     a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
@@ -867,6 +892,7 @@ extern "C" int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, 
     if (Dp == 104) launch_sweep_fast<13, false>(a, nblk, gy, s);
     else if (Dp == 128) launch_sweep_fast<16, false>(a, nblk, gy, s);
     else launch_sweep<4, 1, false>(a, nblk, gy, s);
+    fold_slots(sums8, 8, s);
     SGA_CHECK_LAUNCH("sga_loss_neg_sums");
     return SGA_OK;
 }
@@ -922,13 +948,14 @@ extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT,
     SGA_CHECK_ARG(Z && Dp && sums && out && A >= 0, "sga_loss_anchor_fwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = NT > 1 ? NT - 1 : 0;
-    if (hipMemsetAsync(out, 0, (NT + 2 * M) * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_anchor_fwd: memset failed"); return SGA_ERR_HIP; }
+    if (int rc0 = zero_slots(out, NT + 2 * M, s, "sga_loss_anchor_fwd")) return rc0;
     if (A == 0) return SGA_OK;
     AnchorArgs a{};
     int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial);
     if (rc) return rc;
     a.out = out;
     hipLaunchKernelGGL(anchor_kernel<false>, dim3((A + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    fold_slots(out, NT + 2 * M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_fwd");
     return SGA_OK;
 }
@@ -938,7 +965,7 @@ extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT,
                                    double* gs, void* stream) {
     SGA_CHECK_ARG(Z && Dp && sums && coef && M1 && gs && A >= 0, "sga_loss_anchor_bwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(gs, 0, NT * 8 * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_anchor_bwd: memset failed"); return SGA_ERR_HIP; }
+    if (int rc0 = zero_slots(gs, NT * 8, s, "sga_loss_anchor_bwd")) return rc0;
     if (A == 0) return SGA_OK;
     AnchorArgs a{};
     int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial);
@@ -946,6 +973,7 @@ extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT,
     a.coef = coef; a.gs = gs;
     for (int k = 0; k < NT; ++k) { SGA_CHECK_ARG(M1[k], "sga_loss_anchor_bwd: null stash %d", k); a.M1[k] = M1[k]; }
     hipLaunchKernelGGL(anchor_kernel<true>, dim3((A + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    fold_slots(gs, NT * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_bwd");
     return SGA_OK;
 }
@@ -984,7 +1012,7 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* be
                                    float tau1, double* sums, void* stream) {
     SGA_CHECK_ARG(Z && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sums, 0, (size_t)(M + 1) * 8 * sizeof(double), s) != hipSuccess) { sga_set_error("sga_loss_multi_sums: memset failed"); return SGA_ERR_HIP; }
+    if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums")) return rc0;
     if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
     MultiArgs a{};
     int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false);
@@ -994,6 +1022,7 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* be
     if (M == 2) launch_sweep_multi<2, 0, 2, false>(a, nwg, s);
     else if (M == 3) launch_sweep_multi<3, 0, 3, false>(a, nwg, s);
     else launch_sweep_multi<4, 0, 2, false>(a, nwg, s);
+    fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums");
     return SGA_OK;
 }
@@ -1007,11 +1036,13 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* be
     int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, true);
     if (rc) return rc;
     a.gs = gs; a.gamma = gamma;
+    if (int rc0 = zero_slots(gamma, M, s, "sga_loss_multi_grad")) return rc0;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }
     const int nwg = plan_multi(a, 160);
     if (M == 2) launch_sweep_multi<2, 0, 2, true>(a, nwg, s);
     else if (M == 3) launch_sweep_multi<3, 0, 3, true>(a, nwg, s);
     else { launch_sweep_multi<4, 0, 2, true>(a, nwg, s); launch_sweep_multi<4, 2, 2, true>(a, nwg, s); }
+    fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad");
     return SGA_OK;
 }
@@ -1046,3 +1077,5 @@ extern "C" int sga_loss_check_norms(const float* nrm, int n, float* poison, void
     SGA_CHECK_LAUNCH("sga_loss_check_norms");
     return SGA_OK;
 }
+
+extern "C" int sga_loss_slots(void) { return SGA_SLOTS; }

@@ -244,16 +244,18 @@ class ContrastiveTermsFn(torch.autograd.Function):
         zs, nrms, dps = [], [], []
         sums = torch.empty((nt, 8), device=dev, dtype=torch.float64)
         st = _stream()
+        slots = 1 + L.sga_loss_slots()          # scalar accumulators are [result | per-wave slots] (contrastive.hip)
         for k, e in enumerate(tables):
             d = e.shape[1]
             dp = (d + 7) // 8 * 8
             z = torch.empty((s.R, dp), device=dev, dtype=torch.float32)
             nrm = torch.empty((s.R,), device=dev, dtype=torch.float32)
             _lib.check(L.sga_loss_gather(_p(e), T, d, _p(s.idx), s.R, _p(z), dp, _p(nrm), st), 'sga_loss_gather')
-            _lib.check(L.sga_loss_neg_sums(_p(z), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, sums[k].data_ptr(), st),
-                       'sga_loss_neg_sums')
+            sk = torch.empty((slots * 8,), device=dev, dtype=torch.float64)
+            _lib.check(L.sga_loss_neg_sums(_p(z), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), st), 'sga_loss_neg_sums')
+            sums[k].copy_(sk[:8])
             zs.append(z); nrms.append(nrm); dps.append(dp)
-        out = torch.empty((nt + 2 * m,), device=dev, dtype=torch.float64)
+        out = torch.empty((slots * (nt + 2 * m),), device=dev, dtype=torch.float64)
         zarr = _ptr_array(zs)
         dparr = (_ct.c_int * nt)(*dps)
         _lib.check(L.sga_loss_anchor_fwd(zarr, dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), st),
@@ -261,7 +263,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
         ctx.s, ctx.alpha, ctx.dps, ctx.nt = s, float(alpha), dps, nt
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.save_for_backward(sums, *zs, *nrms)
-        return out.float()
+        return out[:nt + 2 * m].float()
 
     @staticmethod
     def backward(ctx, gout):
@@ -274,10 +276,11 @@ class ContrastiveTermsFn(torch.autograd.Function):
         coef = gout.contiguous().float()
         A = s.A
         m1 = [torch.empty((A, A), device=dev, dtype=torch.float32) for _ in range(nt)]
-        gs = torch.empty((nt, 8), device=dev, dtype=torch.float64)
+        gs = torch.empty((1 + L.sga_loss_slots(), nt, 8), device=dev, dtype=torch.float64)
         dparr = (_ct.c_int * nt)(*dps)
         _lib.check(L.sga_loss_anchor_bwd(_ptr_array(zs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
                                          _ptr_array(m1), _p(gs), st), 'sga_loss_anchor_bwd')
+        gs = gs[0]
         grads = []
         for k in range(nt):
             z, dp = zs[k], dps[k]
@@ -471,18 +474,20 @@ class FusedContrastiveFn(torch.autograd.Function):
             _lib.check(L.sga_loss_check_norms(_p(nrm), s.R, _p(poison), st), 'sga_loss_check_norms')
             zs.append(z); nrms.append(nrm)
         zarr = _ptr_array(zs)
-        sums = torch.empty((nt, 8), device=dev, dtype=torch.float64)
+        slots = 1 + L.sga_loss_slots()
+        sums = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
         _lib.check(L.sga_loss_multi_sums(zarr, M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), st), 'sga_loss_multi_sums')
+        sums = sums[0]
         zj = torch.empty((2 * s.A, M * dp), device=dev, dtype=torch.float32)
         _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')
-        out = torch.empty((nt + 2 * M,), device=dev, dtype=torch.float64)
+        out = torch.empty((slots * (nt + 2 * M),), device=dev, dtype=torch.float64)
         dps = [dp] * M + [M * dp]
         _lib.check(L.sga_loss_anchor_fwd(_ptr_array(zs + [zj]), (_ct.c_int * nt)(*dps), nt, s.A, _p(sums), float(alpha),
                                          TAU_ICL, TAU_IAL, _p(out), st), 'sga_loss_anchor_fwd')
         ctx.s, ctx.alpha, ctx.M = s, float(alpha), M
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.save_for_backward(sums, beta, zj, *zs, *nrms)
-        return out.float() + poison
+        return out[:nt + 2 * M].float() + poison
 
     @staticmethod
     def backward(ctx, gout):
@@ -497,12 +502,15 @@ class FusedContrastiveFn(torch.autograd.Function):
         A = s.A
         coef = gout.contiguous().float()
         m1 = [torch.empty((A, A), device=dev, dtype=torch.float32) for _ in range(nt)]
-        gs = torch.empty((nt, 8), device=dev, dtype=torch.float64)
+        slots = 1 + L.sga_loss_slots()
+        gs = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
         dps = [dp] * M + [M * dp]
         _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
                                          TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gs), st), 'sga_loss_anchor_bwd')
+        gs = gs[0]
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for _ in range(M)]
-        gam = torch.zeros((2, M), device=dev, dtype=torch.float64)      # [0]: via negatives, [1]: via the anchor rows of ZJ
+        gam_neg = torch.empty((slots, M), device=dev, dtype=torch.float64)   # dL/dbeta via the negatives (zeroed by the callee)
+        gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via sqrt(beta) in the anchor rows of ZJ
         if A > 0:
             for k in range(M):
                 gemm(m1[k], zs[k][A:2 * A], True, False, A, dp, A, out=dzs[k][0:A])
@@ -512,14 +520,14 @@ class FusedContrastiveFn(torch.autograd.Function):
             gemm(m1[M], zj[A:2 * A], True, False, A, M * dp, A, out=dzj[0:A])
             gemm(m1[M], zj[0:A], False, False, A, M * dp, A, out=dzj[A:2 * A])
             m1[M] = None
-            _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), gam[1].data_ptr(), st),
+            _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), _p(gam_anc), st),
                        'sga_loss_fold_joint')
         ev = None
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         _lib.check(L.sga_loss_multi_grad(_ptr_array(zs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
-                                         gam[0].data_ptr(), st), 'sga_loss_multi_grad')
+                                         _p(gam_neg), st), 'sga_loss_multi_grad')
         if ev is not None:
             ev[1].record()
             KERNEL_EVENTS.setdefault(f'sweep_multi_kernel<{M},grad>', []).append(ev + ((A, s.J1, s.J2, M),))
@@ -530,7 +538,9 @@ class FusedContrastiveFn(torch.autograd.Function):
             _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
             grads.append(de)
         # d/dbeta_m: through the negatives (gamma) + through sqrt(beta_m) in the anchor rows of ZJ
-        gbeta = (gam[0] + gam[1] / (2.0 * torch.sqrt(beta.double()))).float()
+        if A == 0 or (s.J1 == 0 and s.J2 == 0):
+            gam_neg.zero_()
+        gbeta = (gam_neg[0] + gam_anc / (2.0 * torch.sqrt(beta.double()))).float()
         return (None, None, gbeta, *grads)
 
 
