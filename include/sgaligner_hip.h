@@ -92,6 +92,8 @@ int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, con
 int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums, float alpha,
                         float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, void* stream);
 
+/* dZ[0:A,:] += M1^T Z[A:2A,:] ; dZ[A:2A,:] += M1 Z[0:A,:]  (M1 from sga_loss_anchor_bwd; dZ zero-initialised) */
+int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, void* stream);
 /* fused variants for the normal pipeline, where the last table is the fusion of the M others: every joint
  * similarity is S_J = sum_m beta_m S_m (beta_m = w_m^2 / sum w^2, w = softmax(fusion.weight), sg_aligner.py:32-34
  * + losses.py:44,73), so the 300-d table is never multiplied.  Z[m] [R+32, 104] (Dp must be 104, 32 readable rows of

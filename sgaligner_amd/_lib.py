@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsga_hip.so')
+LIB_PATH = os.environ.get('SGA_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libsga_hip.so')   # override: kernel experiments
 _lib = None
 
 P = c_void_p
@@ -44,6 +44,7 @@ SIGNATURES = {
     'sga_loss_fold_joint': (I, [P, I, P, P, I, P, P, P]),
     'sga_loss_check_norms': (I, [P, I, P, P]),
     'sga_loss_slots': (I, []),
+    'sga_loss_stash_grad': (I, [P, P, I, I, P, P]),
     'sga_fusion_fwd': (I, [P, I, P, P, I, I, P]),
     'sga_fusion_bwd_workspace_bytes': (c_size_t, [I]),
     'sga_fusion_bwd': (I, [P, I, P, P, P, P, I, I, P, c_size_t, P]),

@@ -32,7 +32,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float QEPS = 1e-9f;
 
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#ifdef SGA_DBG_NOEXP
+__device__ __forceinline__ float fexp2(float x) { return x; }
+#else
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
 // Global scalar accumulators (loss sums, dL/d(sums), Gamma) are hit by every wave of every workgroup; a single
@@ -479,7 +483,9 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
             float* buf = lds + (it & 1) * BUF_F;
             const int j0 = seg.row0 + jt * OT;
             __syncthreads();                               // tile `it` landed (vmcnt drained) / other buffer free
+#ifndef SGA_DBG_NODMA
             if (jt + nsplit < ntile) issue(seg.row0 + (jt + nsplit) * OT, lds + ((it + 1) & 1) * BUF_F);
+#endif
 
             // ---- S tiles of the M tables: lane = owner row, registers = other rows
             f32x16 sacc[M];
@@ -823,6 +829,59 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dZ anchor rows from the dL/dS stash (M1[j*A + i] = dL/dS[i,j]) without LDS:
+//   TRANS = 1 :  dX1[i, :] += sum_j M1[j, i] X2[j, :]      (A operand column-read: coalesced along i)
+//   TRANS = 0 :  dX2[j, :] += sum_i M1[j, i] X1[i, :]      (A operand row-read: float4 along i)
+// One wave owns a 32-row output block and NCT 32-column tiles; both MFMA operands are loaded straight from
+// global/L2 in fragment order (the B rows X[k, :] are shared by every wave and stay L2/L1 resident), K is split
+// across blockIdx.y and the partial tiles are added atomically into the zero-initialised dZ rows.
+// ------------------------------------------------------------------------------------------------
+template <int NCT, bool TRANS>
+__global__ __launch_bounds__(256) void stash_gemm_kernel(const float* __restrict__ M1, const float* __restrict__ X,
+                                                         float* __restrict__ out, int A, int ld, int Dp, int k_per_split) {
+    // X / out point at the first column of this launch's column block; rows are `ld` floats apart, Dp columns are valid
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
+    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    if (m0 >= A) return;
+    const int kbeg = blockIdx.y * k_per_split, kend = min(A, kbeg + k_per_split);
+    const int m = min(m0 + l31, A - 1);                 // clamped rows are computed but never stored
+    f32x16 acc[NCT];
+    zero_acc<NCT>(acc);
+    int ncol[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) ncol[ct] = min(ct * 32 + l31, Dp - 1);
+    for (int k0 = kbeg; k0 < kend; k0 += 8) {           // A, k_per_split multiples of 8 are not required: tail clamps + masks
+        float av[4];
+        float kmask[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + 4 * h + r;
+            kmask[r] = k < kend ? 1.f : 0.f;
+            const int kc = min(k, A - 1);
+            av[r] = (TRANS ? M1[(size_t)kc * A + m] : M1[(size_t)m * A + kc]) * kmask[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kc = min(k0 + 4 * h + r, A - 1);
+            const float* xr = X + (size_t)kc * ld;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], xr[ncol[ct]], acc[ct], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int d = ct * 32 + l31;
+        if (d < Dp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + mfma32_row(r, h);
+                if (row < A) atomicAdd(out + (size_t)row * ld + d, acc[ct][r]);
+            }
+        }
+    }
+}
+
 int rows_grid(int R) {
     int g = (R + 3) / 4;
     const int cap = sga_num_cus() * 8;
@@ -1079,3 +1138,31 @@ extern "C" int sga_loss_check_norms(const float* nrm, int n, float* poison, void
 }
 
 extern "C" int sga_loss_slots(void) { return SGA_SLOTS; }
+
+/* dZ[0:A] += M1^T X2 and dZ[A:2A] += M1 X1 for one table (Z = [X1 | X2 | ...] rows of width Dp) */
+extern "C" int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, void* stream) {
+    SGA_CHECK_ARG(M1 && Z && dZ && A >= 0 && Dp >= 8 && Dp % 8 == 0, "sga_loss_stash_grad: bad argument");
+    if (A == 0) return SGA_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int gx = (A + 127) / 128;
+    int splits = (6 * sga_num_cus() + gx - 1) / gx;
+    int kper = ((A + splits - 1) / splits + 7) / 8 * 8;
+    if (kper < 64) kper = 64;
+    splits = (A + kper - 1) / kper;
+    const float* X1 = Z;
+    const float* X2 = Z + (size_t)A * Dp;
+    for (int c0 = 0; c0 < Dp; c0 += 320) {               // column blocks of <= 320 (the 104*M-wide joint operand takes one or two)
+        const int w = Dp - c0 < 320 ? Dp - c0 : 320;
+        float* o1 = dZ + c0;
+        float* o2 = dZ + (size_t)A * Dp + c0;
+        if (w <= 128) {
+            hipLaunchKernelGGL((stash_gemm_kernel<4, true>), dim3(gx, splits), dim3(256), 0, s, M1, X2 + c0, o1, A, Dp, w, kper);
+            hipLaunchKernelGGL((stash_gemm_kernel<4, false>), dim3(gx, splits), dim3(256), 0, s, M1, X1 + c0, o2, A, Dp, w, kper);
+        } else {
+            hipLaunchKernelGGL((stash_gemm_kernel<10, true>), dim3(gx, splits), dim3(256), 0, s, M1, X2 + c0, o1, A, Dp, w, kper);
+            hipLaunchKernelGGL((stash_gemm_kernel<10, false>), dim3(gx, splits), dim3(256), 0, s, M1, X1 + c0, o2, A, Dp, w, kper);
+        }
+    }
+    SGA_CHECK_LAUNCH("sga_loss_stash_grad");
+    return SGA_OK;
+}

@@ -287,8 +287,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
             dz = torch.zeros((s.R, dp), device=dev, dtype=torch.float32)
             if A > 0:
                 # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]
-                gemm(m1[k], z[A:2 * A], True, False, A, dp, A, out=dz[0:A])
-                gemm(m1[k], z[0:A], False, False, A, dp, A, out=dz[A:2 * A])
+                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(z), A, dp, _p(dz), st), 'sga_loss_stash_grad')
             m1[k] = None
             ev = None
             if KERNEL_EVENTS is not None and dp <= 128:
@@ -513,12 +512,10 @@ class FusedContrastiveFn(torch.autograd.Function):
         gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via sqrt(beta) in the anchor rows of ZJ
         if A > 0:
             for k in range(M):
-                gemm(m1[k], zs[k][A:2 * A], True, False, A, dp, A, out=dzs[k][0:A])
-                gemm(m1[k], zs[k][0:A], False, False, A, dp, A, out=dzs[k][A:2 * A])
+                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), st), 'sga_loss_stash_grad')
                 m1[k] = None
-            dzj = torch.empty((2 * A, M * dp), device=dev, dtype=torch.float32)
-            gemm(m1[M], zj[A:2 * A], True, False, A, M * dp, A, out=dzj[0:A])
-            gemm(m1[M], zj[0:A], False, False, A, M * dp, A, out=dzj[A:2 * A])
+            dzj = torch.zeros((2 * A, M * dp), device=dev, dtype=torch.float32)
+            _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), st), 'sga_loss_stash_grad')
             m1[M] = None
             _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), _p(gam_anc), st),
                        'sga_loss_fold_joint')
