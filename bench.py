@@ -109,11 +109,11 @@ def main():
         evs = events.get(key, [])
         if evs:
             durs = [a.elapsed_time(b) for a, b, _ in evs]
-            A, J1, J2, M = evs[0][2]
+            ns, A, J1, J2, M = evs[0][2]          # ns = anchors in this rank's shard (== A on one GPU)
             d_sum = 100 * M + 100 * M
-            fwd_flops = 2.0 * d_sum * 2.0 * A * (J1 + J2)
+            fwd_flops = 2.0 * d_sum * 2.0 * ns * (J1 + J2)
             alg = 2.0 * fwd_flops
-            executed = 2.0 * (2.0 * A * (J1 + J2)) * 2.0 * M * (104 + 128)      # two sweeps x M x (S K=104 + grad 128 cols)
+            executed = 2.0 * (2.0 * ns * (J1 + J2)) * 2.0 * M * (104 + 128)      # two sweeps x M x (S K=104 + grad 128 cols)
             avg_ms = float(np.mean(durs))
             ach = alg / (avg_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',

@@ -86,22 +86,24 @@ int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, float tau0,
 int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
                       float* dZ, void* stream);
 /* anchors x anchors terms for NT tables (modalities..., joint): out = [NT icl sums | M iala | M ialb], M = NT-1 */
+/* [a_lo, a_hi) (here and below): the anchor shard this process owns (0, A on one GPU).  Outputs are that shard's partial
+ * contribution; the sum over a partition of [0, A) equals the unsharded result (one process per GPU all-reduces it). */
 int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums, float alpha,
-                        float tau_icl, float tau_ial, double* out, void* stream);
+                        float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream);
 /* given coef = dL/d(out): M1[k][j*A+i] = dL/dS_k[i,j] and gs[k][8] = dL/d(sums) */
 int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums, float alpha,
                         float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, void* stream);
 
-/* dZ[0:A,:] += M1^T Z[A:2A,:] ; dZ[A:2A,:] += M1 Z[0:A,:]  (M1 from sga_loss_anchor_bwd; dZ zero-initialised) */
-int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, void* stream);
+/* dZ[a_lo:a_hi,:] += M1^T Z[A:2A,:] ; dZ[A:2A,:] += M1 Z[a_lo:a_hi,:]  (M1 [A, a_hi-a_lo] from sga_loss_anchor_bwd; dZ zero-initialised) */
+int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi, void* stream);
 /* fused variants for the normal pipeline, where the last table is the fusion of the M others: every joint
  * similarity is S_J = sum_m beta_m S_m (beta_m = w_m^2 / sum w^2, w = softmax(fusion.weight), sg_aligner.py:32-34
  * + losses.py:44,73), so the 300-d table is never multiplied.  Z[m] [R+32, 104] (Dp must be 104, 32 readable rows of
  * slack), beta [M] device.  sums/gs [(M+1)][8] with the joint in row M; gamma[m] += dL/dbeta_m through the negatives. */
 int sga_loss_multi_sums(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                        double* sums, void* stream);
+                        double* sums, int a_lo, int a_hi, void* stream);
 int sga_loss_multi_grad(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                        const double* gs, float* const* dZ, double* gamma, void* stream);
+                        const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
 /* ZJ[r, m*104+d] = sqrt(beta_m) Z_m[r,d] for the anchor rows (operand of the anchors x anchors kernels), and its adjoint */
 int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream);
 int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows, float* const* dZ,

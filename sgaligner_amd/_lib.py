@@ -36,15 +36,15 @@ SIGNATURES = {
     'sga_loss_scatter': (I, [P, P, P, P, I, I, I, P, P]),
     'sga_loss_neg_sums': (I, [P, I, I, I, I, F, F, P, P]),
     'sga_loss_neg_grad': (I, [P, I, I, I, I, F, F, P, P, P]),
-    'sga_loss_anchor_fwd': (I, [P, P, I, I, P, F, F, F, P, P]),
-    'sga_loss_anchor_bwd': (I, [P, P, I, I, P, F, F, F, P, P, P, P]),
-    'sga_loss_multi_sums': (I, [P, I, P, I, I, I, F, F, P, P]),
-    'sga_loss_multi_grad': (I, [P, I, P, I, I, I, F, F, P, P, P, P]),
+    'sga_loss_anchor_fwd': (I, [P, P, I, I, P, F, F, F, P, I, I, P]),
+    'sga_loss_anchor_bwd': (I, [P, P, I, I, P, F, F, F, P, P, P, I, I, P]),
+    'sga_loss_multi_sums': (I, [P, I, P, I, I, I, F, F, P, I, I, P]),
+    'sga_loss_multi_grad': (I, [P, I, P, I, I, I, F, F, P, P, P, I, I, P]),
     'sga_loss_build_joint': (I, [P, I, P, I, P, P]),
     'sga_loss_fold_joint': (I, [P, I, P, P, I, P, P, P]),
     'sga_loss_check_norms': (I, [P, I, P, P]),
     'sga_loss_slots': (I, []),
-    'sga_loss_stash_grad': (I, [P, P, I, I, P, P]),
+    'sga_loss_stash_grad': (I, [P, P, I, I, P, I, I, P]),
     'sga_fusion_fwd': (I, [P, I, P, P, I, I, P]),
     'sga_fusion_bwd_workspace_bytes': (c_size_t, [I]),
     'sga_fusion_bwd': (I, [P, I, P, P, P, P, I, I, P, c_size_t, P]),

@@ -76,8 +76,11 @@ class OverallLoss(nn.Module):
             fused = (src is not None and FUSED_JOINT and 2 <= m <= 4 and len(src[1]) == m
                      and all(a is b for a, b in zip(src[1], tabs)) and all(t.shape[1] <= 104 for t in tabs))
             if fused:      # the joint table IS the fusion of these tables: never multiply the 100*M-d table
-                sums, s = ops.fused_contrastive_terms(tabs, src[0], data_dict, alpha=self.contrastive_loss.alpha)
+                sums, s = ops.fused_contrastive_terms(tabs, src[0], data_dict, alpha=self.contrastive_loss.alpha,
+                                                      shard=data_dict.get('_sga_shard'), reduce=data_dict.get('_sga_reduce'))
             else:          # arbitrary joint table: treat it as an independent (M+1)-th table
+                if data_dict.get('_sga_shard') is not None:
+                    raise RuntimeError('sgaligner_amd: anchor sharding is implemented for the fused joint path only')
                 sums, s = ops.contrastive_terms(tabs + [output_dict['joint']], data_dict, alpha=self.contrastive_loss.alpha)
             nt = m + 1
             a2 = float(s.A * s.A)

@@ -666,7 +666,7 @@ __global__ void check_norms_kernel(const float* __restrict__ nrm, int n, float* 
 // anchors x anchors: loss terms (fwd) and dL/dS + dL/d(sums) (bwd), all tables in one pass
 // ------------------------------------------------------------------------------------------------
 struct AnchorArgs {
-    int NT, A;
+    int NT, A, i_lo, i_hi;           // anchor rows [i_lo, i_hi) are this process's shard of block I
     const float* Z[CT_MAXT]; int Dp[CT_MAXT];
     const double* sums;            // [NT][8]
     float alpha, kc, ki, itc, iti; // ICL alpha; log2e/tau and 1/tau for ICL (c) and IAL (i)
@@ -690,9 +690,10 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
     double* const out_s = BWD ? nullptr : a.out + (NT + 2 * M) * (1 + my_slot());
     double* const gs_s = BWD ? a.gs + NT * 8 * (1 + my_slot()) : nullptr;
     for (int e = tid; e < NT * 8; e += CT_THREADS) inv_s[e] = (float)(1.0 / (a.sums[e] + 1e-9));
-    const int i0 = blockIdx.x * 128, j0 = blockIdx.y * OT;
+    const int i0 = a.i_lo + blockIdx.x * 128, j0 = blockIdx.y * OT;
     const int my_i = i0 + wave * 32 + (lane & 31);
-    const bool iv = my_i < A;
+    const bool iv = my_i < a.i_hi;
+    const int ns = a.i_hi - a.i_lo;
 
     f32x16 xJ[NJT], gJ[NJT];
     zero_acc<NJT>(xJ);
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int j = j0 + t * 32 + mfma32_row(r, h);
-                        if (j < A) m1[(size_t)j * A + my_i] = P[t][r];
+                        if (j < A) m1[(size_t)j * ns + (my_i - a.i_lo)] = P[t][r];
                     }
             }
         }
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + t * 32 + mfma32_row(r, h);
-                if (j < A) m1[(size_t)j * A + my_i] = gJ[t][r];
+                if (j < A) m1[(size_t)j * ns + (my_i - a.i_lo)] = gJ[t][r];
             }
     }
 }
@@ -839,13 +840,14 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int NCT, bool TRANS>
 __global__ __launch_bounds__(256) void stash_gemm_kernel(const float* __restrict__ M1, const float* __restrict__ X,
-                                                         float* __restrict__ out, int A, int ld, int Dp, int k_per_split) {
+                                                         float* __restrict__ out, int MR, int KR, int ldm, int ld, int Dp, int k_per_split) {
+    // out[MR rows] += op(M1)[MR, KR] X[KR rows];  op(M1)[m,k] = TRANS ? M1[k*ldm + m] : M1[m*ldm + k].
     // X / out point at the first column of this launch's column block; rows are `ld` floats apart, Dp columns are valid
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
     const int m0 = (blockIdx.x * 4 + wave) * 32;
-    if (m0 >= A) return;
-    const int kbeg = blockIdx.y * k_per_split, kend = min(A, kbeg + k_per_split);
-    const int m = min(m0 + l31, A - 1);                 // clamped rows are computed but never stored
+    if (m0 >= MR) return;
+    const int kbeg = blockIdx.y * k_per_split, kend = min(KR, kbeg + k_per_split);
+    const int m = min(m0 + l31, MR - 1);                // clamped rows are computed but never stored
     f32x16 acc[NCT];
     zero_acc<NCT>(acc);
     int ncol[NCT];
@@ -858,12 +860,12 @@ __global__ __launch_bounds__(256) void stash_gemm_kernel(const float* __restrict
         for (int r = 0; r < 4; ++r) {
             const int k = k0 + 4 * h + r;
             kmask[r] = k < kend ? 1.f : 0.f;
-            const int kc = min(k, A - 1);
-            av[r] = (TRANS ? M1[(size_t)kc * A + m] : M1[(size_t)m * A + kc]) * kmask[r];
+            const int kc = min(k, KR - 1);
+            av[r] = (TRANS ? M1[(size_t)kc * ldm + m] : M1[(size_t)m * ldm + kc]) * kmask[r];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int kc = min(k0 + 4 * h + r, A - 1);
+            const int kc = min(k0 + 4 * h + r, KR - 1);
             const float* xr = X + (size_t)kc * ld;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], xr[ncol[ct]], acc[ct], 0, 0, 0);
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(256) void stash_gemm_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + mfma32_row(r, h);
-                if (row < A) atomicAdd(out + (size_t)row * ld + d, acc[ct][r]);
+                if (row < MR) atomicAdd(out + (size_t)row * ld + d, acc[ct][r]);
             }
         }
     }
@@ -909,20 +911,23 @@ extern "C" int sga_loss_scatter(const float* dZ, const float* Z, const float* nr
     return SGA_OK;
 }
 
-static void fill_groups(SweepArgs& a, int A, int J1, int J2, bool grad) {
-    const int x1 = 0, x2 = A, n1 = 2 * A, n2 = 2 * A + J1;
+// Owner/other row groups of the sweeps.  [a_lo, a_hi) is the anchor shard this process owns (one process per GPU shards
+// the anchors; 0..A on a single GPU): anchor-owner groups cover only the shard, negative-owner groups see only the shard's
+// anchors as "others" -- summing the ranks' outputs gives the unsharded result.
+static void fill_groups(SweepArgs& a, int A, int J1, int J2, bool grad, int a_lo, int a_hi) {
+    const int x1 = 0, x2 = A, n1 = 2 * A, n2 = 2 * A + J1, ns = a_hi - a_lo;
     int blk = 0, g = 0;
     auto add = [&](int own0, int nown, SweepSeg s0, SweepSeg s1) {
         if (nown <= 0) return;
         SweepGroup& G = a.grp[g++];
-        G.own0 = own0; G.nown = nown; G.blk0 = blk; G.nseg = 2; G.seg[0] = s0; G.seg[1] = s1;
+        G.own0 = own0; G.nown = nown; G.blk0 = blk; G.nseg = 2; G.seg[0] = s0; G.seg[1] = s1; G.nsplit = 1;
         blk += (nown + 127) / 128;
     };
-    add(x1, A, SweepSeg{n1, J1, 0}, SweepSeg{n2, J2, 1});       // s11, s12
-    add(x2, A, SweepSeg{n2, J2, 2}, SweepSeg{n1, J1, 3});       // s22, s21
+    add(x1 + a_lo, ns, SweepSeg{n1, J1, 0}, SweepSeg{n2, J2, 1});       // s11, s12
+    add(x2 + a_lo, ns, SweepSeg{n2, J2, 2}, SweepSeg{n1, J1, 3});       // s22, s21
     if (grad) {
-        add(n1, J1, SweepSeg{x1, A, 0}, SweepSeg{x2, A, 3});
-        add(n2, J2, SweepSeg{x1, A, 1}, SweepSeg{x2, A, 2});
+        add(n1, J1, SweepSeg{x1 + a_lo, ns, 0}, SweepSeg{x2 + a_lo, ns, 3});
+        add(n2, J2, SweepSeg{x1 + a_lo, ns, 1}, SweepSeg{x2 + a_lo, ns, 2});
     }
     a.ngroups = g;
 }
@@ -942,7 +947,7 @@ extern "C" int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, 
     SweepArgs a{};
     a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     a.sums = sums8; a.gs = nullptr; a.dZ = nullptr; a.col0 = 0;
-    fill_groups(a, A, J1, J2, false);
+    fill_groups(a, A, J1, J2, false, 0, A);
     const int nblk = total_blocks(a);
     const int jt = ((J1 > J2 ? J1 : J2) + 127) / 128;
     int gy = (8 * sga_num_cus() + nblk - 1) / nblk;
@@ -964,7 +969,7 @@ extern "C" int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, 
     SweepArgs a{};
     a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     a.sums = nullptr; a.gs = gs8; a.dZ = dZ;
-    fill_groups(a, A, J1, J2, true);
+    fill_groups(a, A, J1, J2, true, 0, A);
     const int nblk = total_blocks(a);
     int mx = A > J1 ? A : J1;
     if (J2 > mx) mx = J2;
@@ -991,9 +996,10 @@ extern "C" int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, 
 }
 
 static int fill_anchor(AnchorArgs& a, const float* const* Z, const int* Dp, int NT, int A, const double* sums,
-                       float alpha, float tau_icl, float tau_ial) {
+                       float alpha, float tau_icl, float tau_ial, int a_lo, int a_hi) {
     if (NT < 1 || NT > CT_MAXT) { sga_set_error("sga_loss_anchor: NT=%d outside [1,%d]", NT, CT_MAXT); return SGA_ERR_ARG; }
-    a.NT = NT; a.A = A; a.sums = sums; a.alpha = alpha;
+    if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("sga_loss_anchor: anchor shard [%d,%d) outside [0,%d]", a_lo, a_hi, A); return SGA_ERR_ARG; }
+    a.NT = NT; a.A = A; a.sums = sums; a.alpha = alpha; a.i_lo = a_lo; a.i_hi = a_hi;
     a.kc = LOG2E / tau_icl; a.ki = LOG2E / tau_ial; a.itc = 1.f / tau_icl; a.iti = 1.f / tau_ial;
     for (int k = 0; k < NT; ++k) {
         if (!Z[k] || Dp[k] % 8) { sga_set_error("sga_loss_anchor: table %d null or Dp %% 8 != 0", k); return SGA_ERR_ARG; }
@@ -1003,17 +1009,17 @@ static int fill_anchor(AnchorArgs& a, const float* const* Z, const int* Dp, int 
 }
 
 extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
-                                   float alpha, float tau_icl, float tau_ial, double* out, void* stream) {
+                                   float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && Dp && sums && out && A >= 0, "sga_loss_anchor_fwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = NT > 1 ? NT - 1 : 0;
     if (int rc0 = zero_slots(out, NT + 2 * M, s, "sga_loss_anchor_fwd")) return rc0;
-    if (A == 0) return SGA_OK;
+    if (A == 0 || a_hi <= a_lo) return SGA_OK;
     AnchorArgs a{};
-    int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial);
+    int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
     if (rc) return rc;
     a.out = out;
-    hipLaunchKernelGGL(anchor_kernel<false>, dim3((A + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    hipLaunchKernelGGL(anchor_kernel<false>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(out, NT + 2 * M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_fwd");
     return SGA_OK;
@@ -1021,17 +1027,17 @@ extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT,
 
 extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
                                    float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
-                                   double* gs, void* stream) {
+                                   double* gs, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && Dp && sums && coef && M1 && gs && A >= 0, "sga_loss_anchor_bwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(gs, NT * 8, s, "sga_loss_anchor_bwd")) return rc0;
-    if (A == 0) return SGA_OK;
+    if (A == 0 || a_hi <= a_lo) return SGA_OK;
     AnchorArgs a{};
-    int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial);
+    int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
     if (rc) return rc;
     a.coef = coef; a.gs = gs;
     for (int k = 0; k < NT; ++k) { SGA_CHECK_ARG(M1[k], "sga_loss_anchor_bwd: null stash %d", k); a.M1[k] = M1[k]; }
-    hipLaunchKernelGGL(anchor_kernel<true>, dim3((A + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    hipLaunchKernelGGL(anchor_kernel<true>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(gs, NT * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_bwd");
     return SGA_OK;
@@ -1039,13 +1045,14 @@ extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT,
 
 // ---- fused multi-table entry points (joint table == fusion of the M tables) ----------------------------
 static int fill_multi(MultiArgs& a, const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
-                      float tau1, bool grad) {
+                      float tau1, bool grad, int a_lo, int a_hi) {
+    if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("sga_loss_multi: anchor shard [%d,%d) outside [0,%d]", a_lo, a_hi, A); return SGA_ERR_ARG; }
     if (M < 2 || M > 4) { sga_set_error("sga_loss_multi: M=%d outside [2,4]", M); return SGA_ERR_ARG; }
     a.M = M;
     for (int m = 0; m < M; ++m) { if (!Z[m]) { sga_set_error("sga_loss_multi: null table"); return SGA_ERR_ARG; } a.Z[m] = Z[m]; }
     a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     SweepArgs tmp{};
-    fill_groups(tmp, A, J1, J2, grad);
+    fill_groups(tmp, A, J1, J2, grad, a_lo, a_hi);
     a.ngroups = tmp.ngroups;
     for (int g = 0; g < 4; ++g) a.grp[g] = tmp.grp[g];
     return SGA_OK;
@@ -1068,13 +1075,13 @@ static int plan_multi(MultiArgs& a, int target_steps) {
 }
 
 extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
-                                   float tau1, double* sums, void* stream) {
+                                   float tau1, double* sums, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums")) return rc0;
-    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     MultiArgs a{};
-    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false);
+    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi);
     if (rc) return rc;
     a.sums = sums;
     const int nwg = plan_multi(a, 160);
@@ -1087,15 +1094,16 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* be
 }
 
 extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
-                                   float tau1, const double* gs, float* const* dZ, double* gamma, void* stream) {
+                                   float tau1, const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi,
+                                   void* stream) {
     SGA_CHECK_ARG(Z && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    if (int rcz = zero_slots(gamma, M > 0 ? M : 1, s, "sga_loss_multi_grad")) return rcz;
+    if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     MultiArgs a{};
-    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, true);
+    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, true, a_lo, a_hi);
     if (rc) return rc;
     a.gs = gs; a.gamma = gamma;
-    if (int rc0 = zero_slots(gamma, M, s, "sga_loss_multi_grad")) return rc0;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }
     const int nwg = plan_multi(a, 160);
     if (M == 2) launch_sweep_multi<2, 0, 2, true>(a, nwg, s);
@@ -1139,29 +1147,36 @@ extern "C" int sga_loss_check_norms(const float* nrm, int n, float* poison, void
 
 extern "C" int sga_loss_slots(void) { return SGA_SLOTS; }
 
-/* dZ[0:A] += M1^T X2 and dZ[A:2A] += M1 X1 for one table (Z = [X1 | X2 | ...] rows of width Dp) */
-extern "C" int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, void* stream) {
-    SGA_CHECK_ARG(M1 && Z && dZ && A >= 0 && Dp >= 8 && Dp % 8 == 0, "sga_loss_stash_grad: bad argument");
-    if (A == 0) return SGA_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int gx = (A + 127) / 128;
+/* For one table (Z = [X1 | X2 | ...] rows of width Dp) and the anchor shard [a_lo, a_hi) that produced M1 [A, a_hi-a_lo]:
+ * dZ[a_lo:a_hi] += M1^T X2   and   dZ[A:2A] += M1 X1[a_lo:a_hi] */
+static void launch_stash(bool trans, int nct10, const float* M1, const float* X, float* out, int MR, int KR, int ldm, int ld,
+                         int w, hipStream_t s) {
+    const int gx = (MR + 127) / 128;
     int splits = (6 * sga_num_cus() + gx - 1) / gx;
-    int kper = ((A + splits - 1) / splits + 7) / 8 * 8;
+    int kper = ((KR + splits - 1) / splits + 7) / 8 * 8;
     if (kper < 64) kper = 64;
-    splits = (A + kper - 1) / kper;
-    const float* X1 = Z;
-    const float* X2 = Z + (size_t)A * Dp;
+    splits = (KR + kper - 1) / kper;
+    dim3 grid(gx, splits), blk(256);
+    if (trans) {
+        if (nct10) hipLaunchKernelGGL((stash_gemm_kernel<10, true>), grid, blk, 0, s, M1, X, out, MR, KR, ldm, ld, w, kper);
+        else hipLaunchKernelGGL((stash_gemm_kernel<4, true>), grid, blk, 0, s, M1, X, out, MR, KR, ldm, ld, w, kper);
+    } else {
+        if (nct10) hipLaunchKernelGGL((stash_gemm_kernel<10, false>), grid, blk, 0, s, M1, X, out, MR, KR, ldm, ld, w, kper);
+        else hipLaunchKernelGGL((stash_gemm_kernel<4, false>), grid, blk, 0, s, M1, X, out, MR, KR, ldm, ld, w, kper);
+    }
+}
+
+extern "C" int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi, void* stream) {
+    SGA_CHECK_ARG(M1 && Z && dZ && A >= 0 && Dp >= 8 && Dp % 8 == 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi, "sga_loss_stash_grad: bad argument");
+    const int ns = a_hi - a_lo;
+    if (A == 0 || ns == 0) return SGA_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* X1 = Z + (size_t)a_lo * Dp;             // the shard's X1 rows
+    const float* X2 = Z + (size_t)A * Dp;                // all X2 rows
     for (int c0 = 0; c0 < Dp; c0 += 320) {               // column blocks of <= 320 (the 104*M-wide joint operand takes one or two)
         const int w = Dp - c0 < 320 ? Dp - c0 : 320;
-        float* o1 = dZ + c0;
-        float* o2 = dZ + (size_t)A * Dp + c0;
-        if (w <= 128) {
-            hipLaunchKernelGGL((stash_gemm_kernel<4, true>), dim3(gx, splits), dim3(256), 0, s, M1, X2 + c0, o1, A, Dp, w, kper);
-            hipLaunchKernelGGL((stash_gemm_kernel<4, false>), dim3(gx, splits), dim3(256), 0, s, M1, X1 + c0, o2, A, Dp, w, kper);
-        } else {
-            hipLaunchKernelGGL((stash_gemm_kernel<10, true>), dim3(gx, splits), dim3(256), 0, s, M1, X2 + c0, o1, A, Dp, w, kper);
-            hipLaunchKernelGGL((stash_gemm_kernel<10, false>), dim3(gx, splits), dim3(256), 0, s, M1, X1 + c0, o2, A, Dp, w, kper);
-        }
+        launch_stash(true, w > 128, M1, X2 + c0, dZ + (size_t)a_lo * Dp + c0, ns, A, ns, Dp, w, s);
+        launch_stash(false, w > 128, M1, X1 + c0, dZ + (size_t)A * Dp + c0, A, ns, ns, Dp, w, s);
     }
     SGA_CHECK_LAUNCH("sga_loss_stash_grad");
     return SGA_OK;

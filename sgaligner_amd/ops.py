@@ -258,7 +258,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
         out = torch.empty((slots * (nt + 2 * m),), device=dev, dtype=torch.float64)
         zarr = _ptr_array(zs)
         dparr = (_ct.c_int * nt)(*dps)
-        _lib.check(L.sga_loss_anchor_fwd(zarr, dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), st),
+        _lib.check(L.sga_loss_anchor_fwd(zarr, dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), 0, s.A, st),
                    'sga_loss_anchor_fwd')
         ctx.s, ctx.alpha, ctx.dps, ctx.nt = s, float(alpha), dps, nt
         ctx.shapes = [tuple(t.shape) for t in tables]
@@ -279,7 +279,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
         gs = torch.empty((1 + L.sga_loss_slots(), nt, 8), device=dev, dtype=torch.float64)
         dparr = (_ct.c_int * nt)(*dps)
         _lib.check(L.sga_loss_anchor_bwd(_ptr_array(zs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
-                                         _ptr_array(m1), _p(gs), st), 'sga_loss_anchor_bwd')
+                                         _ptr_array(m1), _p(gs), 0, A, st), 'sga_loss_anchor_bwd')
         gs = gs[0]
         grads = []
         for k in range(nt):
@@ -287,7 +287,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
             dz = torch.zeros((s.R, dp), device=dev, dtype=torch.float32)
             if A > 0:
                 # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]
-                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(z), A, dp, _p(dz), st), 'sga_loss_stash_grad')
+                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(z), A, dp, _p(dz), 0, A, st), 'sga_loss_stash_grad')
             m1[k] = None
             ev = None
             if KERNEL_EVENTS is not None and dp <= 128:
@@ -443,13 +443,26 @@ def simrank(emb, pair_counts, q_pair, q_idx, q_tgt, k: int):
     return rank[:Q], tk[:Q, :k], ts[:Q, :k]
 
 
+def _allreduce_sum(t, group_reduce):
+    """Sum a device tensor over the ranks that shard the anchors (identity on one GPU)."""
+    if group_reduce is not None:
+        group_reduce(t)
+    return t
+
+
 class FusedContrastiveFn(torch.autograd.Function):
     """Same outputs as ContrastiveTermsFn for tables (E_1..E_M, joint) when joint == MultiModalFusion(E_1..E_M):
     the joint similarities are derived from the modality tiles (S_J = sum_m beta_m S_m), so the 300-d table is
-    never swept.  Inputs: beta [M] (= softmax(w)^2 / sum, differentiable), the M modality tables."""
+    never swept.  Inputs: beta [M] (= softmax(w)^2 / sum, differentiable), the M modality tables.
+
+    Sharding (one process per GPU): `shard = (a_lo, a_hi)` is the anchor range this rank owns and `reduce` an in-place
+    SUM all-reduce.  Each rank evaluates its shard's share of every global sum / loss term (all-reduced, so the
+    returned values are the batch-global ones on every rank) and, in backward, its shard's share of dL/dE for ALL
+    rows -- the caller sums those over ranks (dist.AllGatherRows with reduce_grad=True).  dL/dbeta is returned as
+    this rank's share as well (the parameter-gradient all-reduce completes it)."""
 
     @staticmethod
-    def forward(ctx, index_sets, alpha, beta, *tables):
+    def forward(ctx, index_sets, alpha, shard, reduce, beta, *tables):
         L = _lib.lib()
         M = len(tables)
         nt = M + 1
@@ -457,6 +470,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         beta = _req(beta.contiguous(), 'beta')
         dev = tables[0].device
         s = index_sets
+        a_lo, a_hi = (0, s.A) if shard is None else (int(shard[0]), int(shard[1]))
         T = tables[0].shape[0]
         st = _stream()
         dp = 104
@@ -475,23 +489,27 @@ class FusedContrastiveFn(torch.autograd.Function):
         zarr = _ptr_array(zs)
         slots = 1 + L.sga_loss_slots()
         sums = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
-        _lib.check(L.sga_loss_multi_sums(zarr, M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), st), 'sga_loss_multi_sums')
-        sums = sums[0]
+        _lib.check(L.sga_loss_multi_sums(zarr, M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), a_lo, a_hi, st),
+                   'sga_loss_multi_sums')
+        sums = _allreduce_sum(sums[0].contiguous(), reduce)
         zj = torch.empty((2 * s.A, M * dp), device=dev, dtype=torch.float32)
         _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')
         out = torch.empty((slots * (nt + 2 * M),), device=dev, dtype=torch.float64)
         dps = [dp] * M + [M * dp]
         _lib.check(L.sga_loss_anchor_fwd(_ptr_array(zs + [zj]), (_ct.c_int * nt)(*dps), nt, s.A, _p(sums), float(alpha),
-                                         TAU_ICL, TAU_IAL, _p(out), st), 'sga_loss_anchor_fwd')
-        ctx.s, ctx.alpha, ctx.M = s, float(alpha), M
+                                         TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi, st), 'sga_loss_anchor_fwd')
+        out = _allreduce_sum(out[:nt + 2 * M].contiguous(), reduce)
+        ctx.s, ctx.alpha, ctx.M, ctx.shard, ctx.reduce = s, float(alpha), M, (a_lo, a_hi), reduce
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.save_for_backward(sums, beta, zj, *zs, *nrms)
-        return out[:nt + 2 * M].float() + poison
+        return out.float() + poison
 
     @staticmethod
     def backward(ctx, gout):
         L = _lib.lib()
         s, M = ctx.s, ctx.M
+        a_lo, a_hi = ctx.shard
+        ns = a_hi - a_lo
         nt = M + 1
         sums, beta, zj, *rest = ctx.saved_tensors
         zs, nrms = rest[:M], rest[M:]
@@ -500,22 +518,22 @@ class FusedContrastiveFn(torch.autograd.Function):
         dp = 104
         A = s.A
         coef = gout.contiguous().float()
-        m1 = [torch.empty((A, A), device=dev, dtype=torch.float32) for _ in range(nt)]
+        m1 = [torch.empty((A, max(ns, 1)), device=dev, dtype=torch.float32) for _ in range(nt)]
         slots = 1 + L.sga_loss_slots()
         gs = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
         dps = [dp] * M + [M * dp]
         _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
-                                         TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gs), st), 'sga_loss_anchor_bwd')
-        gs = gs[0]
+                                         TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gs), a_lo, a_hi, st), 'sga_loss_anchor_bwd')
+        gs = _allreduce_sum(gs[0].contiguous(), ctx.reduce)          # dL/d(global sums) needs every shard's tiles
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for _ in range(M)]
         gam_neg = torch.empty((slots, M), device=dev, dtype=torch.float64)   # dL/dbeta via the negatives (zeroed by the callee)
         gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via sqrt(beta) in the anchor rows of ZJ
-        if A > 0:
+        if A > 0 and ns > 0:
             for k in range(M):
-                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), st), 'sga_loss_stash_grad')
+                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), a_lo, a_hi, st), 'sga_loss_stash_grad')
                 m1[k] = None
             dzj = torch.zeros((2 * A, M * dp), device=dev, dtype=torch.float32)
-            _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), st), 'sga_loss_stash_grad')
+            _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), a_lo, a_hi, st), 'sga_loss_stash_grad')
             m1[M] = None
             _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), _p(gam_anc), st),
                        'sga_loss_fold_joint')
@@ -524,10 +542,10 @@ class FusedContrastiveFn(torch.autograd.Function):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         _lib.check(L.sga_loss_multi_grad(_ptr_array(zs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
-                                         _p(gam_neg), st), 'sga_loss_multi_grad')
+                                         _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad')
         if ev is not None:
             ev[1].record()
-            KERNEL_EVENTS.setdefault(f'sweep_multi_kernel<{M},grad>', []).append(ev + ((A, s.J1, s.J2, M),))
+            KERNEL_EVENTS.setdefault(f'sweep_multi_kernel<{M},grad>', []).append(ev + ((ns, A, s.J1, s.J2, M),))
         grads = []
         for k in range(M):
             t, d = ctx.shapes[k]
@@ -535,15 +553,14 @@ class FusedContrastiveFn(torch.autograd.Function):
             _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
             grads.append(de)
         # d/dbeta_m: through the negatives (gamma) + through sqrt(beta_m) in the anchor rows of ZJ
-        if A == 0 or (s.J1 == 0 and s.J2 == 0):
-            gam_neg.zero_()
         gbeta = (gam_neg[0] + gam_anc / (2.0 * torch.sqrt(beta.double()))).float()
-        return (None, None, gbeta, *grads)
+        return (None, None, None, None, gbeta, *grads)
 
 
-def fused_contrastive_terms(tables, fusion_weight, data_dict, alpha=ALPHA):
-    """tables: the M modality tables the joint table was fused from; fusion_weight: the [M,1] parameter."""
+def fused_contrastive_terms(tables, fusion_weight, data_dict, alpha=ALPHA, shard=None, reduce=None):
+    """tables: the M modality tables the joint table was fused from; fusion_weight: the [M,1] parameter.
+    shard / reduce: see FusedContrastiveFn (anchor range owned by this rank, in-place SUM all-reduce)."""
     s = IndexSets.of(data_dict, tables[0].device)
     w = torch.softmax(fusion_weight.reshape(-1), dim=0)                # sg_aligner.py:32
     beta = (w * w) / (w * w).sum()
-    return FusedContrastiveFn.apply(s, alpha, beta, *tables), s
+    return FusedContrastiveFn.apply(s, alpha, shard, reduce, beta, *tables), s

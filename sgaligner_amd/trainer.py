@@ -70,15 +70,22 @@ class AlignerSteps:
 
     # -- batch-global loss across ranks -------------------------------------------------------------
     def _global_loss(self, output_dict, data_dict):
-        """All-gather the tables and index sets; every rank evaluates the batch-global loss (a replica:
-        identical value on every rank) and back-propagates only into its own rows -- so the table
-        gradient needs no reduction, and the parameter gradients are summed by allreduce_grads."""
-        world = dist.get_world_size()
+        """Batch-global loss over all ranks' pairs.  Tables and index sets are all-gathered (RCCL).
+        M >= 2 (fused joint path): the anchors are SHARDED -- each rank evaluates the loss terms / global sums of its own
+        anchors against all negatives (partial scalars all-reduced inside ops.FusedContrastiveFn, so every rank holds the
+        global loss value) and its share of dL/dE for all rows, summed over ranks in AllGatherRows.backward.
+        M == 1: every rank evaluates the (small) global loss as a replica and keeps only its own rows' gradient."""
+        world, rank = dist.get_world_size(), dist.get_rank()
         t_local = int(data_dict['tot_obj_pts'].shape[0])
-        rows = [None] * world
-        dist.all_gather_object(rows, t_local)
-        gathered = sdist.gather_tables(output_dict, rows, reduce_grad=False)
-        if 'joint' in gathered:          # the gathered joint is the fusion of the gathered tables (replicated weight)
-            gathered['joint']._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
+        info = [None] * world
+        dist.all_gather_object(info, (t_local, int(len(data_dict['e1i']))))
+        rows = [i[0] for i in info]
+        anchors = [i[1] for i in info]
+        sharded = len(self.modules) > 1
+        gathered = sdist.gather_tables(output_dict, rows, reduce_grad=sharded)
         gdd = sdist.gather_index_sets(data_dict, rows)
+        if sharded:        # the gathered joint is the fusion of the gathered tables (replicated weight)
+            gathered['joint']._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
+            gdd['_sga_shard'] = (sum(anchors[:rank]), sum(anchors[:rank + 1]))
+            gdd['_sga_reduce'] = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return self.loss_func(gathered, gdd)

@@ -194,3 +194,57 @@ def test_fused_path_fails_loudly_on_zero_rows():
     fn = L.OverallLoss(L.CustomMultiLossLayer(2).cuda(), L.CustomMultiLossLayer(2).cuda(), 'cuda',
                        {'zoom': 0.1, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': ['point', 'rel']})
     assert torch.isnan(fn(out, dd)['loss']).item()
+
+
+def test_anchor_sharded_loss_equals_unsharded():
+    """Multi-GPU loss sharding, simulated on one GPU: R 'ranks' each own a contiguous anchor range; the all-reduces
+    inside ops.FusedContrastiveFn (2 in forward, 1 in backward) are replayed deterministically: round n supplies the
+    totals of reduce #0..n-1 recorded in earlier rounds and records the partials of reduce #n.  Summed over ranks, the
+    loss and every gradient must equal the unsharded result (what AlignerSteps._global_loss does over RCCL)."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(5, 24, 8, seed=11, ragged=True, anchors='val')
+    T = int(dd['tot_obj_count'].sum())
+    M, R = 3, 3
+    torch.manual_seed(0)
+    base = [torch.randn(T, 100, device='cuda') for _ in range(M)]
+    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')
+    cot = torch.randn(M + 1 + 2 * M, device='cuda')
+
+    def run(shard, reduce):
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        w = w0.clone().requires_grad_(True)
+        sums, s = ops.fused_contrastive_terms(tabs, w, dict(dd), shard=shard, reduce=reduce)
+        (sums * cot).sum().backward()
+        torch.cuda.synchronize()
+        return sums.detach(), [t.grad for t in tabs], w.grad, s
+
+    ref_sums, ref_grads, ref_w, s = run(None, None)
+    A = s.A
+    cuts = [0, A // 3 + 1, 2 * A // 3, A]
+    totals = []                                   # totals[n] = sum over ranks of the n-th all-reduced tensor
+    n_reduces = 3
+    results = None
+    for rnd in range(n_reduces + 1):
+        partial = [None] * R
+        results = []
+        for rank in range(R):
+            def reduce(t, rank=rank, state={'n': 0}):
+                n = state['n']
+                state['n'] += 1
+                if n < len(totals):
+                    t.copy_(totals[n])
+                elif n == len(totals):
+                    partial[rank] = t.clone()
+            reduce.__defaults__[1]['n'] = 0
+            results.append(run((cuts[rank], cuts[rank + 1]), reduce))
+        if rnd < n_reduces:
+            assert all(p is not None for p in partial), rnd
+            totals.append(sum(partial))
+    for r in range(R):
+        assert torch.allclose(results[r][0], ref_sums, rtol=1e-4, atol=1e-5)       # every rank holds the global values
+    for m in range(M):
+        g = sum(results[r][1][m] for r in range(R))
+        assert (g - ref_grads[m]).abs().max() < 1e-4 * max(1.0, ref_grads[m].abs().max().item()), m
+    gw = sum(results[r][2] for r in range(R))
+    assert (gw - ref_w).abs().max() < 1e-4 * max(1.0, ref_w.abs().max().item())
