@@ -20,8 +20,9 @@ def init_from_env(backend=None):
     rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
     if not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+            backend = os.environ.get('SGA_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()       # several ranks may share a GPU in gloo test runs
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -93,3 +94,29 @@ def allreduce_grads(params, average: bool = False):
         n = p.grad.numel()
         p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
+
+
+def shard_data_dict(data_dict, lo: int, hi: int):
+    """The pairs [lo, hi) of a collated batch as a self-contained data_dict (what this rank's loader would have
+    collated): tensors sliced by object / edge ranges, index sets re-based to the shard's first object."""
+    cnt = np.asarray(data_dict['tot_obj_count']).reshape(-1)
+    offs = np.concatenate([[0], np.cumsum(cnt)])
+    o0, o1 = int(offs[lo]), int(offs[hi])
+    out = {}
+    for k in ('tot_obj_pts', 'tot_bow_vec_object_attr_feats', 'tot_bow_vec_object_edge_feats', 'tot_rel_pose'):
+        if k in data_dict:
+            out[k] = data_dict[k][o0:o1]
+    if 'edges' in data_dict:
+        ec = np.asarray(data_dict['graph_per_edge_count']).reshape(-1, 2)
+        eo = np.concatenate([[0], np.cumsum(ec.sum(1))])
+        out['edges'] = data_dict['edges'][int(eo[lo]):int(eo[hi])]
+        out['graph_per_edge_count'] = ec[lo:hi]
+    for name, ck in (('e1i', 'e1i_count'), ('e2i', 'e2i_count'), ('e1j', 'e1j_count'), ('e2j', 'e2j_count')):
+        c = np.asarray(data_dict[ck]).reshape(-1)
+        co = np.concatenate([[0], np.cumsum(c)])
+        out[name] = (np.asarray(data_dict[name])[int(co[lo]):int(co[hi])] - o0).astype(np.int32)
+        out[ck] = c[lo:hi]
+    out['tot_obj_count'] = cnt[lo:hi]
+    out['graph_per_obj_count'] = np.asarray(data_dict['graph_per_obj_count'])[lo:hi]
+    out['batch_size'] = hi - lo
+    return out
