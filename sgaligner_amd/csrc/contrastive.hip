@@ -451,8 +451,15 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
 #pragma unroll
     for (int m = 0; m < M; ++m) gam[m] = 0.f;
 
+    // The LDS destination of global_load_lds travels in M0 and must be PROVABLY wave-uniform: with the plain wave id
+    // (derived from threadIdx) hipcc wraps every DMA in a waterfall loop with s_waitcnt vmcnt(0) in front of it, i.e.
+    // the pieces are issued one L2 round trip at a time (measured: 4 ms of this kernel).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int j0, float* buf) {             // DMA the M [32][104] tiles starting at row j0
-        for (int c = wave; c < NCHUNK; c += 4) {
+#pragma unroll
+        for (int c0 = 0; c0 < NCHUNK; c0 += 4) {
+            const int c = c0 + wave_u;
+            if (c >= NCHUNK) break;
             const int m = c / 13, cc = c - m * 13;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(a.Z[m] + (size_t)j0 * DP + cc * 256 + lane * 4),
@@ -517,17 +524,18 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
                 for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool ok = iv && (j0 + mfma32_row(r, h) < j_end);
+                    // masks as multipliers: `ok ? exp : 0` is compiled into an exec-mask branch per element
+                    const float okf = (iv && (j0 + mfma32_row(r, h) < j_end)) ? 1.f : 0.f;
                     float sj = 0.f;
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
                         const float sv = sacc[m][r];
                         sj = fmaf(beta[m], sv, sj);
-                        p0[m] += ok ? fexp2(sv * a.k0) : 0.f;
-                        p1[m] += ok ? fexp2(sv * a.k1) : 0.f;
+                        p0[m] = fmaf(okf, fexp2(sv * a.k0), p0[m]);
+                        p1[m] = fmaf(okf, fexp2(sv * a.k1), p1[m]);
                     }
-                    p0[M] += ok ? fexp2(sj * a.k0) : 0.f;
-                    p1[M] += ok ? fexp2(sj * a.k1) : 0.f;
+                    p0[M] = fmaf(okf, fexp2(sj * a.k0), p0[M]);
+                    p1[M] = fmaf(okf, fexp2(sj * a.k1), p1[M]);
                 }
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
@@ -538,11 +546,11 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
                 float cj[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool ok = iv && (j0 + mfma32_row(r, h) < j_end);
+                    const float okf = (iv && (j0 + mfma32_row(r, h) < j_end)) ? 1.f : 0.f;
                     float sj = 0.f;
 #pragma unroll
                     for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][r], sj);
-                    cj[r] = ok ? c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1) : 0.f;
+                    cj[r] = okf * (c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1));
                 }
                 if (G0 == 0 && g < 2) {                         // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
 #pragma unroll
@@ -556,9 +564,9 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
                     float cm[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const bool ok = iv && (j0 + mfma32_row(r, h) < j_end);
+                        const float okf = (iv && (j0 + mfma32_row(r, h) < j_end)) ? 1.f : 0.f;
                         const float sv = sacc[m][r];
-                        cm[r] = ok ? fmaf(beta[m], cj[r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1)) : 0.f;
+                        cm[r] = okf * fmaf(beta[m], cj[r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1));
                     }
                     const float* bb = buf + m * TILE_F + (lane & 31);
                     float bc[NCT], bn[NCT];
