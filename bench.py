@@ -35,7 +35,9 @@ def cpu_baseline(seconds_budget=20.0):
     with the same (objects, points, modules) as the GPU workload."""
     from oracle import sga_oracle as O
     from sgaligner_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    # Thread count: on the 2 x 64-core EPYC 9575F GPU host a sweep over {4,8,16,32,64,128} threads (tools/cpu_threads.py)
+    # peaks at 32 (5.9 pairs/s); all 256 hardware threads are 20x SLOWER (0.26 pairs/s) on these small per-graph ops.
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     b = 2
     dd = make_batch(b, N_OBJ, N_PTS, seed=43, device='cpu')
@@ -50,7 +52,32 @@ def cpu_baseline(seconds_budget=20.0):
     med = float(np.median(times))
     return {'value': b / med, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
             'sample': f'oracle fwd+loss+bwd, b={b} pairs x {N_OBJ} obj x {N_PTS} pts, {"+".join(MODULES)}, '
-                      f'{len(times)} iterations, median {med*1e3:.1f} ms, torch {torch.__version__} CPU, {cores} threads'}
+                      f'{len(times)} iterations, median {med*1e3:.1f} ms, torch {torch.__version__} CPU, {cores} threads '
+                      f'(best of a thread-count sweep; host has {os.cpu_count()} hardware threads)'}
+
+
+def pmc_traffic_bytes():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
+    (profiles/r01_e_pmc_sweep_multi.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of bench.py, KiB per dispatch;
+    gfx950 correction: FETCH_SIZE counts wide coalesced reads at half their size -> x2, MI355X_MICROARCH.md, HBM)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_e_pmc_sweep_multi.csv')
+    try:
+        f = w = None
+        for line in open(path):
+            if line.startswith('#') or ', true>' not in line:
+                continue
+            parts = line.strip().split(',')
+            name_end = len(parts) - 7
+            counter, value = parts[name_end], float(parts[name_end + 1])
+            if counter == 'FETCH_SIZE':
+                f = value
+            elif counter == 'WRITE_SIZE':
+                w = value
+        if f is None or w is None:
+            return None
+        return int((2.0 * f + w) * 1024)
+    except OSError:
+        return None
 
 
 def main():
@@ -117,7 +144,7 @@ def main():
             avg_ms = float(np.mean(durs))
             ach = alg / (avg_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': None,
+                    'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': pmc_traffic_bytes() if world == 1 else None,
                     'kernel': f'sweep_multi_kernel<{M},0,{M},true> (loss: negatives backward, all {M}+1 tables)',
                     'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4),
                     'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed,

@@ -756,6 +756,8 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
                         la += ok ? ta : 0.f;
                         lb += ok ? tb : 0.f;
                     }
+                    // one element at a time: fully interleaved, the 32 unrolled elements need >512 registers (spills, 1 wave/SIMD)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             icl = wave_sum(icl);
             if (lane == 0) atomicAdd(out_s + k, (double)icl);
@@ -799,6 +801,7 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
                         gs_j[0] += uA * MA.dsa; gs_j[1] += uA * MA.dsb; gs_j[2] += uB * MB.dsa; gs_j[3] += uB * MB.dsb;
                     }
                     P[t][r] = gx;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
