@@ -894,6 +894,275 @@ __global__ __launch_bounds__(256) void stash_gemm_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused anchors x anchors kernel for the "joint = fusion of the M tables" case (Dp == 104).
+//
+// Same math as anchor_kernel, but S_J = sum_m beta_m S_m is derived in registers, so neither the 312-wide joint
+// operand nor its dL/dS stash exist: G_m = dL/dS_m + beta_m dL/dS_J is written directly, and Gamma_m = sum dL/dS_J S_m
+// (dL/dbeta) is accumulated on the side.  Geometry, chosen from the counters of anchor_kernel (49 % of wave time in
+// waitcnt/barrier on single-buffered K-chunk staging, 512 registers -> 1 wave/SIMD):
+//   * a workgroup owns 32 anchor rows I for ALL its J tiles: X1_I / X2_I of the M tables (2*M*13 KiB) are staged into
+//     LDS once and are the MFMA B operands (ds_read_b128), so "lane = anchor row i";
+//   * each of the 4 waves walks its own 32-row J tiles; the J-side operands go straight from global/L2 into MFMA
+//     A-operand fragments (one float4 per lane per 4 MFMAs) -- no staging, no barriers in the loop;
+//   * all 2*M S tiles of a (I,J) tile stay in registers (96 for M = 3), ~200 VGPRs total -> 2 waves per SIMD, so one
+//     wave's transcendental-heavy epilogue overlaps the other's MFMAs / loads.
+// ------------------------------------------------------------------------------------------------
+struct AnchorMultiArgs {
+    int M, A, i_lo, i_hi, nsplit;
+    const float* Z[4];
+    const float* beta;             // [M]
+    const double* sums;            // [(M+1)][8]
+    float alpha, kc, ki, itc, iti;
+    double* out;                   // fwd: [(M+1) + 2M] (+ slots)
+    const float* coef;             // bwd: dL/d(out)
+    float* M1[4];                  // bwd: M1[m][j*ns + (i - i_lo)] = dL/dS_m[i,j] (+ beta_m dL/dS_J)
+    double* gs;                    // bwd: [(M+1)][8] (+ slots)
+    double* gamma;                 // bwd: [M] (+ slots)
+};
+
+template <int M, bool BWD>
+__global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_kernel(AnchorMultiArgs a) {
+    constexpr int DP = 104, NQ = 13, NT = M + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][32][DP] own rows + inv_s[NT*8]
+    float* inv_s = lds + M * 2 * 32 * DP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int A = a.A, ns = a.i_hi - a.i_lo;
+    const int ib = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
+    const int i0 = a.i_lo + ib * 32;
+    const int my_i = i0 + l31;
+    const bool iv = my_i < a.i_hi;
+
+    // ---- stage the I block (rows past the shard end are clamped; masked in the epilogue)
+    for (int e = tid; e < M * 2 * 32 * (DP / 4); e += CT_THREADS) {
+        const int c = (e % (DP / 4)) * 4, r = (e / (DP / 4)) % 32, side = (e / (DP / 4) / 32) % 2, m = e / (DP / 4) / 64;
+        const int row = min(i0 + r, a.i_hi - 1) + side * A;
+        *reinterpret_cast<f32x4*>(lds + ((m * 2 + side) * 32 + r) * DP + c) = *reinterpret_cast<const f32x4*>(a.Z[m] + (size_t)row * DP + c);
+    }
+    for (int e = tid; e < NT * 8; e += CT_THREADS) inv_s[e] = (float)(1.0 / (a.sums[e] + 1e-9));
+    __syncthreads();
+    float beta[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
+
+    // per-lane partial sums over all this wave's tiles
+    float acc_out[BWD ? 1 : NT + 2 * M];
+    float acc_gam[BWD ? M : 1];
+#pragma unroll
+    for (int e = 0; e < (BWD ? 1 : NT + 2 * M); ++e) acc_out[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < (BWD ? M : 1); ++e) acc_gam[e] = 0.f;
+
+    const int ntile = (A + 31) / 32;
+    for (int jt = split * 4 + wave; jt < ntile; jt += a.nsplit * 4) {
+        const int j0 = jt * 32;
+        const int jrow = min(j0 + l31, A - 1);                       // this lane's J row as an MFMA A-operand row
+        // ---- S tiles: P[m][r] = S_m[i = lane, j = j0 + row(r,h)],  Q[m][r] = S_m[j, i]
+        f32x16 P[M], Q[M];
+        zero_acc<M>(P);
+        zero_acc<M>(Q);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float* gp = a.Z[m] + (size_t)(A + jrow) * DP + 4 * h;      // X2[j] for P
+            const float* gq = a.Z[m] + (size_t)jrow * DP + 4 * h;            // X1[j] for Q
+            const float* bp = lds + ((m * 2 + 0) * 32 + l31) * DP + 4 * h;   // X1[i]
+            const float* bq = lds + ((m * 2 + 1) * 32 + l31) * DP + 4 * h;   // X2[i]
+            // J-side fragments are prefetched exactly one K-group ahead into the other of two register pairs; the
+            // sched_barrier per group stops the scheduler from hoisting all 2*13 global loads of the table (spills).
+            f32x4 apA = *reinterpret_cast<const f32x4*>(gp), aqA = *reinterpret_cast<const f32x4*>(gq), apB = apA, aqB = aqA;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) {
+                    if (q & 1) { apA = *reinterpret_cast<const f32x4*>(gp + 8 * (q + 1)); aqA = *reinterpret_cast<const f32x4*>(gq + 8 * (q + 1)); }
+                    else { apB = *reinterpret_cast<const f32x4*>(gp + 8 * (q + 1)); aqB = *reinterpret_cast<const f32x4*>(gq + 8 * (q + 1)); }
+                }
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 8 * q);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(bq + 8 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    P[m] = __builtin_amdgcn_mfma_f32_32x32x2f32((q & 1) ? apB[r] : apA[r], b1[r], P[m], 0, 0, 0);
+                    Q[m] = __builtin_amdgcn_mfma_f32_32x32x2f32((q & 1) ? aqB[r] : aqA[r], b2[r], Q[m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // From here on the S tiles are handled as SCALARS: in-place element updates of the 16-wide accumulator vectors
+        // (Q[m][r] = ...) make hipcc keep several versions of each vector alive -- >6 KB of scratch per lane.
+        float xs[M][16], ys[M][16];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { xs[m][r] = P[m][r]; ys[m][r] = Q[m][r]; }
+        // ---- epilogue, one element at a time (forward)
+        const float* js = inv_s + M * 8;
+        if (!BWD)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + mfma32_row(r, h);
+            const bool ok = iv && j < A;
+            float xj = 0.f, yj = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], xs[m][r], xj); yj = fmaf(beta[m], ys[m][r], yj); }
+            {
+                const float dji = fexp2(xj * a.ki);
+                const float qma = g_val(dji, js[1], js[3]), qmb = g_val(dji, js[5], js[7]);
+                const float lqma = flog(qma), lqmb = flog(qmb);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const float x = k < M ? xs[k < M ? k : 0][r] : xj, y = k < M ? ys[k < M ? k : 0][r] : yj;
+                    const float* is = inv_s + k * 8;
+                    const float qa = g_val(fexp2(x * a.kc), is[0], is[2]);
+                    const float qb = g_val(fexp2(y * a.kc), is[4], is[6]);
+                    const float term = -flog(a.alpha * qa + (1.f - a.alpha) * qb);
+                    acc_out[k] += ok ? term : 0.f;
+                    if (k < M) {
+                        const float dm = fexp2(x * a.ki);
+                        const float qoa = g_val(dm, is[1], is[3]), qob = g_val(dm, is[5], is[7]);
+                        const float ta = __expf(qoa) * (qoa - lqma), tb = __expf(qob) * (qob - lqmb);
+                        acc_out[NT + (k < M ? k : 0)] += ok ? ta : 0.f;
+                        acc_out[NT + M + (k < M ? k : 0)] += ok ? tb : 0.f;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue (backward) in table-major passes: only ONE table's 8 sum coefficients / 3 upstream coefficients and
+        // one element's temporaries are live at a time (element-major with everything live needed > 512 registers).
+        //   pass 0: joint ICL      -> gJ[r]
+        //   pass 1: per modality   -> ICL_m + IAL_m (qo part) into ys[m][r]; EA/EB[r] = sum_m c_m exp(qo_m)
+        //   pass 2: joint IAL (qm) -> gJ[r] += ...
+        //   pass 3: Gamma_m += gJ S_m ;  xs[m][r] = dL/dS_m + beta_m dL/dS_J
+        if (BWD) {
+            // dL/d(sums) partials live only during their table's pass (keeping all (M+1)*8 per lane for the whole kernel
+            // pushed the kernel over 256 registers); each pass ends with 8 wave-sums into this wave's slot.
+            double* const gs_slot = a.gs + NT * 8 * (1 + my_slot());
+            auto flush8 = [&](float (&g8)[8], int k) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = wave_sum(g8[e]);
+                    if (lane == 0 && v != 0.f) atomicAdd(gs_slot + k * 8 + e, (double)v);
+                }
+            };
+            float gJ[16], EA[16], EB[16];
+            float gsJ[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            {
+                const float* is = inv_s + M * 8;
+                const float c = a.coef[M];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = iv && (j0 + mfma32_row(r, h) < A);
+                    float xj = 0.f, yj = 0.f;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], xs[m][r], xj); yj = fmaf(beta[m], ys[m][r], yj); }
+                    asm volatile("" : "+v"(xj), "+v"(yj));
+                    const float dx = fexp2(xj * a.kc), dy = fexp2(yj * a.kc);
+                    const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
+                    const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
+                    const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
+                    const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
+                    gJ[r] = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
+                    gsJ[0] += wA * Ax.dsa; gsJ[2] += wA * Ax.dsb;
+                    gsJ[4] += wB * Bx.dsa; gsJ[6] += wB * Bx.dsb;
+                    EA[r] = 0.f; EB[r] = 0.f;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float* is = inv_s + m * 8;
+                const float c = a.coef[m], ca = a.coef[NT + m], cb = a.coef[NT + M + m];
+                float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = iv && (j0 + mfma32_row(r, h) < A);
+                    const float x = xs[m][r], y = ys[m][r];
+                    float xj = 0.f;
+#pragma unroll
+                    for (int mm = 0; mm < M; ++mm) xj = fmaf(beta[mm], xs[mm][r], xj);
+                    // opaque: otherwise the joint-table terms (identical in every modality's pass) are CSE'd across the
+                    // passes and kept live for all 16 elements -- thousands of spilled registers instead of a few flops
+                    asm volatile("" : "+v"(xj));
+                    const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
+                    const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
+                    const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
+                    const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
+                    const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
+                    float gx = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
+                    g8[0] += wA * Ax.dsa; g8[2] += wA * Ax.dsb;
+                    g8[4] += wB * Bx.dsa; g8[6] += wB * Bx.dsb;
+                    // IAL: qo from this table, qm from the joint one (values only here; its derivative in pass 2)
+                    const float dm = fexp2(x * a.ki), dji = fexp2(xj * a.ki);
+                    const GV OA = g_full(dm, is[1], is[3]), OB = g_full(dm, is[5], is[7]);
+                    const float lqma = flog(g_val(dji, js[1], js[3])), lqmb = flog(g_val(dji, js[5], js[7]));
+                    const float eA = ok ? ca * __expf(OA.q) : 0.f, eB = ok ? cb * __expf(OB.q) : 0.f;
+                    const float tA = eA * (OA.q - lqma + 1.f), tB = eB * (OB.q - lqmb + 1.f);
+                    gx += (tA * OA.dd + tB * OB.dd) * dm * a.iti;
+                    g8[1] += tA * OA.dsa; g8[3] += tA * OA.dsb;
+                    g8[5] += tB * OB.dsa; g8[7] += tB * OB.dsb;
+                    EA[r] += eA; EB[r] += eB;
+                    ys[m][r] = gx;                                       // y_m is dead from here on
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                flush8(g8, m);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float xj = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) xj = fmaf(beta[m], xs[m][r], xj);
+                asm volatile("" : "+v"(xj));
+                const float dji = fexp2(xj * a.ki);
+                const GV MA = g_full(dji, js[1], js[3]), MB = g_full(dji, js[5], js[7]);
+                const float uA = -EA[r] * frcp(MA.q), uB = -EB[r] * frcp(MB.q);
+                gJ[r] += (uA * MA.dd + uB * MB.dd) * dji * a.iti;
+                gsJ[1] += uA * MA.dsa; gsJ[3] += uA * MA.dsb;
+                gsJ[5] += uB * MB.dsa; gsJ[7] += uB * MB.dsb;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            flush8(gsJ, M);
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc_gam[m] = fmaf(gJ[r], xs[m][r], acc_gam[m]);
+                    xs[m][r] = fmaf(beta[m], gJ[r], ys[m][r]);           // dL/dS_m total
+                }
+        }
+        if (BWD && iv) {
+            // The 16*M store addresses depend only on the tile, so the scheduler would compute them BEFORE the epilogue
+            // and keep ~100 address registers alive through it (the whole epilogue then spills).  An offset that only
+            // becomes known here pins the address arithmetic after the passes.
+            int late = 0;
+            asm volatile("" : "+v"(late));
+            const size_t col = (size_t)(my_i - a.i_lo + late);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                float* m1 = a.M1[m];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + mfma32_row(r, h);
+                    if (j < A) m1[(size_t)j * ns + col] = xs[m][r];
+                }
+            }
+        }
+    }
+    // ---- flush the wave's partial sums into its slot
+    const int slot = my_slot();
+    if (!BWD) {
+#pragma unroll
+        for (int e = 0; e < NT + 2 * M; ++e) {
+            const float v = wave_sum(acc_out[BWD ? 0 : e]);
+            if (lane == 0 && v != 0.f) atomicAdd(a.out + (NT + 2 * M) * (1 + slot) + e, (double)v);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float v = wave_sum(acc_gam[BWD ? m : 0]);
+            if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + slot) + m, (double)v);
+        }
+    }
+}
+
 int rows_grid(int R) {
     int g = (R + 3) / 4;
     const int cap = sga_num_cus() * 8;
@@ -1189,5 +1458,68 @@ extern "C" int sga_loss_stash_grad(const float* M1, const float* Z, int A, int D
         launch_stash(false, w > 128, M1, X1 + c0, dZ + (size_t)A * Dp + c0, A, ns, ns, Dp, w, s);
     }
     SGA_CHECK_LAUNCH("sga_loss_stash_grad");
+    return SGA_OK;
+}
+
+// ---- fused anchors x anchors entry points -------------------------------------------------------------------------
+static int fill_anchor_multi(AnchorMultiArgs& a, const float* const* Z, int M, const float* beta, int A, const double* sums,
+                             float alpha, float tau_icl, float tau_ial, int a_lo, int a_hi) {
+    if (M < 2 || M > 3) { sga_set_error("sga_loss_anchor_multi: M=%d not in {2,3} (use the per-table kernels)", M); return SGA_ERR_ARG; }
+    if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("sga_loss_anchor_multi: anchor shard [%d,%d) outside [0,%d]", a_lo, a_hi, A); return SGA_ERR_ARG; }
+    a.M = M; a.A = A; a.i_lo = a_lo; a.i_hi = a_hi; a.beta = beta; a.sums = sums; a.alpha = alpha;
+    a.kc = LOG2E / tau_icl; a.ki = LOG2E / tau_ial; a.itc = 1.f / tau_icl; a.iti = 1.f / tau_ial;
+    for (int m = 0; m < M; ++m) { if (!Z[m]) { sga_set_error("sga_loss_anchor_multi: null table"); return SGA_ERR_ARG; } a.Z[m] = Z[m]; }
+    const int nib = (a_hi - a_lo + 31) / 32, ntile = (A + 31) / 32;
+    int ns = (4 * sga_num_cus() + nib - 1) / (nib > 0 ? nib : 1);
+    if (ns > (ntile + 3) / 4) ns = (ntile + 3) / 4;
+    if (ns < 1) ns = 1;
+    a.nsplit = ns;
+    return SGA_OK;
+}
+
+template <int M, bool BWD>
+static void launch_anchor_multi(const AnchorMultiArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(M * 2 * 32 * 104 + (M + 1) * 8) * sizeof(float);
+    auto k = anchor_multi_kernel<M, BWD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nib = (a.i_hi - a.i_lo + 31) / 32;
+    hipLaunchKernelGGL(k, dim3(nib * a.nsplit), dim3(CT_THREADS), lds, s, a);
+}
+
+extern "C" int sga_loss_anchor_multi_fwd(const float* const* Z, int M, const float* beta, int A, const double* sums,
+                                         float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi,
+                                         void* stream) {
+    SGA_CHECK_ARG(Z && beta && sums && out && A >= 0, "sga_loss_anchor_multi_fwd: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n = (M + 1) + 2 * M;
+    if (int rc0 = zero_slots(out, n, s, "sga_loss_anchor_multi_fwd")) return rc0;
+    if (A == 0 || a_hi <= a_lo) return SGA_OK;
+    AnchorMultiArgs a{};
+    int rc = fill_anchor_multi(a, Z, M, beta, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
+    if (rc) return rc;
+    a.out = out;
+    if (M == 2) launch_anchor_multi<2, false>(a, s); else launch_anchor_multi<3, false>(a, s);
+    fold_slots(out, n, s);
+    SGA_CHECK_LAUNCH("sga_loss_anchor_multi_fwd");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const float* beta, int A, const double* sums,
+                                         float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
+                                         double* gs, double* gamma, int a_lo, int a_hi, void* stream) {
+    SGA_CHECK_ARG(Z && beta && sums && coef && M1 && gs && gamma && A >= 0, "sga_loss_anchor_multi_bwd: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc0 = zero_slots(gs, (M + 1) * 8, s, "sga_loss_anchor_multi_bwd")) return rc0;
+    if (int rc1 = zero_slots(gamma, M, s, "sga_loss_anchor_multi_bwd")) return rc1;
+    if (A == 0 || a_hi <= a_lo) return SGA_OK;
+    AnchorMultiArgs a{};
+    int rc = fill_anchor_multi(a, Z, M, beta, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
+    if (rc) return rc;
+    a.coef = coef; a.gs = gs; a.gamma = gamma;
+    for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(M1[m], "sga_loss_anchor_multi_bwd: null stash"); a.M1[m] = M1[m]; }
+    if (M == 2) launch_anchor_multi<2, true>(a, s); else launch_anchor_multi<3, true>(a, s);
+    fold_slots(gs, (M + 1) * 8, s);
+    fold_slots(gamma, M, s);
+    SGA_CHECK_LAUNCH("sga_loss_anchor_multi_bwd");
     return SGA_OK;
 }

@@ -218,6 +218,7 @@ class IndexSets:
         return c
 
 
+FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
 KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel with HIP events on the launch stream
 
 TAU_ICL = 0.1      # losses.py:39 (ctor argument ignored by the reference)
@@ -496,8 +497,12 @@ class FusedContrastiveFn(torch.autograd.Function):
         _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')
         out = torch.empty((slots * (nt + 2 * M),), device=dev, dtype=torch.float64)
         dps = [dp] * M + [M * dp]
-        _lib.check(L.sga_loss_anchor_fwd(_ptr_array(zs + [zj]), (_ct.c_int * nt)(*dps), nt, s.A, _p(sums), float(alpha),
-                                         TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi, st), 'sga_loss_anchor_fwd')
+        if M <= 3 and FUSED_ANCHOR_FWD:      # joint similarities derived in registers, I block resident in LDS
+            _lib.check(L.sga_loss_anchor_multi_fwd(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out),
+                                                   a_lo, a_hi, st), 'sga_loss_anchor_multi_fwd')
+        else:
+            _lib.check(L.sga_loss_anchor_fwd(_ptr_array(zs + [zj]), (_ct.c_int * nt)(*dps), nt, s.A, _p(sums), float(alpha),
+                                             TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi, st), 'sga_loss_anchor_fwd')
         out = _allreduce_sum(out[:nt + 2 * M].contiguous(), reduce)
         ctx.s, ctx.alpha, ctx.M, ctx.shard, ctx.reduce = s, float(alpha), M, (a_lo, a_hi), reduce
         ctx.shapes = [tuple(t.shape) for t in tables]
