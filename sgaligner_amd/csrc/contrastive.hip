@@ -913,6 +913,7 @@ struct AnchorMultiArgs {
     const float* Z[4];
     const float* beta;             // [M]
     const double* sums;            // [(M+1)][8]
+    const float* inv;              // [(M+1)][8] = 1/(sums + 1e-9) as floats (inv_sums_kernel): uniform global loads -> SGPRs
     float alpha, kc, ki, itc, iti;
     double* out;                   // fwd: [(M+1) + 2M] (+ slots)
     const float* coef;             // bwd: dL/d(out)
@@ -1160,6 +1161,180 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_kernel(AnchorMulti
             const float v = wave_sum(acc_gam[BWD ? m : 0]);
             if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + slot) + m, (double)v);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the fused anchors x anchors terms on 16x16x4 MFMA tiles.
+// The 32x32 form of this epilogue (16 elements per lane, 4 table-major passes, everything unrolled) is ~25 000
+// instructions in one loop body and hipcc's register allocator collapses on it (6 KB/lane of scratch, 50 ms).  With
+// v_mfma_f32_16x16x4_f32 a lane holds 4 elements of a 16x16 tile, the J loop stays ROLLED, and the body is 4x smaller:
+// no scratch, <= 128 registers.  Same geometry otherwise: 32 anchor rows of all M tables resident in LDS (MFMA B
+// operand, "lane & 15 = anchor row"), J-side fragments straight from global/L2, waves = (anchor half, J interleave).
+// ------------------------------------------------------------------------------------------------
+__global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restrict__ inv, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[i] = (float)(1.0 / (sums[i] + 1e-9));
+}
+
+template <int M>
+__global__ __launch_bounds__(CT_THREADS) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
+    constexpr int DP = 104, NT = M + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][32][DP] own rows
+    // the (M+1)*8 sum coefficients are read from global memory at uniform addresses: s_load -> SGPRs.  As LDS reads
+    // each of the 32 values cost an address VGPR + a data VGPR and pushed the kernel into scratch.
+    const float* __restrict__ inv_s = a.inv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+    const int A = a.A, ns = a.i_hi - a.i_lo;
+    const int ib = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
+    const int i0 = a.i_lo + ib * 32;
+    const int ih = wave & 1;                                         // which 16 anchor rows of the block
+    const int my_i = i0 + ih * 16 + l15;
+    const bool iv = my_i < a.i_hi;
+
+    for (int e = tid; e < M * 2 * 32 * (DP / 4); e += CT_THREADS) {
+        const int c = (e % (DP / 4)) * 4, r = (e / (DP / 4)) % 32, side = (e / (DP / 4) / 32) % 2, m = e / (DP / 4) / 64;
+        const int row = min(i0 + r, a.i_hi - 1) + side * A;
+        *reinterpret_cast<f32x4*>(lds + ((m * 2 + side) * 32 + r) * DP + c) = *reinterpret_cast<const f32x4*>(a.Z[m] + (size_t)row * DP + c);
+    }
+    __syncthreads();
+    float beta[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
+
+    float acc_gs[NT][8], acc_gam[M];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc_gs[k][e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc_gam[m] = 0.f;
+    const float* js = inv_s + M * 8;
+
+    const int ntile = (A + 15) / 16;
+#pragma unroll 1
+    for (int jt = split * 2 + (wave >> 1); jt < ntile; jt += a.nsplit * 2) {
+        const int j0 = jt * 16;
+        const int jrow = min(j0 + l15, A - 1);
+        f32x4 P[M], Q[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            P[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Q[m] = P[m];
+            const float* gp = a.Z[m] + (size_t)(A + jrow) * DP;              // X2[j] for P
+            const float* gq = a.Z[m] + (size_t)jrow * DP;                    // X1[j] for Q
+            const float* bp = lds + ((m * 2 + 0) * 32 + ih * 16 + l15) * DP;   // X1[i]
+            const float* bq = lds + ((m * 2 + 1) * 32 + ih * 16 + l15) * DP;   // X2[i]
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {                                    // k = 16q + 4g + r
+                const f32x4 ap = *reinterpret_cast<const f32x4*>(gp + 16 * q + 4 * g);
+                const f32x4 aq = *reinterpret_cast<const f32x4*>(gq + 16 * q + 4 * g);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 16 * q + 4 * g);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(bq + 16 * q + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r], b1[r], P[m], 0, 0, 0);
+                    Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[r], b2[r], Q[m], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                                    // tail k = 96 + 4t + g
+                const int kk = 96 + 4 * t + g;
+                P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[kk], bp[kk], P[m], 0, 0, 0);
+                Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[kk], bq[kk], Q[m], 0, 0, 0);
+            }
+        }
+        // P[m][r] = S_m[i = lane&15, j = j0 + 4g + r], Q[m][r] = S_m[j, i]
+        float xs[M][4], ys[M][4], gJ[4], EA[4], EB[4];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { xs[m][r] = P[m][r]; ys[m][r] = Q[m][r]; }
+        // pass 0: joint ICL
+        {
+            const float* is = js;
+            const float c = a.coef[M];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = iv && (j0 + 4 * g + r < A);
+                float xj = 0.f, yj = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], xs[m][r], xj); yj = fmaf(beta[m], ys[m][r], yj); }
+                const float dx = fexp2(xj * a.kc), dy = fexp2(yj * a.kc);
+                const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
+                const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
+                const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
+                const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
+                gJ[r] = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
+                acc_gs[M][0] += wA * Ax.dsa; acc_gs[M][2] += wA * Ax.dsb; acc_gs[M][4] += wB * Bx.dsa; acc_gs[M][6] += wB * Bx.dsb;
+                EA[r] = 0.f; EB[r] = 0.f;
+            }
+        }
+        // pass 1: per modality ICL + IAL (qo part)
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float* is = inv_s + m * 8;
+            const float c = a.coef[m], ca = a.coef[NT + m], cb = a.coef[NT + M + m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = iv && (j0 + 4 * g + r < A);
+                const float x = xs[m][r], y = ys[m][r];
+                float xj = 0.f;
+#pragma unroll
+                for (int mm = 0; mm < M; ++mm) xj = fmaf(beta[mm], xs[mm][r], xj);
+                const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
+                const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
+                const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
+                const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
+                const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
+                float gx = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
+                acc_gs[m][0] += wA * Ax.dsa; acc_gs[m][2] += wA * Ax.dsb; acc_gs[m][4] += wB * Bx.dsa; acc_gs[m][6] += wB * Bx.dsb;
+                const float dm = fexp2(x * a.ki), dji = fexp2(xj * a.ki);
+                const GV OA = g_full(dm, is[1], is[3]), OB = g_full(dm, is[5], is[7]);
+                const float lqma = flog(g_val(dji, js[1], js[3])), lqmb = flog(g_val(dji, js[5], js[7]));
+                const float eA = ok ? ca * __expf(OA.q) : 0.f, eB = ok ? cb * __expf(OB.q) : 0.f;
+                const float tA = eA * (OA.q - lqma + 1.f), tB = eB * (OB.q - lqmb + 1.f);
+                gx += (tA * OA.dd + tB * OB.dd) * dm * a.iti;
+                acc_gs[m][1] += tA * OA.dsa; acc_gs[m][3] += tA * OA.dsb; acc_gs[m][5] += tB * OB.dsa; acc_gs[m][7] += tB * OB.dsb;
+                EA[r] += eA; EB[r] += eB;
+                ys[m][r] = gx;
+            }
+        }
+        // pass 2: joint IAL (qm part), pass 3: totals + stash
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float xj = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; ++m) xj = fmaf(beta[m], xs[m][r], xj);
+            const float dji = fexp2(xj * a.ki);
+            const GV MA = g_full(dji, js[1], js[3]), MB = g_full(dji, js[5], js[7]);
+            const float uA = -EA[r] * frcp(MA.q), uB = -EB[r] * frcp(MB.q);
+            gJ[r] += (uA * MA.dd + uB * MB.dd) * dji * a.iti;
+            acc_gs[M][1] += uA * MA.dsa; acc_gs[M][3] += uA * MA.dsb; acc_gs[M][5] += uB * MB.dsa; acc_gs[M][7] += uB * MB.dsb;
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float* m1 = a.M1[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc_gam[m] = fmaf(gJ[r], xs[m][r], acc_gam[m]);
+                const int j = j0 + 4 * g + r;
+                if (iv && j < A) m1[(size_t)j * ns + (my_i - a.i_lo)] = fmaf(beta[m], gJ[r], ys[m][r]);
+            }
+        }
+    }
+    const int slot = my_slot();
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = wave_sum(acc_gs[k][e]);
+            if (lane == 0 && v != 0.f) atomicAdd(a.gs + NT * 8 * (1 + slot) + k * 8 + e, (double)v);
+        }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const float v = wave_sum(acc_gam[m]);
+        if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + slot) + m, (double)v);
     }
 }
 
@@ -1516,8 +1691,28 @@ extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const flo
     int rc = fill_anchor_multi(a, Z, M, beta, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
     if (rc) return rc;
     a.coef = coef; a.gs = gs; a.gamma = gamma;
+    // float copy of 1/(sums+eps): lives in the block after the gs slots (gs buffers hold (2 + slots) * (M+1)*8 doubles)
+    float* inv = reinterpret_cast<float*>(gs + (size_t)(1 + SGA_SLOTS) * (M + 1) * 8);
+    hipLaunchKernelGGL(inv_sums_kernel, dim3(1), dim3(64), 0, s, sums, inv, (M + 1) * 8);
+    a.inv = inv;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(M1[m], "sga_loss_anchor_multi_bwd: null stash"); a.M1[m] = M1[m]; }
-    if (M == 2) launch_anchor_multi<2, true>(a, s); else launch_anchor_multi<3, true>(a, s);
+    {
+        const size_t lds = (size_t)(M * 2 * 32 * 104 + (M + 1) * 8) * sizeof(float);
+        const int nib = (a.i_hi - a.i_lo + 31) / 32, ntile16 = (A + 15) / 16;
+        int nsp = (6 * sga_num_cus() + nib - 1) / (nib > 0 ? nib : 1);
+        if (nsp > (ntile16 + 1) / 2) nsp = (ntile16 + 1) / 2;
+        if (nsp < 1) nsp = 1;
+        a.nsplit = nsp;
+        if (M == 2) {
+            auto k = anchor_multi_bwd16_kernel<2>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
+        } else {
+            auto k = anchor_multi_bwd16_kernel<3>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
+        }
+    }
     fold_slots(gs, (M + 1) * 8, s);
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_multi_bwd");

@@ -218,6 +218,7 @@ class IndexSets:
         return c
 
 
+FUSED_ANCHOR_BWD = True
 FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
 KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel with HIP events on the launch stream
 
@@ -523,25 +524,41 @@ class FusedContrastiveFn(torch.autograd.Function):
         dp = 104
         A = s.A
         coef = gout.contiguous().float()
-        m1 = [torch.empty((A, max(ns, 1)), device=dev, dtype=torch.float32) for _ in range(nt)]
         slots = 1 + L.sga_loss_slots()
-        gs = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
-        dps = [dp] * M + [M * dp]
-        _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
-                                         TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gs), a_lo, a_hi, st), 'sga_loss_anchor_bwd')
-        gs = _allreduce_sum(gs[0].contiguous(), ctx.reduce)          # dL/d(global sums) needs every shard's tiles
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for _ in range(M)]
         gam_neg = torch.empty((slots, M), device=dev, dtype=torch.float64)   # dL/dbeta via the negatives (zeroed by the callee)
-        gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via sqrt(beta) in the anchor rows of ZJ
-        if A > 0 and ns > 0:
-            for k in range(M):
-                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), a_lo, a_hi, st), 'sga_loss_stash_grad')
-                m1[k] = None
-            dzj = torch.zeros((2 * A, M * dp), device=dev, dtype=torch.float32)
-            _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), a_lo, a_hi, st), 'sga_loss_stash_grad')
-            m1[M] = None
-            _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), _p(gam_anc), st),
-                       'sga_loss_fold_joint')
+        gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via the anchors x anchors terms
+        if M <= 3 and FUSED_ANCHOR_BWD:
+            # fused: M1[m] already holds dL/dS_m + beta_m dL/dS_J, dL/dbeta comes out directly; no joint operand / stash
+            m1 = [torch.empty((A, max(ns, 1)), device=dev, dtype=torch.float32) for _ in range(M)]
+            gs = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)     # + one block: float copy of 1/(sums+eps)
+            gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
+            _lib.check(L.sga_loss_anchor_multi_bwd(_ptr_array(zs), M, _p(beta), A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
+                                                   _ptr_array(m1), _p(gs), _p(gam2), a_lo, a_hi, st), 'sga_loss_anchor_multi_bwd')
+            gs = _allreduce_sum(gs[0].contiguous(), ctx.reduce)
+            if A > 0 and ns > 0:
+                gam_anc = gam2[0]
+                for k in range(M):
+                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), a_lo, a_hi, st), 'sga_loss_stash_grad')
+                    m1[k] = None
+        else:
+            m1 = [torch.empty((A, max(ns, 1)), device=dev, dtype=torch.float32) for _ in range(nt)]
+            gs = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
+            dps = [dp] * M + [M * dp]
+            _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
+                                             TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gs), a_lo, a_hi, st), 'sga_loss_anchor_bwd')
+            gs = _allreduce_sum(gs[0].contiguous(), ctx.reduce)          # dL/d(global sums) needs every shard's tiles
+            if A > 0 and ns > 0:
+                for k in range(M):
+                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), a_lo, a_hi, st), 'sga_loss_stash_grad')
+                    m1[k] = None
+                dzj = torch.zeros((2 * A, M * dp), device=dev, dtype=torch.float32)
+                _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), a_lo, a_hi, st), 'sga_loss_stash_grad')
+                m1[M] = None
+                gam_sq = torch.zeros((M,), device=dev, dtype=torch.float64)
+                _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), _p(gam_sq), st),
+                           'sga_loss_fold_joint')
+                gam_anc = gam_sq / (2.0 * torch.sqrt(beta.double()))     # through sqrt(beta_m) in the anchor rows of ZJ
         ev = None
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -558,7 +575,7 @@ class FusedContrastiveFn(torch.autograd.Function):
             _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
             grads.append(de)
         # d/dbeta_m: through the negatives (gamma) + through sqrt(beta_m) in the anchor rows of ZJ
-        gbeta = (gam_neg[0] + gam_anc / (2.0 * torch.sqrt(beta.double()))).float()
+        gbeta = (gam_neg[0] + gam_anc).float()
         return (None, None, None, None, gbeta, *grads)
 
 
