@@ -230,9 +230,11 @@ namespace {
 constexpr int PB_WAVES = 8;
 constexpr int PB_THREADS = PB_WAVES * 64;
 
-// PH == 0: gW1, gb1 (lane = row orientation, dH1 = dZ2 W2).  PH == 1: gW3, gb3, gb2.  PH == 2: gW2 (lane = channel).
-// Three launches keep every phase's accumulators in registers (fused they spilled >130 VGPRs to scratch,
-// and accumulating gW2 through LDS atomics instead cost more than the MFMA work itself).
+// PH == 0: gW1, gb1, gW3, gb3 (lane = row orientation: Z2 recompute, dH1 = dZ2 W2).
+// PH == 2: gW2, gb2 (lane = channel orientation: Z2 recompute, gW2 += dZ2^T H1).
+// Two launches keep every phase's accumulators in registers (fused they spilled >130 VGPRs to scratch,
+// and accumulating gW2 through LDS atomics instead cost more than the MFMA work itself); each phase
+// recomputes Z2 once in the orientation its products need, 512 MFMAs per 32-row tile in total.
 template <int PH, int NW>
 __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
     const float* __restrict__ x, const int* __restrict__ argmax, const float* __restrict__ y,
@@ -256,11 +258,12 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
     __syncthreads();
 
     const int lane = tid & 63, wave0 = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    static_assert(PH == 0 || PH == 2, "two phases");
     static_assert(PH == 2 || NW == 8, "row-tile-private accumulators need one tile per wave");
     // persistent per-lane accumulators
-    float gw3a[PH == 1 ? 64 : 1];   // [cb][s] : gW3[wave*32 + row(s,h)][cb*32 + l31]
+    float gw3a[PH == 0 ? 64 : 1];   // [cb][gq][r] : gW3[wave*32 + l31][cb*32 + 8gq + 4h + r]
 #pragma unroll
-    for (int i = 0; i < (PH == 1 ? 64 : 1); ++i) gw3a[i] = 0.f;
+    for (int i = 0; i < (PH == 0 ? 64 : 1); ++i) gw3a[i] = 0.f;
     f32x16 gw2a[PH == 2 ? 8 : 1];   // [cb][kt] : gW2[cb*32 + row(r,h)][kt*32 + l31]
 #pragma unroll
     for (int i = 0; i < (PH == 2 ? 8 : 1); ++i)
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
         const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
         const float yv = y[(size_t)t * C3 + c];
         const float g = yv > 0.f ? gy[(size_t)t * C3 + c] : 0.f;
-        if (PH == 1 && h == 0) gb3a += g;
+        if (PH == 0 && h == 0) gb3a += g;
 
         // ---- H1 in "lane = row" layout (k = 8q + 4h + r), as in the forward
         float h1[32];
@@ -324,7 +327,11 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
             for (int gq = 0; gq < 4; ++gq) {
                 const f32x4 w3v = *reinterpret_cast<const f32x4*>(w3 + (size_t)c * 128 + cb * 32 + 8 * gq + 4 * h_o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[gq * 4 + r] = (acc[gq * 4 + r] > 0.f ? g : 0.f) * w3v[r];
+                for (int r = 0; r < 4; ++r) {
+                    const float z = acc[gq * 4 + r];
+                    gw3a[PH == 0 ? cb * 16 + gq * 4 + r : 0] = fmaf(g, fmaxf(z, 0.f), gw3a[PH == 0 ? cb * 16 + gq * 4 + r : 0]);
+                    acc[gq * 4 + r] = (z > 0.f ? g : 0.f) * w3v[r];
+                }
             }
             // dH1[row][k1] += sum_ch2 dZ2[row][ch2] W2[ch2][k1]   (A = dZ2 regs, B = W2 rows from LDS)
 #pragma unroll
@@ -362,8 +369,8 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
             }
         }
 
-        // ======== orientation 2: lane = ch2, regs = rows  ->  gW3, gb2, gW2 += dZ2^T H1
-        if (PH >= 1)
+        // ======== orientation 2: lane = ch2, regs = rows  ->  gb2, gW2 += dZ2^T H1
+        if (PH == 2)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             __builtin_amdgcn_sched_barrier(0);
@@ -383,14 +390,13 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
                 const int cr = wave * 32 + mfma32_row(s, h_o);
                 const float z = acc[s];
                 const float gsv = __shfl(g, mfma32_row(s, h), 64);
-                if (PH == 1) gw3a[cb * 16 + s] = fmaf(gsv, fmaxf(z, 0.f), gw3a[cb * 16 + s]);
                 const float w3e = w3[(size_t)cr * 128 + cb * 32 + l31_o];      // unconditional load: a select here
                 const float dz = (z > 0.f ? gsv : 0.f) * w3e;                   // would be turned into 64 branches
                 acc[s] = dz;
                 colsum += dz;
             }
-            if (PH == 1) gb2a[cb] += colsum;
-            if (PH == 2) {
+            gb2a[cb] += colsum;
+            {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -402,19 +408,12 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
 
     // ---- flush the per-workgroup partials
     const int wave = wave0;
-    if (PH == 1) {
+    if (PH == 2) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int cr = wave * 32 + mfma32_row(s, h);
-            atomicAdd(gw3 + (size_t)cr * 128 + cb * 32 + l31, gw3a[cb * 16 + s]);
+        for (int cb = 0; cb < 4; ++cb) {
+            const float v = gb2a[cb] + __shfl_xor(gb2a[cb], 32, 64);
+            if (h == 0) atomicAdd(gb2 + cb * 32 + l31, v);
         }
-        const float v = gb2a[cb] + __shfl_xor(gb2a[cb], 32, 64);
-        if (h == 0) atomicAdd(gb2 + cb * 32 + l31, v);
-    }
-    if (h == 0) atomicAdd(gb3 + wave * 32 + l31, gb3a);
-    } else if (PH == 2) {
         // gw2a[cb*2+kt][r] = gW2[cb*32 + row(r,h)][kt*32 + l31]: combine the 8 waves in LDS, then one atomic per element
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -424,6 +423,10 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
         __syncthreads();
         for (int d = tid; d < 8192; d += NW * 64) atomicAdd(gw2 + d, gw2s[d]);
     } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i)     // gw3a[cb*16 + gq*4 + r] = gW3[wave*32 + l31][cb*32 + 8gq + 4h + r]
+        atomicAdd(gw3 + (size_t)(wave * 32 + l31) * 128 + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * h + (i & 3), gw3a[PH == 0 ? i : 0]);
+    if (h == 0) atomicAdd(gb3 + wave * 32 + l31, gb3a);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         const int k1 = kt * 32 + l31;
@@ -459,13 +462,10 @@ extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const flo
     const size_t lds_bytes = 3 * 8192 * sizeof(float);
     int grid = T < sga_num_cus() ? T : sga_num_cus();
     auto k0 = pointnet_bwd_kernel<0, 8>;
-    auto k1 = pointnet_bwd_kernel<1, 8>;
     auto k2 = pointnet_bwd_kernel<2, 4>;     // 4 waves -> one wave per SIMD, the full 512-register file for the 8 gW2 tiles
     hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(k2, dim3(grid), dim3(256), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
-    hipLaunchKernelGGL(k1, dim3(grid), dim3(512), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
     hipLaunchKernelGGL(k0, dim3(grid), dim3(512), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
     SGA_CHECK_LAUNCH("sga_pointnet_bwd");
     return SGA_OK;
