@@ -64,22 +64,27 @@ static void fold_slots(double* buf, int n, hipStream_t s) {
 
 struct GV { float q, dd, dsa, dsb; };
 
-// g and its derivatives wrt d, sa, sb; a = 1/(sa+eps), b = 1/(sb+eps)
+// g = 1 / (1 + 1/u + 1/v + eps), u = d a + eps, v = d b + eps, and its derivatives wrt d, sa, sb; a = 1/(sa+eps),
+// b = 1/(sb+eps) (losses.py:17-27 written per element).  Evaluated with ONE reciprocal: with
+// w = 1 / ((1+eps) u v + u + v):  g = u v w,  g/u = v w,  g/v = u w  (transcendentals are quarter rate and this
+// epilogue is VALU bound).
 __device__ __forceinline__ GV g_full(float d, float a, float b) {
     const float u = fmaf(d, a, QEPS), v = fmaf(d, b, QEPS);
-    const float ru = frcp(u), rv = frcp(v);
-    const float q = frcp(1.f + ru + rv + QEPS);
-    const float q2 = q * q, ru2 = ru * ru, rv2 = rv * rv;
+    const float uv = u * v;
+    const float w = frcp(fmaf(1.f + QEPS, uv, u + v));
+    const float qu = v * w, qv = u * w;               // g/u, g/v
+    const float au = a * qu * qu, bv = b * qv * qv;
     GV o;
-    o.q = q;
-    o.dd = q2 * (a * ru2 + b * rv2);
-    o.dsa = -q2 * d * a * a * ru2;
-    o.dsb = -q2 * d * b * b * rv2;
+    o.q = uv * w;
+    o.dd = au + bv;
+    o.dsa = -d * a * au;
+    o.dsb = -d * b * bv;
     return o;
 }
 __device__ __forceinline__ float g_val(float d, float a, float b) {
-    const float ru = frcp(fmaf(d, a, QEPS)), rv = frcp(fmaf(d, b, QEPS));
-    return frcp(1.f + ru + rv + QEPS);
+    const float u = fmaf(d, a, QEPS), v = fmaf(d, b, QEPS);
+    const float uv = u * v;
+    return uv * frcp(fmaf(1.f + QEPS, uv, u + v));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1178,7 +1183,7 @@ __global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restri
 }
 
 template <int M>
-__global__ __launch_bounds__(CT_THREADS) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
+__global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
     constexpr int DP = 104, NT = M + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][32][DP] own rows
     // the (M+1)*8 sum coefficients are read from global memory at uniform addresses: s_load -> SGPRs.  As LDS reads
@@ -1216,6 +1221,11 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_multi_bwd16_kernel(AnchorMu
     for (int jt = split * 2 + (wave >> 1); jt < ntile; jt += a.nsplit * 2) {
         const int j0 = jt * 16;
         const int jrow = min(j0 + l15, A - 1);
+        // The anchor-row operands are loop invariant; left alone, LICM parks all M*2*26 of them in registers
+        // (156 for M = 3) and the kernel drops to one wave per SIMD with AGPR/scratch spills.  An opaque zero
+        // offset keeps the ds_reads inside the loop: ~100 registers, two waves per SIMD hide each other's loads.
+        int lofs = 0;
+        asm volatile("" : "+v"(lofs));
         f32x4 P[M], Q[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -1223,8 +1233,8 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_multi_bwd16_kernel(AnchorMu
             Q[m] = P[m];
             const float* gp = a.Z[m] + (size_t)(A + jrow) * DP;              // X2[j] for P
             const float* gq = a.Z[m] + (size_t)jrow * DP;                    // X1[j] for Q
-            const float* bp = lds + ((m * 2 + 0) * 32 + ih * 16 + l15) * DP;   // X1[i]
-            const float* bq = lds + ((m * 2 + 1) * 32 + ih * 16 + l15) * DP;   // X2[i]
+            const float* bp = lds + lofs + ((m * 2 + 0) * 32 + ih * 16 + l15) * DP;   // X1[i]
+            const float* bq = lds + lofs + ((m * 2 + 1) * 32 + ih * 16 + l15) * DP;   // X2[i]
 #pragma unroll
             for (int q = 0; q < 6; ++q) {                                    // k = 16q + 4g + r
                 const f32x4 ap = *reinterpret_cast<const f32x4*>(gp + 16 * q + 4 * g);
@@ -1243,84 +1253,79 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_multi_bwd16_kernel(AnchorMu
                 P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[kk], bp[kk], P[m], 0, 0, 0);
                 Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[kk], bq[kk], Q[m], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);       // one table's operands in flight at a time (104 registers)
         }
-        // P[m][r] = S_m[i = lane&15, j = j0 + 4g + r], Q[m][r] = S_m[j, i]
-        float xs[M][4], ys[M][4], gJ[4], EA[4], EB[4];
+        // P[m][r] = S_m[i = lane&15, j = j0 + 4g + r], Q[m][r] = S_m[j, i].  One element (r) at a time, with a
+        // scheduling barrier between elements: interleaving the four independent chains keeps ~4x the temporaries
+        // live and pushes the loop into scratch.  Masks are multiplied in (rows/columns past the end are clamped
+        // copies of valid rows, so every intermediate is finite) -- selects here become 28 exec-mask branches.
+        const float cJ = a.coef[M];
 #pragma unroll
-        for (int m = 0; m < M; ++m)
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 4 * g + r;
+            const bool ok = iv && (j < A);
+            const float okf = ok ? 1.f : 0.f;
+            float xj = 0.f, yj = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { xs[m][r] = P[m][r]; ys[m][r] = Q[m][r]; }
-        // pass 0: joint ICL
-        {
-            const float* is = js;
-            const float c = a.coef[M];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = iv && (j0 + 4 * g + r < A);
-                float xj = 0.f, yj = 0.f;
-#pragma unroll
-                for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], xs[m][r], xj); yj = fmaf(beta[m], ys[m][r], yj); }
+            for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], P[m][r], xj); yj = fmaf(beta[m], Q[m][r], yj); }
+            float gJ, EA = 0.f, EB = 0.f;
+            // joint ICL
+            {
                 const float dx = fexp2(xj * a.kc), dy = fexp2(yj * a.kc);
-                const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
-                const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
-                const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
-                const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
-                gJ[r] = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
+                const GV Ax = g_full(dx, js[0], js[2]), Bx = g_full(dx, js[4], js[6]);
+                const float qAy = g_val(dy, js[0], js[2]), qBy = g_val(dy, js[4], js[6]);
+                const float wA = okf * (-cJ * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy);
+                const float wB = okf * (-cJ * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q);
+                gJ = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
                 acc_gs[M][0] += wA * Ax.dsa; acc_gs[M][2] += wA * Ax.dsb; acc_gs[M][4] += wB * Bx.dsa; acc_gs[M][6] += wB * Bx.dsb;
-                EA[r] = 0.f; EB[r] = 0.f;
             }
-        }
-        // pass 1: per modality ICL + IAL (qo part)
+            // joint IAL reference distribution (qm), shared by every modality
+            const float dji = fexp2(xj * a.ki);
+            const GV MA = g_full(dji, js[1], js[3]), MB = g_full(dji, js[5], js[7]);
+            const float lqma = flog(MA.q), lqmb = flog(MB.q);
+            float gx[M];
+            // per modality ICL + IAL (qo part)
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const float* is = inv_s + m * 8;
-            const float c = a.coef[m], ca = a.coef[NT + m], cb = a.coef[NT + M + m];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = iv && (j0 + 4 * g + r < A);
-                const float x = xs[m][r], y = ys[m][r];
-                float xj = 0.f;
-#pragma unroll
-                for (int mm = 0; mm < M; ++mm) xj = fmaf(beta[mm], xs[mm][r], xj);
+            for (int m = 0; m < M; ++m) {
+                const float* is = inv_s + m * 8;
+                const float c = a.coef[m], ca = a.coef[NT + m], cb = a.coef[NT + M + m];
+                const float x = P[m][r], y = Q[m][r];
                 const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
                 const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
                 const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
-                const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
-                const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
-                float gx = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
+                const float wA = okf * (-c * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy);
+                const float wB = okf * (-c * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q);
+                float gxm = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
                 acc_gs[m][0] += wA * Ax.dsa; acc_gs[m][2] += wA * Ax.dsb; acc_gs[m][4] += wB * Bx.dsa; acc_gs[m][6] += wB * Bx.dsb;
-                const float dm = fexp2(x * a.ki), dji = fexp2(xj * a.ki);
+                const float dm = fexp2(x * a.ki);
                 const GV OA = g_full(dm, is[1], is[3]), OB = g_full(dm, is[5], is[7]);
-                const float lqma = flog(g_val(dji, js[1], js[3])), lqmb = flog(g_val(dji, js[5], js[7]));
-                const float eA = ok ? ca * __expf(OA.q) : 0.f, eB = ok ? cb * __expf(OB.q) : 0.f;
+                const float eA = okf * ca * __expf(OA.q), eB = okf * cb * __expf(OB.q);
                 const float tA = eA * (OA.q - lqma + 1.f), tB = eB * (OB.q - lqmb + 1.f);
-                gx += (tA * OA.dd + tB * OB.dd) * dm * a.iti;
+                gxm += (tA * OA.dd + tB * OB.dd) * dm * a.iti;
                 acc_gs[m][1] += tA * OA.dsa; acc_gs[m][3] += tA * OA.dsb; acc_gs[m][5] += tB * OB.dsa; acc_gs[m][7] += tB * OB.dsb;
-                EA[r] += eA; EB[r] += eB;
-                ys[m][r] = gx;
+                EA += eA; EB += eB;
+                gx[m] = gxm;
             }
-        }
-        // pass 2: joint IAL (qm part), pass 3: totals + stash
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float xj = 0.f;
-#pragma unroll
-            for (int m = 0; m < M; ++m) xj = fmaf(beta[m], xs[m][r], xj);
-            const float dji = fexp2(xj * a.ki);
-            const GV MA = g_full(dji, js[1], js[3]), MB = g_full(dji, js[5], js[7]);
-            const float uA = -EA[r] * frcp(MA.q), uB = -EB[r] * frcp(MB.q);
-            gJ[r] += (uA * MA.dd + uB * MB.dd) * dji * a.iti;
-            acc_gs[M][1] += uA * MA.dsa; acc_gs[M][3] += uA * MA.dsb; acc_gs[M][5] += uB * MB.dsa; acc_gs[M][7] += uB * MB.dsb;
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            float* m1 = a.M1[m];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc_gam[m] = fmaf(gJ[r], xs[m][r], acc_gam[m]);
-                const int j = j0 + 4 * g + r;
-                if (iv && j < A) m1[(size_t)j * ns + (my_i - a.i_lo)] = fmaf(beta[m], gJ[r], ys[m][r]);
+            // joint IAL (qm part), totals + stash
+            {
+                const float uA = -EA * frcp(MA.q), uB = -EB * frcp(MB.q);
+                gJ += (uA * MA.dd + uB * MB.dd) * dji * a.iti;
+                acc_gs[M][1] += uA * MA.dsa; acc_gs[M][3] += uA * MA.dsb; acc_gs[M][5] += uB * MB.dsa; acc_gs[M][7] += uB * MB.dsb;
             }
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                acc_gam[m] = fmaf(gJ, P[m][r], acc_gam[m]);
+                if (ok) a.M1[m][(size_t)j * ns + (my_i - a.i_lo)] = fmaf(beta[m], gJ, gx[m]);
+            }
+            // pin the running sums here: otherwise their updates are sunk into the loop latch (they are only
+            // consumed by the next iteration) and every factor of all four elements stays live until then
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(acc_gs[k][e]));
+#pragma unroll
+            for (int m = 0; m < M; ++m) asm volatile("" : "+v"(acc_gam[m]));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const int slot = my_slot();
