@@ -635,6 +635,294 @@ static void launch_sweep_multi(const MultiArgs& a, int nwg, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(nwg), dim3(CT_THREADS), lds, s, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16x16x4 form of the fused multi-table sweep (M = 2, 3; the path the benchmark runs).
+//
+// The 32x32 kernel above keeps M*52 owner-operand registers and M*64 gradient accumulators per lane: the whole
+// 512-entry file, one wave per SIMD, so nothing overlaps its exp2/coefficient VALU work with MFMA (measured 70 % of
+// the fp32 MFMA peak).  Here a wave owns 16 rows instead of 32: M*26 operand + M*28 accumulator registers, 8 waves
+// per workgroup = two per SIMD, and the second wave's MFMAs run under the first one's epilogue.  Same workgroup
+// geometry otherwise (128 owner rows, 32-row other tiles of all M tables through the double-buffered DMA ring), so
+// plan_multi's uniform work units are shared.  The gradient GEMM is 7 column tiles of 16 (112 >= 104) instead of
+// 4 of 32 (128): 12 % less padded MFMA work.
+//
+// MFMA bookkeeping (v_mfma_f32_16x16x4_f32: A lane&15 = row, B lane&15 = column, lane>>4 = k; D[4*(lane>>4)+r][lane&15]):
+//   S^T tile:  A = other rows from LDS, B = owner rows (registers)  ->  lane&15 = owner row, (lane>>4, r) = other row
+//   which is exactly the A-operand layout of  dZ[own, :] += C[own, other] * Z[other, :]  with k = lane>>4.
+// D row rho = 4*(lane>>4) + r holds other row pi(rho) = rho with bits 1 and 2 swapped: the gradient GEMM's B reads
+// (ds_read_b32, lanes 0-31 = two k groups) then hit rows 2 apart = 16 banks apart instead of the same 16 banks.
+// ------------------------------------------------------------------------------------------------
+#ifndef SGA_S16_WAVES
+#define SGA_S16_WAVES 4
+#endif
+constexpr int S16_WAVES = SGA_S16_WAVES;   // waves per workgroup; with 4, two workgroups share a CU (2 x 78 KiB of LDS)
+constexpr int S16_THREADS = S16_WAVES * 64;
+constexpr int S16_OWN = S16_WAVES * 16;     // owner rows per workgroup
+__device__ __forceinline__ int s16_pi(int rho) { return (rho & 9) | ((rho & 2) << 1) | ((rho & 4) >> 1); }
+
+template <int M, bool GRAD>
+__global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 2 : 1) void sweep16_kernel(MultiArgs a) {
+    constexpr int DP = 104, OT = 32, NCT = 7;
+    constexpr int TILE_F = OT * DP, BUF_F = M * TILE_F, NCHUNK = M * 13;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][M][OT][DP] + slack for the 7th column tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
+    const SweepGroup& grp = a.grp[g];
+    const int wg_in_grp = (int)blockIdx.x - grp.blk0;
+    const int nsplit = grp.nsplit, split = wg_in_grp % nsplit;
+    const int own0 = grp.own0 + (wg_in_grp / nsplit) * S16_OWN;
+    const int own_end = grp.own0 + grp.nown;
+    const int my_i = own0 + wave * 16 + l15;
+    const bool iv = my_i < own_end;
+
+    f32x4 own[M][6];
+    float ownt[M][2], beta[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const float* src = a.Z[m] + (size_t)(iv ? my_i : own0) * DP;
+        const float msk = iv ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 16 * q + 4 * g4) * msk;   // k = 16q + 4g4 + r
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ownt[m][t] = src[96 + 4 * t + g4] * msk;                                       // k = 96 + 4t + g4
+        beta[m] = a.beta[m];
+    }
+    f32x4 gacc[GRAD ? M : 1][NCT];
+#pragma unroll
+    for (int m = 0; m < (GRAD ? M : 1); ++m)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) gacc[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gam[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) gam[m] = 0.f;
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
+    auto issue = [&](int j0, float* buf) {
+#pragma unroll
+        for (int c0 = 0; c0 < NCHUNK; c0 += S16_WAVES) {
+            const int c = c0 + wave_u;
+            if (c >= NCHUNK) break;
+            const int m = c / 13, cc = c - m * 13;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(a.Z[m] + (size_t)j0 * DP + cc * 256 + lane * 4),
+                (__attribute__((address_space(3))) void*)(buf + m * TILE_F + cc * 256), 16, 0, 0);
+        }
+    };
+    // this lane's other rows inside a 32-row tile: element (jh, r) <-> row jh*16 + pi(4*g4 + r)
+    int jrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) jrow[r] = s16_pi(4 * g4 + r);
+    const int arow = s16_pi(l15);                                  // the other row this lane feeds as MFMA A operand
+
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        if (sg >= grp.nseg) break;
+        const SweepSeg seg = grp.seg[sg];
+        const int ntile = (seg.n + OT - 1) / OT;
+        const int j_end = seg.row0 + seg.n;
+        float c0[M + 1], c1[M + 1];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) {
+            c0[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
+            c1[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
+        }
+        double dsum[M + 1][2];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
+
+        __syncthreads();
+        if (split < ntile) issue(seg.row0 + split * OT, lds);
+        int it = 0;
+        for (int jt = split; jt < ntile; jt += nsplit, ++it) {
+            float* buf = lds + (it & 1) * BUF_F;
+            const int j0 = seg.row0 + jt * OT;
+#ifndef SGA_DBG_NOBAR
+            __syncthreads();                               // tile `it` landed / other buffer free
+#endif
+#ifndef SGA_DBG_NODMA
+            if (jt + nsplit < ntile) issue(seg.row0 + (jt + nsplit) * OT, lds + ((it + 1) & 1) * BUF_F);
+#endif
+
+            // ---- S^T tiles of the M tables: lane&15 = owner row, (g4, r) = other row.
+            // Per 16-row half the M accumulation chains are interleaved (a dependent MFMA is M issues away) and the
+            // A operands are read one K group ahead into the other of two register sets (assigning alternately, never
+            // copying, keeps hipcc from folding the two sets back into one load->wait->use chain).
+            f32x4 sacc[M][2];
+#ifdef SGA_DBG_NOS
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                for (int m = 0; m < M; ++m) { sacc[m][jh] = f32x4{0.1f, 0.2f, 0.3f, 0.4f} * buf[lane]; }
+#else
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                const float* ap = buf + (jh * 16 + arow) * DP + 4 * g4;
+                const float* at = buf + (jh * 16 + arow) * DP + 96 + g4;
+                f32x4 avA[M], avB[M];
+                float tl[M][2];
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    sacc[m][jh] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    avA[m] = *reinterpret_cast<const f32x4*>(ap + m * TILE_F);
+                    avB[m] = avA[m];
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, M, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    if (q < 5) {
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            if (q & 1) avA[m] = *reinterpret_cast<const f32x4*>(ap + m * TILE_F + 16 * (q + 1));
+                            else avB[m] = *reinterpret_cast<const f32x4*>(ap + m * TILE_F + 16 * (q + 1));
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < M; ++m) { tl[m][0] = at[m * TILE_F]; tl[m][1] = at[m * TILE_F + 4]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int m = 0; m < M; ++m)
+                            sacc[m][jh] = __builtin_amdgcn_mfma_f32_16x16x4f32((q & 1) ? avB[m][r] : avA[m][r], own[m][q][r], sacc[m][jh], 0, 0, 0);
+                    if (q < 5) __builtin_amdgcn_sched_group_barrier(0x100, M, 0);          // next group's reads first ...
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 2 * M, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * M, 0);                 // ... then this group's MFMAs
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+                        sacc[m][jh] = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[m][t], ownt[m][t], sacc[m][jh], 0, 0, 0);
+            }
+#endif
+
+            if (!GRAD) {
+                float p0[M + 1], p1[M + 1];
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float okf = (iv && (j0 + jh * 16 + jrow[r] < j_end)) ? 1.f : 0.f;
+                        float sj = 0.f;
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            const float sv = sacc[m][jh][r];
+                            sj = fmaf(beta[m], sv, sj);
+                            p0[m] = fmaf(okf, fexp2(sv * a.k0), p0[m]);
+                            p1[m] = fmaf(okf, fexp2(sv * a.k1), p1[m]);
+                        }
+                        p0[M] = fmaf(okf, fexp2(sj * a.k0), p0[M]);
+                        p1[M] = fmaf(okf, fexp2(sj * a.k1), p1[M]);
+                    }
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
+            } else {
+                float cj[2][4], okf[2][4];
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        okf[jh][r] = (iv && (j0 + jh * 16 + jrow[r] < j_end)) ? 1.f : 0.f;
+                        float sj = 0.f;
+#pragma unroll
+                        for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][jh][r], sj);
+                        cj[jh][r] = okf[jh][r] * (c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1));
+                    }
+                if (g < 2) {                                    // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[jh][r], sacc[m][jh][r], gam[m]);
+                }
+                // c_m = dL/dS_m + beta_m dL/dS_J, then dZ_m[own, :] += c_m * Z_m[other, :].  The M*8 (table, other row)
+                // steps are software pipelined: while step e's 7 MFMAs issue, step e+1's coefficient (2 exp2 + ~8 VALU)
+                // and its 7 B operands (ds_read_b32) are produced into the other register set.
+                float cmv[2], bv[2][NCT];
+                auto coef = [&](int e) {
+                    const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
+                    const float sv = sacc[m][jh][r];
+                    return okf[jh][r] * fmaf(beta[m], cj[jh][r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1));
+                };
+                auto bload = [&](int e, float* dst) {
+                    const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
+                    const float* bb = buf + m * TILE_F + (jh * 16 + jrow[r]) * DP + l15;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) dst[ct] = bb[ct * 16];
+                };
+                cmv[0] = coef(0);
+                bload(0, bv[0]);
+#pragma unroll
+                for (int e = 0; e < M * 8; ++e) {
+                    if (e + 1 < M * 8) { cmv[(e + 1) & 1] = coef(e + 1); bload(e + 1, bv[(e + 1) & 1]); }
+#ifdef SGA_DBG_NOG
+                    gacc[GRAD ? (e >> 3) : 0][0][0] += cmv[e & 1] * bv[e & 1][0];
+#else
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        gacc[GRAD ? (e >> 3) : 0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmv[e & 1], bv[e & 1][ct], gacc[GRAD ? (e >> 3) : 0][ct], 0, 0, 0);
+#endif
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < M; ++m) asm volatile("" : "+v"(gam[m]));     // keep the updates out of the loop latch
+            }
+        }
+        if (!GRAD) {
+#pragma unroll
+            for (int m = 0; m <= M; ++m)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const double v = wave_sum_d(dsum[m][tt]);
+                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + (M + 1) * 8 * (1 + my_slot()) + m * 8 + seg.fam * 2 + tt, v);
+                }
+        }
+    }
+    if (GRAD) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float* dz = a.dZ[m];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int d = ct * 16 + l15;
+                if (d < DP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = own0 + wave * 16 + 4 * g4 + r;
+                        if (i < own_end) atomicAdd(dz + (size_t)i * DP + d, gacc[GRAD ? m : 0][ct][r]);
+                    }
+                }
+            }
+        }
+        if (g < 2) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float v = wave_sum(gam[m]);
+                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + m, (double)v);
+            }
+        }
+    }
+}
+
+template <int M, bool GRAD>
+static void launch_sweep16(const MultiArgs& a, int nwg, hipStream_t s) {
+    const size_t lds = ((size_t)2 * M * 32 * 104 + 32) * sizeof(float);
+    auto k = sweep16_kernel<M, GRAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(S16_THREADS), lds, s, a);
+}
+
 // joint operand rows for the anchors x anchors kernels: ZJ[r, m*104 + d] = sqrt(beta_m) Z_m[r, d]
 __global__ void build_joint_kernel(MultiArgs a, float* __restrict__ ZJ, int rows) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
@@ -1518,7 +1806,7 @@ static int fill_multi(MultiArgs& a, const float* const* Z, int M, const float* b
 }
 // Split every group's other-tile list so that all workgroups run ~`target` 32-row steps: uniform work units keep
 // the 256 CUs busy to the end (anchor-owner blocks see 2.4x more other rows than negative-owner blocks).
-static int plan_multi(MultiArgs& a, int target_steps) {
+static int plan_multi(MultiArgs& a, int target_steps, int own_rows = 128) {
     int nwg = 0;
     for (int g = 0; g < a.ngroups; ++g) {
         SweepGroup& G = a.grp[g];
@@ -1528,7 +1816,7 @@ static int plan_multi(MultiArgs& a, int target_steps) {
         if (ns < 1) ns = 1;
         G.nsplit = ns;
         G.blk0 = nwg;
-        nwg += ((G.nown + 127) / 128) * ns;
+        nwg += ((G.nown + own_rows - 1) / own_rows) * ns;
     }
     return nwg;
 }
@@ -1543,9 +1831,9 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* be
     int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi);
     if (rc) return rc;
     a.sums = sums;
-    const int nwg = plan_multi(a, 160);
-    if (M == 2) launch_sweep_multi<2, 0, 2, false>(a, nwg, s);
-    else if (M == 3) launch_sweep_multi<3, 0, 3, false>(a, nwg, s);
+    const int nwg = plan_multi(a, 160, M <= 3 ? S16_OWN : 128);
+    if (M == 2) launch_sweep16<2, false>(a, nwg, s);
+    else if (M == 3) launch_sweep16<3, false>(a, nwg, s);
     else launch_sweep_multi<4, 0, 2, false>(a, nwg, s);
     fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums");
@@ -1564,9 +1852,9 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* be
     if (rc) return rc;
     a.gs = gs; a.gamma = gamma;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }
-    const int nwg = plan_multi(a, 160);
-    if (M == 2) launch_sweep_multi<2, 0, 2, true>(a, nwg, s);
-    else if (M == 3) launch_sweep_multi<3, 0, 3, true>(a, nwg, s);
+    const int nwg = plan_multi(a, 160, M <= 3 ? S16_OWN : 128);
+    if (M == 2) launch_sweep16<2, true>(a, nwg, s);
+    else if (M == 3) launch_sweep16<3, true>(a, nwg, s);
     else { launch_sweep_multi<4, 0, 2, true>(a, nwg, s); launch_sweep_multi<4, 2, 2, true>(a, nwg, s); }
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad");

@@ -39,9 +39,16 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     C3 = w3.shape[0]
     y = torch.empty((T, C3), device=x_tp3.device, dtype=torch.float32)
     am = torch.empty((T, C3), device=x_tp3.device, dtype=torch.int32) if want_argmax else None
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = _lib.lib().sga_pointnet_fwd(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
                                      T, P, C3, _stream())
     _lib.check(rc, 'sga_pointnet_fwd')
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.setdefault('pointnet_fwd_kernel', []).append(ev + ((T, P, w1.shape[0], w2.shape[0], C3),))
     return y, am
 
 
@@ -567,7 +574,7 @@ class FusedContrastiveFn(torch.autograd.Function):
                                          _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad')
         if ev is not None:
             ev[1].record()
-            KERNEL_EVENTS.setdefault(f'sweep_multi_kernel<{M},grad>', []).append(ev + ((ns, A, s.J1, s.J2, M),))
+            KERNEL_EVENTS.setdefault('loss_multi_grad', []).append(ev + ((ns, A, s.J1, s.J2, M),))
         grads = []
         for k in range(M):
             t, d = ctx.shapes[k]
