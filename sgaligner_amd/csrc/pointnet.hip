@@ -247,7 +247,11 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
     float* w2s = lds;               // operand order [4 cb][8 q][64 lane][4]
     float* w2r = lds + 8192;        // row-major [128][64]
     float* gw2s = lds + 16384;      // accumulator [128][64]
+    float* w1s = lds + 24576;       // [64][3]  (every per-tile constant comes from LDS: as global loads their L2 latency
+    float* b1s = w1s + 192;         // [64]      is exposed once per tile -- phase 2 runs a single wave per SIMD)
+    float* b2s = b1s + 64;          // [128]
     const int tid = threadIdx.x;
+    for (int d = tid; d < 384; d += NW * 64) w1s[d] = d < 192 ? w1[d] : (d < 256 ? b1[d - 192] : b2[d - 256]);
     for (int d = tid; d < 2048; d += NW * 64) {
         const int ln = d & 63, q = (d >> 6) & 7, cb = d >> 9;
         const int row = cb * 32 + (ln & 31), k = 8 * q + 4 * (ln >> 5);
@@ -285,15 +289,33 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
         const float g = yv > 0.f ? gy[(size_t)t * C3 + c] : 0.f;
         if (PH == 0 && h == 0) gb3a += g;
 
+        // Phase 2 runs one wave per SIMD: nobody hides the L2 latency of the 64 W3 elements this tile needs, so they are all
+        // requested up front (64 of the 140 spare registers) instead of 16 at a time in front of their use.
+        float w3t[PH == 2 ? 64 : 1], gs[PH == 2 ? 16 : 1];
+        if (PH == 2) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {           // g of row(s, h): two addresses per wave, no cross-lane shuffle
+                const size_t ri = (size_t)t * C3 + wave * 32 + mfma32_row(s, h_o);
+                const float yr = y[ri], gr = gy[ri];
+                gs[PH == 2 ? s : 0] = yr > 0.f ? gr : 0.f;
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    w3t[PH == 2 ? cb * 16 + s : 0] = w3[(size_t)(wave * 32 + mfma32_row(s, h_o)) * 128 + cb * 32 + l31_o];
+        }
+
+
         // ---- H1 in "lane = row" layout (k = 8q + 4h + r), as in the forward
         float h1[32];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = 8 * q + 4 * h_o;
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(w1 + k * 3);
-            const f32x4 wb = *reinterpret_cast<const f32x4*>(w1 + k * 3 + 4);
-            const f32x4 wc = *reinterpret_cast<const f32x4*>(w1 + k * 3 + 8);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + k);
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(w1s + k * 3);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w1s + k * 3 + 4);
+            const f32x4 wc = *reinterpret_cast<const f32x4*>(w1s + k * 3 + 8);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + k);
             h1[q * 4 + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
             h1[q * 4 + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
             h1[q * 4 + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
@@ -313,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
             f32x16 acc;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * gq + 4 * h_o);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + cb * 32 + 8 * gq + 4 * h_o);
                 acc[gq * 4 + 0] = bb[0]; acc[gq * 4 + 1] = bb[1]; acc[gq * 4 + 2] = bb[2]; acc[gq * 4 + 3] = bb[3];
             }
 #pragma unroll
@@ -348,18 +370,31 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
         // ---- H1 again in "lane = k1, regs = rows" layout (x of row(s,h) fetched by lane shuffle);
         //      dZ1 = dH1 * (H1 > 0); gW1 / gb1 partial sums
         f32x16 h1c[2];
-        {
-            const float wa0 = w1[l31_o * 3 + 0], wb0 = w1[l31_o * 3 + 1], wc0 = w1[l31_o * 3 + 2], bb0 = b1[l31_o];
-            const float wa1 = w1[(32 + l31_o) * 3 + 0], wb1 = w1[(32 + l31_o) * 3 + 1], wc1 = w1[(32 + l31_o) * 3 + 2], bb1 = b1[32 + l31_o];
+        if (PH == 2) {
+            // as two K = 2 MFMAs per 32 channels: D[row][k1] = x0 W1[k1][0] + x1 W1[k1][1] + x2 W1[k1][2] + 1 * b1[k1]
+            // (A: lane = row, h = k; B: lane = k1, h = k) -- lands directly in the "lane = k1, regs = rows" layout
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int k1 = kt * 32 + l31_o;
+                const float bA = w1s[k1 * 3 + h_o];
+                const float bB = h_o ? b1s[k1] : w1s[k1 * 3 + 2];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? x1 : x0, bA, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? 1.f : x2, bB, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1c[kt][r] = fmaxf(acc[r], 0.f);
+            }
+        } else {
+            const float wa0 = w1s[l31_o * 3 + 0], wb0 = w1s[l31_o * 3 + 1], wc0 = w1s[l31_o * 3 + 2], bb0 = b1s[l31_o];
+            const float wa1 = w1s[(32 + l31_o) * 3 + 0], wb1 = w1s[(32 + l31_o) * 3 + 1], wc1 = w1s[(32 + l31_o) * 3 + 2], bb1 = b1s[32 + l31_o];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int src = mfma32_row(s, h);
                 const float sx0 = __shfl(x0, src, 64), sx1 = __shfl(x1, src, 64), sx2 = __shfl(x2, src, 64);
                 const float hv0 = fmaxf(fmaf(wc0, sx2, fmaf(wb0, sx1, fmaf(wa0, sx0, bb0))), 0.f);
                 const float hv1 = fmaxf(fmaf(wc1, sx2, fmaf(wb1, sx1, fmaf(wa1, sx0, bb1))), 0.f);
-                h1c[0][s] = hv0;
-                h1c[1][s] = hv1;
-                if (PH != 0) continue;
                 const float dz0 = hv0 > 0.f ? dh1[0][s] : 0.f;
                 const float dz1 = hv1 > 0.f ? dh1[1][s] : 0.f;
                 gw1a[0][0] = fmaf(dz0, sx0, gw1a[0][0]); gw1a[0][1] = fmaf(dz0, sx1, gw1a[0][1]); gw1a[0][2] = fmaf(dz0, sx2, gw1a[0][2]);
@@ -375,7 +410,7 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
         for (int cb = 0; cb < 4; ++cb) {
             __builtin_amdgcn_sched_barrier(0);
             f32x16 acc;
-            const float bv = b2[cb * 32 + l31_o];
+            const float bv = b2s[cb * 32 + l31_o];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = bv;
 #pragma unroll
@@ -389,8 +424,8 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
             for (int s = 0; s < 16; ++s) {
                 const int cr = wave * 32 + mfma32_row(s, h_o);
                 const float z = acc[s];
-                const float gsv = __shfl(g, mfma32_row(s, h), 64);
-                const float w3e = w3[(size_t)cr * 128 + cb * 32 + l31_o];      // unconditional load: a select here
+                const float gsv = gs[PH == 2 ? s : 0];
+                const float w3e = w3t[PH == 2 ? cb * 16 + s : 0];              // unconditional load: a select there
                 const float dz = (z > 0.f ? gsv : 0.f) * w3e;                   // would be turned into 64 branches
                 acc[s] = dz;
                 colsum += dz;
@@ -459,7 +494,7 @@ extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const flo
     hipMemsetAsync(gw3, 0, 256 * 128 * sizeof(float), s);
     hipMemsetAsync(gb3, 0, 256 * sizeof(float), s);
     if (T == 0) return SGA_OK;
-    const size_t lds_bytes = 3 * 8192 * sizeof(float);
+    const size_t lds_bytes = (3 * 8192 + 384) * sizeof(float);
     int grid = T < sga_num_cus() ? T : sga_num_cus();
     auto k0 = pointnet_bwd_kernel<0, 8>;
     auto k2 = pointnet_bwd_kernel<2, 4>;     // 4 waves -> one wave per SIMD, the full 512-register file for the 8 gW2 tiles
