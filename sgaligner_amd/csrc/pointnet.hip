@@ -276,17 +276,32 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
     float gb3a = 0.f, gb2a[4] = {0.f, 0.f, 0.f, 0.f};
     float gw1a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb1a[2] = {0.f, 0.f};
 
-    for (int t = blockIdx.x; t < T; t += gridDim.x)
-    for (int wave = wave0; wave < 8; wave += NW) {       // wave = winner-row tile of this object
+    // Tiles (object t, winner-row tile `wave`) are walked as one flat sequence so that the next tile's winner index,
+    // its point (a dependent gather: two L2 round trips) and its g can be fetched while this tile computes.
+    constexpr int PER_OBJ = 8 / NW;
+    const int n_obj = (T - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n_iter = n_obj * PER_OBJ;
+    float nx0, nx1, nx2, ng;
+    {
+        const size_t ri = (size_t)blockIdx.x * C3 + wave0 * 32 + (lane & 31);
+        const int p0 = min(max(argmax[ri], 0), P - 1);
+        const float* xp = x + ((size_t)blockIdx.x * P + p0) * 3;
+        nx0 = xp[0]; nx1 = xp[1]; nx2 = xp[2];
+        ng = y[ri] > 0.f ? gy[ri] : 0.f;
+    }
+    for (int it = 0; it < n_iter; ++it) {
+        const int t = (int)blockIdx.x + (it / PER_OBJ) * (int)gridDim.x;
+        const int wave = wave0 + (it % PER_OBJ) * NW;        // wave = winner-row tile of this object
         int lane_o = lane, h_o = h;
         asm volatile("" : "+v"(lane_o), "+v"(h_o));          // keep weight reads inside the loop (see fwd):
         const int l31_o = lane_o & 31;                       // every weight address below goes through these
         const int c = wave * 32 + l31_o;                     // this lane's winner row (lane = row layouts)
-        const int p = min(max(argmax[(size_t)t * C3 + c], 0), P - 1);
-        const float* xp = x + ((size_t)t * P + p) * 3;
-        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
-        const float yv = y[(size_t)t * C3 + c];
-        const float g = yv > 0.f ? gy[(size_t)t * C3 + c] : 0.f;
+        const float x0 = nx0, x1 = nx1, x2 = nx2, g = ng;
+        // next tile (clamped to this one at the end): winner index now, its point after the H1 section below
+        const int itn = min(it + 1, n_iter - 1);
+        const size_t rin = (size_t)((int)blockIdx.x + (itn / PER_OBJ) * (int)gridDim.x) * C3 + (wave0 + (itn % PER_OBJ) * NW) * 32 + l31_o;
+        const int pn_raw = argmax[rin];
+        const float yn = y[rin], gyn = gy[rin];
         if (PH == 0 && h == 0) gb3a += g;
 
         // Phase 2 runs one wave per SIMD: nobody hides the L2 latency of the 64 W3 elements this tile needs, so they are all
@@ -367,6 +382,12 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
 
         }
         __builtin_amdgcn_sched_barrier(0);
+        {   // the next tile's point: its index arrived during the H1 section
+            const int pn = min(max(pn_raw, 0), P - 1);
+            const float* xpn = x + ((size_t)(rin / C3) * P + pn) * 3;
+            nx0 = xpn[0]; nx1 = xpn[1]; nx2 = xpn[2];
+            ng = yn > 0.f ? gyn : 0.f;
+        }
         // ---- H1 again in "lane = k1, regs = rows" layout (x of row(s,h) fetched by lane shuffle);
         //      dZ1 = dH1 * (H1 > 0); gW1 / gb1 partial sums
         f32x16 h1c[2];
