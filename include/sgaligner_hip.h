@@ -127,6 +127,19 @@ int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, int B, in
                 const int32_t* q_pair, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
                 int32_t* topk_idx, float* topk_sim, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- per-object farthest-point sampling (the step in front of the path) -----------------
+ * replaces utils/point_cloud.py:61-89 pcl_farthest_sample as called by preprocessing/scan3r/preprocess.py:96-98.
+ * pts [sum N,3] f32 packed per object, offsets [n_obj+1]; start[obj] = the first sample (the reference draws it with
+ * np.random.randint, :77 -- the caller owns the RNG); out_idx [n_obj, npoint] object-local indices, bit-identical to
+ * the reference's sequence for the same start (fp32, same summation order, first arg-max).  Every object needs
+ * N >= npoint (the reference's N < npoint branch is a random draw with replacement and stays on the host).
+ * work_small / work_mid / work_large: device lists of object ids with N <= 2048, <= 8192, > 8192 points (register-
+ * resident vs global-walk kernels); scratch: sga_fps_scratch_floats(total points) floats, only read when n_large > 0. */
+size_t sga_fps_scratch_floats(int total_points);
+int sga_fps(const float* pts, const int32_t* offsets, int n_obj, const int32_t* start, int npoint,
+            const int32_t* work_small, int n_small, const int32_t* work_mid, int n_mid,
+            const int32_t* work_large, int n_large, int32_t* out_idx, float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

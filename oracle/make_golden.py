@@ -307,8 +307,60 @@ def gen_full_multimodal(losses, sg_aligner):
         g_lv_icl=icl_layer.log_vars.grad, sd_keys=np.array(list(model.state_dict().keys())), **arrs)
 
 
+def gen_fps():
+    """Per-object farthest-point sampling: utils/point_cloud.py:61-89 run as is, with np.random.randint
+    patched to hand back a recorded start index.  cv2 / open3d.ml.torch / trimesh (imported at the top of that file,
+    unused by this function) are stubbed."""
+    import importlib.util
+    for name in ('cv2', 'open3d', 'open3d.ml', 'open3d.ml.torch', 'trimesh'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    spec = importlib.util.spec_from_file_location('ref_point_cloud', os.path.join(REF, 'utils', 'point_cloud.py'))
+    ref_pc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_pc)
+    from oracle import fps_oracle
+    rng = np.random.default_rng(7)
+    cases = {}
+    # (N, npoint): tiny, ragged, duplicates (exact ties -> first arg-max), one > 2048 and one > 8192 points
+    specs = [(5, 5), (37, 16), (300, 64), (1000, 256), (2500, 128), (9000, 64)]
+    real = np.load(os.path.join(REF, 'example_data', 'scene_1', 'data.npy'))
+    for k, (n, m) in enumerate(specs):
+        pts = (rng.standard_normal((n, 3)) * np.array([2.0, 1.0, 0.3])).astype(np.float32)
+        if k == 2:
+            pts[100:200] = pts[0:100]                     # exact duplicates
+        if k == 3:
+            pts = np.round(pts * 4) / 4                    # a coarse lattice: many equal distances
+        start = int(rng.integers(0, n))
+        orig = np.random.randint
+        np.random.randint = lambda lo, hi=None, *a, **kw: start
+        try:
+            sampled, idx = ref_pc.pcl_farthest_sample(pts, m, return_idxs=True)
+        finally:
+            np.random.randint = orig
+        assert np.array_equal(idx, fps_oracle.farthest_point_sample_idx(pts, m, start)), 'oracle != reference'
+        assert np.array_equal(sampled, pts[idx])
+        cases[f'pts{k}'] = pts; cases[f'start{k}'] = np.int32(start); cases[f'idx{k}'] = idx.astype(np.int32)
+    # a real object of the example scan (f4 vertices as the preprocessing sees them)
+    obj = real[real['objectId'] == np.bincount(real['objectId'].astype(np.int64)).argmax()]
+    pts = np.stack([obj['x'], obj['y'], obj['z']], 1).astype(np.float32)
+    start = 3
+    orig = np.random.randint
+    np.random.randint = lambda lo, hi=None, *a, **kw: start
+    try:
+        _, idx = ref_pc.pcl_farthest_sample(pts, 256, return_idxs=True)
+    finally:
+        np.random.randint = orig
+    assert np.array_equal(idx, fps_oracle.farthest_point_sample_idx(pts, 256, start))
+    k = len(specs)
+    cases[f'pts{k}'] = pts; cases[f'start{k}'] = np.int32(start); cases[f'idx{k}'] = idx.astype(np.int32)
+    npz('fps_cases', n_cases=np.int32(k + 1), **cases)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'fps':
+        gen_fps()
+        return
     losses, pointnet, sg_aligner, alignment = import_reference()
+    gen_fps()
     gen_pointnet(pointnet)
     gen_fusion(sg_aligner)
     gen_losses(losses)
