@@ -355,12 +355,48 @@ def gen_fps():
     npz('fps_cases', n_cases=np.int32(k + 1), **cases)
 
 
+def gen_dataset():
+    """Dataset/collate: the reference's Scan3RDataset (src/datasets/scan3r.py) run on a synthetic
+    on-disk dataset written by sgaligner_amd.datasets.synthetic_scan3r (deterministic in its seed; the test re-writes the
+    same files).  `plyfile` (imported by utils/scan3r.py, unused here) is stubbed."""
+    import tempfile
+    sys.modules.setdefault('plyfile', types.ModuleType('plyfile'))
+    sys.modules['plyfile'].PlyData = object
+    sys.path.insert(0, os.path.join(REF, 'src'))
+    sys.path.insert(0, REF)
+    import datasets.scan3r as ref_ds
+    from sgaligner_amd.datasets import synthetic_scan3r as S
+    root = tempfile.mkdtemp(prefix='sga_scan3r_')
+    S.write_dataset(root, n_pairs=6, seed=5)
+    for split, kw in (('val', {}), ('train', {}), ('val', {'overlap_low': 0.3, 'overlap_high': 0.8})):
+        cfg = S.make_cfg(root, pc_res=64, **kw)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds = ref_ds.Scan3RDataset(cfg, split)
+        np.random.seed(123)
+        batch = ds.collate_fn([ds[i] for i in range(len(ds))])
+        arrs = {}
+        for k, v in batch.items():
+            if k == 'batch_size':
+                arrs[k] = np.int64(v)
+            elif k == 'scene_ids':
+                arrs[k] = np.asarray(v).astype('U16')
+            else:
+                arrs[k] = v
+        tag = split + ('_overlap' if kw else '')
+        npz(f'scan3r_collate_{tag}', n_items=np.int64(len(ds)), **arrs)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'fps':
         gen_fps()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'dataset':
+        gen_dataset()
+        return
     losses, pointnet, sg_aligner, alignment = import_reference()
     gen_fps()
+    gen_dataset()
     gen_pointnet(pointnet)
     gen_fusion(sg_aligner)
     gen_losses(losses)
