@@ -23,7 +23,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-MODULES = ['point', 'gat', 'rel']
+# BASELINE.json configs[1] is P+S+R; SGA_BENCH_MODULES (e.g. point,gat,rel,attr) is for side experiments only
+MODULES = os.environ.get('SGA_BENCH_MODULES', 'point,gat,rel').split(',')
 PAIRS_PER_GPU, N_OBJ, N_PTS = 512, 64, 512
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) dense peak
 PEAK_HBM_GBS = 8000.0

@@ -661,7 +661,7 @@ constexpr int S16_OWN = S16_WAVES * 16;     // owner rows per workgroup
 __device__ __forceinline__ int s16_pi(int rho) { return (rho & 9) | ((rho & 2) << 1) | ((rho & 4) >> 1); }
 
 template <int M, bool GRAD>
-__global__ __launch_bounds__(S16_THREADS, S16_WAVES == 4 ? 2 : 1) void sweep16_kernel(MultiArgs a) {
+__global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) void sweep16_kernel(MultiArgs a) {
     constexpr int DP = 104, OT = 32, NCT = 7;
     constexpr int TILE_F = OT * DP, BUF_F = M * TILE_F, NCHUNK = M * 13;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][M][OT][DP] + slack for the 7th column tile
@@ -1216,7 +1216,7 @@ struct AnchorMultiArgs {
 };
 
 template <int M, bool BWD>
-__global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_kernel(AnchorMultiArgs a) {
+__global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_kernel(AnchorMultiArgs a) {
     constexpr int DP = 104, NQ = 13, NT = M + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][32][DP] own rows + inv_s[NT*8]
     float* inv_s = lds + M * 2 * 32 * DP;
@@ -1471,7 +1471,7 @@ __global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restri
 }
 
 template <int M>
-__global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
+__global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
     constexpr int DP = 104, NT = M + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][32][DP] own rows
     // the (M+1)*8 sum coefficients are read from global memory at uniform addresses: s_load -> SGPRs.  As LDS reads
@@ -1831,10 +1831,10 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* be
     int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi);
     if (rc) return rc;
     a.sums = sums;
-    const int nwg = plan_multi(a, 160, M <= 3 ? S16_OWN : 128);
+    const int nwg = plan_multi(a, 160, S16_OWN);
     if (M == 2) launch_sweep16<2, false>(a, nwg, s);
     else if (M == 3) launch_sweep16<3, false>(a, nwg, s);
-    else launch_sweep_multi<4, 0, 2, false>(a, nwg, s);
+    else launch_sweep16<4, false>(a, nwg, s);
     fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums");
     return SGA_OK;
@@ -1852,10 +1852,10 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* be
     if (rc) return rc;
     a.gs = gs; a.gamma = gamma;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }
-    const int nwg = plan_multi(a, 160, M <= 3 ? S16_OWN : 128);
+    const int nwg = plan_multi(a, 160, S16_OWN);
     if (M == 2) launch_sweep16<2, true>(a, nwg, s);
     else if (M == 3) launch_sweep16<3, true>(a, nwg, s);
-    else { launch_sweep_multi<4, 0, 2, true>(a, nwg, s); launch_sweep_multi<4, 2, 2, true>(a, nwg, s); }
+    else launch_sweep16<4, true>(a, nwg, s);          // one workgroup per CU (104 KiB ring, ~300 registers per lane)
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad");
     return SGA_OK;
@@ -1932,7 +1932,7 @@ extern "C" int sga_loss_stash_grad(const float* M1, const float* Z, int A, int D
 // ---- fused anchors x anchors entry points -------------------------------------------------------------------------
 static int fill_anchor_multi(AnchorMultiArgs& a, const float* const* Z, int M, const float* beta, int A, const double* sums,
                              float alpha, float tau_icl, float tau_ial, int a_lo, int a_hi) {
-    if (M < 2 || M > 3) { sga_set_error("sga_loss_anchor_multi: M=%d not in {2,3} (use the per-table kernels)", M); return SGA_ERR_ARG; }
+    if (M < 2 || M > 4) { sga_set_error("sga_loss_anchor_multi: M=%d not in {2,3,4} (use the per-table kernels)", M); return SGA_ERR_ARG; }
     if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("sga_loss_anchor_multi: anchor shard [%d,%d) outside [0,%d]", a_lo, a_hi, A); return SGA_ERR_ARG; }
     a.M = M; a.A = A; a.i_lo = a_lo; a.i_hi = a_hi; a.beta = beta; a.sums = sums; a.alpha = alpha;
     a.kc = LOG2E / tau_icl; a.ki = LOG2E / tau_ial; a.itc = 1.f / tau_icl; a.iti = 1.f / tau_ial;
@@ -1966,7 +1966,7 @@ extern "C" int sga_loss_anchor_multi_fwd(const float* const* Z, int M, const flo
     int rc = fill_anchor_multi(a, Z, M, beta, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
     if (rc) return rc;
     a.out = out;
-    if (M == 2) launch_anchor_multi<2, false>(a, s); else launch_anchor_multi<3, false>(a, s);
+    if (M == 2) launch_anchor_multi<2, false>(a, s); else if (M == 3) launch_anchor_multi<3, false>(a, s); else launch_anchor_multi<4, false>(a, s);
     fold_slots(out, n, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_multi_fwd");
     return SGA_OK;
@@ -2000,8 +2000,12 @@ extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const flo
             auto k = anchor_multi_bwd16_kernel<2>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
-        } else {
+        } else if (M == 3) {
             auto k = anchor_multi_bwd16_kernel<3>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
+        } else {
+            auto k = anchor_multi_bwd16_kernel<4>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
         }

@@ -505,7 +505,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')
         out = torch.empty((slots * (nt + 2 * M),), device=dev, dtype=torch.float64)
         dps = [dp] * M + [M * dp]
-        if M <= 3 and FUSED_ANCHOR_FWD:      # joint similarities derived in registers, I block resident in LDS
+        if M <= 4 and FUSED_ANCHOR_FWD:      # joint similarities derived in registers, I block resident in LDS
             _lib.check(L.sga_loss_anchor_multi_fwd(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out),
                                                    a_lo, a_hi, st), 'sga_loss_anchor_multi_fwd')
         else:
@@ -535,7 +535,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for _ in range(M)]
         gam_neg = torch.empty((slots, M), device=dev, dtype=torch.float64)   # dL/dbeta via the negatives (zeroed by the callee)
         gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via the anchors x anchors terms
-        if M <= 3 and FUSED_ANCHOR_BWD:
+        if M <= 4 and FUSED_ANCHOR_BWD:
             # fused: M1[m] already holds dL/dS_m + beta_m dL/dS_J, dL/dbeta comes out directly; no joint operand / stash
             m1 = [torch.empty((A, max(ns, 1)), device=dev, dtype=torch.float32) for _ in range(M)]
             gs = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)     # + one block: float copy of 1/(sums+eps)
