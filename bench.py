@@ -159,7 +159,7 @@ def main():
             executed = 2.0 * (2.0 * ns * (J1 + J2)) * 2.0 * M * (104 + 112)
             avg_ms = float(np.mean(durs))
             ach = alg / (avg_ms * 1e-3) / 1e12
-            kname = f'sweep16_kernel<{M},true>' if M <= 3 else f'sweep_multi_kernel<{M},*,2,true>'
+            kname = f'sweep16_kernel<{M},true>'
             roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': pmc_traffic_bytes(f'sweep16_kernel<{M},true>') if world == 1 else None,
                           'kernel': f'{kname} (loss: negatives backward, all {M}+1 tables)',

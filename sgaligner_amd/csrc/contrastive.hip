@@ -400,10 +400,10 @@ static void launch_sweep_fast(const SweepArgs& a, int nblk, int gy, hipStream_t 
 //   GRAD mode: forms c_m = dL/dS_m + beta_m dL/dS_J, chains the M gradient GEMMs from the accumulators,
 //              and accumulates Gamma_m = sum dL/dS_J * S_m  (= dL/dbeta_m through the negatives).
 // vs. the per-table path this removes the joint table's S and gradient GEMMs (~half of all loss FLOPs).
-// Geometry: 4 waves, one per SIMD (the M owner-row operands + M gradient tiles need ~410 registers, so
-// the kernel takes the whole 512-entry file); 32-row other tiles for all M tables are streamed into a
-// double-buffered LDS ring by global_load_lds DMA (no VGPR round trip) one step ahead of the MFMAs.
-// Requires Dp == 104 (emb_dim 100) and 32 readable rows past the end of every Z buffer.
+// 32-row other tiles for all M tables are streamed into a double-buffered LDS ring by global_load_lds DMA (no VGPR
+// round trip) one step ahead of the MFMAs.  Requires Dp == 104 (emb_dim 100) and 32 readable rows past the end of
+// every Z buffer.  (A 32x32x2 form of this kernel -- 32 owner rows per wave, the whole 512-entry register file, one
+// wave per SIMD -- ran the gradient sweep in 22.5 ms; sweep16_kernel below replaced it at 19.4 ms.)
 // ------------------------------------------------------------------------------------------------
 struct MultiArgs {
     int M; const float* Z[4]; int ngroups; SweepGroup grp[4];
@@ -415,230 +415,10 @@ struct MultiArgs {
     double* gamma;                  // [M]                   GRAD out
 };
 
-template <int M, int G0, int NG, bool GRAD>
-__global__ __launch_bounds__(CT_THREADS) void sweep_multi_kernel(MultiArgs a) {
-    constexpr int DP = 104, NQ = 13, OT = 32, NCT = 4;
-    constexpr int TILE_F = OT * DP;                     // 3328 floats = 13 KiB per table
-    constexpr int BUF_F = M * TILE_F;
-    constexpr int NCHUNK = M * 13;                      // 1 KiB DMA pieces per step
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][M][OT][DP]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    int g = 0;
-#pragma unroll
-    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
-    const SweepGroup& grp = a.grp[g];
-    const int wg_in_grp = (int)blockIdx.x - grp.blk0;
-    const int nsplit = grp.nsplit, split = wg_in_grp % nsplit;          // the group's other tiles are dealt round-robin to nsplit workgroups
-    const int own0 = grp.own0 + (wg_in_grp / nsplit) * 128;
-    const int own_end = grp.own0 + grp.nown;
-    const int my_i = own0 + wave * 32 + (lane & 31);
-    const bool iv = my_i < own_end;
-
-    f32x4 own[M][NQ];
-    float beta[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const float* src = a.Z[m] + (size_t)(iv ? my_i : own0) * DP + 4 * h;
-        const float msk = iv ? 1.f : 0.f;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 8 * q) * msk;
-        beta[m] = a.beta[m];
-    }
-    f32x16 gacc[GRAD ? NG : 1][NCT];
-    if (GRAD) {
-#pragma unroll
-        for (int m = 0; m < NG; ++m) zero_acc<NCT>(gacc[m]);
-    }
-    float gam[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) gam[m] = 0.f;
-
-    // The LDS destination of global_load_lds travels in M0 and must be PROVABLY wave-uniform: with the plain wave id
-    // (derived from threadIdx) hipcc wraps every DMA in a waterfall loop with s_waitcnt vmcnt(0) in front of it, i.e.
-    // the pieces are issued one L2 round trip at a time (measured: 4 ms of this kernel).
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto issue = [&](int j0, float* buf) {             // DMA the M [32][104] tiles starting at row j0
-#pragma unroll
-        for (int c0 = 0; c0 < NCHUNK; c0 += 4) {
-            const int c = c0 + wave_u;
-            if (c >= NCHUNK) break;
-            const int m = c / 13, cc = c - m * 13;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(a.Z[m] + (size_t)j0 * DP + cc * 256 + lane * 4),
-                (__attribute__((address_space(3))) void*)(buf + m * TILE_F + cc * 256), 16, 0, 0);
-        }
-    };
-
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-        if (sg >= grp.nseg) break;
-        const SweepSeg seg = grp.seg[sg];
-        const int ntile = (seg.n + OT - 1) / OT;
-        const int j_end = seg.row0 + seg.n;
-        float c0[M + 1], c1[M + 1];
-#pragma unroll
-        for (int m = 0; m <= M; ++m) {
-            c0[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
-            c1[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
-        }
-        double dsum[M + 1][2];
-#pragma unroll
-        for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
-
-        __syncthreads();                                   // ring free (previous segment fully consumed)
-        if (split < ntile) issue(seg.row0 + split * OT, lds);
-        int it = 0;
-        for (int jt = split; jt < ntile; jt += nsplit, ++it) {
-            float* buf = lds + (it & 1) * BUF_F;
-            const int j0 = seg.row0 + jt * OT;
-            __syncthreads();                               // tile `it` landed (vmcnt drained) / other buffer free
-#ifndef SGA_DBG_NODMA
-            if (jt + nsplit < ntile) issue(seg.row0 + (jt + nsplit) * OT, lds + ((it + 1) & 1) * BUF_F);
-#endif
-
-            // ---- S tiles of the M tables: lane = owner row, registers = other rows
-            f32x16 sacc[M];
-            zero_acc<M>(sacc);
-            {   // one wave per SIMD: nobody else hides the LDS latency, so the A operand is read one K-group ahead
-                // into the OTHER of two register quads (no copy: a copy lets the compiler fold the buffers back together)
-                const float* ap = buf + (lane & 31) * DP + 4 * h;
-                f32x4 avA = *reinterpret_cast<const f32x4*>(ap), avB = avA;
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // the prologue read
-#pragma unroll
-                for (int gq = 0; gq < M * NQ; ++gq) {
-                    const int m = gq / NQ, q = gq % NQ;
-                    const int nm = (gq + 1) / NQ, nq = (gq + 1) % NQ;
-                    if (gq + 1 < M * NQ) {
-                        if (gq & 1) avA = *reinterpret_cast<const f32x4*>(ap + nm * TILE_F + 8 * nq);
-                        else avB = *reinterpret_cast<const f32x4*>(ap + nm * TILE_F + 8 * nq);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        sacc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32((gq & 1) ? avB[r] : avA[r], own[m][q][r], sacc[m], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // next group's ds_read first ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // ... then this group's 4 MFMAs
-                }
-            }
-            // ---- joint similarity, sums / coefficients
-            if (!GRAD) {
-                float p0[M + 1], p1[M + 1];
-#pragma unroll
-                for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // masks as multipliers: `ok ? exp : 0` is compiled into an exec-mask branch per element
-                    const float okf = (iv && (j0 + mfma32_row(r, h) < j_end)) ? 1.f : 0.f;
-                    float sj = 0.f;
-#pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        const float sv = sacc[m][r];
-                        sj = fmaf(beta[m], sv, sj);
-                        p0[m] = fmaf(okf, fexp2(sv * a.k0), p0[m]);
-                        p1[m] = fmaf(okf, fexp2(sv * a.k1), p1[m]);
-                    }
-                    p0[M] = fmaf(okf, fexp2(sj * a.k0), p0[M]);
-                    p1[M] = fmaf(okf, fexp2(sj * a.k1), p1[M]);
-                }
-#pragma unroll
-                for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
-            } else {
-                // dL/dS_J for this tile (kept in VGPRs), then per table: c_m = dL/dS_m + beta_m dL/dS_J -> gradient GEMM.
-                // Only cj and ONE table's coefficients are live at a time: the MFMA A operand must be a VGPR and the
-                // M owner operands already take 156 of the 256.
-                float cj[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float okf = (iv && (j0 + mfma32_row(r, h) < j_end)) ? 1.f : 0.f;
-                    float sj = 0.f;
-#pragma unroll
-                    for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][r], sj);
-                    cj[r] = okf * (c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1));
-                }
-                if (G0 == 0 && g < 2) {                         // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
-#pragma unroll
-                    for (int m = 0; m < M; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) gam[m] = fmaf(cj[r], sacc[m][r], gam[m]);
-                }
-#pragma unroll
-                for (int mm = 0; mm < NG; ++mm) {
-                    const int m = G0 + mm;
-                    float cm[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float okf = (iv && (j0 + mfma32_row(r, h) < j_end)) ? 1.f : 0.f;
-                        const float sv = sacc[m][r];
-                        cm[r] = okf * fmaf(beta[m], cj[r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1));
-                    }
-                    const float* bb = buf + m * TILE_F + (lane & 31);
-                    float bc[NCT], bn[NCT];
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) bc[ct] = bb[mfma32_row(0, h) * DP + ct * 32];
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) bn[ct] = bb[mfma32_row(s + 1 < 16 ? s + 1 : s, h) * DP + ct * 32];
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct)
-                            gacc[mm][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(cm[s], bc[ct], gacc[mm][ct], 0, 0, 0);
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) bc[ct] = bn[ct];
-                        __builtin_amdgcn_sched_group_barrier(0x100, NCT, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        if (!GRAD) {
-#pragma unroll
-            for (int m = 0; m <= M; ++m)
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const double v = wave_sum_d(dsum[m][tt]);
-                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + (M + 1) * 8 * (1 + my_slot()) + m * 8 + seg.fam * 2 + tt, v);
-                }
-        }
-    }
-    if (GRAD) {
-#pragma unroll
-        for (int mm = 0; mm < NG; ++mm) {
-            float* dz = a.dZ[G0 + mm];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int d = ct * 32 + (lane & 31);
-                if (d < DP) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int i = own0 + wave * 32 + mfma32_row(r, h);
-                        if (i < own_end) atomicAdd(dz + (size_t)i * DP + d, gacc[mm][ct][r]);
-                    }
-                }
-            }
-        }
-        if (G0 == 0 && g < 2) {
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const float v = wave_sum(gam[m]);
-                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + m, (double)v);
-            }
-        }
-    }
-}
-
-template <int M, int G0, int NG, bool GRAD>
-static void launch_sweep_multi(const MultiArgs& a, int nwg, hipStream_t s) {
-    const size_t lds = (size_t)2 * M * 32 * 104 * sizeof(float);
-    auto k = sweep_multi_kernel<M, G0, NG, GRAD>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(CT_THREADS), lds, s, a);
-}
-
 // ------------------------------------------------------------------------------------------------
 // 16x16x4 form of the fused multi-table sweep (M = 2, 3; the path the benchmark runs).
 //
-// The 32x32 kernel above keeps M*52 owner-operand registers and M*64 gradient accumulators per lane: the whole
+// The 32x32 predecessor kept M*52 owner-operand registers and M*64 gradient accumulators per lane: the whole
 // 512-entry file, one wave per SIMD, so nothing overlaps its exp2/coefficient VALU work with MFMA (measured 70 % of
 // the fp32 MFMA peak).  Here a wave owns 16 rows instead of 32: M*26 operand + M*28 accumulator registers, 8 waves
 // per workgroup = two per SIMD, and the second wave's MFMAs run under the first one's epilogue.  Same workgroup
