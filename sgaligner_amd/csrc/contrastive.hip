@@ -1020,12 +1020,9 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_kerne
     for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
 
     // per-lane partial sums over all this wave's tiles
-    float acc_out[BWD ? 1 : NT + 2 * M];
-    float acc_gam[BWD ? M : 1];
+    float acc_out[NT + 2 * M];
 #pragma unroll
-    for (int e = 0; e < (BWD ? 1 : NT + 2 * M); ++e) acc_out[e] = 0.f;
-#pragma unroll
-    for (int e = 0; e < (BWD ? M : 1); ++e) acc_gam[e] = 0.f;
+    for (int e = 0; e < NT + 2 * M; ++e) acc_out[e] = 0.f;
 
     const int ntile = (A + 31) / 32;
     for (int jt = split * 4 + wave; jt < ntile; jt += a.nsplit * 4) {
@@ -1069,7 +1066,6 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_kerne
             for (int r = 0; r < 16; ++r) { xs[m][r] = P[m][r]; ys[m][r] = Q[m][r]; }
         // ---- epilogue, one element at a time (forward)
         const float* js = inv_s + M * 8;
-        if (!BWD)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = j0 + mfma32_row(r, h);
@@ -1098,142 +1094,17 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_kerne
                     }
                 }
             }
+#pragma unroll
+            for (int e = 0; e < NT + 2 * M; ++e) asm volatile("" : "+v"(acc_out[e]));   // keep the updates out of the loop latch
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- epilogue (backward) in table-major passes: only ONE table's 8 sum coefficients / 3 upstream coefficients and
-        // one element's temporaries are live at a time (element-major with everything live needed > 512 registers).
-        //   pass 0: joint ICL      -> gJ[r]
-        //   pass 1: per modality   -> ICL_m + IAL_m (qo part) into ys[m][r]; EA/EB[r] = sum_m c_m exp(qo_m)
-        //   pass 2: joint IAL (qm) -> gJ[r] += ...
-        //   pass 3: Gamma_m += gJ S_m ;  xs[m][r] = dL/dS_m + beta_m dL/dS_J
-        if (BWD) {
-            // dL/d(sums) partials live only during their table's pass (keeping all (M+1)*8 per lane for the whole kernel
-            // pushed the kernel over 256 registers); each pass ends with 8 wave-sums into this wave's slot.
-            double* const gs_slot = a.gs + NT * 8 * (1 + my_slot());
-            auto flush8 = [&](float (&g8)[8], int k) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = wave_sum(g8[e]);
-                    if (lane == 0 && v != 0.f) atomicAdd(gs_slot + k * 8 + e, (double)v);
-                }
-            };
-            float gJ[16], EA[16], EB[16];
-            float gsJ[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            {
-                const float* is = inv_s + M * 8;
-                const float c = a.coef[M];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = iv && (j0 + mfma32_row(r, h) < A);
-                    float xj = 0.f, yj = 0.f;
-#pragma unroll
-                    for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], xs[m][r], xj); yj = fmaf(beta[m], ys[m][r], yj); }
-                    asm volatile("" : "+v"(xj), "+v"(yj));
-                    const float dx = fexp2(xj * a.kc), dy = fexp2(yj * a.kc);
-                    const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
-                    const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
-                    const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
-                    const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
-                    gJ[r] = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
-                    gsJ[0] += wA * Ax.dsa; gsJ[2] += wA * Ax.dsb;
-                    gsJ[4] += wB * Bx.dsa; gsJ[6] += wB * Bx.dsb;
-                    EA[r] = 0.f; EB[r] = 0.f;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const float* is = inv_s + m * 8;
-                const float c = a.coef[m], ca = a.coef[NT + m], cb = a.coef[NT + M + m];
-                float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = iv && (j0 + mfma32_row(r, h) < A);
-                    const float x = xs[m][r], y = ys[m][r];
-                    float xj = 0.f;
-#pragma unroll
-                    for (int mm = 0; mm < M; ++mm) xj = fmaf(beta[mm], xs[mm][r], xj);
-                    // opaque: otherwise the joint-table terms (identical in every modality's pass) are CSE'd across the
-                    // passes and kept live for all 16 elements -- thousands of spilled registers instead of a few flops
-                    asm volatile("" : "+v"(xj));
-                    const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
-                    const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
-                    const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
-                    const float wA = ok ? -c * a.alpha * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) : 0.f;
-                    const float wB = ok ? -c * (1.f - a.alpha) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) : 0.f;
-                    float gx = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
-                    g8[0] += wA * Ax.dsa; g8[2] += wA * Ax.dsb;
-                    g8[4] += wB * Bx.dsa; g8[6] += wB * Bx.dsb;
-                    // IAL: qo from this table, qm from the joint one (values only here; its derivative in pass 2)
-                    const float dm = fexp2(x * a.ki), dji = fexp2(xj * a.ki);
-                    const GV OA = g_full(dm, is[1], is[3]), OB = g_full(dm, is[5], is[7]);
-                    const float lqma = flog(g_val(dji, js[1], js[3])), lqmb = flog(g_val(dji, js[5], js[7]));
-                    const float eA = ok ? ca * __expf(OA.q) : 0.f, eB = ok ? cb * __expf(OB.q) : 0.f;
-                    const float tA = eA * (OA.q - lqma + 1.f), tB = eB * (OB.q - lqmb + 1.f);
-                    gx += (tA * OA.dd + tB * OB.dd) * dm * a.iti;
-                    g8[1] += tA * OA.dsa; g8[3] += tA * OA.dsb;
-                    g8[5] += tB * OB.dsa; g8[7] += tB * OB.dsb;
-                    EA[r] += eA; EB[r] += eB;
-                    ys[m][r] = gx;                                       // y_m is dead from here on
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                flush8(g8, m);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float xj = 0.f;
-#pragma unroll
-                for (int m = 0; m < M; ++m) xj = fmaf(beta[m], xs[m][r], xj);
-                asm volatile("" : "+v"(xj));
-                const float dji = fexp2(xj * a.ki);
-                const GV MA = g_full(dji, js[1], js[3]), MB = g_full(dji, js[5], js[7]);
-                const float uA = -EA[r] * frcp(MA.q), uB = -EB[r] * frcp(MB.q);
-                gJ[r] += (uA * MA.dd + uB * MB.dd) * dji * a.iti;
-                gsJ[1] += uA * MA.dsa; gsJ[3] += uA * MA.dsb;
-                gsJ[5] += uB * MB.dsa; gsJ[7] += uB * MB.dsb;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            flush8(gsJ, M);
-#pragma unroll
-            for (int m = 0; m < M; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc_gam[m] = fmaf(gJ[r], xs[m][r], acc_gam[m]);
-                    xs[m][r] = fmaf(beta[m], gJ[r], ys[m][r]);           // dL/dS_m total
-                }
-        }
-        if (BWD && iv) {
-            // The 16*M store addresses depend only on the tile, so the scheduler would compute them BEFORE the epilogue
-            // and keep ~100 address registers alive through it (the whole epilogue then spills).  An offset that only
-            // becomes known here pins the address arithmetic after the passes.
-            int late = 0;
-            asm volatile("" : "+v"(late));
-            const size_t col = (size_t)(my_i - a.i_lo + late);
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                float* m1 = a.M1[m];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = j0 + mfma32_row(r, h);
-                    if (j < A) m1[(size_t)j * ns + col] = xs[m][r];
-                }
-            }
         }
     }
     // ---- flush the wave's partial sums into its slot
     const int slot = my_slot();
-    if (!BWD) {
 #pragma unroll
-        for (int e = 0; e < NT + 2 * M; ++e) {
-            const float v = wave_sum(acc_out[BWD ? 0 : e]);
-            if (lane == 0 && v != 0.f) atomicAdd(a.out + (NT + 2 * M) * (1 + slot) + e, (double)v);
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const float v = wave_sum(acc_gam[BWD ? m : 0]);
-            if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + slot) + m, (double)v);
-        }
+    for (int e = 0; e < NT + 2 * M; ++e) {
+        const float v = wave_sum(acc_out[e]);
+        if (lane == 0 && v != 0.f) atomicAdd(a.out + (NT + 2 * M) * (1 + slot) + e, (double)v);
     }
 }
 
