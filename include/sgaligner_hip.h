@@ -127,6 +127,20 @@ int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, int B, in
                 const int32_t* q_pair, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
                 int32_t* topk_idx, float* topk_sim, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Point-Cloud-Transformer object encoder, inference path ('pct' module) ---------
+ * sga_gemm_ex: C = act(op(A) op(B) + bias) (+ resid), act 0 none / 1 ReLU / 2 LeakyReLU(0.2): the conv1d(k=1) +
+ *   eval-mode BatchNorm (folded into weight and bias by the caller) + activation (+ SA residual) layers of
+ *   src/aligner/networks/pct.py:115-124 (Embedding), :223-229 (SA tail), :289-293 (linear), :311-315 (head).
+ * sga_pct_attention: SA.forward's attention (pct.py:211-222) for T objects of N points each, flash style:
+ *   Q [T*N,32] (= q_conv(x) = k_conv(x): shared weight, pct.py:199), V [T*N,128] (= v_conv(x) + bias) ->
+ *   Xs[j,:] = sum_i softmax_row_i(Q Q^T / sqrt(32))[i,j] V[i,:].  stats: 2*T*N floats of workspace.
+ * sga_segment_max: G[t,c] = max over the N points of object t (pct.py:308). */
+int sga_gemm_ex(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                float* C, long ldc, const float* bias, int act, const float* resid, long ldr, void* stream);
+int sga_pct_attention(const float* Q, long ldq, const float* V, long ldv, int T, int N, float* stats, float* Xs,
+                      long ldx, void* stream);
+int sga_segment_max(const float* Y, long ldy, int T, int N, int C, float* G, void* stream);
+
 /* ---- per-object farthest-point sampling (the step in front of the path) -----------------
  * replaces utils/point_cloud.py:61-89 pcl_farthest_sample as called by preprocessing/scan3r/preprocess.py:96-98.
  * pts [sum N,3] f32 packed per object, offsets [n_obj+1]; start[obj] = the first sample (the reference draws it with

@@ -387,7 +387,38 @@ def gen_dataset():
         npz(f'scan3r_collate_{tag}', n_items=np.int64(len(ds)), **arrs)
 
 
+def gen_pct():
+    """NaivePCT, eval mode: the reference module itself (src/aligner/networks/pct.py) with
+    randomised BatchNorm statistics/affines; checks oracle/pct_oracle.py against it and stores inputs, state_dict, outputs."""
+    import_reference()
+    import aligner.networks.pct as ref_pct
+    from oracle import pct_oracle
+    torch.manual_seed(0)
+    m = ref_pct.NaivePCT()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 2.0)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    m.eval()
+    arrs = {'sd__' + k: v for k, v in m.state_dict().items()}      # one set of weights (5 MB), three inputs
+    for tag, (T, N) in {'small': (3, 96), 'p512': (2, 512), 'ragged': (5, 45)}.items():
+        x = torch.randn(T, 3, N) * torch.tensor([1.0, 0.6, 0.3]).reshape(1, 3, 1)
+        with torch.no_grad():
+            y = m(x)
+            yo = pct_oracle.naive_pct_forward(x, m.state_dict())
+        assert (y - yo).abs().max() < 1e-5 * max(1.0, y.abs().max().item()), (tag, (y - yo).abs().max())
+        arrs['x_' + tag] = x
+        arrs['y_' + tag] = y
+    npz('pct_eval', **arrs)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'pct':
+        gen_pct()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'fps':
         gen_fps()
         return
@@ -397,6 +428,7 @@ def main():
     losses, pointnet, sg_aligner, alignment = import_reference()
     gen_fps()
     gen_dataset()
+    gen_pct()
     gen_pointnet(pointnet)
     gen_fusion(sg_aligner)
     gen_losses(losses)

@@ -29,6 +29,9 @@ SIGNATURES = {
     'sga_elu_bwd': (I, [P, P, P, c_size_t, P]),
     'sga_simrank_workspace_bytes': (c_size_t, [I]),
     'sga_simrank': (I, [P, I, I, P, I, I, P, P, P, I, I, P, P, P, P, c_size_t, P]),
+    'sga_gemm_ex': (I, [I, I, I, I, I, P, c_long, P, c_long, P, c_long, P, I, P, c_long, P]),
+    'sga_pct_attention': (I, [P, c_long, P, c_long, I, I, P, P, c_long, P]),
+    'sga_segment_max': (I, [P, c_long, I, I, I, P, P]),
     'sga_fps_scratch_floats': (c_size_t, [I]),
     'sga_fps': (I, [P, P, I, P, I, P, I, P, I, P, I, P, P, P]),
     'sga_gemm': (I, [I, I, I, I, I, P, c_long, I, P, c_long, P, c_long, P, I, P]),

@@ -1,0 +1,136 @@
+"""Point-Cloud-Transformer object encoder -- drop-in for the reference's `NaivePCT` (src/aligner/networks/pct.py:
+275-317, with `Embedding` :101-125 and `SA` :187-232; selected by `modules: ['pct', ...]`,
+configs/scan3r/scan3r_ground_truth.yaml:5).  Same class names, constructor signatures, sub-module names and
+state_dict keys, so reference checkpoints load with strict=True.
+
+Scope: the INFERENCE path.  In eval mode the forward runs on the HIP kernels -- per-point
+convolutions as exact-fp32 MFMA GEMMs with the eval-mode BatchNorm folded into weight/bias (sga_gemm_ex), the
+self-attention flash style (sga_pct_attention), the point max (sga_segment_max); Dropout is the identity.  Train
+mode (batch-statistic BatchNorm over all objects and points + two Dropout(0.5)) is not implemented and raises.
+"""
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ...ops import _p, _stream
+
+
+def _gemm_ex(a, w, bias, act=0, resid=None, out=None):
+    """out[m, n] = act(a[m, k] @ w[n, k]^T + bias) (+ resid);  a / out / resid may be column slices of wider buffers."""
+    m, k = a.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    rc = _lib.lib().sga_gemm_ex(0, 1, m, n, k, _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias),
+                                act, _p(resid), resid.stride(0) if resid is not None else 0, _stream())
+    _lib.check(rc, 'sga_gemm_ex')
+    return out
+
+
+def _fold(conv_w, conv_b, bn):
+    """conv1d(k=1) / linear followed by an eval-mode BatchNorm1d -> one affine map: W' = s W, b' = s (b - mean) + beta,
+    s = gamma / sqrt(running_var + eps).  Tiny tensors; done on the device with torch ops once per forward."""
+    w = conv_w.reshape(conv_w.shape[0], -1).float()
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    b = -bn.running_mean if conv_b is None else conv_b - bn.running_mean
+    return (w * s[:, None]).contiguous(), (b * s + bn.bias).contiguous()
+
+
+class Embedding(nn.Module):
+    """pct.py:101-125: two Conv1d(k=1, bias=False) + BatchNorm + ReLU layers."""
+
+    def __init__(self, in_channels=3, out_channels=128):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_channels, out_channels, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(out_channels, out_channels, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm1d(out_channels)
+        self.bn2 = nn.BatchNorm1d(out_channels)
+
+    def forward_rows(self, x_rows):
+        """x_rows [T*N, in] point-major -> [T*N, out]."""
+        w1, b1 = _fold(self.conv1.weight, None, self.bn1)
+        w2, b2 = _fold(self.conv2.weight, None, self.bn2)
+        h = _gemm_ex(x_rows, w1, b1, act=1)
+        return _gemm_ex(h, w2, b2, act=1)
+
+
+class SA(nn.Module):
+    """pct.py:187-232.  q_conv and k_conv share one weight tensor (:199) -- both keys appear in the state_dict."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.da = channels // 4
+        self.q_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
+        self.k_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
+        self.q_conv.weight = self.k_conv.weight
+        self.v_conv = nn.Conv1d(channels, channels, 1)
+        self.trans_conv = nn.Conv1d(channels, channels, 1)
+        self.after_norm = nn.BatchNorm1d(channels)
+        self.act = nn.ReLU()
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward_rows(self, x_rows, n_obj, n_pts, out):
+        """x_rows [T*N, 128] (may be a column slice) -> out (column slice) = x + relu(bn(trans_conv(x_v @ attention)))."""
+        if self.q_conv.weight.data_ptr() != self.k_conv.weight.data_ptr() and not torch.equal(self.q_conv.weight, self.k_conv.weight):
+            raise RuntimeError('sgaligner_amd SA: q_conv / k_conv weights differ; the HIP attention relies on the shared '
+                               'weight of the reference (pct.py:199) for a symmetric energy matrix')
+        if self.da != 32 or x_rows.shape[1] != 128:
+            raise NotImplementedError('sgaligner_amd SA: channels must be 128 (NaivePCT)')
+        dev = x_rows.device
+        q = _gemm_ex(x_rows, self.k_conv.weight.reshape(self.da, -1), None)
+        v = _gemm_ex(x_rows, self.v_conv.weight.reshape(128, -1), self.v_conv.bias)
+        stats = torch.empty((2 * n_obj * n_pts,), device=dev, dtype=torch.float32)
+        xs = torch.empty((n_obj * n_pts, 128), device=dev, dtype=torch.float32)
+        rc = _lib.lib().sga_pct_attention(_p(q), q.stride(0), _p(v), v.stride(0), n_obj, n_pts, _p(stats), _p(xs), xs.stride(0), _stream())
+        _lib.check(rc, 'sga_pct_attention')
+        wt, bt = _fold(self.trans_conv.weight, self.trans_conv.bias, self.after_norm)
+        return _gemm_ex(xs, wt, bt, act=1, resid=x_rows, out=out)
+
+
+class NaivePCT(nn.Module):
+    """pct.py:275-317."""
+
+    def __init__(self):
+        super().__init__()
+        self.embedding = Embedding(3, 128)
+        self.sa1 = SA(128)
+        self.sa2 = SA(128)
+        self.sa3 = SA(128)
+        self.sa4 = SA(128)
+        self.linear = nn.Sequential(nn.Conv1d(512, 1024, kernel_size=1, bias=False), nn.BatchNorm1d(1024),
+                                    nn.LeakyReLU(negative_slope=0.2))
+        self.linear1 = nn.Linear(1024, 512, bias=False)
+        self.linear2 = nn.Linear(512, 256)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.dp1 = nn.Dropout(p=0.5)
+        self.dp2 = nn.Dropout(p=0.5)
+
+    def forward(self, x):
+        """x [T, 3, N] as in the reference (a permuted view of data_dict['tot_obj_pts'] [T,N,3]) -> [T, 256]."""
+        if self.training:
+            raise NotImplementedError("sgaligner_amd NaivePCT: only the eval-mode (inference) forward runs on the HIP path; "
+                                      "call model.eval() (train-mode BatchNorm statistics / Dropout: SURVEY.md 8(f), next)")
+        if not x.is_cuda:
+            raise RuntimeError('sgaligner_amd NaivePCT: input must be on the HIP device (no CPU path)')
+        xt = x.permute(0, 2, 1)
+        if not xt.is_contiguous():
+            xt = xt.contiguous()
+        t, n, _ = xt.shape
+        rows = xt.reshape(t * n, 3).float()
+        with torch.no_grad():
+            h = self.embedding.forward_rows(rows)
+            cat = torch.empty((t * n, 512), device=x.device, dtype=torch.float32)      # x1 | x2 | x3 | x4 (pct.py:302)
+            src = h
+            for k, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):
+                dst = cat[:, 128 * k:128 * (k + 1)]
+                sa.forward_rows(src, t, n, dst)
+                src = dst
+            w5, b5 = _fold(self.linear[0].weight, None, self.linear[1])
+            y = _gemm_ex(cat, w5, b5, act=2)                                           # LeakyReLU(0.2)
+            g = torch.empty((t, 1024), device=x.device, dtype=torch.float32)
+            _lib.check(_lib.lib().sga_segment_max(_p(y), y.stride(0), t, n, 1024, _p(g), _stream()), 'sga_segment_max')
+            w6, b6 = _fold(self.linear1.weight, None, self.bn1)
+            w7, b7 = _fold(self.linear2.weight, self.linear2.bias, self.bn2)
+            f = _gemm_ex(g, w6, b6, act=1)
+            return _gemm_ex(f, w7, b7, act=1)

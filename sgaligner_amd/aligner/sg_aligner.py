@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from .networks.gat import MultiGAT
+from .networks.pct import NaivePCT
 from .networks.pointnet import PointNetfeat
 
 
@@ -52,7 +53,7 @@ class MultiModalFusion(nn.Module):
 
 
 class MultiModalEncoder(nn.Module):
-    """sg_aligner.py:37-137.  `modules` (list of 'point' | 'gat' | 'rel' | 'attr') is kept as an attribute
+    """sg_aligner.py:37-137.  `modules` (list of 'point' | 'pct' | 'gat' | 'rel' | 'attr') is kept as an attribute
     with the reference's name -- it shadows nn.Module.modules(), exactly as in the reference (:41)."""
 
     def __init__(self, modules, rel_dim, attr_dim, hidden_units=[3, 128, 128], heads=[2, 2], emb_dim=100,
@@ -76,8 +77,7 @@ class MultiModalEncoder(nn.Module):
             self.object_encoder = PointNetfeat(global_feat=True, batch_norm=True, point_size=3, input_transform=False,
                                                feature_transform=False, out_size=self.pt_out_dim)
         elif 'pct' in self.modules:
-            raise NotImplementedError("sgaligner_amd: the 'pct' object encoder (NaivePCT) is outside the PointNet hot path "
-                                      "(SURVEY.md 8f, next)")
+            self.object_encoder = NaivePCT()                             # sg_aligner.py:59-60; inference path only
         else:
             raise NotImplementedError                                   # sg_aligner.py:61-62
         self.object_embedding = _Linear(self.pt_out_dim, self.emb_dim)
@@ -97,7 +97,7 @@ class MultiModalEncoder(nn.Module):
                 gb = ops.GraphBatch.of(data_dict)
                 emb = self.structure_encoder.forward_batched(data_dict['tot_rel_pose'], gb)
                 emb = self.structure_embedding(emb)
-            elif module == 'point':
+            elif module in ('point', 'pct'):
                 emb = self.object_encoder(pts.permute(0, 2, 1))         # :72,:115
                 emb = self.object_embedding(emb)
             elif module == 'rel':

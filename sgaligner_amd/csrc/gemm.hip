@@ -63,7 +63,8 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(const TA* __restrict__
                                                           float* __restrict__ C, long ldc,
                                                           const float* __restrict__ bias, int M, int N, int K,
                                                           int accumulate, int k_per_split, int use_atomic,
-                                                          int a_vec_ok, int b_vec_ok) {
+                                                          int a_vec_ok, int b_vec_ok, int act,
+                                                          const float* __restrict__ resid, long ldr) {
     __shared__ __attribute__((aligned(16))) float As[128 * SGA_LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Bs[128 * SGA_LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,9 +93,13 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(const TA* __restrict__
             const int m = m0 + t * 32 + mfma32_row(r, h);
             if (m < M) {
                 float* p = C + (size_t)m * ldc + n;
-                const float v = acc[t][r] + bv;
-                if (use_atomic) atomicAdd(p, v);
-                else *p = accumulate ? (*p + v) : v;
+                float v = acc[t][r] + bv;
+                if (use_atomic) { atomicAdd(p, v); continue; }
+                if (accumulate) v += *p;
+                if (act == 1) v = fmaxf(v, 0.f);                       // ReLU
+                else if (act == 2) v = v > 0.f ? v : 0.2f * v;        // LeakyReLU(0.2)
+                if (resid) v += resid[(size_t)m * ldr + n];           // residual AFTER the activation (x + act(...))
+                *p = v;
             }
         }
     }
@@ -129,18 +134,19 @@ extern "C" int sga_cast_f64_f32(const double* in, float* out, size_t n, void* st
     return SGA_OK;
 }
 
-extern "C" int sga_gemm(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64,
-                        const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
-                        void* stream) {
+static int gemm_launch(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64,
+                       const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
+                       int act, const float* resid, long ldr, void* stream) {
     SGA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sga_gemm: negative size");
     SGA_CHECK_ARG(A && B && C, "sga_gemm: null pointer");
+    SGA_CHECK_ARG(act >= 0 && act <= 2, "sga_gemm_ex: act=%d (0 none, 1 relu, 2 leaky-relu 0.2)", act);
     if (M == 0 || N == 0) return SGA_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = (M + 127) / 128, gy = (N + 127) / 128;
     // split K when the output grid cannot fill the chip (weight-gradient shape)
     int splits = 1;
     const int ncu = sga_num_cus();
-    if (gx * gy < ncu && K >= 4096) {
+    if (gx * gy < ncu && K >= 4096 && act == 0 && !resid) {          // split-K partial sums cannot carry an epilogue
         // ~4 workgroups per CU, at least 256 K-rows each (64 splits of 1024 left 3/4 of the chip idle: 350-470 us per
         // weight gradient at K = 65536 objects)
         splits = min((4 * ncu) / (gx * gy), (K + 255) / 256);
@@ -162,12 +168,27 @@ extern "C" int sga_gemm(int transA, int transB, int M, int N, int K, const void*
     dim3 grid(gx, gy, splits);
     if (a_is_f64)
         hipLaunchKernelGGL(gemm_kernel<double>, grid, dim3(GM_THREADS), 0, s, static_cast<const double*>(A), lda, transA, B, ldb,
-                           transB, C, ldc, bias, M, N, K, accumulate, kper, use_atomic, 0, (int)b_al);
+                           transB, C, ldc, bias, M, N, K, accumulate, kper, use_atomic, 0, (int)b_al, act, resid, ldr);
     else
         hipLaunchKernelGGL(gemm_kernel<float>, grid, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, transA, B, ldb,
-                           transB, C, ldc, bias, M, N, K, accumulate, kper, use_atomic, (int)a_al, (int)b_al);
+                           transB, C, ldc, bias, M, N, K, accumulate, kper, use_atomic, (int)a_al, (int)b_al, act, resid, ldr);
     SGA_CHECK_LAUNCH("sga_gemm");
     return SGA_OK;
+}
+
+extern "C" int sga_gemm(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64,
+                        const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
+                        void* stream) {
+    return gemm_launch(transA, transB, M, N, K, A, lda, a_is_f64, B, ldb, C, ldc, bias, accumulate, 0, nullptr, 0, stream);
+}
+
+// C = act(op(A) op(B) + bias) (+ resid): the per-point layers of the PCT object encoder (conv1d k=1 with the
+// eval-mode BatchNorm folded into weight/bias, then ReLU / LeakyReLU(0.2), then the SA residual; pct.py:115-124,
+// 223-229, 289-293, 311-315)
+extern "C" int sga_gemm_ex(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
+                           long ldb, float* C, long ldc, const float* bias, int act, const float* resid, long ldr,
+                           void* stream) {
+    return gemm_launch(transA, transB, M, N, K, A, lda, 0, B, ldb, C, ldc, bias, 0, act, resid, ldr, stream);
 }
 
 extern "C" int sga_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream) {

@@ -1,0 +1,91 @@
+"""'pct' object encoder (NaivePCT), inference path: HIP kernels vs vectors produced by the
+reference module in eval mode and vs the torch oracle; attention kernel vs a dense softmax on its own."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+TOL = 1e-3
+
+
+def _sd(g):
+    return {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('sd__')}
+
+
+def test_pct_oracle_matches_reference_golden():
+    from oracle import pct_oracle
+    g = load_golden('pct_eval')
+    sd = _sd(g)
+    for tag in ('small', 'p512', 'ragged'):
+        y = pct_oracle.naive_pct_forward(torch.from_numpy(g['x_' + tag]), sd)
+        assert (y - torch.from_numpy(g['y_' + tag])).abs().max() < 1e-5 * max(1.0, np.abs(g['y_' + tag]).max())
+
+
+def test_pct_state_dict_keys_match_reference():
+    from sgaligner_amd.aligner.networks.pct import NaivePCT
+    g = load_golden('pct_eval')
+    m = NaivePCT()
+    assert set(m.state_dict()) == set(_sd(g))
+    m.load_state_dict(_sd(g), strict=True)                      # as engine/base_tester.py:61 loads checkpoints
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['small', 'p512', 'ragged'])
+def test_pct_eval_forward_golden(tag):
+    from sgaligner_amd.aligner.networks.pct import NaivePCT
+    g = load_golden('pct_eval')
+    m = NaivePCT()
+    m.load_state_dict(_sd(g), strict=True)
+    m = m.cuda().eval()
+    x = torch.from_numpy(g['x_' + tag]).cuda()
+    y = m(x).cpu().numpy()
+    ref = g['y_' + tag]
+    err = np.abs(y - ref).max()
+    assert err < TOL * max(1.0, np.abs(ref).max()), err
+    assert err < 2e-4 * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,N', [(1, 32), (3, 100), (2, 512), (7, 33), (2, 640)])
+def test_pct_attention_vs_dense_softmax(T, N):
+    from sgaligner_amd import _lib
+    from sgaligner_amd.ops import _p, _stream
+    torch.manual_seed(T * 1000 + N)
+    q = torch.randn(T * N, 32, device='cuda') * 0.8
+    v = torch.randn(T * N, 128, device='cuda')
+    stats = torch.empty(2 * T * N, device='cuda')
+    xs = torch.empty(T * N, 128, device='cuda')
+    _lib.check(_lib.lib().sga_pct_attention(_p(q), 32, _p(v), 128, T, N, _p(stats), _p(xs), 128, _stream()), 'sga_pct_attention')
+    q64, v64 = q.double().reshape(T, N, 32), v.double().reshape(T, N, 128)
+    att = torch.softmax(torch.bmm(q64, q64.transpose(1, 2)) / math.sqrt(32), dim=-1)      # [T, N(i), N(j)], rows sum to 1
+    ref = torch.bmm(att.transpose(1, 2), v64).reshape(T * N, 128)                          # Xs[j] = sum_i att[i,j] V[i]
+    err = (xs.double() - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+    # size-independent property: with V = all-ones the output is the COLUMN sum of a row-stochastic matrix; its total is N
+    ones = torch.ones(T * N, 128, device='cuda')
+    _lib.check(_lib.lib().sga_pct_attention(_p(q), 32, _p(ones), 128, T, N, _p(stats), _p(xs), 128, _stream()), 'sga_pct_attention')
+    tot = xs[:, 0].double().reshape(T, N).sum(1)
+    assert torch.allclose(tot, torch.full_like(tot, float(N)), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_pct_in_multimodal_encoder_eval_and_train_raises():
+    from oracle import pct_oracle
+    from sgaligner_amd.aligner.sg_aligner import MultiModalEncoder
+    from sgaligner_amd.synthetic import make_batch, to_device
+    torch.manual_seed(0)
+    model = MultiModalEncoder(modules=['pct', 'rel'], rel_dim=41, attr_dim=164).cuda()
+    dd = to_device(make_batch(2, 6, 64, seed=1), 'cuda')
+    with pytest.raises(NotImplementedError):
+        model(dd)                                               # train mode: loud, not wrong
+    model.eval()
+    with torch.no_grad():
+        out = model(dd)
+    sd = {k: v.detach().cpu() for k, v in model.object_encoder.state_dict().items()}
+    feat = pct_oracle.naive_pct_forward(dd['tot_obj_pts'].cpu().permute(0, 2, 1), sd)
+    emb = feat @ model.object_embedding.weight.detach().cpu().t() + model.object_embedding.bias.detach().cpu()
+    assert (out['pct'].cpu() - emb).abs().max() < TOL
+    assert out['joint'].shape == (dd['tot_obj_pts'].shape[0], 200)
