@@ -1,0 +1,52 @@
+"""NaivePCT inference throughput (eval mode) and the attention kernel's MFMA rate."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sgaligner_amd import _lib
+from sgaligner_amd.aligner.networks.pct import NaivePCT
+from sgaligner_amd.ops import _p, _stream
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = 512
+torch.manual_seed(0)
+m = NaivePCT().cuda().eval()
+x = torch.randn(T, 3, N, device='cuda')
+for _ in range(2):
+    y = m(x)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    y = m(x)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 5
+# per object: convs 2*N*(3*128 + 128*128 + 4*(128*32 + 2*128*128) + 512*1024) + attention 4 * 2*N*N*(32 + 128) + head
+conv = 2.0 * N * (3 * 128 + 128 * 128 + 4 * (128 * 32 + 2 * 128 * 128) + 512 * 1024) + 2.0 * (1024 * 512 + 512 * 256)
+attn = 4 * 2.0 * N * N * (32 + 128)
+print(f'NaivePCT eval forward: T={T} objects x {N} pts: {dt*1e3:.2f} ms = {T/dt:.0f} objects/s, '
+      f'{(conv + attn) * T / dt / 1e12:.1f} TFLOP/s algorithmic ({(conv + attn) / 1e9:.2f} GFLOP/object, attention {attn / 1e9:.2f})')
+q = torch.randn(T * N, 32, device='cuda'); v = torch.randn(T * N, 128, device='cuda')
+st = torch.empty(2 * T * N, device='cuda'); xs = torch.empty(T * N, 128, device='cuda')
+L = _lib.lib()
+L.sga_pct_attention(_p(q), 32, _p(v), 128, T, N, _p(st), _p(xs), 128, _stream())
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    L.sga_pct_attention(_p(q), 32, _p(v), 128, T, N, _p(st), _p(xs), 128, _stream())
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+alg = 2.0 * N * N * (32 + 128) * T
+print(f'sga_pct_attention: {ms:.3f} ms per SA layer, {alg / ms / 1e9:.1f} TFLOP/s algorithmic '
+      f'({alg * (32 * 2 + 128) / (32 + 128) / ms / 1e9:.1f} executed: the energy tiles are computed in both passes) of 157.3 peak')
+# CPU baseline: the torch oracle (pinned to the reference module) on a bounded sample, 32 threads
+from oracle import pct_oracle
+torch.set_num_threads(32)
+sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+xc = x[:64].cpu()
+pct_oracle.naive_pct_forward(xc[:8], sd)
+t0 = time.perf_counter()
+for _ in range(3):
+    yc = pct_oracle.naive_pct_forward(xc, sd)
+cpu = (time.perf_counter() - t0) / 3
+err = (yc - y[:64].cpu()).abs().max().item()
+print(f'CPU oracle (32 threads, 64 objects): {cpu*1e3:.1f} ms = {64/cpu:.0f} objects/s; max |GPU - oracle| on those objects {err:.2e}')
