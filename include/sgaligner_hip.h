@@ -141,6 +141,21 @@ int sga_pct_attention(const float* Q, long ldq, const float* V, long ldv, int T,
                       long ldx, void* stream);
 int sga_segment_max(const float* Y, long ldy, int T, int N, int C, float* G, void* stream);
 
+/* BatchNorm1d over point-major activations [R, C] fused with the following activation (0 none, 1 ReLU, 2 LeakyReLU 0.2)
+ * and residual: the train-mode layers of pct.py:122-123, :226-229, :289-293, :311-315.  sums: 2*C doubles.
+ *   sga_bn_stats:     sums = [sum_r x | sum_r x^2]
+ *   sga_bn_apply:     Y = act(X * scale + shift) (+ resid)       (scale = gamma * rstd, shift = beta - mean * scale)
+ *   sga_bn_bwd_stats: sums = [sum_r g | sum_r g * xhat],  g = dY * act'(X * scale + shift)    (= dbeta | dgamma)
+ *   sga_bn_bwd_apply: dX = scale * (g - mean_g - xhat * mean_gx)   (mean_g / mean_gx NULL: eval-mode BN, dX = scale * g) */
+int sga_bn_stats(const float* X, long ldx, int R, int C, double* sums, void* stream);
+int sga_bn_apply(const float* X, long ldx, int R, int C, const float* scale, const float* shift, int act,
+                 const float* resid, long ldr, float* Y, long ldy, void* stream);
+int sga_bn_bwd_stats(const float* X, long ldx, const float* dY, long ldd, int R, int C, const float* scale,
+                     const float* shift, const float* mean, const float* rstd, int act, double* sums, void* stream);
+int sga_bn_bwd_apply(const float* X, long ldx, const float* dY, long ldd, int R, int C, const float* scale,
+                     const float* shift, const float* mean, const float* rstd, const float* mean_g,
+                     const float* mean_gx, int act, float* dX, long ldo, void* stream);
+
 /* ---- per-object farthest-point sampling (the step in front of the path) -----------------
  * replaces utils/point_cloud.py:61-89 pcl_farthest_sample as called by preprocessing/scan3r/preprocess.py:96-98.
  * pts [sum N,3] f32 packed per object, offsets [n_obj+1]; start[obj] = the first sample (the reference draws it with

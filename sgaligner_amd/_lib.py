@@ -32,6 +32,10 @@ SIGNATURES = {
     'sga_gemm_ex': (I, [I, I, I, I, I, P, c_long, P, c_long, P, c_long, P, I, P, c_long, P]),
     'sga_pct_attention': (I, [P, c_long, P, c_long, I, I, P, P, c_long, P]),
     'sga_segment_max': (I, [P, c_long, I, I, I, P, P]),
+    'sga_bn_stats': (I, [P, c_long, I, I, P, P]),
+    'sga_bn_apply': (I, [P, c_long, I, I, P, P, I, P, c_long, P, c_long, P]),
+    'sga_bn_bwd_stats': (I, [P, c_long, P, c_long, I, I, P, P, P, P, I, P, P]),
+    'sga_bn_bwd_apply': (I, [P, c_long, P, c_long, I, I, P, P, P, P, P, P, I, P, c_long, P]),
     'sga_fps_scratch_floats': (c_size_t, [I]),
     'sga_fps': (I, [P, P, I, P, I, P, I, P, I, P, I, P, P, P]),
     'sga_gemm': (I, [I, I, I, I, I, P, c_long, I, P, c_long, P, c_long, P, I, P]),

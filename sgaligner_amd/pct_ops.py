@@ -1,0 +1,73 @@
+"""Autograd wrappers of the PCT object-encoder kernels (csrc/bn.hip, csrc/pct.hip, csrc/gemm.hip): every forward and
+backward below is a HIP launch through the C ABI; torch only owns the buffers and the tiny per-channel vectors."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .ops import _p, _stream
+
+
+def _chk(rc, what):
+    _lib.check(rc, what)
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """y = act(BatchNorm1d(x)) (+ resid) over rows of x [R, C] (any row stride).  Train mode uses the batch statistics
+    and updates running_mean / running_var / num_batches_tracked exactly like nn.BatchNorm1d (momentum 0.1, unbiased
+    running variance); eval mode uses the running statistics.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, act, resid, out):
+        R, C = x.shape
+        dev = x.device
+        L = _lib.lib()
+        if training:
+            sums = torch.empty((2 * C,), device=dev, dtype=torch.float64)
+            _chk(L.sga_bn_stats(_p(x), x.stride(0), R, C, _p(sums), _stream()), 'sga_bn_stats')
+            mean64 = sums[:C] / R
+            var64 = (sums[C:] / R - mean64 * mean64).clamp_min_(0.0)          # biased, as BN normalises with
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean64.float(), alpha=momentum)
+                running_var.mul_(1 - momentum).add_((var64 * (R / max(R - 1, 1))).float(), alpha=momentum)
+                if num_batches_tracked is not None:
+                    num_batches_tracked.add_(1)
+            mean = mean64.float()
+            rstd = torch.rsqrt(var64 + eps).float()
+        else:
+            mean = running_mean.float()
+            rstd = torch.rsqrt(running_var.float() + eps)
+        scale = (gamma * rstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        y = out if out is not None else torch.empty((R, C), device=dev, dtype=torch.float32)
+        _chk(L.sga_bn_apply(_p(x), x.stride(0), R, C, _p(scale), _p(shift), act, _p(resid), resid.stride(0) if resid is not None else 0,
+                            _p(y), y.stride(0), _stream()), 'sga_bn_apply')
+        ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous())
+        ctx.act, ctx.training, ctx.has_resid = act, training, resid is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, rstd = ctx.saved_tensors
+        R, C = x.shape
+        L = _lib.lib()
+        dyc = dy if dy.stride(1) == 1 else dy.contiguous()
+        sums = torch.empty((2 * C,), device=x.device, dtype=torch.float64)
+        _chk(L.sga_bn_bwd_stats(_p(x), x.stride(0), _p(dyc), dyc.stride(0), R, C, _p(scale), _p(shift), _p(mean), _p(rstd), ctx.act,
+                                _p(sums), _stream()), 'sga_bn_bwd_stats')
+        dbeta, dgamma = sums[:C].float(), sums[C:].float()
+        dx = torch.empty((R, C), device=x.device, dtype=torch.float32)
+        if ctx.training:
+            mg, mgx = (sums[:C] / R).float().contiguous(), (sums[C:] / R).float().contiguous()
+        else:
+            mg = mgx = None
+        _chk(L.sga_bn_bwd_apply(_p(x), x.stride(0), _p(dyc), dyc.stride(0), R, C, _p(scale), _p(shift), _p(mean), _p(rstd), _p(mg), _p(mgx),
+                                ctx.act, _p(dx), dx.stride(0), _stream()), 'sga_bn_bwd_apply')
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, (dy if ctx.has_resid else None), None
+
+
+def batch_norm_act(x, bn: torch.nn.BatchNorm1d, act=0, resid=None, out=None):
+    """nn.BatchNorm1d `bn` applied to rows of x, then the activation, then `+ resid`."""
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training, mom,
+                                bn.eps, act, resid, out)

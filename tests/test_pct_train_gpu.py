@@ -1,0 +1,50 @@
+"""Training-path pieces of the 'pct' object encoder against plain torch autograd on the same device."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('R,C,act,with_resid', [(1000, 128, 1, True), (333, 1024, 2, False), (7, 256, 1, False), (4096, 128, 0, False)])
+@pytest.mark.parametrize('training', [True, False])
+def test_batch_norm_act_vs_torch(R, C, act, with_resid, training):
+    from sgaligner_amd import pct_ops
+    torch.manual_seed(R + C)
+    x0 = (torch.randn(R, C, device='cuda') * 1.7 + 0.3)
+    r0 = torch.randn(R, C, device='cuda') if with_resid else None
+    cot = torch.randn(R, C, device='cuda')
+    res = {}
+    for which in ('hip', 'torch'):
+        bn = torch.nn.BatchNorm1d(C).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+            bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0)
+        torch.manual_seed(1)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, device='cuda') + 0.5); bn.bias.copy_(torch.randn(C, device='cuda') * 0.2)
+            bn.running_mean.copy_(torch.randn(C, device='cuda') * 0.3); bn.running_var.copy_(torch.rand(C, device='cuda') + 0.5)
+        bn.train(training)
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if with_resid else None
+        if which == 'hip':
+            y = pct_ops.batch_norm_act(x, bn, act=act, resid=r)
+        else:
+            z = bn(x)
+            y = F.relu(z) if act == 1 else (F.leaky_relu(z, 0.2) if act == 2 else z)
+            if r is not None:
+                y = y + r
+        (y * cot).sum().backward()
+        res[which] = (y.detach(), x.grad, bn.weight.grad, bn.bias.grad, r.grad if r is not None else None,
+                      bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))
+    h, t = res['hip'], res['torch']
+    for a, b, name in zip(h[:7], t[:7], ('y', 'dx', 'dgamma', 'dbeta', 'dresid', 'running_mean', 'running_var')):
+        if a is None:
+            assert b is None
+            continue
+        err = (a - b).abs().max().item()
+        assert err < 2e-4 * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
+    assert h[7] == t[7]
