@@ -134,12 +134,17 @@ int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, int B, in
  * sga_pct_attention: SA.forward's attention (pct.py:211-222) for T objects of N points each, flash style:
  *   Q [T*N,32] (= q_conv(x) = k_conv(x): shared weight, pct.py:199), V [T*N,128] (= v_conv(x) + bias) ->
  *   Xs[j,:] = sum_i softmax_row_i(Q Q^T / sqrt(32))[i,j] V[i,:].  stats: 2*T*N floats of workspace.
- * sga_segment_max: G[t,c] = max over the N points of object t (pct.py:308). */
+ * sga_segment_max: G[t,c] = max over the N points of object t (pct.py:308), argmax (nullable) = the winning point;
+ * sga_segment_max_bwd: its backward, dY[t*N + argmax[t,c], c] = dG[t,c], zero elsewhere. */
 int sga_gemm_ex(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                 float* C, long ldc, const float* bias, int act, const float* resid, long ldr, void* stream);
 int sga_pct_attention(const float* Q, long ldq, const float* V, long ldv, int T, int N, float* stats, float* Xs,
                       long ldx, void* stream);
-int sga_segment_max(const float* Y, long ldy, int T, int N, int C, float* G, void* stream);
+/* backward of sga_pct_attention (autograd of pct.py:211-222): stats as left by the forward, work = T*N floats */
+int sga_pct_attention_bwd(const float* Q, long ldq, const float* V, long ldv, const float* dXs, long ldd, int T, int N,
+                          const float* stats, float* work, float* dQ, long ldo, float* dV, long ldw, void* stream);
+int sga_segment_max(const float* Y, long ldy, int T, int N, int C, float* G, int32_t* argmax, void* stream);
+int sga_segment_max_bwd(const float* dG, const int32_t* argmax, int T, int N, int C, float* dY, long ldd, void* stream);
 
 /* BatchNorm1d over point-major activations [R, C] fused with the following activation (0 none, 1 ReLU, 2 LeakyReLU 0.2)
  * and residual: the train-mode layers of pct.py:122-123, :226-229, :289-293, :311-315.  sums: 2*C doubles.

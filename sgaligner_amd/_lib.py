@@ -31,7 +31,9 @@ SIGNATURES = {
     'sga_simrank': (I, [P, I, I, P, I, I, P, P, P, I, I, P, P, P, P, c_size_t, P]),
     'sga_gemm_ex': (I, [I, I, I, I, I, P, c_long, P, c_long, P, c_long, P, I, P, c_long, P]),
     'sga_pct_attention': (I, [P, c_long, P, c_long, I, I, P, P, c_long, P]),
-    'sga_segment_max': (I, [P, c_long, I, I, I, P, P]),
+    'sga_pct_attention_bwd': (I, [P, c_long, P, c_long, P, c_long, I, I, P, P, P, c_long, P, c_long, P]),
+    'sga_segment_max': (I, [P, c_long, I, I, I, P, P, P]),
+    'sga_segment_max_bwd': (I, [P, P, I, I, I, P, c_long, P]),
     'sga_bn_stats': (I, [P, c_long, I, I, P, P]),
     'sga_bn_apply': (I, [P, c_long, I, I, P, P, I, P, c_long, P, c_long, P]),
     'sga_bn_bwd_stats': (I, [P, c_long, P, c_long, I, I, P, P, P, P, I, P, P]),

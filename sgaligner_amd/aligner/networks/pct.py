@@ -129,7 +129,7 @@ class NaivePCT(nn.Module):
             w5, b5 = _fold(self.linear[0].weight, None, self.linear[1])
             y = _gemm_ex(cat, w5, b5, act=2)                                           # LeakyReLU(0.2)
             g = torch.empty((t, 1024), device=x.device, dtype=torch.float32)
-            _lib.check(_lib.lib().sga_segment_max(_p(y), y.stride(0), t, n, 1024, _p(g), _stream()), 'sga_segment_max')
+            _lib.check(_lib.lib().sga_segment_max(_p(y), y.stride(0), t, n, 1024, _p(g), None, _stream()), 'sga_segment_max')
             w6, b6 = _fold(self.linear1.weight, None, self.bn1)
             w7, b7 = _fold(self.linear2.weight, self.linear2.bias, self.bn2)
             f = _gemm_ex(g, w6, b6, act=1)

@@ -1,4 +1,4 @@
-// Point-Cloud-Transformer object encoder ('pct' module) -- inference (eval-mode) kernels.
+// Point-Cloud-Transformer object encoder ('pct' module): attention forward / backward, point max.
 //
 // Replaces, together with sga_gemm_ex (gemm.hip), the forward of NaivePCT (src/aligner/networks/pct.py:275-317) in
 // eval mode: the per-point convolutions are GEMMs over the point-major activation matrix [T*N, C] with the eval-mode
@@ -84,6 +84,9 @@ constexpr int QS = 36;                 // LDS row strides (floats): 16-byte alig
 constexpr int VS = DV + 4;
 constexpr int BUF_F = 32 * QS + 32 * VS + 64;       // Q tile, V tile, m[32], 1/l[32]
 
+// OWN == false (forward):  out[own j, :] = sum_{tile i} exp(s (E[i,j] - m_i)) / l_i * V[i, :]          (tile-row statistics)
+// OWN == true  (backward):  out[own i, :] = sum_{tile j} exp(s (E[i,j] - m_i)) / l_i * dXs[j, :] = dV[i]  (own-row statistics)
+template <bool OWN>
 __global__ __launch_bounds__(PA_THREADS) void attn_apply_kernel(const float* __restrict__ Q, long ldq,
                                                                 const float* __restrict__ V, long ldv, int T, int N,
                                                                 float scale, const float* __restrict__ mstat,
@@ -100,6 +103,8 @@ __global__ __launch_bounds__(PA_THREADS) void attn_apply_kernel(const float* __r
 
     float bq[16];
     load_q16(Qt + (size_t)min(j0 + l31, N - 1) * ldq, h, bq);
+    const float m_own = OWN ? mt[min(j0 + l31, N - 1)] : 0.f;
+    const float rl_own = OWN ? 1.f / lt[min(j0 + l31, N - 1)] : 0.f;
     f32x16 out[4];
     zero_acc<4>(out);
 
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_apply_kernel(const float* __r
         if (tid < 32) {
             const bool ok = i0 + tid < N;
             buf[32 * QS + 32 * VS + tid] = ok ? mt[i0 + tid] : 0.f;
-            buf[32 * QS + 32 * VS + 32 + tid] = ok ? 1.f / lt[i0 + tid] : 0.f;      // rows past N contribute nothing
+            buf[32 * QS + 32 * VS + 32 + tid] = ok ? (OWN ? 1.f : 1.f / lt[i0 + tid]) : 0.f;   // rows past N contribute nothing
         }
     };
 
@@ -145,7 +150,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_apply_kernel(const float* __r
             const f32x4 m4 = *reinterpret_cast<const f32x4*>(ms + 8 * g + 4 * h);
             const f32x4 r4 = *reinterpret_cast<const f32x4*>(ms + 32 + 8 * g + 4 * h);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[4 * g + u] = __builtin_amdgcn_exp2f((acc[4 * g + u] - m4[u]) * c) * r4[u];
+            for (int u = 0; u < 4; ++u)
+                acc[4 * g + u] = OWN ? __builtin_amdgcn_exp2f((acc[4 * g + u] - m_own) * c) * (rl_own * r4[u])
+                                     : __builtin_amdgcn_exp2f((acc[4 * g + u] - m4[u]) * c) * r4[u];
         }
         // Xs[j, :] += sum_i p[i,j] V[i, :]   (A = p from the accumulators, B = V rows from LDS)
         const float* vs = buf + 32 * QS + l31;
@@ -167,19 +174,172 @@ __global__ __launch_bounds__(PA_THREADS) void attn_apply_kernel(const float* __r
         }
 }
 
-// ---- G[t, c] = max_n Y[t*N + n, c]
-__global__ void segment_max_kernel(const float* __restrict__ Y, long ldy, int T, int N, int C, float* __restrict__ G) {
+// ---- delta_i = <V[i, :], dV[i, :]>   (= sum_j P[i,j] dP[i,j], the softmax-backward row term)
+__global__ void rowdot_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb, size_t R,
+                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t r = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float s = A[r * lda + lane] * B[r * ldb + lane] + A[r * lda + 64 + lane] * B[r * ldb + 64 + lane];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[r] = s;
+}
+
+// ---- backward, dQ:  dQ[i, :] = s * sum_j ( P[i,j] (dP[i,j] - delta_i) + P[j,i] (dP[j,i] - delta_j) ) Q[j, :]
+// with dP[i,j] = V[i] . dXs[j] (the energy uses ONE shared Q, so both the "query" and the "key" role of row i collect
+// here).  A wave owns 32 rows i; per 32-row tile j: E (16 MFMAs), dP[i,j] and dP[j,i] (64 + 64, K = 128), then the
+// 32x32 coefficient tile -- lane = i, registers = j, the A-operand layout -- feeds dQ += G Q[j] (16 MFMAs).
+constexpr int DQ_BUF_F = 32 * QS + 2 * 32 * VS + 4 * 32;      // Q, V, dXs tiles + m, 1/l, delta, valid of the tile rows
+
+__global__ __launch_bounds__(PA_THREADS) void attn_bwd_dq_kernel(const float* __restrict__ Q, long ldq,
+                                                                 const float* __restrict__ V, long ldv,
+                                                                 const float* __restrict__ dXs, long ldd, int T, int N,
+                                                                 float scale, const float* __restrict__ mstat,
+                                                                 const float* __restrict__ lstat,
+                                                                 const float* __restrict__ delta,
+                                                                 float* __restrict__ dQ, long ldo) {
+    extern __shared__ __attribute__((aligned(16))) float dlds[];       // [2][DQ_BUF_F]
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int i0 = (blockIdx.y * 4 + wave) * 32;
+    const size_t base = (size_t)t * N;
+    const float* Qt = Q + base * ldq;
+    const float* Vt = V + base * ldv;
+    const float* Dt = dXs + base * ldd;
+    const float c = scale * LOG2E_F;
+    const int my_i = min(i0 + l31, N - 1);
+
+    float bq[16], bv[64], bd[64];
+    load_q16(Qt + (size_t)my_i * ldq, h, bq);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {                             // k mapping of the K = 128 products: step s, half h <-> channel 64 h + s
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Vt + (size_t)my_i * ldv + 64 * h + 4 * v);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(Dt + (size_t)my_i * ldd + 64 * h + 4 * v);
+        bv[4 * v] = a[0]; bv[4 * v + 1] = a[1]; bv[4 * v + 2] = a[2]; bv[4 * v + 3] = a[3];
+        bd[4 * v] = b[0]; bd[4 * v + 1] = b[1]; bd[4 * v + 2] = b[2]; bd[4 * v + 3] = b[3];
+    }
+    const float m_i = mstat[base + my_i], rl_i = 1.f / lstat[base + my_i], dl_i = delta[base + my_i];
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+
+    auto stage = [&](int j0, float* buf) {
+        {
+            const int r = tid >> 3, c4 = (tid & 7) * 4;
+            const int row = min(j0 + r, N - 1);
+            *reinterpret_cast<f32x4*>(buf + r * QS + c4) = *reinterpret_cast<const f32x4*>(Qt + (size_t)row * ldq + c4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = k * PA_THREADS + tid, r = e >> 5, c4 = (e & 31) * 4;
+            const int row = min(j0 + r, N - 1);
+            *reinterpret_cast<f32x4*>(buf + 32 * QS + r * VS + c4) = *reinterpret_cast<const f32x4*>(Vt + (size_t)row * ldv + c4);
+            *reinterpret_cast<f32x4*>(buf + 32 * QS + 32 * VS + r * VS + c4) = *reinterpret_cast<const f32x4*>(Dt + (size_t)row * ldd + c4);
+        }
+        if (tid < 32) {
+            const bool ok = j0 + tid < N;
+            float* st = buf + 32 * QS + 2 * 32 * VS;
+            st[tid] = ok ? mstat[base + j0 + tid] : 0.f;
+            st[32 + tid] = ok ? 1.f / lstat[base + j0 + tid] : 0.f;
+            st[64 + tid] = ok ? delta[base + j0 + tid] : 0.f;
+            st[96 + tid] = ok ? 1.f : 0.f;
+        }
+    };
+
+    const int ntile = (N + 31) / 32;
+    stage(0, dlds);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        if (it + 1 < ntile) stage((it + 1) * 32, dlds + ((it + 1) & 1) * DQ_BUF_F);
+        const float* buf = dlds + (it & 1) * DQ_BUF_F;
+        // all three products as D[m = tile row j][n = own row i]: lane = i, registers = j
+        f32x16 e, p1, p2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { e[r] = 0.f; p1[r] = 0.f; p2[r] = 0.f; }
+        {
+            const float* qs = buf + l31 * QS + 16 * h;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(qs + 4 * v);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], bq[4 * v + u], e, 0, 0, 0);
+            }
+            const float* vs = buf + 32 * QS + l31 * VS + 64 * h;            // V[j]   . dXs[i]  -> dP[j,i]
+            const float* ds = vs + 32 * VS;                                   // dXs[j] . V[i]    -> dP[i,j]
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(vs + 4 * v);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(ds + 4 * v);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    p2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], bd[4 * v + u], p2, 0, 0, 0);
+                    p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d4[u], bv[4 * v + u], p1, 0, 0, 0);
+                }
+            }
+        }
+        // G[i,j] = s ( P[i,j] (dP[i,j] - delta_i) + P[j,i] (dP[j,i] - delta_j) ), tile rows past N masked
+        const float* st = buf + 32 * QS + 2 * 32 * VS;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(st + 8 * g + 4 * h);
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(st + 32 + 8 * g + 4 * h);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + 8 * g + 4 * h);
+            const f32x4 ok4 = *reinterpret_cast<const f32x4*>(st + 96 + 8 * g + 4 * h);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * g + u;
+                const float pij = __builtin_amdgcn_exp2f((e[r] - m_i) * c) * rl_i;
+                const float pji = __builtin_amdgcn_exp2f((e[r] - m4[u]) * c) * r4[u];
+                e[r] = ok4[u] * scale * (pij * (p1[r] - dl_i) + pji * (p2[r] - d4[u]));
+            }
+        }
+        // dQ[i, :] += sum_j G[i,j] Q[j, :]
+        const float* qrow = buf + l31;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(e[s], qrow[mfma32_row(s, h) * QS], dq, 0, 0, 0);
+    }
+    if (i0 >= N) return;
+    float* qo = dQ + base * ldo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + mfma32_row(r, h);
+        if (i < N) qo[(size_t)i * ldo + l31] = dq[r];
+    }
+}
+
+// ---- G[t, c] = max_n Y[t*N + n, c]   (first maximum on ties, as torch.max)
+__global__ void segment_max_kernel(const float* __restrict__ Y, long ldy, int T, int N, int C, float* __restrict__ G,
+                                   int* __restrict__ amax) {
     const int t = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), rw = threadIdx.x >> 6;
     __shared__ float red[4][64];
+    __shared__ int redi[4][64];
     float m = -INFINITY;
+    int mi = 0;
     if (c < C)
-        for (int n = rw; n < N; n += 4) m = fmaxf(m, Y[((size_t)t * N + n) * ldy + c]);
+        for (int n = rw; n < N; n += 4) {
+            const float v = Y[((size_t)t * N + n) * ldy + c];
+            if (v > m) { m = v; mi = n; }
+        }
     red[rw][threadIdx.x & 63] = m;
+    redi[rw][threadIdx.x & 63] = mi;
     __syncthreads();
     if (rw == 0 && c < C) {
         const int k = threadIdx.x;
-        G[(size_t)t * C + c] = fmaxf(fmaxf(red[0][k], red[1][k]), fmaxf(red[2][k], red[3][k]));
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (red[w][k] > m || (red[w][k] == m && redi[w][k] < mi)) { m = red[w][k]; mi = redi[w][k]; }
+        G[(size_t)t * C + c] = m;
+        if (amax) amax[(size_t)t * C + c] = mi;
     }
+}
+
+// backward of the point max: dY[t*N + amax[t,c], c] = dG[t,c] (dY zeroed by the caller of the kernel)
+__global__ void segment_max_bwd_kernel(const float* __restrict__ dG, const int* __restrict__ amax, int T, int N, int C,
+                                       float* __restrict__ dY, long ldd) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)T * C) return;
+    const int t = (int)(e / C), c = (int)(e % C);
+    dY[((size_t)t * N + amax[e]) * ldd + c] = dG[e];
 }
 
 }  // namespace
@@ -197,15 +357,52 @@ extern "C" int sga_pct_attention(const float* Q, long ldq, const float* V, long 
     float* lstat = stats + (size_t)T * N;
     dim3 grid(T, (N + 127) / 128);
     hipLaunchKernelGGL(attn_stats_kernel, grid, dim3(PA_THREADS), 0, s, Q, ldq, T, N, scale, mstat, lstat);
-    hipLaunchKernelGGL(attn_apply_kernel, grid, dim3(PA_THREADS), 0, s, Q, ldq, V, ldv, T, N, scale, mstat, lstat, Xs, ldx);
+    hipLaunchKernelGGL(attn_apply_kernel<false>, grid, dim3(PA_THREADS), 0, s, Q, ldq, V, ldv, T, N, scale, mstat, lstat, Xs, ldx);
     SGA_CHECK_LAUNCH("sga_pct_attention");
     return SGA_OK;
 }
 
-extern "C" int sga_segment_max(const float* Y, long ldy, int T, int N, int C, float* G, void* stream) {
+// backward of sga_pct_attention: stats as left by the forward; work: T*N floats (delta); outputs dQ [T*N,32], dV [T*N,128]
+extern "C" int sga_pct_attention_bwd(const float* Q, long ldq, const float* V, long ldv, const float* dXs, long ldd, int T,
+                                     int N, const float* stats, float* work, float* dQ, long ldo, float* dV, long ldw,
+                                     void* stream) {
+    SGA_CHECK_ARG(Q && V && dXs && stats && work && dQ && dV, "sga_pct_attention_bwd: null pointer");
+    SGA_CHECK_ARG(T >= 0 && N >= 1 && ldq >= DA && ldv >= DV && ldd >= DV && ldo >= DA && ldw >= DV, "sga_pct_attention_bwd: bad sizes");
+    SGA_CHECK_ARG(ldq % 4 == 0 && ldv % 4 == 0 && ldd % 4 == 0 && reinterpret_cast<uintptr_t>(Q) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(V) % 16 == 0 && reinterpret_cast<uintptr_t>(dXs) % 16 == 0,
+                  "sga_pct_attention_bwd: Q / V / dXs rows must be 16-byte aligned");
+    if (T == 0) return SGA_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float scale = 1.0f / sqrtf((float)DA);
+    const float* mstat = stats;
+    const float* lstat = stats + (size_t)T * N;
+    dim3 grid(T, (N + 127) / 128);
+    // dV[i] = sum_j P[i,j] dXs[j]: the forward kernel with own-row statistics and dXs as the second tile
+    hipLaunchKernelGGL(attn_apply_kernel<true>, grid, dim3(PA_THREADS), 0, s, Q, ldq, dXs, ldd, T, N, scale, mstat, lstat, dV, ldw);
+    const size_t R = (size_t)T * N;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, V, ldv, dV, ldw, R, work);
+    const size_t lds = (size_t)2 * DQ_BUF_F * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(PA_THREADS), lds, s, Q, ldq, V, ldv, dXs, ldd, T, N, scale, mstat, lstat, work, dQ, ldo);
+    SGA_CHECK_LAUNCH("sga_pct_attention_bwd");
+    return SGA_OK;
+}
+
+extern "C" int sga_segment_max(const float* Y, long ldy, int T, int N, int C, float* G, int32_t* argmax, void* stream) {
     SGA_CHECK_ARG(Y && G && T >= 0 && N >= 1 && C >= 1 && ldy >= C, "sga_segment_max: bad argument");
     if (T == 0) return SGA_OK;
-    hipLaunchKernelGGL(segment_max_kernel, dim3(T, (C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), Y, ldy, T, N, C, G);
+    hipLaunchKernelGGL(segment_max_kernel, dim3(T, (C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), Y, ldy, T, N, C, G, argmax);
     SGA_CHECK_LAUNCH("sga_segment_max");
+    return SGA_OK;
+}
+
+extern "C" int sga_segment_max_bwd(const float* dG, const int32_t* argmax, int T, int N, int C, float* dY, long ldd, void* stream) {
+    SGA_CHECK_ARG(dG && argmax && dY && T >= 0 && N >= 1 && C >= 1 && ldd >= C, "sga_segment_max_bwd: bad argument");
+    if (T == 0) return SGA_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemset2DAsync(dY, ldd * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)T * N, s) != hipSuccess) { sga_set_error("sga_segment_max_bwd: memset failed"); return SGA_ERR_HIP; }
+    const size_t n = (size_t)T * C;
+    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dG, argmax, T, N, C, dY, ldd);
+    SGA_CHECK_LAUNCH("sga_segment_max_bwd");
     return SGA_OK;
 }

@@ -71,3 +71,63 @@ def batch_norm_act(x, bn: torch.nn.BatchNorm1d, act=0, resid=None, out=None):
     mom = 0.1 if bn.momentum is None else bn.momentum
     return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training, mom,
                                 bn.eps, act, resid, out)
+
+
+class PCTAttentionFn(torch.autograd.Function):
+    """xs[j] = sum_i softmax_row_i(q q^T / sqrt(32))[i, j] v[i] per object (pct.py:211-222 with the shared q/k weight);
+    q [T*N, 32], v [T*N, 128] point-major (column slices allowed), every object has n_pts points."""
+
+    @staticmethod
+    def forward(ctx, q, v, n_obj, n_pts):
+        dev = q.device
+        stats = torch.empty((2 * n_obj * n_pts,), device=dev, dtype=torch.float32)
+        xs = torch.empty((n_obj * n_pts, 128), device=dev, dtype=torch.float32)
+        _chk(_lib.lib().sga_pct_attention(_p(q), q.stride(0), _p(v), v.stride(0), n_obj, n_pts, _p(stats), _p(xs), xs.stride(0), _stream()),
+             'sga_pct_attention')
+        ctx.save_for_backward(q, v, stats)
+        ctx.dims = (n_obj, n_pts)
+        return xs
+
+    @staticmethod
+    def backward(ctx, dxs):
+        q, v, stats = ctx.saved_tensors
+        n_obj, n_pts = ctx.dims
+        dxs = dxs.contiguous()
+        dev = q.device
+        work = torch.empty((n_obj * n_pts,), device=dev, dtype=torch.float32)
+        dq = torch.empty((n_obj * n_pts, 32), device=dev, dtype=torch.float32)
+        dv = torch.empty((n_obj * n_pts, 128), device=dev, dtype=torch.float32)
+        _chk(_lib.lib().sga_pct_attention_bwd(_p(q), q.stride(0), _p(v), v.stride(0), _p(dxs), dxs.stride(0), n_obj, n_pts, _p(stats),
+                                             _p(work), _p(dq), dq.stride(0), _p(dv), dv.stride(0), _stream()), 'sga_pct_attention_bwd')
+        return dq, dv, None, None
+
+
+def pct_attention(q, v, n_obj, n_pts):
+    return PCTAttentionFn.apply(q, v, n_obj, n_pts)
+
+
+class SegmentMaxFn(torch.autograd.Function):
+    """g[t, c] = max over the n_pts rows of object t (pct.py:308); backward routes to the first arg-max row."""
+
+    @staticmethod
+    def forward(ctx, y, n_obj, n_pts):
+        C = y.shape[1]
+        g = torch.empty((n_obj, C), device=y.device, dtype=torch.float32)
+        am = torch.empty((n_obj, C), device=y.device, dtype=torch.int32)
+        _chk(_lib.lib().sga_segment_max(_p(y), y.stride(0), n_obj, n_pts, C, _p(g), _p(am), _stream()), 'sga_segment_max')
+        ctx.save_for_backward(am)
+        ctx.dims = (n_obj, n_pts, C)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (am,) = ctx.saved_tensors
+        n_obj, n_pts, C = ctx.dims
+        dg = dg.contiguous()
+        dy = torch.empty((n_obj * n_pts, C), device=dg.device, dtype=torch.float32)
+        _chk(_lib.lib().sga_segment_max_bwd(_p(dg), _p(am), n_obj, n_pts, C, _p(dy), dy.stride(0), _stream()), 'sga_segment_max_bwd')
+        return dy, None, None
+
+
+def segment_max(y, n_obj, n_pts):
+    return SegmentMaxFn.apply(y, n_obj, n_pts)

@@ -48,3 +48,42 @@ def test_batch_norm_act_vs_torch(R, C, act, with_resid, training):
         err = (a - b).abs().max().item()
         assert err < 2e-4 * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
     assert h[7] == t[7]
+
+
+@pytest.mark.parametrize('T,N', [(1, 32), (2, 100), (2, 512), (5, 33), (1, 160)])
+def test_attention_backward_vs_dense_autograd(T, N):
+    from sgaligner_amd import pct_ops
+    torch.manual_seed(T * 100 + N)
+    q0 = torch.randn(T * N, 32, device='cuda') * 0.7
+    v0 = torch.randn(T * N, 128, device='cuda')
+    cot = torch.randn(T * N, 128, device='cuda')
+    q = q0.clone().requires_grad_(True)
+    v = v0.clone().requires_grad_(True)
+    xs = pct_ops.pct_attention(q, v, T, N)
+    (xs * cot).sum().backward()
+    q64 = q0.double().reshape(T, N, 32).requires_grad_(True)
+    v64 = v0.double().reshape(T, N, 128).requires_grad_(True)
+    att = torch.softmax(torch.bmm(q64, q64.transpose(1, 2)) / math.sqrt(32), dim=-1)
+    ref = torch.bmm(att.transpose(1, 2), v64)
+    (ref * cot.double().reshape(T, N, 128)).sum().backward()
+    assert (xs.double().reshape(T, N, 128) - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max().item())
+    for a, b, name in ((v.grad, v64.grad, 'dv'), (q.grad, q64.grad, 'dq')):
+        err = (a.double().reshape(b.shape) - b).abs().max().item()
+        assert err < 2e-4 * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
+
+
+def test_segment_max_forward_backward():
+    from sgaligner_amd import pct_ops
+    torch.manual_seed(0)
+    T, N, C = 7, 45, 200
+    y0 = torch.randn(T * N, C, device='cuda')
+    y0[3 * N + 5, 17] = y0[3 * N + 9, 17] = 9.0                      # a tie: the first row wins (torch.max)
+    y = y0.clone().requires_grad_(True)
+    g = pct_ops.segment_max(y, T, N)
+    cot = torch.randn(T, C, device='cuda')
+    (g * cot).sum().backward()
+    yr = y0.clone().reshape(T, N, C).requires_grad_(True)
+    gr = yr.max(dim=1)[0]
+    (gr * cot).sum().backward()
+    assert torch.equal(g, gr)
+    assert torch.equal(y.grad.reshape(T, N, C), yr.grad)
