@@ -414,6 +414,50 @@ def gen_pct():
         arrs['y_' + tag] = y
     npz('pct_eval', **arrs)
 
+    # train mode (batch statistics, running-stat updates), Dropout p = 0, on the SAME weights: the reference module's
+    # output, a subset of its parameter gradients (the full set is 5 MB) and the updated running statistics; the
+    # train-mode oracle is checked against ALL gradients here.
+    m.train()
+    m.dp1.p = 0.0
+    m.dp2.p = 0.0
+    torch.manual_seed(3)
+    T, N = 6, 80
+    x = torch.randn(T, 3, N) * torch.tensor([1.0, 0.6, 0.3]).reshape(1, 3, 1)
+    cot = torch.randn(T, 256)
+    sd_before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.zero_grad()
+    y = m(x)
+    (y * cot).sum().backward()
+    sd_o = {k: v.clone() for k, v in sd_before.items()}
+    leaves = {}
+    for name, p_ in m.named_parameters():
+        leaves[name] = sd_o[name].clone().requires_grad_(True)
+        sd_o[name] = leaves[name]
+    for sa in ('sa1', 'sa2', 'sa3', 'sa4'):                     # q_conv.weight IS k_conv.weight (pct.py:199)
+        sd_o[sa + '.k_conv.weight'] = sd_o[sa + '.q_conv.weight']      # named_parameters() lists the tied tensor as q_conv.weight
+    yo, ns = pct_oracle.naive_pct_forward_train(x, sd_o)
+    (yo * cot).sum().backward()
+    assert (y - yo).abs().max() < 1e-4 * max(1.0, y.abs().max().item()), (y - yo).abs().max()
+    gmax = max(p_.grad.abs().max().item() for p_ in m.parameters())
+    for name, p_ in m.named_parameters():
+        g_ref, g_o = p_.grad, leaves[name].grad
+        # (a bias in front of a train-mode BatchNorm has an exactly-zero gradient: both sides hold rounding noise there)
+        assert (g_ref - g_o).abs().max() < 2e-4 * max(g_ref.abs().max().item(), 1e-2 * gmax), (name, (g_ref - g_o).abs().max(), g_ref.abs().max())
+    sd_after = m.state_dict()
+    for k, v in ns.items():
+        assert (sd_after[k] - v).abs().max() < 1e-5 * max(1.0, v.abs().max().item()), k
+    tr = {'x': x, 'cot': cot, 'y': y}
+    keep = ['embedding.conv1.weight', 'embedding.conv2.weight', 'embedding.bn1.weight', 'embedding.bn2.bias', 'sa1.q_conv.weight',
+            'sa1.v_conv.weight', 'sa1.v_conv.bias', 'sa3.trans_conv.weight', 'sa4.after_norm.weight', 'sa4.after_norm.bias',
+            'linear.1.weight', 'linear2.weight', 'linear2.bias', 'bn1.weight', 'bn2.bias']
+    named = dict(m.named_parameters())
+    for k in keep:
+        tr['g__' + k] = named[k].grad
+    for k, v in sd_after.items():
+        if 'running_' in k or 'num_batches' in k:
+            tr['after__' + k] = v
+    npz('pct_train', **tr)
+
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'pct':

@@ -3,10 +3,15 @@
 configs/scan3r/scan3r_ground_truth.yaml:5).  Same class names, constructor signatures, sub-module names and
 state_dict keys, so reference checkpoints load with strict=True.
 
-Scope: the INFERENCE path.  In eval mode the forward runs on the HIP kernels -- per-point
-convolutions as exact-fp32 MFMA GEMMs with the eval-mode BatchNorm folded into weight/bias (sga_gemm_ex), the
-self-attention flash style (sga_pct_attention), the point max (sga_segment_max); Dropout is the identity.  Train
-mode (batch-statistic BatchNorm over all objects and points + two Dropout(0.5)) is not implemented and raises.
+Eval mode (inference): per-point convolutions as exact-fp32 MFMA GEMMs with the eval-mode BatchNorm folded into
+weight/bias (sga_gemm_ex), the self-attention flash style (sga_pct_attention), the point max (sga_segment_max);
+Dropout is the identity; no autograd graph.
+Train mode: the same computation as differentiable HIP ops (sgaligner_amd.pct_ops): GEMM forward/backward, BatchNorm
+with BATCH statistics over all objects x points (running statistics updated as nn.BatchNorm1d does) fused with the
+activation / SA residual, attention forward + backward, arg-max routed point max; the two Dropout(0.5) of the head
+draw their masks from torch's device RNG (F.dropout on the [T, 512] / [T, 256] tensors -- the reference's CPU/CUDA
+streams cannot be reproduced anyway, parity is tested with p = 0).  Activations are materialised point-major
+([T*N, C] fp32, the widest is [T*N, 1024]): sized for the reference's batch sizes, not for configs[1]'s 65 536 objects.
 """
 import torch
 import torch.nn as nn
@@ -108,9 +113,6 @@ class NaivePCT(nn.Module):
 
     def forward(self, x):
         """x [T, 3, N] as in the reference (a permuted view of data_dict['tot_obj_pts'] [T,N,3]) -> [T, 256]."""
-        if self.training:
-            raise NotImplementedError("sgaligner_amd NaivePCT: only the eval-mode (inference) forward runs on the HIP path; "
-                                      "call model.eval() (train-mode BatchNorm statistics / Dropout: SURVEY.md 8(f), next)")
         if not x.is_cuda:
             raise RuntimeError('sgaligner_amd NaivePCT: input must be on the HIP device (no CPU path)')
         xt = x.permute(0, 2, 1)
@@ -118,6 +120,8 @@ class NaivePCT(nn.Module):
             xt = xt.contiguous()
         t, n, _ = xt.shape
         rows = xt.reshape(t * n, 3).float()
+        if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(rows, t, n)
         with torch.no_grad():
             h = self.embedding.forward_rows(rows)
             cat = torch.empty((t * n, 512), device=x.device, dtype=torch.float32)      # x1 | x2 | x3 | x4 (pct.py:302)
@@ -134,3 +138,27 @@ class NaivePCT(nn.Module):
             w7, b7 = _fold(self.linear2.weight, self.linear2.bias, self.bn2)
             f = _gemm_ex(g, w6, b6, act=1)
             return _gemm_ex(f, w7, b7, act=1)
+
+    # ---- differentiable path (train mode, or eval mode with gradients enabled) -------------------------------------
+    def _forward_autograd(self, rows, t, n):
+        import torch.nn.functional as F
+        from ... import pct_ops as P
+        e = self.embedding
+        h = P.batch_norm_act(P.rows_linear(rows, e.conv1.weight), e.bn1, act=1)
+        h = P.batch_norm_act(P.rows_linear(h, e.conv2.weight), e.bn2, act=1)
+        xs = []
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            if sa.q_conv.weight is not sa.k_conv.weight and not torch.equal(sa.q_conv.weight, sa.k_conv.weight):
+                raise RuntimeError('sgaligner_amd SA: q_conv / k_conv weights differ (pct.py:199 ties them)')
+            q = P.rows_linear(h, sa.k_conv.weight)                       # = q_conv(x) = k_conv(x): one shared weight
+            v = P.rows_linear(h, sa.v_conv.weight, sa.v_conv.bias)
+            a = P.pct_attention(q, v, t, n)
+            h = P.batch_norm_act(P.rows_linear(a, sa.trans_conv.weight, sa.trans_conv.bias), sa.after_norm, act=1, resid=h)
+            xs.append(h)
+        cat = torch.cat(xs, dim=1)
+        y = P.batch_norm_act(P.rows_linear(cat, self.linear[0].weight), self.linear[1], act=2)
+        g = P.segment_max(y, t, n)
+        f = P.batch_norm_act(P.rows_linear(g, self.linear1.weight), self.bn1, act=1)
+        f = F.dropout(f, self.dp1.p, self.training)
+        f = P.batch_norm_act(P.rows_linear(f, self.linear2.weight, self.linear2.bias), self.bn2, act=1)
+        return F.dropout(f, self.dp2.p, self.training)

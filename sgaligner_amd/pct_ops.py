@@ -131,3 +131,39 @@ class SegmentMaxFn(torch.autograd.Function):
 
 def segment_max(y, n_obj, n_pts):
     return SegmentMaxFn.apply(y, n_obj, n_pts)
+
+
+class RowsLinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) over point-major rows: Conv1d(k=1) / nn.Linear of the PCT encoder.  W may be [out, in] or the
+    Conv1d layout [out, in, 1]; the bias is optional (pct.py uses bias=False in front of every BatchNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import ops
+        x = x if x.is_contiguous() else x.contiguous()
+        w = weight.reshape(weight.shape[0], -1)
+        r, k = x.shape
+        y = ops.gemm(x, w, False, True, r, w.shape[0], k, bias=bias)
+        ctx.save_for_backward(x, w)
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x, w = ctx.saved_tensors
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        r, k = x.shape
+        n = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.gemm(gy, w, False, False, r, k, n)                       # dX = dY W
+        if ctx.needs_input_grad[1]:
+            gw = ops.gemm(gy, x, True, False, n, k, r).reshape(ctx.wshape)    # dW = dY^T X (split-K over the rows)
+        if ctx.needs_input_grad[2]:
+            gb = ops.colsum(gy)
+        return gx, gw, gb
+
+
+def rows_linear(x, weight, bias=None):
+    return RowsLinearFn.apply(x, weight, bias)

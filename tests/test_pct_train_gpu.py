@@ -87,3 +87,80 @@ def test_segment_max_forward_backward():
     (gr * cot).sum().backward()
     assert torch.equal(g, gr)
     assert torch.equal(y.grad.reshape(T, N, C), yr.grad)
+
+
+def _load_sd(g):
+    return {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('sd__')}
+
+
+def test_naive_pct_train_step_vs_reference_golden_and_oracle():
+    """Train mode (batch-statistic BatchNorm, running-stat updates, Dropout p = 0): output, parameter gradients and
+    the updated running statistics against the reference module's own run (golden subset) and the oracle (everything)."""
+    from conftest import load_golden
+    from oracle import pct_oracle
+    from sgaligner_amd.aligner.networks.pct import NaivePCT
+    ge, gt = load_golden('pct_eval'), load_golden('pct_train')
+    sd = _load_sd(ge)
+    m = NaivePCT()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    m.dp1.p = 0.0
+    m.dp2.p = 0.0
+    x = torch.from_numpy(gt['x']).cuda()
+    cot = torch.from_numpy(gt['cot']).cuda()
+    y = m(x)
+    (y * cot).sum().backward()
+    torch.cuda.synchronize()
+    ref_y = gt['y']
+    assert np.abs(y.detach().cpu().numpy() - ref_y).max() < 1e-3 * max(1.0, np.abs(ref_y).max())
+    named = dict(m.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in m.parameters() if p.grad is not None)
+    for k in [k for k in gt.keys() if k.startswith('g__')]:
+        ref = gt[k]
+        got = named[k[3:]].grad.cpu().numpy()
+        assert np.abs(got - ref).max() < 1e-3 * max(np.abs(ref).max(), 1e-2 * gmax), (k, np.abs(got - ref).max(), np.abs(ref).max())
+    after = m.state_dict()
+    for k in [k for k in gt.keys() if k.startswith('after__')]:
+        ref = gt[k]
+        got = after[k[7:]].cpu().numpy()
+        if 'num_batches' in k:
+            assert int(got) == int(ref)
+        else:
+            assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
+    # every gradient against the oracle
+    sd_o = {k: v.clone() for k, v in sd.items()}
+    leaves = {}
+    for name in named:
+        leaves[name] = sd_o[name].clone().requires_grad_(True)
+        sd_o[name] = leaves[name]
+    for sa in ('sa1', 'sa2', 'sa3', 'sa4'):
+        sd_o[sa + '.k_conv.weight'] = sd_o[sa + '.q_conv.weight']
+    yo, _ = pct_oracle.naive_pct_forward_train(torch.from_numpy(gt['x']), sd_o)
+    (yo * torch.from_numpy(gt['cot'])).sum().backward()
+    for name, p in named.items():
+        ref = leaves[name].grad
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err < 1e-3 * max(ref.abs().max().item(), 1e-2 * gmax), (name, err, ref.abs().max().item())
+
+
+def test_pct_train_step_inside_the_aligner():
+    """modules = ['pct', 'gat', 'rel', 'attr'] (configs/scan3r/scan3r_ground_truth.yaml:5): one optimiser step runs and
+    lowers the loss on the same batch; Dropout active (p = 0.5)."""
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    steps = AlignerSteps(['pct', 'gat', 'rel', 'attr'], device='cuda', seed=1)
+    dd = to_device(make_batch(4, 10, 64, seed=3), 'cuda')
+    opt = torch.optim.Adam(steps.params, lr=1e-3)
+    losses = []
+    for _ in range(4):
+        steps.model.train()
+        opt.zero_grad(set_to_none=True)
+        _, ld = steps.train_step(0, 0, dd)
+        ld['loss'].backward()
+        opt.step()
+        losses.append(float(ld['loss'].detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    steps.model.eval()
+    with torch.no_grad():
+        out = steps.model(dd)
+    assert torch.isfinite(out['joint']).all()
