@@ -50,3 +50,20 @@ for _ in range(3):
 cpu = (time.perf_counter() - t0) / 3
 err = (yc - y[:64].cpu()).abs().max().item()
 print(f'CPU oracle (32 threads, 64 objects): {cpu*1e3:.1f} ms = {64/cpu:.0f} objects/s; max |GPU - oracle| on those objects {err:.2e}')
+# training step of the encoder alone (forward + backward, batch-statistic BatchNorm), reference-like batch: 1024 objects
+Tt = 1024
+mt = NaivePCT().cuda().train()
+xt = torch.randn(Tt, 3, N, device='cuda')
+cot = torch.randn(Tt, 256, device='cuda')
+for _ in range(2):
+    mt.zero_grad(set_to_none=True)
+    (mt(xt) * cot).sum().backward()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    mt.zero_grad(set_to_none=True)
+    (mt(xt) * cot).sum().backward()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+print(f'NaivePCT train step (fwd+bwd, T={Tt} x {N} pts): {dt*1e3:.1f} ms = {Tt/dt:.0f} objects/s '
+      f'({3 * (conv + attn) * Tt / dt / 1e12:.1f} TFLOP/s at 3x the forward FLOPs), peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB')
