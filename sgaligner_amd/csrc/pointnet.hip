@@ -221,22 +221,24 @@ extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1
 //   dZ2   = g_r W3[r,:] * (Z2 > 0)      gW2 += dZ2^T H1    gb2 += colsum(dZ2)
 //   dZ1   = (dZ2 W2) * (H1 > 0)         gW1 += dZ1^T X     gb1 += colsum(dZ1)
 // One wave owns one 32-row tile of the object.  Reductions over rows need the rows on the MFMA K
-// dimension, reductions over channels need the channels there, so layer 2 is recomputed in both
-// accumulator orientations (lane=row / lane=channel) instead of transposing through LDS; gW3 rows are
-// private to (wave, lane) and accumulate in registers across objects, gW2 accumulates in LDS.
+// dimension, reductions over channels need the channels there: dZ2 is computed once (lane = row) and
+// transposed through a wave-private LDS tile for the other orientation; every weight-gradient partial
+// accumulates in registers across objects and is flushed once per workgroup.
 // =================================================================================================
 namespace {
 
-constexpr int PB_WAVES = 8;
-constexpr int PB_THREADS = PB_WAVES * 64;
+// -------------------------------------------------------------------------------------------------
+// Fused backward: ONE recomputation of Z2 per winner-row tile (384 MFMAs instead of 512).
+// dZ2 is produced in the lane = row orientation (what dH1 = dZ2 W2 needs as its A operand) and TRANSPOSED through a
+// wave-private 32x32 LDS tile per channel block into the lane = channel orientation that gW2 += dZ2^T H1 needs:
+// 4 ds_write_b128 + 16 ds_read_b32 per lane instead of 32 more MFMAs (the two-phase predecessor recomputed Z2 in
+// each orientation: 512 MFMAs per tile, 10.2 ms at configs[1]; this kernel: 7.7 ms).  One wave per SIMD (the 8 gW2 tiles + 64 gW3
+// partials + dH1 need ~400 registers); a workgroup's 4 waves own 4 fixed tile indices -- even workgroups tiles 0-3,
+// odd ones 4-7 -- so the gW3 partials stay private to (wave, lane) across objects.
+// -------------------------------------------------------------------------------------------------
+constexpr int TRS = 36;            // transpose tile row stride (floats): 16-byte aligned rows, conflict-free column reads
 
-// PH == 0: gW1, gb1, gW3, gb3 (lane = row orientation: Z2 recompute, dH1 = dZ2 W2).
-// PH == 2: gW2, gb2 (lane = channel orientation: Z2 recompute, gW2 += dZ2^T H1).
-// Two launches keep every phase's accumulators in registers (fused they spilled >130 VGPRs to scratch,
-// and accumulating gW2 through LDS atomics instead cost more than the MFMA work itself); each phase
-// recomputes Z2 once in the orientation its products need, 512 MFMAs per 32-row tile in total.
-template <int PH, int NW>
-__global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
+__global__ __launch_bounds__(256) void pointnet_bwd_fused_kernel(
     const float* __restrict__ x, const int* __restrict__ argmax, const float* __restrict__ y,
     const float* __restrict__ gy, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
@@ -246,83 +248,58 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w2s = lds;               // operand order [4 cb][8 q][64 lane][4]
     float* w2r = lds + 8192;        // row-major [128][64]
-    float* gw2s = lds + 16384;      // accumulator [128][64]
-    float* w1s = lds + 24576;       // [64][3]  (every per-tile constant comes from LDS: as global loads their L2 latency
-    float* b1s = w1s + 192;         // [64]      is exposed once per tile -- phase 2 runs a single wave per SIMD)
-    float* b2s = b1s + 64;          // [128]
+    float* trs = lds + 16384;       // [4 waves][32][TRS] transpose tiles; reused as the gW2 combine buffer at the end
+    float* w1s = lds + 16384 + 8192;
+    float* b1s = w1s + 192;
+    float* b2s = b1s + 64;
     const int tid = threadIdx.x;
-    for (int d = tid; d < 384; d += NW * 64) w1s[d] = d < 192 ? w1[d] : (d < 256 ? b1[d - 192] : b2[d - 256]);
-    for (int d = tid; d < 2048; d += NW * 64) {
+    for (int d = tid; d < 384; d += 256) w1s[d] = d < 192 ? w1[d] : (d < 256 ? b1[d - 192] : b2[d - 256]);
+    for (int d = tid; d < 2048; d += 256) {
         const int ln = d & 63, q = (d >> 6) & 7, cb = d >> 9;
         const int row = cb * 32 + (ln & 31), k = 8 * q + 4 * (ln >> 5);
         *reinterpret_cast<f32x4*>(w2s + d * 4) = *reinterpret_cast<const f32x4*>(w2 + row * 64 + k);
         *reinterpret_cast<f32x4*>(w2r + d * 4) = *reinterpret_cast<const f32x4*>(w2 + d * 4);
-        *reinterpret_cast<f32x4*>(gw2s + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
 
     const int lane = tid & 63, wave0 = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    static_assert(PH == 0 || PH == 2, "two phases");
-    static_assert(PH == 2 || NW == 8, "row-tile-private accumulators need one tile per wave");
-    // persistent per-lane accumulators
-    float gw3a[PH == 0 ? 64 : 1];   // [cb][gq][r] : gW3[wave*32 + l31][cb*32 + 8gq + 4h + r]
+    const int wave = (blockIdx.x & 1) * 4 + wave0;           // this wave's winner-row tile, fixed for the whole kernel
+    float* tr = trs + wave0 * 32 * TRS;
+    float gw3a[64];                 // [cb][gq][r] : gW3[wave*32 + l31][cb*32 + 8gq + 4h + r]
 #pragma unroll
-    for (int i = 0; i < (PH == 0 ? 64 : 1); ++i) gw3a[i] = 0.f;
-    f32x16 gw2a[PH == 2 ? 8 : 1];   // [cb][kt] : gW2[cb*32 + row(r,h)][kt*32 + l31]
+    for (int i = 0; i < 64; ++i) gw3a[i] = 0.f;
+    f32x16 gw2a[8];                 // [cb][kt] : gW2[cb*32 + row(r,h)][kt*32 + l31]
 #pragma unroll
-    for (int i = 0; i < (PH == 2 ? 8 : 1); ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gw2a[i][r] = 0.f;
     float gb3a = 0.f, gb2a[4] = {0.f, 0.f, 0.f, 0.f};
     float gw1a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb1a[2] = {0.f, 0.f};
 
-    // Tiles (object t, winner-row tile `wave`) are walked as one flat sequence so that the next tile's winner index,
-    // its point (a dependent gather: two L2 round trips) and its g can be fetched while this tile computes.
-    constexpr int PER_OBJ = 8 / NW;
-    const int n_obj = (T - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int n_iter = n_obj * PER_OBJ;
-    float nx0, nx1, nx2, ng;
-    {
-        const size_t ri = (size_t)blockIdx.x * C3 + wave0 * 32 + (lane & 31);
+    const int obj0 = (int)blockIdx.x >> 1, ostep = ((int)gridDim.x + 1) >> 1;
+    const int n_iter = obj0 < T ? (T - obj0 + ostep - 1) / ostep : 0;
+    float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, ng = 0.f;
+    if (n_iter > 0) {
+        const size_t ri = (size_t)obj0 * C3 + wave * 32 + l31;
         const int p0 = min(max(argmax[ri], 0), P - 1);
-        const float* xp = x + ((size_t)blockIdx.x * P + p0) * 3;
+        const float* xp = x + ((size_t)obj0 * P + p0) * 3;
         nx0 = xp[0]; nx1 = xp[1]; nx2 = xp[2];
         ng = y[ri] > 0.f ? gy[ri] : 0.f;
     }
     for (int it = 0; it < n_iter; ++it) {
-        const int t = (int)blockIdx.x + (it / PER_OBJ) * (int)gridDim.x;
-        const int wave = wave0 + (it % PER_OBJ) * NW;        // wave = winner-row tile of this object
+        const int t = obj0 + it * ostep;
         int lane_o = lane, h_o = h;
-        asm volatile("" : "+v"(lane_o), "+v"(h_o));          // keep weight reads inside the loop (see fwd):
-        const int l31_o = lane_o & 31;                       // every weight address below goes through these
+        asm volatile("" : "+v"(lane_o), "+v"(h_o));          // keep weight reads inside the loop (see fwd)
+        const int l31_o = lane_o & 31;
         const int c = wave * 32 + l31_o;                     // this lane's winner row (lane = row layouts)
         const float x0 = nx0, x1 = nx1, x2 = nx2, g = ng;
-        // next tile (clamped to this one at the end): winner index now, its point after the H1 section below
-        const int itn = min(it + 1, n_iter - 1);
-        const size_t rin = (size_t)((int)blockIdx.x + (itn / PER_OBJ) * (int)gridDim.x) * C3 + (wave0 + (itn % PER_OBJ) * NW) * 32 + l31_o;
+        const int tn = obj0 + min(it + 1, n_iter - 1) * ostep;
+        const size_t rin = (size_t)tn * C3 + wave * 32 + l31_o;
         const int pn_raw = argmax[rin];
         const float yn = y[rin], gyn = gy[rin];
-        if (PH == 0 && h == 0) gb3a += g;
+        if (h == 0) gb3a += g;
 
-        // Phase 2 runs one wave per SIMD: nobody hides the L2 latency of the 64 W3 elements this tile needs, so they are all
-        // requested up front (64 of the 140 spare registers) instead of 16 at a time in front of their use.
-        float w3t[PH == 2 ? 64 : 1], gs[PH == 2 ? 16 : 1];
-        if (PH == 2) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {           // g of row(s, h): two addresses per wave, no cross-lane shuffle
-                const size_t ri = (size_t)t * C3 + wave * 32 + mfma32_row(s, h_o);
-                const float yr = y[ri], gr = gy[ri];
-                gs[PH == 2 ? s : 0] = yr > 0.f ? gr : 0.f;
-            }
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    w3t[PH == 2 ? cb * 16 + s : 0] = w3[(size_t)(wave * 32 + mfma32_row(s, h_o)) * 128 + cb * 32 + l31_o];
-        }
-
-
-        // ---- H1 in "lane = row" layout (k = 8q + 4h + r), as in the forward
+        // ---- H1, lane = row layout (k = 8q + 4h + r)
         float h1[32];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -336,10 +313,30 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
             h1[q * 4 + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
             h1[q * 4 + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
         }
+        // ---- H1, lane = k1 / regs = rows layout, from two K = 2 MFMAs per 32 channels:
+        //      D[row][k1] = x0 W1[k1][0] + x1 W1[k1][1] + x2 W1[k1][2] + 1 * b1[k1]  (A: lane = row, h = k; B: lane = k1, h = k)
+        f32x16 h1c[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int k1 = kt * 32 + l31_o;
+            const float bA = w1s[k1 * 3 + h_o];
+            const float bB = h_o ? b1s[k1] : w1s[k1 * 3 + 2];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? x1 : x0, bA, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? 1.f : x2, bB, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1c[kt][r] = fmaxf(acc[r], 0.f);
+        }
+        {   // the next tile's point: its index arrived during the H1 section
+            const int pn = min(max(pn_raw, 0), P - 1);
+            const float* xpn = x + ((size_t)tn * P + pn) * 3;
+            nx0 = xpn[0]; nx1 = xpn[1]; nx2 = xpn[2];
+            ng = yn > 0.f ? gyn : 0.f;
+        }
 
-        // ======== orientation 1: lane = row, regs = ch2  ->  dZ2 -> dH1 = dZ2 W2
         f32x16 dh1[2];
-        if (PH == 0) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -347,6 +344,7 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             __builtin_amdgcn_sched_barrier(0);
+            // Z2[row = lane][ch2 = cb*32 + 8gq + 4h + r]
             f32x16 acc;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
@@ -359,18 +357,21 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], h1[q * 4 + r], acc, 0, 0, 0);
             }
-            // dZ2[row][ch2] = g * W3[c][ch2] * (Z2 > 0), ch2 = cb*32 + 8gq + 4h + r
+            // dZ2 = g * W3[c][ch2] * (Z2 > 0); gW3 partials; the tile goes to LDS for the transpose
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const f32x4 w3v = *reinterpret_cast<const f32x4*>(w3 + (size_t)c * 128 + cb * 32 + 8 * gq + 4 * h_o);
+                f32x4 dz;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z = acc[gq * 4 + r];
-                    gw3a[PH == 0 ? cb * 16 + gq * 4 + r : 0] = fmaf(g, fmaxf(z, 0.f), gw3a[PH == 0 ? cb * 16 + gq * 4 + r : 0]);
-                    acc[gq * 4 + r] = (z > 0.f ? g : 0.f) * w3v[r];
+                    gw3a[cb * 16 + gq * 4 + r] = fmaf(g, fmaxf(z, 0.f), gw3a[cb * 16 + gq * 4 + r]);
+                    dz[r] = (z > 0.f ? g : 0.f) * w3v[r];
+                    acc[gq * 4 + r] = dz[r];
                 }
+                *reinterpret_cast<f32x4*>(tr + l31_o * TRS + 8 * gq + 4 * h_o) = dz;       // tr[row][ch2 local]
             }
-            // dH1[row][k1] += sum_ch2 dZ2[row][ch2] W2[ch2][k1]   (A = dZ2 regs, B = W2 rows from LDS)
+            // dH1[row][k1] += sum_ch2 dZ2[row][ch2] W2[ch2][k1]
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const float* wrow = w2r + (cb * 32 + mfma32_row(s, h_o)) * 64 + l31_o;
@@ -378,110 +379,41 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
                 for (int kt = 0; kt < 2; ++kt)
                     dh1[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s], wrow[kt * 32], dh1[kt], 0, 0, 0);
             }
-        }
-
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {   // the next tile's point: its index arrived during the H1 section
-            const int pn = min(max(pn_raw, 0), P - 1);
-            const float* xpn = x + ((size_t)(rin / C3) * P + pn) * 3;
-            nx0 = xpn[0]; nx1 = xpn[1]; nx2 = xpn[2];
-            ng = yn > 0.f ? gyn : 0.f;
-        }
-        // ---- H1 again in "lane = k1, regs = rows" layout (x of row(s,h) fetched by lane shuffle);
-        //      dZ1 = dH1 * (H1 > 0); gW1 / gb1 partial sums
-        f32x16 h1c[2];
-        if (PH == 2) {
-            // as two K = 2 MFMAs per 32 channels: D[row][k1] = x0 W1[k1][0] + x1 W1[k1][1] + x2 W1[k1][2] + 1 * b1[k1]
-            // (A: lane = row, h = k; B: lane = k1, h = k) -- lands directly in the "lane = k1, regs = rows" layout
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int k1 = kt * 32 + l31_o;
-                const float bA = w1s[k1 * 3 + h_o];
-                const float bB = h_o ? b1s[k1] : w1s[k1 * 3 + 2];
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? x1 : x0, bA, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? 1.f : x2, bB, acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h1c[kt][r] = fmaxf(acc[r], 0.f);
-            }
-        } else {
-            const float wa0 = w1s[l31_o * 3 + 0], wb0 = w1s[l31_o * 3 + 1], wc0 = w1s[l31_o * 3 + 2], bb0 = b1s[l31_o];
-            const float wa1 = w1s[(32 + l31_o) * 3 + 0], wb1 = w1s[(32 + l31_o) * 3 + 1], wc1 = w1s[(32 + l31_o) * 3 + 2], bb1 = b1s[32 + l31_o];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int src = mfma32_row(s, h);
-                const float sx0 = __shfl(x0, src, 64), sx1 = __shfl(x1, src, 64), sx2 = __shfl(x2, src, 64);
-                const float hv0 = fmaxf(fmaf(wc0, sx2, fmaf(wb0, sx1, fmaf(wa0, sx0, bb0))), 0.f);
-                const float hv1 = fmaxf(fmaf(wc1, sx2, fmaf(wb1, sx1, fmaf(wa1, sx0, bb1))), 0.f);
-                const float dz0 = hv0 > 0.f ? dh1[0][s] : 0.f;
-                const float dz1 = hv1 > 0.f ? dh1[1][s] : 0.f;
-                gw1a[0][0] = fmaf(dz0, sx0, gw1a[0][0]); gw1a[0][1] = fmaf(dz0, sx1, gw1a[0][1]); gw1a[0][2] = fmaf(dz0, sx2, gw1a[0][2]);
-                gw1a[1][0] = fmaf(dz1, sx0, gw1a[1][0]); gw1a[1][1] = fmaf(dz1, sx1, gw1a[1][1]); gw1a[1][2] = fmaf(dz1, sx2, gw1a[1][2]);
-                gb1a[0] += dz0;
-                gb1a[1] += dz1;
-            }
-        }
-
-        // ======== orientation 2: lane = ch2, regs = rows  ->  gb2, gW2 += dZ2^T H1
-        if (PH == 2)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
-            const float bv = b2s[cb * 32 + l31_o];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bv;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(w2s + ((cb * 8 + q) * 64 + lane_o) * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[q * 4 + r], wv[r], acc, 0, 0, 0);
-            }
+            // lane = ch2, regs = rows: gb2 and gW2 += dZ2^T H1   (wave-private tile: the waitcnt of the reads orders them
+            // after this wave's own writes; no barrier)
             float colsum = 0.f;
+            f32x16 dzt;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int cr = wave * 32 + mfma32_row(s, h_o);
-                const float z = acc[s];
-                const float gsv = gs[PH == 2 ? s : 0];
-                const float w3e = w3t[PH == 2 ? cb * 16 + s : 0];              // unconditional load: a select there
-                const float dz = (z > 0.f ? gsv : 0.f) * w3e;                   // would be turned into 64 branches
-                acc[s] = dz;
-                colsum += dz;
+                dzt[s] = tr[mfma32_row(s, h_o) * TRS + l31_o];
+                colsum += dzt[s];
             }
             gb2a[cb] += colsum;
-            {
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int s = 0; s < 16; ++s)
-                        gw2a[cb * 2 + kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[s], h1c[kt][s], gw2a[cb * 2 + kt], 0, 0, 0);
-            }
+                for (int s = 0; s < 16; ++s)
+                    gw2a[cb * 2 + kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dzt[s], h1c[kt][s], gw2a[cb * 2 + kt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dZ1 = dH1 * (H1 > 0) in the lane = k1 layout; gW1 / gb1 (x of row(s,h) by lane shuffle)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int src = mfma32_row(s, h);
+            const float sx0 = __shfl(x0, src, 64), sx1 = __shfl(x1, src, 64), sx2 = __shfl(x2, src, 64);
+            const float dz0 = h1c[0][s] > 0.f ? dh1[0][s] : 0.f;
+            const float dz1 = h1c[1][s] > 0.f ? dh1[1][s] : 0.f;
+            gw1a[0][0] = fmaf(dz0, sx0, gw1a[0][0]); gw1a[0][1] = fmaf(dz0, sx1, gw1a[0][1]); gw1a[0][2] = fmaf(dz0, sx2, gw1a[0][2]);
+            gw1a[1][0] = fmaf(dz1, sx0, gw1a[1][0]); gw1a[1][1] = fmaf(dz1, sx1, gw1a[1][1]); gw1a[1][2] = fmaf(dz1, sx2, gw1a[1][2]);
+            gb1a[0] += dz0;
+            gb1a[1] += dz1;
         }
     }
 
     // ---- flush the per-workgroup partials
-    const int wave = wave0;
-    if (PH == 2) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const float v = gb2a[cb] + __shfl_xor(gb2a[cb], 32, 64);
-            if (h == 0) atomicAdd(gb2 + cb * 32 + l31, v);
-        }
-        // gw2a[cb*2+kt][r] = gW2[cb*32 + row(r,h)][kt*32 + l31]: combine the 8 waves in LDS, then one atomic per element
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                atomicAdd(gw2s + ((i >> 1) * 32 + mfma32_row(r, h)) * 64 + (i & 1) * 32 + l31, gw2a[PH == 2 ? i : 0][r]);
-        __syncthreads();
-        for (int d = tid; d < 8192; d += NW * 64) atomicAdd(gw2 + d, gw2s[d]);
-    } else {
-#pragma unroll
-    for (int i = 0; i < 64; ++i)     // gw3a[cb*16 + gq*4 + r] = gW3[wave*32 + l31][cb*32 + 8gq + 4h + r]
-        atomicAdd(gw3 + (size_t)(wave * 32 + l31) * 128 + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * h + (i & 3), gw3a[PH == 0 ? i : 0]);
+    for (int i = 0; i < 64; ++i)
+        atomicAdd(gw3 + (size_t)(wave * 32 + l31) * 128 + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * h + (i & 3), gw3a[i]);
     if (h == 0) atomicAdd(gb3 + wave * 32 + l31, gb3a);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -494,6 +426,26 @@ __global__ __launch_bounds__(NW * 64) void pointnet_bwd_kernel(
         const float vb = gb1a[kt] + __shfl_xor(gb1a[kt], 32, 64);
         if (h == 0) atomicAdd(gb1 + k1, vb);
     }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const float v = gb2a[cb] + __shfl_xor(gb2a[cb], 32, 64);
+        if (h == 0) atomicAdd(gb2 + cb * 32 + l31, v);
+    }
+    // gW2: combine the 4 waves in LDS (the transpose tiles are dead now; 8192 floats needed, 4*32*TRS = 4608 available ->
+    // two halves), then one global atomic per element
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        for (int d = tid; d < 4096; d += 256) trs[d] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(trs + (((half * 4 + i) >> 1) * 32 + mfma32_row(r, h) - half * 64) * 64 + ((half * 4 + i) & 1) * 32 + l31, gw2a[half * 4 + i][r]);
+        __syncthreads();
+        for (int d = tid; d < 4096; d += 256) atomicAdd(gw2 + half * 4096 + d, trs[d]);
+        __syncthreads();
     }
 }
 
@@ -515,14 +467,12 @@ extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const flo
     hipMemsetAsync(gw3, 0, 256 * 128 * sizeof(float), s);
     hipMemsetAsync(gb3, 0, 256 * sizeof(float), s);
     if (T == 0) return SGA_OK;
-    const size_t lds_bytes = (3 * 8192 + 384) * sizeof(float);
-    int grid = T < sga_num_cus() ? T : sga_num_cus();
-    auto k0 = pointnet_bwd_kernel<0, 8>;
-    auto k2 = pointnet_bwd_kernel<2, 4>;     // 4 waves -> one wave per SIMD, the full 512-register file for the 8 gW2 tiles
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(k2, dim3(grid), dim3(256), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
-    hipLaunchKernelGGL(k0, dim3(grid), dim3(512), lds_bytes, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    {
+        const size_t lds_f = (3 * 8192 + 384) * sizeof(float);
+        int g2 = 2 * T < sga_num_cus() ? 2 * T : (sga_num_cus() & ~1);      // workgroups come in (tiles 0-3, tiles 4-7) pairs
+        hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+        hipLaunchKernelGGL(pointnet_bwd_fused_kernel, dim3(g2), dim3(256), lds_f, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    }
     SGA_CHECK_LAUNCH("sga_pointnet_bwd");
     return SGA_OK;
 }
