@@ -168,6 +168,66 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
     }
 }
 
+// C[M,N] += A^T B for A [K,M], B [K,N] both row-major (the weight-gradient shape dW = dY^T X with K = rows of the
+// batch): the row-major [32 k][128] chunks go to LDS as they are (f32x4 in, f32x4 out) and the MFMA operands are read
+// as ds_read_b32 with lane = output index (conflict free), K pair (2s, 2s+1) per step -- no transposed staging.
+// Split over K with atomic adds (C zeroed by the caller); next chunk prefetched into registers under the MFMAs.
+constexpr int TN_STRIDE = 132;
+
+__global__ __launch_bounds__(GM_THREADS) void gemm_tn_kernel(const float* __restrict__ A, long lda,
+                                                             const float* __restrict__ B, long ldb,
+                                                             float* __restrict__ C, long ldc, int M, int N, int K,
+                                                             int k_per_split) {
+    __shared__ __attribute__((aligned(16))) float As[SGA_KC * TN_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[SGA_KC * TN_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * GM_THREADS + tid, r = e >> 5, c = (e & 31) * 4;      // 32 k-rows x 32 quads
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool kin = k0 + r < kend;
+            ra[i] = (kin && m0 + c < M) ? *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + r) * lda + m0 + c) : z;   // M % 4 == 0
+            rb[i] = (kin && n0 + c < N) ? *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + r) * ldb + n0 + c) : z;   // N % 4 == 0
+        }
+    };
+    f32x16 acc[4];
+    zero_acc<4>(acc);
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += SGA_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * GM_THREADS + tid, r = e >> 5, c = (e & 31) * 4;
+            *reinterpret_cast<f32x4*>(As + r * TN_STRIDE + c) = ra[i];
+            *reinterpret_cast<f32x4*>(Bs + r * TN_STRIDE + c) = rb[i];
+        }
+        __syncthreads();
+        if (k0 + SGA_KC < kend) gload(k0 + SGA_KC);
+        const float* ap = As + h * TN_STRIDE + l31;
+        const float* bp = Bs + h * TN_STRIDE + wave * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < SGA_KC / 2; ++s) {
+            const float bv = bp[2 * s * TN_STRIDE];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * TN_STRIDE + t * 32], bv, acc[t], 0, 0, 0);
+        }
+    }
+    const int n = n0 + wave * 32 + l31;
+    if (n >= N) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + t * 32 + mfma32_row(r, h);
+            if (m < M) atomicAdd(C + (size_t)m * ldc + n, acc[t][r]);
+        }
+}
+
 // column sums: out[n] (+)= sum_m X[m*ld + n]   (bias gradients)
 __global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float* __restrict__ out) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -229,6 +289,11 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
     const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
     dim3 grid(gx, gy, splits);
+    if (!a_is_f64 && transA && !transB && use_atomic && a_al && b_al && M % 4 == 0 && N % 4 == 0 && !bias) {
+        hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc, M, N, K, kper);
+        SGA_CHECK_LAUNCH("sga_gemm");
+        return SGA_OK;
+    }
     if (!a_is_f64 && !transA && transB && splits == 1 && a_al && b_al && K % 4 == 0) {
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(gx, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
                            bias, M, N, K, accumulate, act, resid, ldr);

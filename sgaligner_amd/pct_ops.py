@@ -157,7 +157,8 @@ class RowsLinearFn(torch.autograd.Function):
         n = w.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.gemm(gy, w, False, False, r, k, n)                       # dX = dY W
+            wt = w.t().contiguous()                                           # [k, n]: dX = dY (W^T)^T runs on the NT kernel
+            gx = ops.gemm(gy, wt, False, True, r, k, n)
         if ctx.needs_input_grad[1]:
             gw = ops.gemm(gy, x, True, False, n, k, r).reshape(ctx.wshape)    # dW = dY^T X (split-K over the rows)
         if ctx.needs_input_grad[2]:
