@@ -141,7 +141,7 @@ class LinearFn(torch.autograd.Function):
         n = weight.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gemm(gy, weight, False, False, t, k, n)                 # dX = dY W
+            gx = gemm(gy, weight.t().contiguous(), False, True, t, k, n)   # dX = dY W, as dY (W^T)^T: the prefetching NT kernel
         if ctx.needs_input_grad[1]:
             gw = gemm(gy, cast_f32(x), True, False, n, k, t)             # dW = dY^T X
         if ctx.needs_input_grad[2]:
