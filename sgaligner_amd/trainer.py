@@ -82,10 +82,18 @@ class AlignerSteps:
         rows = [i[0] for i in info]
         anchors = [i[1] for i in info]
         sharded = len(self.modules) > 1
-        gathered = sdist.gather_tables(output_dict, rows, reduce_grad=sharded)
         gdd = sdist.gather_index_sets(data_dict, rows)
-        if sharded:        # the gathered joint is the fusion of the gathered tables (replicated weight)
-            gathered['joint']._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
+        if sharded:
+            # only the M modality tables travel: the fused loss derives every joint similarity from them (S_J = sum beta_m
+            # S_m with the replicated fusion weight), so the 100*M-wide joint table is neither gathered nor reduced --
+            # half of the bytes of both collectives.  The placeholder only carries the provenance tag OverallLoss checks.
+            gathered = sdist.gather_tables({m: output_dict[m] for m in self.modules}, rows, reduce_grad=True)
+            joint = torch.empty((0,), device=self.device)
+            joint._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
+            gathered['joint'] = joint
+        else:
+            gathered = sdist.gather_tables(output_dict, rows, reduce_grad=False)
+        if sharded:
             gdd['_sga_shard'] = (sum(anchors[:rank]), sum(anchors[:rank + 1]))
             gdd['_sga_reduce'] = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return self.loss_func(gathered, gdd)
