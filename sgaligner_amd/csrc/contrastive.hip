@@ -438,6 +438,8 @@ struct MultiArgs {
 constexpr int S16_WAVES = SGA_S16_WAVES;   // waves per workgroup; with 4, two workgroups share a CU (2 x 78 KiB of LDS)
 constexpr int S16_THREADS = S16_WAVES * 64;
 constexpr int S16_OWN = S16_WAVES * 16;     // owner rows per workgroup
+// SGA_DBG_NOEXP / NOBAR / NODMA / NOS / NOG: timing-only ablation switches (wrong results) for tools/build_variant.sh;
+// never defined in the product build (DESIGN.md 3b lists what they measured).
 __device__ __forceinline__ int s16_pi(int rho) { return (rho & 9) | ((rho & 2) << 1) | ((rho & 4) >> 1); }
 
 template <int M, bool GRAD>
