@@ -24,6 +24,10 @@
 // accumulators with no LDS transpose and each owner row is accumulated by exactly one wave.
 #include "mfma_tiles.h"
 
+// gemm.hip (include/sgaligner_hip.h): the stash gradient of the anchors x anchors backward runs on the GEMM kernels
+extern "C" int sga_gemm(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64, const float* B,
+                        long ldb, float* C, long ldc, const float* bias, int accumulate, void* stream);
+
 namespace {
 
 constexpr int CT_THREADS = 256;
@@ -1573,6 +1577,15 @@ extern "C" int sga_loss_stash_grad(const float* M1, const float* Z, int A, int D
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float* X1 = Z + (size_t)a_lo * Dp;             // the shard's X1 rows
     const float* X2 = Z + (size_t)A * Dp;                // all X2 rows
+    if (ns % 4 == 0 && Dp % 4 == 0 && reinterpret_cast<uintptr_t>(M1) % 16 == 0 && reinterpret_cast<uintptr_t>(Z) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(dZ) % 16 == 0) {
+        // the two products as plain GEMMs on the stash M1 [A (j), ns (i)] = G^T (gemm.hip: row-major TN / NN kernels,
+        // split over the contraction with atomic accumulation into dZ):
+        //   dX1[i, :] += sum_j M1[j, i] X2[j, :]      (TN)          dX2[j, :] += sum_i M1[j, i] X1[i, :]      (NN)
+        int rc = sga_gemm(1, 0, ns, Dp, A, M1, ns, 0, X2, Dp, dZ + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
+        if (rc) return rc;
+        return sga_gemm(0, 0, A, Dp, ns, M1, ns, 0, X1, Dp, dZ + (size_t)A * Dp, Dp, nullptr, 1, stream);
+    }
     for (int c0 = 0; c0 < Dp; c0 += 320) {               // column blocks of <= 320 (the 104*M-wide joint operand takes one or two)
         const int w = Dp - c0 < 320 ? Dp - c0 : 320;
         launch_stash(true, w > 128, M1, X2 + c0, dZ + (size_t)a_lo * Dp + c0, ns, A, ns, Dp, w, s);

@@ -228,6 +228,74 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_tn_kernel(const float* __rest
         }
 }
 
+// C[M,N] (+)= A B for A [M,K] (k contiguous) and B [K,N] (n contiguous), no epilogue: A chunks staged [128 m][32 k]
+// and read as ds_read_b128 (4 MFMAs per read), B chunks staged row-major [32 k][128 n] as they are and read as
+// lane-contiguous ds_read_b32.  Optional split over K with atomic adds.  (dS E of the loss backward: M1 [A, ns] x X1.)
+__global__ __launch_bounds__(GM_THREADS) void gemm_nn_kernel(const float* __restrict__ A, long lda,
+                                                             const float* __restrict__ B, long ldb,
+                                                             float* __restrict__ C, long ldc, int M, int N, int K,
+                                                             int accumulate, int k_per_split, int use_atomic) {
+    __shared__ __attribute__((aligned(16))) float As[128 * SGA_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[SGA_KC * TN_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    constexpr int V = SGA_KC / 4;
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * GM_THREADS + tid;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const int r = e / V, c = (e % V) * 4;                                   // A: 128 rows x 8 quads of k
+            ra[i] = (m0 + r < M && k0 + c < kend) ? *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * lda + k0 + c) : z;
+            const int kr = e >> 5, cn = (e & 31) * 4;                               // B: 32 k-rows x 32 quads of n
+            rb[i] = (k0 + kr < kend && n0 + cn < N) ? *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + kr) * ldb + n0 + cn) : z;
+        }
+    };
+    f32x16 acc[4];
+    zero_acc<4>(acc);
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += SGA_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * GM_THREADS + tid;
+            *reinterpret_cast<f32x4*>(As + (e / V) * SGA_LDS_STRIDE + (e % V) * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(Bs + (e >> 5) * TN_STRIDE + (e & 31) * 4) = rb[i];
+        }
+        __syncthreads();
+        if (k0 + SGA_KC < kend) gload(k0 + SGA_KC);
+        const float* ap = As + l31 * SGA_LDS_STRIDE + 4 * h;                        // k = 8q + 4h + r
+        const float* bp = Bs + (4 * h) * TN_STRIDE + wave * 32 + l31;
+#pragma unroll
+        for (int q = 0; q < SGA_KC / 8; ++q) {
+            f32x4 a4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a4[t] = *reinterpret_cast<const f32x4*>(ap + t * 32 * SGA_LDS_STRIDE + 8 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bv = bp[(8 * q + r) * TN_STRIDE];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][r], bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int n = n0 + wave * 32 + l31;
+    if (n >= N) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + t * 32 + mfma32_row(r, h);
+            if (m < M) {
+                float* p = C + (size_t)m * ldc + n;
+                if (use_atomic) atomicAdd(p, acc[t][r]);
+                else *p = accumulate ? (*p + acc[t][r]) : acc[t][r];
+            }
+        }
+}
+
 // column sums: out[n] (+)= sum_m X[m*ld + n]   (bias gradients)
 __global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float* __restrict__ out) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -291,6 +359,12 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     dim3 grid(gx, gy, splits);
     if (!a_is_f64 && transA && !transB && use_atomic && a_al && b_al && M % 4 == 0 && N % 4 == 0 && !bias) {
         hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc, M, N, K, kper);
+        SGA_CHECK_LAUNCH("sga_gemm");
+        return SGA_OK;
+    }
+    if (!a_is_f64 && !transA && !transB && a_al && b_al && K % 4 == 0 && N % 4 == 0 && !bias && act == 0 && !resid) {
+        hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc, M, N, K,
+                           accumulate, kper, use_atomic);
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;
     }
