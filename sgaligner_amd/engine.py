@@ -40,7 +40,7 @@ from .trainer import AlignerSteps
 
 class EpochBasedTrainer:
     def __init__(self, steps: AlignerSteps, output_dir: str, max_epoch: int, lr: float = 1e-3, weight_decay: float = 0.0,
-                 log_steps: int = 10, grad_acc_steps: int = 1, logger: logging.Logger | None = None):
+                 log_steps: int = 10, grad_acc_steps: int = 1, logger: logging.Logger | None = None, run_grad_check: bool = False):
         self.steps = steps
         self.model = steps.model
         self.loss_func = steps.loss_func
@@ -48,6 +48,7 @@ class EpochBasedTrainer:
         self.max_epoch = max_epoch
         self.log_steps = log_steps
         self.grad_acc_steps = grad_acc_steps
+        self.run_grad_check = run_grad_check          # epoch_based_trainer.py:65-73 (default off, as in the reference)
         self.snapshot_dir = osp.join(output_dir, 'snapshots')
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1
         self.rank = dist.get_rank() if self.distributed else 0
@@ -154,6 +155,22 @@ class EpochBasedTrainer:
             data_dict = sdist.shard_data_dict(data_dict, lo, hi)
         return DeviceBatch(data_dict, self.device)
 
+    def check_gradients(self, epoch, iteration, data_dict, output_dict, result_dict):
+        """NaN / Inf scan of every gradient (one device-side reduction; the reference dumps data/model and drops into ipdb,
+        epoch_based_trainer.py:65-73 -- here: dump and raise)."""
+        if not self.run_grad_check:
+            return
+        bad = torch.zeros((), device=self.device)
+        for p in self.steps.params:
+            if p.grad is not None:
+                bad += (~torch.isfinite(p.grad)).sum()
+        if float(bad) > 0:
+            if self.rank == 0:
+                torch.save({k: v for k, v in data_dict.items()}, osp.join(self.snapshot_dir, 'bad_grad_data.pth'))
+                torch.save(self.model.state_dict(), osp.join(self.snapshot_dir, 'bad_grad_model.pth'))
+            raise FloatingPointError(f'Epoch {epoch}, iter {iteration}: invalid gradients ({int(bad)} non-finite values); '
+                                     f'data_dict and model saved under {self.snapshot_dir}')
+
     def _optimizer_step(self, iteration):
         if iteration % self.grad_acc_steps == 0:
             self.optimizer.step()
@@ -185,6 +202,7 @@ class EpochBasedTrainer:
                         p.grad /= self.world
                 sdist.allreduce_grads(self.steps.params)
             self.after_backward(self.epoch, self.inner_iteration, data_dict, output_dict, result_dict)
+            self.check_gradients(self.epoch, self.inner_iteration, data_dict, output_dict, result_dict)
             self._optimizer_step(self.inner_iteration)
             self.after_train_step(self.epoch, self.inner_iteration, data_dict, output_dict, result_dict)
             # running sums stay on the device; one host read-back per log_steps
