@@ -110,6 +110,7 @@ class NaivePCT(nn.Module):
         self.bn2 = nn.BatchNorm1d(256)
         self.dp1 = nn.Dropout(p=0.5)
         self.dp2 = nn.Dropout(p=0.5)
+        self.eval_chunk_rows = 1 << 19       # inference: points per chunk (x 1024 channels x 4 B = 2 GiB for the widest activation)
 
     def forward(self, x):
         """x [T, 3, N] as in the reference (a permuted view of data_dict['tot_obj_pts'] [T,N,3]) -> [T, 256]."""
@@ -123,6 +124,18 @@ class NaivePCT(nn.Module):
         if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_autograd(rows, t, n)
         with torch.no_grad():
+            # objects are independent in eval mode (running-statistic BatchNorm), so the batch is walked in chunks that
+            # keep the widest activation ([chunk*N, 1024] fp32) around 2 GiB -- configs[1]'s 65 536 objects x 512 points
+            # would otherwise need 137 GB for that tensor alone
+            chunk = max(1, self.eval_chunk_rows // max(n, 1))
+            if t > chunk:
+                outs = [self._forward_eval_rows(rows[c * n:min(t, c + chunk) * n], min(t, c + chunk) - c, n) for c in range(0, t, chunk)]
+                return torch.cat(outs)
+            return self._forward_eval_rows(rows, t, n)
+
+    def _forward_eval_rows(self, rows, t, n):
+        with torch.no_grad():
+            x = rows
             h = self.embedding.forward_rows(rows)
             cat = torch.empty((t * n, 512), device=x.device, dtype=torch.float32)      # x1 | x2 | x3 | x4 (pct.py:302)
             src = h

@@ -91,3 +91,17 @@ def test_pct_in_multimodal_encoder_eval():
     emb = feat @ model.object_embedding.weight.detach().cpu().t() + model.object_embedding.bias.detach().cpu()
     assert (out['pct'].cpu() - emb).abs().max() < TOL
     assert out['joint'].shape == (dd['tot_obj_pts'].shape[0], 200)
+
+
+@pytest.mark.gpu
+def test_pct_eval_chunked_equals_unchunked():
+    """Inference walks the objects in memory-bounded chunks (objects are independent in eval mode): same output."""
+    from sgaligner_amd.aligner.networks.pct import NaivePCT
+    torch.manual_seed(4)
+    m = NaivePCT().cuda().eval()
+    x = torch.randn(23, 3, 70, device='cuda')
+    with torch.no_grad():
+        y_all = m(x)
+        m.eval_chunk_rows = 5 * 70                                # 5 objects per chunk: 4 full chunks + 3
+        y_chunk = m(x)
+    assert y_all.shape == (23, 256) and torch.equal(y_all, y_chunk)
