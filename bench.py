@@ -155,8 +155,8 @@ def main():
             # = 2 x [ sum_tab 2*D_tab * 2A(J1+J2) ]  with sum_tab D_tab = 100*M + 100*M.
             d_sum = 100 * M + 100 * M
             alg = 2.0 * (2.0 * d_sum * 2.0 * ns * (J1 + J2))
-            # executed: two sweeps x M tables x (S with K = 104 + gradient GEMM with 112 columns); the joint table is derived
-            executed = 2.0 * (2.0 * ns * (J1 + J2)) * 2.0 * M * (104 + 112)
+            # executed: two sweeps x M tables x (S with K = 100 + gradient GEMM with 112 columns); the joint table is derived
+            executed = 2.0 * (2.0 * ns * (J1 + J2)) * 2.0 * M * (100 + 112)
             avg_ms = float(np.mean(durs))
             ach = alg / (avg_ms * 1e-3) / 1e12
             kname = f'sweep16_kernel<{M},true>'

@@ -99,10 +99,11 @@ int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* d
 /* fused variants for the normal pipeline, where the last table is the fusion of the M others: every joint
  * similarity is S_J = sum_m beta_m S_m (beta_m = w_m^2 / sum w^2, w = softmax(fusion.weight), sg_aligner.py:32-34
  * + losses.py:44,73), so the 300-d table is never multiplied.  Z[m] [R+32, 104] (Dp must be 104, 32 readable rows of
- * slack), beta [M] device.  sums/gs [(M+1)][8] with the joint in row M; gamma[m] += dL/dbeta_m through the negatives. */
-int sga_loss_multi_sums(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+ * slack), D = the real embedding width (columns D..103 are zero padding; the K step that only covers padding is skipped),
+ * beta [M] device.  sums/gs [(M+1)][8] with the joint in row M; gamma[m] += dL/dbeta_m through the negatives. */
+int sga_loss_multi_sums(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                         double* sums, int a_lo, int a_hi, void* stream);
-int sga_loss_multi_grad(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+int sga_loss_multi_grad(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                         const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
 /* fused anchors x anchors terms (M in {2,3}): same outputs as sga_loss_anchor_fwd/bwd for tables (Z_1..Z_M, joint), with the
  * joint similarities derived in registers; bwd writes M1[m] = dL/dS_m + beta_m dL/dS_J (no joint stash) and gamma[m] += dL/dbeta_m */

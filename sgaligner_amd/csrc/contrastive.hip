@@ -417,6 +417,7 @@ struct MultiArgs {
     const double* gs;               // [(M+1)][8]            GRAD in (joint = row M)
     float* dZ[4];                   // GRAD out, atomic accumulate
     double* gamma;                  // [M]                   GRAD out
+    int ktail;                      // K steps of 4 past k = 96 that hold data: ceil((D - 96) / 4), D = 100 -> 1 (columns 100..103 are zero padding)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -578,10 +579,12 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * M, 0);                 // ... then this group's MFMAs
                 }
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
+                    if (t >= a.ktail) break;                       // uniform: the all-zero padding step is skipped (exact)
 #pragma unroll
                     for (int m = 0; m < M; ++m)
                         sacc[m][jh] = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[m][t], ownt[m][t], sacc[m][jh], 0, 0, 0);
+                }
             }
 #endif
 
@@ -1448,8 +1451,10 @@ extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT,
 }
 
 // ---- fused multi-table entry points (joint table == fusion of the M tables) ----------------------------
-static int fill_multi(MultiArgs& a, const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
+static int fill_multi(MultiArgs& a, const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0,
                       float tau1, bool grad, int a_lo, int a_hi) {
+    if (D < 1 || D > 104) { sga_set_error("sga_loss_multi: D=%d outside [1,104] (the fused sweeps take Dp = 104 tables)", D); return SGA_ERR_ARG; }
+    a.ktail = D > 100 ? 2 : (D > 96 ? 1 : 0);
     if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("sga_loss_multi: anchor shard [%d,%d) outside [0,%d]", a_lo, a_hi, A); return SGA_ERR_ARG; }
     if (M < 2 || M > 4) { sga_set_error("sga_loss_multi: M=%d outside [2,4]", M); return SGA_ERR_ARG; }
     a.M = M;
@@ -1478,14 +1483,14 @@ static int plan_multi(MultiArgs& a, int target_steps, int own_rows = 128) {
     return nwg;
 }
 
-extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
+extern "C" int sga_loss_multi_sums(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0,
                                    float tau1, double* sums, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums")) return rc0;
     if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     MultiArgs a{};
-    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi);
+    int rc = fill_multi(a, Z, M, D, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi);
     if (rc) return rc;
     a.sums = sums;
     const int nwg = plan_multi(a, 160, S16_OWN);
@@ -1497,7 +1502,7 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, const float* be
     return SGA_OK;
 }
 
-extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* beta, int A, int J1, int J2, float tau0,
+extern "C" int sga_loss_multi_grad(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0,
                                    float tau1, const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi,
                                    void* stream) {
     SGA_CHECK_ARG(Z && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad: bad argument");
@@ -1505,7 +1510,7 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, const float* be
     if (int rcz = zero_slots(gamma, M > 0 ? M : 1, s, "sga_loss_multi_grad")) return rcz;
     if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     MultiArgs a{};
-    int rc = fill_multi(a, Z, M, beta, A, J1, J2, tau0, tau1, true, a_lo, a_hi);
+    int rc = fill_multi(a, Z, M, D, beta, A, J1, J2, tau0, tau1, true, a_lo, a_hi);
     if (rc) return rc;
     a.gs = gs; a.gamma = gamma;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }

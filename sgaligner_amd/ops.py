@@ -498,7 +498,8 @@ class FusedContrastiveFn(torch.autograd.Function):
         zarr = _ptr_array(zs)
         slots = 1 + L.sga_loss_slots()
         sums = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
-        _lib.check(L.sga_loss_multi_sums(zarr, M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), a_lo, a_hi, st),
+        dmax = max(e.shape[1] for e in tables)          # real width: the K step that only covers zero padding is skipped
+        _lib.check(L.sga_loss_multi_sums(zarr, M, dmax, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), a_lo, a_hi, st),
                    'sga_loss_multi_sums')
         sums = _allreduce_sum(sums[0].contiguous(), reduce)
         zj = torch.empty((2 * s.A, M * dp), device=dev, dtype=torch.float32)
@@ -570,7 +571,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _lib.check(L.sga_loss_multi_grad(_ptr_array(zs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
+        _lib.check(L.sga_loss_multi_grad(_ptr_array(zs), M, max(d for _, d in ctx.shapes), _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
                                          _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad')
         if ev is not None:
             ev[1].record()
