@@ -24,6 +24,7 @@ constexpr int GAT_H = 2;              // heads
 constexpr int GAT_HS = GAT_C + 1;     // LDS row stride
 constexpr int GAT_MAXN = 128;         // nodes per graph supported by the LDS-resident kernel
 constexpr int GAT_THREADS = 256;
+constexpr int GAT_TB = 8;             // targets (fwd) / sources (bwd) a wave processes together: LDS reads per FMA / 4
 constexpr float GAT_SLOPE = 0.2f;
 
 struct GatLds {
@@ -126,18 +127,31 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_fwd_kernel(
     if (N <= 0) return;
     gat_prologue(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad);
     const float b0 = bias[hd * GAT_C + lane], b1 = bias[hd * GAT_C + 64 + lane];
-    for (int i = wave; i < N; i += GAT_THREADS / 64) {
-        float a0, a1, pre0, pre1, m, den;
-        softmax_row(l, i, N, npad, lane, a0, a1, pre0, pre1, m, den);
-        float acc0 = 0.f, acc1 = 0.f;
-        for (int j = 0; j < N; ++j) {
-            const float a = j < 64 ? __shfl(a0, j, 64) : __shfl(a1, j - 64, 64);
-            acc0 = fmaf(a, l.hs[j * GAT_HS + lane], acc0);
-            acc1 = fmaf(a, l.hs[j * GAT_HS + 64 + lane], acc1);
+    // GAT_TB targets per wave at a time: every h[j] row read from LDS feeds GAT_TB aggregates (the loop is LDS bound)
+    for (int ib = wave * GAT_TB; ib < N; ib += (GAT_THREADS / 64) * GAT_TB) {
+        float a0[GAT_TB], a1[GAT_TB], acc0[GAT_TB], acc1[GAT_TB];
+#pragma unroll
+        for (int u = 0; u < GAT_TB; ++u) {
+            float pre0, pre1, m, den;
+            a0[u] = 0.f; a1[u] = 0.f; acc0[u] = 0.f; acc1[u] = 0.f;
+            if (ib + u < N) softmax_row(l, ib + u, N, npad, lane, a0[u], a1[u], pre0, pre1, m, den);
         }
-        float* o = out + (size_t)(n0 + i) * (GAT_H * GAT_C) + hd * GAT_C;
-        o[lane] = acc0 + b0;
-        o[64 + lane] = acc1 + b1;
+        for (int j = 0; j < N; ++j) {
+            const float h0 = l.hs[j * GAT_HS + lane], h1 = l.hs[j * GAT_HS + 64 + lane];
+#pragma unroll
+            for (int u = 0; u < GAT_TB; ++u) {
+                const float a = j < 64 ? __shfl(a0[u], j, 64) : __shfl(a1[u], j - 64, 64);
+                acc0[u] = fmaf(a, h0, acc0[u]);
+                acc1[u] = fmaf(a, h1, acc1[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GAT_TB; ++u)
+            if (ib + u < N) {
+                float* o = out + (size_t)(n0 + ib + u) * (GAT_H * GAT_C) + hd * GAT_C;
+                o[lane] = acc0[u] + b0;
+                o[64 + lane] = acc1[u] + b1;
+            }
     }
 }
 
@@ -162,24 +176,35 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_bwd_kernel(
 
     // ---- phase 1: per target row i -> d a_d[i], partial d a_s[j], row max / denom
     float das0 = 0.f, das1 = 0.f;
-    for (int i = wave; i < N; i += GAT_THREADS / 64) {
-        float a0, a1, pre0, pre1, m, den;
-        softmax_row(l, i, N, npad, lane, a0, a1, pre0, pre1, m, den);
-        // d alpha_ij = <dO[i], h[j]>
-        float da0 = 0.f, da1 = 0.f;
-        const int j0 = lane < N ? lane : 0, j1 = lane + 64 < N ? lane + 64 : 0;
-        for (int c = 0; c < GAT_C; ++c) {
-            const float d = l.dos[i * GAT_HS + c];
-            da0 = fmaf(d, l.hs[j0 * GAT_HS + c], da0);
-            da1 = fmaf(d, l.hs[j1 * GAT_HS + c], da1);
+    const int j0 = lane < N ? lane : 0, j1 = lane + 64 < N ? lane + 64 : 0;
+    for (int ib = wave * GAT_TB; ib < N; ib += (GAT_THREADS / 64) * GAT_TB) {
+        float a0[GAT_TB], a1[GAT_TB], pre0[GAT_TB], pre1[GAT_TB], m[GAT_TB], den[GAT_TB], da0[GAT_TB], da1[GAT_TB];
+#pragma unroll
+        for (int u = 0; u < GAT_TB; ++u) {
+            a0[u] = 0.f; a1[u] = 0.f; pre0[u] = 0.f; pre1[u] = 0.f; m[u] = 0.f; den[u] = 1.f; da0[u] = 0.f; da1[u] = 0.f;
+            if (ib + u < N) softmax_row(l, ib + u, N, npad, lane, a0[u], a1[u], pre0[u], pre1[u], m[u], den[u]);
         }
-        const float s = wave_sum(a0 * da0 + a1 * da1);
-        const float ds0 = a0 * (da0 - s) * (pre0 > 0.f ? 1.f : GAT_SLOPE);
-        const float ds1 = a1 * (da1 - s) * (pre1 > 0.f ? 1.f : GAT_SLOPE);
-        das0 += ds0;
-        das1 += ds1;
-        const float dd = wave_sum(ds0 + ds1);
-        if (lane == 0) { l.dad[i] = dd; l.mx[i] = m; l.den[i] = den; }
+        // d alpha_ij = <dO[i], h[j]> for GAT_TB targets i at once: the two h reads per channel are shared
+        for (int c = 0; c < GAT_C; ++c) {
+            const float h0 = l.hs[j0 * GAT_HS + c], h1 = l.hs[j1 * GAT_HS + c];
+#pragma unroll
+            for (int u = 0; u < GAT_TB; ++u) {
+                const float d = l.dos[min(ib + u, N - 1) * GAT_HS + c];
+                da0[u] = fmaf(d, h0, da0[u]);
+                da1[u] = fmaf(d, h1, da1[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GAT_TB; ++u) {
+            if (ib + u >= N) continue;
+            const float s = wave_sum(a0[u] * da0[u] + a1[u] * da1[u]);
+            const float ds0 = a0[u] * (da0[u] - s) * (pre0[u] > 0.f ? 1.f : GAT_SLOPE);
+            const float ds1 = a1[u] * (da1[u] - s) * (pre1[u] > 0.f ? 1.f : GAT_SLOPE);
+            das0 += ds0;
+            das1 += ds1;
+            const float dd = wave_sum(ds0 + ds1);
+            if (lane == 0) { l.dad[ib + u] = dd; l.mx[ib + u] = m[u]; l.den[ib + u] = den[u]; }
+        }
     }
     if (lane < N) atomicAdd(&l.das[lane], das0);
     if (lane + 64 < N) atomicAdd(&l.das[lane + 64], das1);
@@ -190,26 +215,40 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_bwd_kernel(
     const float s0 = att_s[hd * GAT_C + lane], s1 = att_s[hd * GAT_C + 64 + lane];
     const float d0 = att_d[hd * GAT_C + lane], d1 = att_d[hd * GAT_C + 64 + lane];
     float gs0 = 0.f, gs1 = 0.f, gd0 = 0.f, gd1 = 0.f;
-    for (int j = wave; j < N; j += GAT_THREADS / 64) {
-        // alpha_ij for i = lane, lane + 64 (vectorised over targets), then broadcast per i
-        const float asj = l.as[j];
-        const int i0 = lane, i1 = lane + 64;
-        float al0 = 0.f, al1 = 0.f;
-        if (i0 < N) { const float c = (float)cb[i0 * npad + j]; if (c > 0.f) al0 = c * __expf(lrelu(asj + l.ad[i0]) - l.mx[i0]) / l.den[i0]; }
-        if (i1 < N) { const float c = (float)cb[i1 * npad + j]; if (c > 0.f) al1 = c * __expf(lrelu(asj + l.ad[i1]) - l.mx[i1]) / l.den[i1]; }
-        float acc0 = 0.f, acc1 = 0.f;
-        for (int i = 0; i < N; ++i) {
-            const float a = i < 64 ? __shfl(al0, i, 64) : __shfl(al1, i - 64, 64);
-            acc0 = fmaf(a, l.dos[i * GAT_HS + lane], acc0);
-            acc1 = fmaf(a, l.dos[i * GAT_HS + 64 + lane], acc1);
+    const int i0 = lane, i1 = lane + 64;
+    for (int jb = wave * GAT_TB; jb < N; jb += (GAT_THREADS / 64) * GAT_TB) {
+        // alpha_ij for i = lane, lane + 64 (vectorised over targets) of GAT_TB sources j, then broadcast per i
+        float al0[GAT_TB], al1[GAT_TB], acc0[GAT_TB], acc1[GAT_TB];
+#pragma unroll
+        for (int u = 0; u < GAT_TB; ++u) {
+            al0[u] = 0.f; al1[u] = 0.f; acc0[u] = 0.f; acc1[u] = 0.f;
+            const int j = jb + u;
+            if (j >= N) continue;
+            const float asj = l.as[j];
+            if (i0 < N) { const float c = (float)cb[i0 * npad + j]; if (c > 0.f) al0[u] = c * __expf(lrelu(asj + l.ad[i0]) - l.mx[i0]) / l.den[i0]; }
+            if (i1 < N) { const float c = (float)cb[i1 * npad + j]; if (c > 0.f) al1[u] = c * __expf(lrelu(asj + l.ad[i1]) - l.mx[i1]) / l.den[i1]; }
         }
-        const float dasj = l.das[j], dadj = l.dad[j];
-        float* o = dH + (size_t)(n0 + j) * (GAT_H * GAT_C) + hd * GAT_C;
-        o[lane] = acc0 + dasj * s0 + dadj * d0;
-        o[64 + lane] = acc1 + dasj * s1 + dadj * d1;
-        const float h0 = l.hs[j * GAT_HS + lane], h1 = l.hs[j * GAT_HS + 64 + lane];
-        gs0 = fmaf(dasj, h0, gs0); gs1 = fmaf(dasj, h1, gs1);
-        gd0 = fmaf(dadj, h0, gd0); gd1 = fmaf(dadj, h1, gd1);
+        for (int i = 0; i < N; ++i) {
+            const float g0 = l.dos[i * GAT_HS + lane], g1 = l.dos[i * GAT_HS + 64 + lane];
+#pragma unroll
+            for (int u = 0; u < GAT_TB; ++u) {
+                const float a = i < 64 ? __shfl(al0[u], i, 64) : __shfl(al1[u], i - 64, 64);
+                acc0[u] = fmaf(a, g0, acc0[u]);
+                acc1[u] = fmaf(a, g1, acc1[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GAT_TB; ++u) {
+            const int j = jb + u;
+            if (j >= N) continue;
+            const float dasj = l.das[j], dadj = l.dad[j];
+            float* o = dH + (size_t)(n0 + j) * (GAT_H * GAT_C) + hd * GAT_C;
+            o[lane] = acc0[u] + dasj * s0 + dadj * d0;
+            o[64 + lane] = acc1[u] + dasj * s1 + dadj * d1;
+            const float h0 = l.hs[j * GAT_HS + lane], h1 = l.hs[j * GAT_HS + 64 + lane];
+            gs0 = fmaf(dasj, h0, gs0); gs1 = fmaf(dasj, h1, gs1);
+            gd0 = fmaf(dadj, h0, gd0); gd1 = fmaf(dadj, h1, gd1);
+        }
     }
     atomicAdd(d_att_s + hd * GAT_C + lane, gs0);
     atomicAdd(d_att_s + hd * GAT_C + 64 + lane, gs1);
