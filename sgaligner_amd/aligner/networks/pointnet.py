@@ -37,6 +37,12 @@ class PointNetfeat(BaseNetwork):
             self.bn1 = nn.BatchNorm1d(64)
             self.bn2 = nn.BatchNorm1d(128)
             self.bn3 = nn.BatchNorm1d(out_size)
+        # The reference's discarded BN calls still update running_mean / running_var / num_batches_tracked in train mode
+        # (pointnet.py:141-142,154-155,158-159).  Those buffers never reach any output, and computing them costs a second
+        # pass over every per-point activation (about one more forward), so the side effect is opt-in:
+        # set this attribute (or SGA_POINTNET_BN_STATS=1) when checkpoint buffers must match the reference's.
+        import os
+        self.update_bn_running_stats = os.environ.get('SGA_POINTNET_BN_STATS', '0') == '1'
         if init_weights:                                     # pointnet.py:116-118
             self.init_weights('constant', 1, target_op='BatchNorm')
             self.init_weights('xavier_normal', 1)
@@ -49,6 +55,44 @@ class PointNetfeat(BaseNetwork):
             xt = xt.contiguous()
         y = ops.pointnet(xt.float() if xt.dtype != torch.float32 else xt, self.conv1.weight, self.conv1.bias,
                          self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias)
+        if self.training and self.use_batch_norm and self.update_bn_running_stats:
+            self._update_bn_running_stats(xt)
         if return_meta:
             return y, torch.zeros([1]), torch.zeros([1])       # pointnet.py:138,151 dummies
         return y
+
+    @torch.no_grad()
+    def _update_bn_running_stats(self, xt, chunk_rows=1 << 20):
+        """Batch statistics of the three PRE-ReLU conv outputs over all T*P points, exactly what the reference's
+        discarded bn1/bn2/bn3 calls fold into their buffers (momentum 0.1, unbiased variance).  HIP passes over
+        point chunks: GEMM (+bias) -> per-channel sum / sum of squares (sga_bn_stats) -> ReLU in place."""
+        from ... import _lib
+        from ...ops import _p, _stream
+        L = _lib.lib()
+        rows = xt.reshape(-1, 3).float()
+        n = rows.shape[0]
+        convs = (self.conv1, self.conv2, self.conv3)
+        bns = (self.bn1, self.bn2, self.bn3)
+        sums = [torch.zeros(2 * c.weight.shape[0], device=rows.device, dtype=torch.float64) for c in convs]
+        for r0 in range(0, n, chunk_rows):
+            h = rows[r0:r0 + chunk_rows]
+            for k, c in enumerate(convs):
+                w = c.weight.reshape(c.weight.shape[0], -1)
+                z = ops.gemm(h, w, False, True, h.shape[0], w.shape[0], w.shape[1], bias=c.bias)
+                part = torch.empty_like(sums[k])
+                _lib.check(L.sga_bn_stats(_p(z), z.stride(0), z.shape[0], z.shape[1], _p(part), _stream()), 'sga_bn_stats')
+                sums[k] += part
+                if k < 2:                                     # h = relu(z), in place (scale 1, shift 0)
+                    one = torch.ones(z.shape[1], device=z.device)
+                    zero = torch.zeros(z.shape[1], device=z.device)
+                    _lib.check(L.sga_bn_apply(_p(z), z.stride(0), z.shape[0], z.shape[1], _p(one), _p(zero), 1, None, 0,
+                                              _p(z), z.stride(0), _stream()), 'sga_bn_apply')
+                h = z
+        for k, bn in enumerate(bns):
+            cch = bn.num_features
+            mean = sums[k][:cch] / n
+            var_unb = (sums[k][cch:] - n * mean * mean) / max(n - 1, 1)
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var_unb.clamp_min(0).float(), alpha=mom)
+            bn.num_batches_tracked.add_(1)

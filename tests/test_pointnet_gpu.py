@@ -87,3 +87,30 @@ def test_pointnet_bwd_oracle(T, P):
         ref = b.grad
         err = (a.grad.cpu().double() - ref).abs().max().item()
         assert err < 2e-4 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('tag', ['small', 'ragged'])
+def test_pointnet_bn_running_stats_side_effect_opt_in(tag):
+    """The reference's discarded BatchNorm calls update their running statistics in train mode (pointnet.py:141-142,
+    154-155,158-159); with `update_bn_running_stats` the HIP path reproduces the buffers of the reference run."""
+    from sgaligner_amd.aligner.networks.pointnet import PointNetfeat
+    g = load_golden('pointnet_' + tag)
+    net = PointNetfeat(global_feat=True, batch_norm=True, point_size=3, input_transform=False, feature_transform=False, out_size=256).cuda()
+    with torch.no_grad():
+        for conv, w, b in ((net.conv1, 'w1', 'b1'), (net.conv2, 'w2', 'b2'), (net.conv3, 'w3', 'b3')):
+            conv.weight.copy_(_dev(g[w])); conv.bias.copy_(_dev(g[b]))
+    x = _dev(g['x'])                                   # [T,3,P] as the reference passes it
+    net.train()
+    y = net(x)                                          # default: buffers untouched
+    assert float(net.bn1.running_mean.abs().max()) == 0.0 and int(net.bn1.num_batches_tracked) == 0
+    net.update_bn_running_stats = True
+    y = net(x)
+    torch.cuda.synchronize()
+    assert np.abs(y.detach().cpu().numpy() - g['y']).max() < 2e-5
+    for bn, rm, rv in ((net.bn1, 'rm1', 'rv1'), (net.bn2, 'rm2', 'rv2'), (net.bn3, 'rm3', 'rv3')):
+        assert np.abs(bn.running_mean.cpu().numpy() - g[rm]).max() < 1e-5 * max(1.0, np.abs(g[rm]).max()), rm
+        assert np.abs(bn.running_var.cpu().numpy() - g[rv]).max() < 1e-5 * max(1.0, np.abs(g[rv]).max()), rv
+        assert int(bn.num_batches_tracked) == 1
+    net.eval()
+    net(x)
+    assert int(net.bn1.num_batches_tracked) == 1       # eval: no update
