@@ -248,3 +248,31 @@ def test_anchor_sharded_loss_equals_unsharded():
         assert (g - ref_grads[m]).abs().max() < 1e-4 * max(1.0, ref_grads[m].abs().max().item()), m
     gw = sum(results[r][2] for r in range(R))
     assert (gw - ref_w).abs().max() < 1e-4 * max(1.0, ref_w.abs().max().item())
+
+
+@pytest.mark.parametrize('emb', [64, 104, 128])
+def test_train_step_other_embedding_widths(emb):
+    """emb_dim != 100: <= 104 stays on the fused path (the real width steers the K tail), wider tables take the general
+    per-table kernels; loss and every parameter gradient against the oracle."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd.aligner.losses import CustomMultiLossLayer, OverallLoss
+    from sgaligner_amd.aligner.sg_aligner import MultiModalEncoder
+    from sgaligner_amd.synthetic import make_batch, to_device
+    mods = ['point', 'gat', 'rel']
+    dd = make_batch(3, 12, 32, seed=2, ragged=True)
+    torch.manual_seed(1)
+    model = MultiModalEncoder(modules=mods, rel_dim=41, attr_dim=164, emb_dim=emb)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if 'num_batches' not in k}
+    _, loss_o, grads_o = O.train_step(params, dd, mods)
+    model = model.cuda()
+    ddd = to_device(dd, 'cuda')
+    loss_fn = OverallLoss(CustomMultiLossLayer(3).cuda(), CustomMultiLossLayer(3).cuda(), 'cuda',
+                          {'zoom': 0.1, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': mods})
+    res = loss_fn(model(ddd), ddd)
+    res['loss'].backward()
+    torch.cuda.synchronize()
+    assert abs(res['loss'].item() - loss_o['loss'].item()) < TOL * max(1, abs(loss_o['loss'].item()))
+    for name, p in model.named_parameters():
+        if name in grads_o and p.grad is not None:
+            ref = grads_o[name]
+            assert (p.grad.cpu() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item()), name
