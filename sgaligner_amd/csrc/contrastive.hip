@@ -85,6 +85,22 @@ __device__ __forceinline__ GV g_full(float d, float a, float b) {
     o.dsb = -d * b * bv;
     return o;
 }
+// g with d g/dd, and the squared ratios the sum derivatives are made of:  dg/dsa = -d a^2 p,  dg/dsb = -d b^2 r
+// (p = (g/u)^2, r = (g/v)^2).  The uniform factors -a^2 / -b^2 are applied once per wave when the partial sums are
+// flushed, so an accumulation costs one fma on (weight * d).
+struct GP { float q, dd, p, r; };
+__device__ __forceinline__ GP g_parts(float d, float a, float b) {
+    const float u = fmaf(d, a, QEPS), v = fmaf(d, b, QEPS);
+    const float uv = u * v;
+    const float w = frcp(fmaf(1.f + QEPS, uv, u + v));
+    const float qu = v * w, qv = u * w;
+    GP o;
+    o.q = uv * w;
+    o.p = qu * qu;
+    o.r = qv * qv;
+    o.dd = fmaf(a, o.p, b * o.r);
+    return o;
+}
 __device__ __forceinline__ float g_val(float d, float a, float b) {
     const float u = fmaf(d, a, QEPS), v = fmaf(d, b, QEPS);
     const float uv = u * v;
@@ -1220,16 +1236,17 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_bwd16
             // joint ICL
             {
                 const float dx = fexp2(xj * a.kc), dy = fexp2(yj * a.kc);
-                const GV Ax = g_full(dx, js[0], js[2]), Bx = g_full(dx, js[4], js[6]);
+                const GP Ax = g_parts(dx, js[0], js[2]), Bx = g_parts(dx, js[4], js[6]);
                 const float qAy = g_val(dy, js[0], js[2]), qBy = g_val(dy, js[4], js[6]);
-                const float wA = okf * (-cJ * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy);
-                const float wB = okf * (-cJ * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q);
-                gJ = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
-                acc_gs[M][0] += wA * Ax.dsa; acc_gs[M][2] += wA * Ax.dsb; acc_gs[M][4] += wB * Bx.dsa; acc_gs[M][6] += wB * Bx.dsb;
+                const float wA = okf * (-cJ * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) * dx;      // weight * d
+                const float wB = okf * (-cJ * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) * dx;
+                gJ = fmaf(wA, Ax.dd, wB * Bx.dd) * a.itc;
+                acc_gs[M][0] = fmaf(wA, Ax.p, acc_gs[M][0]); acc_gs[M][2] = fmaf(wA, Ax.r, acc_gs[M][2]);
+                acc_gs[M][4] = fmaf(wB, Bx.p, acc_gs[M][4]); acc_gs[M][6] = fmaf(wB, Bx.r, acc_gs[M][6]);
             }
             // joint IAL reference distribution (qm), shared by every modality
             const float dji = fexp2(xj * a.ki);
-            const GV MA = g_full(dji, js[1], js[3]), MB = g_full(dji, js[5], js[7]);
+            const GP MA = g_parts(dji, js[1], js[3]), MB = g_parts(dji, js[5], js[7]);
             const float lqma = flog(MA.q), lqmb = flog(MB.q);
             float gx[M];
             // per modality ICL + IAL (qo part)
@@ -1239,26 +1256,29 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_bwd16
                 const float c = a.coef[m], ca = a.coef[NT + m], cb = a.coef[NT + M + m];
                 const float x = P[m][r], y = Q[m][r];
                 const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
-                const GV Ax = g_full(dx, is[0], is[2]), Bx = g_full(dx, is[4], is[6]);
+                const GP Ax = g_parts(dx, is[0], is[2]), Bx = g_parts(dx, is[4], is[6]);
                 const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
-                const float wA = okf * (-c * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy);
-                const float wB = okf * (-c * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q);
-                float gxm = (wA * Ax.dd + wB * Bx.dd) * dx * a.itc;
-                acc_gs[m][0] += wA * Ax.dsa; acc_gs[m][2] += wA * Ax.dsb; acc_gs[m][4] += wB * Bx.dsa; acc_gs[m][6] += wB * Bx.dsb;
+                const float wA = okf * (-c * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) * dx;
+                const float wB = okf * (-c * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) * dx;
+                float gxm = fmaf(wA, Ax.dd, wB * Bx.dd) * a.itc;
+                acc_gs[m][0] = fmaf(wA, Ax.p, acc_gs[m][0]); acc_gs[m][2] = fmaf(wA, Ax.r, acc_gs[m][2]);
+                acc_gs[m][4] = fmaf(wB, Bx.p, acc_gs[m][4]); acc_gs[m][6] = fmaf(wB, Bx.r, acc_gs[m][6]);
                 const float dm = fexp2(x * a.ki);
-                const GV OA = g_full(dm, is[1], is[3]), OB = g_full(dm, is[5], is[7]);
+                const GP OA = g_parts(dm, is[1], is[3]), OB = g_parts(dm, is[5], is[7]);
                 const float eA = okf * ca * __expf(OA.q), eB = okf * cb * __expf(OB.q);
-                const float tA = eA * (OA.q - lqma + 1.f), tB = eB * (OB.q - lqmb + 1.f);
-                gxm += (tA * OA.dd + tB * OB.dd) * dm * a.iti;
-                acc_gs[m][1] += tA * OA.dsa; acc_gs[m][3] += tA * OA.dsb; acc_gs[m][5] += tB * OB.dsa; acc_gs[m][7] += tB * OB.dsb;
+                const float tA = eA * (OA.q - lqma + 1.f) * dm, tB = eB * (OB.q - lqmb + 1.f) * dm;
+                gxm = fmaf(fmaf(tA, OA.dd, tB * OB.dd), a.iti, gxm);
+                acc_gs[m][1] = fmaf(tA, OA.p, acc_gs[m][1]); acc_gs[m][3] = fmaf(tA, OA.r, acc_gs[m][3]);
+                acc_gs[m][5] = fmaf(tB, OB.p, acc_gs[m][5]); acc_gs[m][7] = fmaf(tB, OB.r, acc_gs[m][7]);
                 EA += eA; EB += eB;
                 gx[m] = gxm;
             }
             // joint IAL (qm part), totals + stash
             {
-                const float uA = -EA * frcp(MA.q), uB = -EB * frcp(MB.q);
-                gJ += (uA * MA.dd + uB * MB.dd) * dji * a.iti;
-                acc_gs[M][1] += uA * MA.dsa; acc_gs[M][3] += uA * MA.dsb; acc_gs[M][5] += uB * MB.dsa; acc_gs[M][7] += uB * MB.dsb;
+                const float uA = -EA * frcp(MA.q) * dji, uB = -EB * frcp(MB.q) * dji;
+                gJ = fmaf(fmaf(uA, MA.dd, uB * MB.dd), a.iti, gJ);
+                acc_gs[M][1] = fmaf(uA, MA.p, acc_gs[M][1]); acc_gs[M][3] = fmaf(uA, MA.r, acc_gs[M][3]);
+                acc_gs[M][5] = fmaf(uB, MB.p, acc_gs[M][5]); acc_gs[M][7] = fmaf(uB, MB.r, acc_gs[M][7]);
             }
 #pragma unroll
             for (int m = 0; m < M; ++m) {
@@ -1281,7 +1301,8 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_bwd16
     for (int k = 0; k < NT; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = wave_sum(acc_gs[k][e]);
+            const float iv2 = inv_s[k * 8 + e];
+            const float v = -iv2 * iv2 * wave_sum(acc_gs[k][e]);          // dg/dsum = -d inv^2 (g/u)^2: the uniform factor, once
             if (lane == 0 && v != 0.f) atomicAdd(a.gs + NT * 8 * (1 + slot) + k * 8 + e, (double)v);
         }
 #pragma unroll
