@@ -22,60 +22,74 @@ namespace {
 constexpr int GAT_C = 128;            // channels per head (hidden_units[1:], sg_aligner.py:38)
 constexpr int GAT_H = 2;              // heads
 constexpr int GAT_HS = GAT_C + 1;     // LDS row stride
-constexpr int GAT_MAXN = 128;         // nodes per graph supported by the LDS-resident kernel
+constexpr int GAT_MAXN = 128;         // nodes per graph with the features resident in LDS (NJ = 2 sources per lane)
+constexpr int GAT_MAXN_BIG = 256;     // nodes per graph of the big-graph variant (NJ = 4, features read from global/L2)
 constexpr int GAT_THREADS = 256;
-constexpr int GAT_TB = 8;             // targets (fwd) / sources (bwd) a wave processes together: LDS reads per FMA / 4
+constexpr int GAT_TB = 8;             // targets (fwd) / sources (bwd) a wave processes together: LDS reads per FMA / 8
 constexpr float GAT_SLOPE = 0.2f;
 
+// Two instantiations of every kernel: <NJ = 2, LDSF = true> for graphs of up to 128 nodes (every real 3RScan sub-scan:
+// the head's features [N,128] live in LDS) and <NJ = 4, LDSF = false> for up to 256 nodes, where only the multiplicity
+// matrix and the per-node scalars stay in LDS and feature rows are read from global memory (L2-resident: 128 KiB per
+// graph and head).  NJ = source slots per lane (source j = lane + 64 k).
 struct GatLds {
-    float* hs;      // [N][129]
-    float* dos;     // [N][129]   (bwd only)
-    float* as;      // [128]
-    float* ad;      // [128]
-    float* mx;      // [128]  row max     (bwd)
-    float* den;     // [128]  row denom   (bwd)
-    float* das;     // [128]  d a_s       (bwd)
-    float* dad;     // [128]  d a_d       (bwd)
+    float* hs;      // [N][129]   (LDSF)
+    float* dos;     // [N][129]   (LDSF, bwd only)
+    float* as;      // [maxn]
+    float* ad;      // [maxn]
+    float* mx;      // [maxn]  row max     (bwd)
+    float* den;     // [maxn]  row denom   (bwd)
+    float* das;     // [maxn]  d a_s       (bwd)
+    float* dad;     // [maxn]  d a_d       (bwd)
     unsigned* cnt;  // [N][npad/4] packed u8 multiplicities
 };
 
+template <int NJ, bool LDSF>
 __device__ __forceinline__ GatLds carve(float* base, int nmax, bool bwd) {
+    constexpr int MAXN = NJ * 64;
     GatLds l;
     float* p = base;
-    l.hs = p; p += nmax * GAT_HS;
-    l.dos = p; if (bwd) p += nmax * GAT_HS;
-    l.as = p; p += GAT_MAXN;
-    l.ad = p; p += GAT_MAXN;
-    l.mx = p; p += GAT_MAXN;
-    l.den = p; p += GAT_MAXN;
-    l.das = p; p += GAT_MAXN;
-    l.dad = p; p += GAT_MAXN;
+    l.hs = p; if (LDSF) p += nmax * GAT_HS;
+    l.dos = p; if (LDSF && bwd) p += nmax * GAT_HS;
+    l.as = p; p += MAXN;
+    l.ad = p; p += MAXN;
+    l.mx = p; p += MAXN;
+    l.den = p; p += MAXN;
+    l.das = p; p += MAXN;
+    l.dad = p; p += MAXN;
     l.cnt = reinterpret_cast<unsigned*>(p);
     return l;
 }
 
-__host__ __device__ inline size_t gat_lds_bytes(int nmax, bool bwd) {
+inline size_t gat_lds_bytes(int nmax, bool bwd, int nj, bool ldsf) {
     const int npad = (nmax + 3) & ~3;
-    return sizeof(float) * ((size_t)nmax * GAT_HS * (bwd ? 2 : 1) + 6 * GAT_MAXN) + (size_t)nmax * npad;
+    return sizeof(float) * ((ldsf ? (size_t)nmax * GAT_HS * (bwd ? 2 : 1) : 0) + 6 * (size_t)nj * 64) + (size_t)nmax * npad;
 }
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : GAT_SLOPE * v; }
 
-// common prologue: load this head's features, attention logits' node parts, multiplicity matrix
-__device__ __forceinline__ void gat_prologue(const GatLds& l, const float* __restrict__ H, const float* __restrict__ att_s,
+// feature rows of this (graph, head): LDS copy (stride 129) or the global rows themselves (stride heads * 128)
+struct Rows { const float* p; int stride; };
+
+// common prologue: load this head's features (LDSF), attention logits' node parts, multiplicity matrix
+template <int NJ, bool LDSF>
+__device__ __forceinline__ Rows gat_prologue(const GatLds& l, const float* __restrict__ H, const float* __restrict__ att_s,
                                              const float* __restrict__ att_d, const long long* __restrict__ edges,
                                              int n0, int N, int e0, int E, int hd, int npad) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < N * GAT_C; e += GAT_THREADS) {
-        const int j = e >> 7, c = e & 127;
-        l.hs[j * GAT_HS + c] = H[(size_t)(n0 + j) * (GAT_H * GAT_C) + hd * GAT_C + c];
-    }
+    const float* Hg = H + (size_t)n0 * (GAT_H * GAT_C) + hd * GAT_C;
+    if (LDSF)
+        for (int e = tid; e < N * GAT_C; e += GAT_THREADS) {
+            const int j = e >> 7, c = e & 127;
+            l.hs[j * GAT_HS + c] = Hg[(size_t)j * (GAT_H * GAT_C) + c];
+        }
     for (int e = tid; e < N * (npad >> 2); e += GAT_THREADS) l.cnt[e] = 0u;
     __syncthreads();
+    const Rows hr = LDSF ? Rows{l.hs, GAT_HS} : Rows{Hg, GAT_H * GAT_C};
     const float s0 = att_s[hd * GAT_C + lane], s1 = att_s[hd * GAT_C + 64 + lane];
     const float d0 = att_d[hd * GAT_C + lane], d1 = att_d[hd * GAT_C + 64 + lane];
     for (int j = wave; j < N; j += GAT_THREADS / 64) {
-        const float h0 = l.hs[j * GAT_HS + lane], h1 = l.hs[j * GAT_HS + 64 + lane];
+        const float h0 = hr.p[(size_t)j * hr.stride + lane], h1 = hr.p[(size_t)j * hr.stride + 64 + lane];
         const float vs = wave_sum(h0 * s0 + h1 * s1), vd = wave_sum(h0 * d0 + h1 * d1);
         if (lane == 0) { l.as[j] = vs; l.ad[j] = vd; }
     }
@@ -93,58 +107,74 @@ __device__ __forceinline__ void gat_prologue(const GatLds& l, const float* __res
     unsigned char* cb = reinterpret_cast<unsigned char*>(l.cnt);
     for (int i = tid; i < N; i += GAT_THREADS) cb[i * npad + i] = 1;       // exactly one self loop per node
     __syncthreads();
+    return hr;
 }
 
-// softmax row i for sources j = lane and lane + 64: returns alpha (a0, a1), pre-activations, max, denom
-__device__ __forceinline__ void softmax_row(const GatLds& l, int i, int N, int npad, int lane, float& a0, float& a1,
-                                            float& pre0, float& pre1, float& m, float& den) {
+// softmax row i for sources j = lane + 64 k: alpha a[k], pre-activations, max, denom
+template <int NJ>
+__device__ __forceinline__ void softmax_row(const GatLds& l, int i, int N, int npad, int lane, float (&a)[NJ],
+                                            float (&pre)[NJ], float& m, float& den) {
     const unsigned char* cb = reinterpret_cast<const unsigned char*>(l.cnt);
     const float adi = l.ad[i];
-    const int j0 = lane, j1 = lane + 64;
-    const float c0 = j0 < N ? (float)cb[i * npad + j0] : 0.f;
-    const float c1 = j1 < N ? (float)cb[i * npad + j1] : 0.f;
-    pre0 = j0 < N ? l.as[j0] + adi : 0.f;
-    pre1 = j1 < N ? l.as[j1] + adi : 0.f;
-    const float e0 = lrelu(pre0), e1 = lrelu(pre1);
-    m = wave_max(fmaxf(c0 > 0.f ? e0 : -INFINITY, c1 > 0.f ? e1 : -INFINITY));
-    const float p0 = c0 > 0.f ? c0 * __expf(e0 - m) : 0.f;
-    const float p1 = c1 > 0.f ? c1 * __expf(e1 - m) : 0.f;
-    den = wave_sum(p0 + p1) + 1e-16f;
-    a0 = p0 / den;
-    a1 = p1 / den;
+    float c[NJ], e[NJ], p[NJ];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const int j = lane + 64 * k;
+        c[k] = j < N ? (float)cb[i * npad + j] : 0.f;
+        pre[k] = j < N ? l.as[j] + adi : 0.f;
+        e[k] = lrelu(pre[k]);
+        mloc = fmaxf(mloc, c[k] > 0.f ? e[k] : -INFINITY);
+    }
+    m = wave_max(mloc);
+    float sloc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        p[k] = c[k] > 0.f ? c[k] * __expf(e[k] - m) : 0.f;
+        sloc += p[k];
+    }
+    den = wave_sum(sloc) + 1e-16f;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) a[k] = p[k] / den;
 }
 
+template <int NJ, bool LDSF>
 __global__ __launch_bounds__(GAT_THREADS) void gat_attn_fwd_kernel(
     const float* __restrict__ H, const float* __restrict__ att_s, const float* __restrict__ att_d,
     const float* __restrict__ bias, const long long* __restrict__ edges, const int* __restrict__ node_off,
     const int* __restrict__ edge_off, float* __restrict__ out, int nmax) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    const GatLds l = carve(lds_raw, nmax, false);
+    const GatLds l = carve<NJ, LDSF>(lds_raw, nmax, false);
     const int g = blockIdx.x, hd = blockIdx.y;
     const int n0 = node_off[g], N = node_off[g + 1] - n0, e0 = edge_off[g], E = edge_off[g + 1] - e0;
     const int npad = (nmax + 3) & ~3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (N <= 0) return;
-    gat_prologue(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad);
+    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad);
     const float b0 = bias[hd * GAT_C + lane], b1 = bias[hd * GAT_C + 64 + lane];
-    // GAT_TB targets per wave at a time: every h[j] row read from LDS feeds GAT_TB aggregates (the loop is LDS bound)
+    // GAT_TB targets per wave at a time: every h[j] row read feeds GAT_TB aggregates (the loop is LDS / L2 bound)
     for (int ib = wave * GAT_TB; ib < N; ib += (GAT_THREADS / 64) * GAT_TB) {
-        float a0[GAT_TB], a1[GAT_TB], acc0[GAT_TB], acc1[GAT_TB];
+        float al[GAT_TB][NJ], acc0[GAT_TB], acc1[GAT_TB];
 #pragma unroll
         for (int u = 0; u < GAT_TB; ++u) {
-            float pre0, pre1, m, den;
-            a0[u] = 0.f; a1[u] = 0.f; acc0[u] = 0.f; acc1[u] = 0.f;
-            if (ib + u < N) softmax_row(l, ib + u, N, npad, lane, a0[u], a1[u], pre0, pre1, m, den);
-        }
-        for (int j = 0; j < N; ++j) {
-            const float h0 = l.hs[j * GAT_HS + lane], h1 = l.hs[j * GAT_HS + 64 + lane];
+            float pre[NJ], m, den;
+            acc0[u] = 0.f; acc1[u] = 0.f;
 #pragma unroll
-            for (int u = 0; u < GAT_TB; ++u) {
-                const float a = j < 64 ? __shfl(a0[u], j, 64) : __shfl(a1[u], j - 64, 64);
-                acc0[u] = fmaf(a, h0, acc0[u]);
-                acc1[u] = fmaf(a, h1, acc1[u]);
-            }
+            for (int k = 0; k < NJ; ++k) al[u][k] = 0.f;
+            if (ib + u < N) softmax_row<NJ>(l, ib + u, N, npad, lane, al[u], pre, m, den);
         }
+#pragma unroll
+        for (int k = 0; k < NJ; ++k)
+            for (int jj = 0; jj < 64 && 64 * k + jj < N; ++jj) {
+                const int j = 64 * k + jj;
+                const float h0 = hr.p[(size_t)j * hr.stride + lane], h1 = hr.p[(size_t)j * hr.stride + 64 + lane];
+#pragma unroll
+                for (int u = 0; u < GAT_TB; ++u) {
+                    const float a = __shfl(al[u][k], jj, 64);
+                    acc0[u] = fmaf(a, h0, acc0[u]);
+                    acc1[u] = fmaf(a, h1, acc1[u]);
+                }
+            }
 #pragma unroll
         for (int u = 0; u < GAT_TB; ++u)
             if (ib + u < N) {
@@ -155,59 +185,77 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_fwd_kernel(
     }
 }
 
+template <int NJ, bool LDSF>
 __global__ __launch_bounds__(GAT_THREADS) void gat_attn_bwd_kernel(
     const float* __restrict__ H, const float* __restrict__ dO, const float* __restrict__ att_s,
     const float* __restrict__ att_d, const long long* __restrict__ edges, const int* __restrict__ node_off,
     const int* __restrict__ edge_off, float* __restrict__ dH, float* __restrict__ d_att_s,
     float* __restrict__ d_att_d, int nmax) {
+    constexpr int MAXN = NJ * 64;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    const GatLds l = carve(lds_raw, nmax, true);
+    const GatLds l = carve<NJ, LDSF>(lds_raw, nmax, true);
     const int g = blockIdx.x, hd = blockIdx.y;
     const int n0 = node_off[g], N = node_off[g + 1] - n0, e0 = edge_off[g], E = edge_off[g + 1] - e0;
     const int npad = (nmax + 3) & ~3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (N <= 0) return;
-    for (int e = tid; e < N * GAT_C; e += GAT_THREADS) {
-        const int j = e >> 7, c = e & 127;
-        l.dos[j * GAT_HS + c] = dO[(size_t)(n0 + j) * (GAT_H * GAT_C) + hd * GAT_C + c];
-    }
-    for (int j = tid; j < GAT_MAXN; j += GAT_THREADS) l.das[j] = 0.f;
-    gat_prologue(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad);
+    const float* Dg = dO + (size_t)n0 * (GAT_H * GAT_C) + hd * GAT_C;
+    if (LDSF)
+        for (int e = tid; e < N * GAT_C; e += GAT_THREADS) {
+            const int j = e >> 7, c = e & 127;
+            l.dos[j * GAT_HS + c] = Dg[(size_t)j * (GAT_H * GAT_C) + c];
+        }
+    for (int j = tid; j < MAXN; j += GAT_THREADS) l.das[j] = 0.f;
+    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad);
+    const Rows dr = LDSF ? Rows{l.dos, GAT_HS} : Rows{Dg, GAT_H * GAT_C};
 
     // ---- phase 1: per target row i -> d a_d[i], partial d a_s[j], row max / denom
-    float das0 = 0.f, das1 = 0.f;
-    const int j0 = lane < N ? lane : 0, j1 = lane + 64 < N ? lane + 64 : 0;
+    float das[NJ];
+    int js[NJ];
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) { das[k] = 0.f; js[k] = lane + 64 * k < N ? lane + 64 * k : 0; }
     for (int ib = wave * GAT_TB; ib < N; ib += (GAT_THREADS / 64) * GAT_TB) {
-        float a0[GAT_TB], a1[GAT_TB], pre0[GAT_TB], pre1[GAT_TB], m[GAT_TB], den[GAT_TB], da0[GAT_TB], da1[GAT_TB];
+        float al[GAT_TB][NJ], pre[GAT_TB][NJ], m[GAT_TB], den[GAT_TB], da[GAT_TB][NJ];
 #pragma unroll
         for (int u = 0; u < GAT_TB; ++u) {
-            a0[u] = 0.f; a1[u] = 0.f; pre0[u] = 0.f; pre1[u] = 0.f; m[u] = 0.f; den[u] = 1.f; da0[u] = 0.f; da1[u] = 0.f;
-            if (ib + u < N) softmax_row(l, ib + u, N, npad, lane, a0[u], a1[u], pre0[u], pre1[u], m[u], den[u]);
+            m[u] = 0.f; den[u] = 1.f;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) { al[u][k] = 0.f; pre[u][k] = 0.f; da[u][k] = 0.f; }
+            if (ib + u < N) softmax_row<NJ>(l, ib + u, N, npad, lane, al[u], pre[u], m[u], den[u]);
         }
-        // d alpha_ij = <dO[i], h[j]> for GAT_TB targets i at once: the two h reads per channel are shared
+        // d alpha_ij = <dO[i], h[j]> for GAT_TB targets i at once: the h reads per channel are shared
         for (int c = 0; c < GAT_C; ++c) {
-            const float h0 = l.hs[j0 * GAT_HS + c], h1 = l.hs[j1 * GAT_HS + c];
+            float hv[NJ];
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) hv[k] = hr.p[(size_t)js[k] * hr.stride + c];
 #pragma unroll
             for (int u = 0; u < GAT_TB; ++u) {
-                const float d = l.dos[min(ib + u, N - 1) * GAT_HS + c];
-                da0[u] = fmaf(d, h0, da0[u]);
-                da1[u] = fmaf(d, h1, da1[u]);
+                const float d = dr.p[(size_t)min(ib + u, N - 1) * dr.stride + c];
+#pragma unroll
+                for (int k = 0; k < NJ; ++k) da[u][k] = fmaf(d, hv[k], da[u][k]);
             }
         }
 #pragma unroll
         for (int u = 0; u < GAT_TB; ++u) {
             if (ib + u >= N) continue;
-            const float s = wave_sum(a0[u] * da0[u] + a1[u] * da1[u]);
-            const float ds0 = a0[u] * (da0[u] - s) * (pre0[u] > 0.f ? 1.f : GAT_SLOPE);
-            const float ds1 = a1[u] * (da1[u] - s) * (pre1[u] > 0.f ? 1.f : GAT_SLOPE);
-            das0 += ds0;
-            das1 += ds1;
-            const float dd = wave_sum(ds0 + ds1);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) dot = fmaf(al[u][k], da[u][k], dot);
+            const float s = wave_sum(dot);
+            float dsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) {
+                const float ds = al[u][k] * (da[u][k] - s) * (pre[u][k] > 0.f ? 1.f : GAT_SLOPE);
+                das[k] += ds;
+                dsum += ds;
+            }
+            const float dd = wave_sum(dsum);
             if (lane == 0) { l.dad[ib + u] = dd; l.mx[ib + u] = m[u]; l.den[ib + u] = den[u]; }
         }
     }
-    if (lane < N) atomicAdd(&l.das[lane], das0);
-    if (lane + 64 < N) atomicAdd(&l.das[lane + 64], das1);
+#pragma unroll
+    for (int k = 0; k < NJ; ++k)
+        if (lane + 64 * k < N) atomicAdd(&l.das[lane + 64 * k], das[k]);
     __syncthreads();
 
     // ---- phase 2: per source j -> dH[j] = sum_i alpha_ij dO[i] + d a_s[j] att_s + d a_d[j] att_d ; d att
@@ -215,28 +263,36 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_bwd_kernel(
     const float s0 = att_s[hd * GAT_C + lane], s1 = att_s[hd * GAT_C + 64 + lane];
     const float d0 = att_d[hd * GAT_C + lane], d1 = att_d[hd * GAT_C + 64 + lane];
     float gs0 = 0.f, gs1 = 0.f, gd0 = 0.f, gd1 = 0.f;
-    const int i0 = lane, i1 = lane + 64;
     for (int jb = wave * GAT_TB; jb < N; jb += (GAT_THREADS / 64) * GAT_TB) {
-        // alpha_ij for i = lane, lane + 64 (vectorised over targets) of GAT_TB sources j, then broadcast per i
-        float al0[GAT_TB], al1[GAT_TB], acc0[GAT_TB], acc1[GAT_TB];
+        // alpha_ij for targets i = lane + 64 k (vectorised over targets) of GAT_TB sources j, then broadcast per i
+        float al[GAT_TB][NJ], acc0[GAT_TB], acc1[GAT_TB];
 #pragma unroll
         for (int u = 0; u < GAT_TB; ++u) {
-            al0[u] = 0.f; al1[u] = 0.f; acc0[u] = 0.f; acc1[u] = 0.f;
+            acc0[u] = 0.f; acc1[u] = 0.f;
             const int j = jb + u;
-            if (j >= N) continue;
-            const float asj = l.as[j];
-            if (i0 < N) { const float c = (float)cb[i0 * npad + j]; if (c > 0.f) al0[u] = c * __expf(lrelu(asj + l.ad[i0]) - l.mx[i0]) / l.den[i0]; }
-            if (i1 < N) { const float c = (float)cb[i1 * npad + j]; if (c > 0.f) al1[u] = c * __expf(lrelu(asj + l.ad[i1]) - l.mx[i1]) / l.den[i1]; }
-        }
-        for (int i = 0; i < N; ++i) {
-            const float g0 = l.dos[i * GAT_HS + lane], g1 = l.dos[i * GAT_HS + 64 + lane];
+            const float asj = j < N ? l.as[j] : 0.f;
 #pragma unroll
-            for (int u = 0; u < GAT_TB; ++u) {
-                const float a = i < 64 ? __shfl(al0[u], i, 64) : __shfl(al1[u], i - 64, 64);
-                acc0[u] = fmaf(a, g0, acc0[u]);
-                acc1[u] = fmaf(a, g1, acc1[u]);
+            for (int k = 0; k < NJ; ++k) {
+                al[u][k] = 0.f;
+                const int i = lane + 64 * k;
+                if (j < N && i < N) {
+                    const float c = (float)cb[i * npad + j];
+                    if (c > 0.f) al[u][k] = c * __expf(lrelu(asj + l.ad[i]) - l.mx[i]) / l.den[i];
+                }
             }
         }
+#pragma unroll
+        for (int k = 0; k < NJ; ++k)
+            for (int ii = 0; ii < 64 && 64 * k + ii < N; ++ii) {
+                const int i = 64 * k + ii;
+                const float g0 = dr.p[(size_t)i * dr.stride + lane], g1 = dr.p[(size_t)i * dr.stride + 64 + lane];
+#pragma unroll
+                for (int u = 0; u < GAT_TB; ++u) {
+                    const float a = __shfl(al[u][k], ii, 64);
+                    acc0[u] = fmaf(a, g0, acc0[u]);
+                    acc1[u] = fmaf(a, g1, acc1[u]);
+                }
+            }
 #pragma unroll
         for (int u = 0; u < GAT_TB; ++u) {
             const int j = jb + u;
@@ -245,7 +301,7 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_bwd_kernel(
             float* o = dH + (size_t)(n0 + j) * (GAT_H * GAT_C) + hd * GAT_C;
             o[lane] = acc0[u] + dasj * s0 + dadj * d0;
             o[64 + lane] = acc1[u] + dasj * s1 + dadj * d1;
-            const float h0 = l.hs[j * GAT_HS + lane], h1 = l.hs[j * GAT_HS + 64 + lane];
+            const float h0 = hr.p[(size_t)j * hr.stride + lane], h1 = hr.p[(size_t)j * hr.stride + 64 + lane];
             gs0 = fmaf(dasj, h0, gs0); gs1 = fmaf(dasj, h1, gs1);
             gd0 = fmaf(dadj, h0, gd0); gd1 = fmaf(dadj, h1, gd1);
         }
@@ -272,8 +328,8 @@ __global__ void elu_bwd_kernel(const float* __restrict__ x, const float* __restr
 
 int check_common(int G, int nmax, const char* who) {
     if (G < 0 || nmax < 0) { sga_set_error("%s: negative size", who); return SGA_ERR_ARG; }
-    if (nmax > GAT_MAXN) {
-        sga_set_error("%s: a graph has %d nodes; the LDS-resident GAT kernel supports at most %d per graph", who, nmax, GAT_MAXN);
+    if (nmax > GAT_MAXN_BIG) {
+        sga_set_error("%s: a graph has %d nodes; the GAT kernels support at most %d per graph", who, nmax, GAT_MAXN_BIG);
         return SGA_ERR_ARG;
     }
     return SGA_OK;
@@ -288,10 +344,19 @@ extern "C" int sga_gat_attn_fwd(const float* H, const float* att_src, const floa
     if (rc) return rc;
     SGA_CHECK_ARG(H && att_src && att_dst && bias && node_off && edge_off && out, "sga_gat_attn_fwd: null pointer");
     if (G == 0 || nmax == 0) return SGA_OK;
-    const size_t lds = gat_lds_bytes(nmax, false);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gat_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gat_attn_fwd_kernel, dim3(G, GAT_H), dim3(GAT_THREADS), lds, static_cast<hipStream_t>(stream), H, att_src,
-                       att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax);
+    if (nmax <= GAT_MAXN) {
+        const size_t lds = gat_lds_bytes(nmax, false, 2, true);
+        auto k = gat_attn_fwd_kernel<2, true>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, static_cast<hipStream_t>(stream), H, att_src,
+                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax);
+    } else {                                              // 129..256 nodes: features from global memory
+        const size_t lds = gat_lds_bytes(nmax, false, 4, false);
+        auto k = gat_attn_fwd_kernel<4, false>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, static_cast<hipStream_t>(stream), H, att_src,
+                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax);
+    }
     SGA_CHECK_LAUNCH("sga_gat_attn_fwd");
     return SGA_OK;
 }
@@ -306,10 +371,19 @@ extern "C" int sga_gat_attn_bwd(const float* H, const float* dO, const float* at
     hipMemsetAsync(d_att_src, 0, GAT_H * GAT_C * sizeof(float), s);
     hipMemsetAsync(d_att_dst, 0, GAT_H * GAT_C * sizeof(float), s);
     if (G == 0 || nmax == 0) return SGA_OK;
-    const size_t lds = gat_lds_bytes(nmax, true);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gat_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gat_attn_bwd_kernel, dim3(G, GAT_H), dim3(GAT_THREADS), lds, s, H, dO, att_src, att_dst,
-                       reinterpret_cast<const long long*>(edges), node_off, edge_off, dH, d_att_src, d_att_dst, nmax);
+    if (nmax <= GAT_MAXN) {
+        const size_t lds = gat_lds_bytes(nmax, true, 2, true);
+        auto k = gat_attn_bwd_kernel<2, true>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, s, H, dO, att_src, att_dst,
+                           reinterpret_cast<const long long*>(edges), node_off, edge_off, dH, d_att_src, d_att_dst, nmax);
+    } else {
+        const size_t lds = gat_lds_bytes(nmax, true, 4, false);
+        auto k = gat_attn_bwd_kernel<4, false>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, s, H, dO, att_src, att_dst,
+                           reinterpret_cast<const long long*>(edges), node_off, edge_off, dH, d_att_src, d_att_dst, nmax);
+    }
     SGA_CHECK_LAUNCH("sga_gat_attn_bwd");
     return SGA_OK;
 }

@@ -24,7 +24,8 @@ def _graphs(seed, sizes, extra_dups=True):
     return np.concatenate(edges).astype(np.int64), np.asarray(ecnt)
 
 
-@pytest.mark.parametrize('sizes,dups', [([5, 7], True), ([64, 64, 33, 1, 2, 128], False), ([9, 17, 100, 3], True)])
+@pytest.mark.parametrize('sizes,dups', [([5, 7], True), ([64, 64, 33, 1, 2, 128], False), ([9, 17, 100, 3], True),
+                                        ([129, 40], True), ([256, 3, 200], True), ([130, 255, 64], False)])
 def test_multigat_fwd_bwd(sizes, dups):
     from oracle import sga_oracle as O
     from sgaligner_amd import ops
@@ -63,8 +64,8 @@ def test_multigat_fwd_bwd(sizes, dups):
 
 def test_gat_too_many_nodes_fails_loudly():
     from sgaligner_amd import ops
-    edges, ecnt = _graphs(0, [130], False)
-    gb = ops.GraphBatch(np.asarray([130]), ecnt, torch.from_numpy(edges).cuda())
-    h = torch.randn(130, 256, device='cuda')
-    with pytest.raises(RuntimeError, match='at most 128'):
+    edges, ecnt = _graphs(0, [257], False)
+    gb = ops.GraphBatch(np.asarray([257]), ecnt, torch.from_numpy(edges).cuda())
+    h = torch.randn(257, 256, device='cuda')
+    with pytest.raises(RuntimeError, match='at most 256'):
         ops._attn_fwd(h, torch.randn(256, device='cuda'), torch.randn(256, device='cuda'), torch.zeros(256, device='cuda'), gb)
