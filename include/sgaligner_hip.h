@@ -60,7 +60,7 @@ int sga_fusion_bwd(const float* const* embs, int M, const float* weight, const f
  * replaces torch_geometric.nn.GATConv (2.2.0, un-vendored) as used by src/aligner/networks/gat.py:36-37,44,
  * for ALL graphs of a batch in one launch (sg_aligner.py:86-110 issues 2B sequential calls):
  * H [T,256] = x W^T (2 heads x 128), att_src/att_dst/bias [256]; edges [sumE,2] int64 graph-local (col 0 source,
- * col 1 target); node_off/edge_off [G+1] int32 prefix sums; nmax = max nodes per graph (<= 128).
+ * col 1 target); node_off/edge_off [G+1] int32 prefix sums; nmax = max nodes per graph (<= 256; up to 128 the features stay in LDS).
  * out[i] = sum_j softmax_j(leaky_relu(a_s[j]+a_d[i], 0.2)) H[j] + bias, self loops normalised as PyG does. */
 int sga_gat_attn_fwd(const float* H, const float* att_src, const float* att_dst, const float* bias,
                      const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G, int nmax,
