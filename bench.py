@@ -59,10 +59,10 @@ def cpu_baseline(seconds_budget=20.0):
 
 def pmc_traffic_bytes(kernel_tag):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes of THIS workload
-    (profiles/r01_j_pmc_traffic.csv, written by tools/pmc_traffic.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of
+    (profiles/r01_o_pmc_traffic.csv, written by tools/pmc_traffic.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of
     bench.py, KiB per dispatch; gfx950 correction: FETCH_SIZE counts wide coalesced reads at half their size -> x2,
     MI355X_MICROARCH.md, HBM)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_j_pmc_traffic.csv')
+    path = os.path.join(ROOT, 'profiles', 'r01_o_pmc_traffic.csv')
     try:
         f = w = None
         for line in open(path):
