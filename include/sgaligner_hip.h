@@ -92,7 +92,8 @@ int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, con
                         float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream);
 /* given coef = dL/d(out): M1[k][j*A+i] = dL/dS_k[i,j] and gs[k][8] = dL/d(sums) */
 int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums, float alpha,
-                        float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, void* stream);
+                        float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, int a_lo, int a_hi,
+                        void* stream);
 
 /* dZ[a_lo:a_hi,:] += M1^T Z[A:2A,:] ; dZ[A:2A,:] += M1 Z[a_lo:a_hi,:]  (M1 [A, a_hi-a_lo] from sga_loss_anchor_bwd; dZ zero-initialised) */
 int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi, void* stream);

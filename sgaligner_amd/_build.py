@@ -35,7 +35,7 @@ def _compile(src, obj, extra):
 
 def build_lib(verbose: bool = True, extra_flags=()) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
-    hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h')))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(CSRC, '..', '..', 'include', '*.h')))
     jobs = []
     objs = []
     for s in srcs:

@@ -4,6 +4,7 @@ loss kernels (csrc/contrastive.hip).  The heavy op is ops.contrastive_terms, whi
 double-summed terms; what remains here is the reference's scalar arithmetic on 1-element tensors."""
 import torch
 from torch import nn
+import torch.nn.functional as F  # noqa: F401  (re-exported by `from aligner.losses import *`, as the reference does)
 
 from .. import ops
 

@@ -3,6 +3,7 @@ constructor signatures, attributes, state_dict keys and data_dict contract), com
 kernels through sgaligner_amd.ops.  There is no CPU path: tensors must live on the MI355X."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401  (re-exported by `from aligner.sg_aligner import *`, as the reference does)
 
 from .. import ops
 from .networks.gat import MultiGAT

@@ -1322,9 +1322,10 @@ int rows_grid(int R) {
 
 extern "C" int sga_loss_gather(const float* E, int T, int D, const int32_t* idx, int R, float* Z, int Dp, float* nrm,
                                void* stream) {
-    SGA_CHECK_ARG(E && idx && Z && nrm && D >= 1 && Dp >= D && Dp % 8 == 0 && R >= 0, "sga_loss_gather: bad argument (Dp must be a multiple of 8 >= D)");
     (void)T;
+    SGA_CHECK_ARG(D >= 1 && Dp >= D && Dp % 8 == 0 && R >= 0, "sga_loss_gather: bad argument (Dp must be a multiple of 8 >= D)");
     if (R == 0) return SGA_OK;
+    SGA_CHECK_ARG(E && idx && Z && nrm, "sga_loss_gather: null pointer");
     hipLaunchKernelGGL(gather_normalize_kernel, dim3(rows_grid(R)), dim3(256), 0, static_cast<hipStream_t>(stream), E, D, idx, R, Z, Dp, nrm);
     SGA_CHECK_LAUNCH("sga_loss_gather");
     return SGA_OK;
@@ -1332,8 +1333,9 @@ extern "C" int sga_loss_gather(const float* E, int T, int D, const int32_t* idx,
 
 extern "C" int sga_loss_scatter(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int R, int D,
                                 int Dp, float* dE, void* stream) {
-    SGA_CHECK_ARG(dZ && Z && nrm && idx && dE && D >= 1 && Dp >= D, "sga_loss_scatter: bad argument");
+    SGA_CHECK_ARG(D >= 1 && Dp >= D && R >= 0, "sga_loss_scatter: bad argument");
     if (R == 0) return SGA_OK;
+    SGA_CHECK_ARG(dZ && Z && nrm && idx && dE, "sga_loss_scatter: null pointer");
     hipLaunchKernelGGL(scatter_normalize_bwd_kernel, dim3(rows_grid(R)), dim3(256), 0, static_cast<hipStream_t>(stream), dZ, Z, nrm, idx, R, D, Dp, dE);
     SGA_CHECK_LAUNCH("sga_loss_scatter");
     return SGA_OK;

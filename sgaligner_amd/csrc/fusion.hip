@@ -106,7 +106,7 @@ int grid_for_rows(int T, int wpb) {
 extern "C" int sga_fusion_fwd(const float* const* embs, int M, const float* weight, float* joint, int T, int D,
                               void* stream) {
     SGA_CHECK_ARG(M >= 1 && M <= FU_MAXM, "sga_fusion_fwd: modal_num %d outside [1,%d]", M, FU_MAXM);
-    SGA_CHECK_ARG(embs && weight && joint && T >= 0 && D >= 1, "sga_fusion_fwd: bad argument");
+    SGA_CHECK_ARG(embs && weight && (joint || T == 0) && T >= 0 && D >= 1, "sga_fusion_fwd: bad argument");
     if (T == 0) return SGA_OK;
     FusionPtrs p{};
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(embs[m], "sga_fusion_fwd: null table %d", m); p.p[m] = embs[m]; }
@@ -122,7 +122,7 @@ extern "C" int sga_fusion_bwd(const float* const* embs, int M, const float* weig
                               float* const* gembs, float* gweight, int T, int D, void* workspace,
                               size_t workspace_bytes, void* stream) {
     SGA_CHECK_ARG(M >= 1 && M <= FU_MAXM, "sga_fusion_bwd: modal_num %d outside [1,%d]", M, FU_MAXM);
-    SGA_CHECK_ARG(embs && weight && gjoint && gembs && gweight && T >= 0 && D >= 1, "sga_fusion_bwd: bad argument");
+    SGA_CHECK_ARG(embs && weight && (gjoint || T == 0) && gembs && gweight && T >= 0 && D >= 1, "sga_fusion_bwd: bad argument");
     if (workspace_bytes < sga_fusion_bwd_workspace_bytes(M) || !workspace) {
         sga_set_error("sga_fusion_bwd: workspace too small");
         return SGA_ERR_WORKSPACE;

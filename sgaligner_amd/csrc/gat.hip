@@ -342,8 +342,8 @@ extern "C" int sga_gat_attn_fwd(const float* H, const float* att_src, const floa
                                 int nmax, float* out, void* stream) {
     int rc = check_common(G, nmax, "sga_gat_attn_fwd");
     if (rc) return rc;
-    SGA_CHECK_ARG(H && att_src && att_dst && bias && node_off && edge_off && out, "sga_gat_attn_fwd: null pointer");
     if (G == 0 || nmax == 0) return SGA_OK;
+    SGA_CHECK_ARG(H && att_src && att_dst && bias && node_off && edge_off && out, "sga_gat_attn_fwd: null pointer");
     if (nmax <= GAT_MAXN) {
         const size_t lds = gat_lds_bytes(nmax, false, 2, true);
         auto k = gat_attn_fwd_kernel<2, true>;
@@ -366,7 +366,7 @@ extern "C" int sga_gat_attn_bwd(const float* H, const float* dO, const float* at
                                 int nmax, float* dH, float* d_att_src, float* d_att_dst, void* stream) {
     int rc = check_common(G, nmax, "sga_gat_attn_bwd");
     if (rc) return rc;
-    SGA_CHECK_ARG(H && dO && att_src && att_dst && node_off && edge_off && dH && d_att_src && d_att_dst, "sga_gat_attn_bwd: null pointer");
+    SGA_CHECK_ARG(((G == 0 || nmax == 0) || (H && dO && node_off && edge_off && dH)) && att_src && att_dst && d_att_src && d_att_dst, "sga_gat_attn_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipMemsetAsync(d_att_src, 0, GAT_H * GAT_C * sizeof(float), s);
     hipMemsetAsync(d_att_dst, 0, GAT_H * GAT_C * sizeof(float), s);
@@ -389,8 +389,8 @@ extern "C" int sga_gat_attn_bwd(const float* H, const float* dO, const float* at
 }
 
 extern "C" int sga_elu_fwd(const float* x, float* y, size_t n, void* stream) {
-    SGA_CHECK_ARG(x && y, "sga_elu_fwd: null pointer");
     if (n == 0) return SGA_OK;
+    SGA_CHECK_ARG(x && y, "sga_elu_fwd: null pointer");
     size_t g = (n + 255) / 256; if (g > 8192) g = 8192;
     hipLaunchKernelGGL(elu_fwd_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n);
     SGA_CHECK_LAUNCH("sga_elu_fwd");
@@ -398,8 +398,8 @@ extern "C" int sga_elu_fwd(const float* x, float* y, size_t n, void* stream) {
 }
 
 extern "C" int sga_elu_bwd(const float* x, const float* gy, float* gx, size_t n, void* stream) {
-    SGA_CHECK_ARG(x && gy && gx, "sga_elu_bwd: null pointer");
     if (n == 0) return SGA_OK;
+    SGA_CHECK_ARG(x && gy && gx, "sga_elu_bwd: null pointer");
     size_t g = (n + 255) / 256; if (g > 8192) g = 8192;
     hipLaunchKernelGGL(elu_bwd_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), x, gy, gx, n);
     SGA_CHECK_LAUNCH("sga_elu_bwd");

@@ -316,8 +316,8 @@ __global__ void cast_f64_f32_kernel(const double* __restrict__ in, float* __rest
 }  // namespace
 
 extern "C" int sga_cast_f64_f32(const double* in, float* out, size_t n, void* stream) {
-    SGA_CHECK_ARG(in && out, "sga_cast_f64_f32: null pointer");
     if (n == 0) return SGA_OK;
+    SGA_CHECK_ARG(in && out, "sga_cast_f64_f32: null pointer");
     size_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, n);
@@ -329,9 +329,10 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
                        const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
                        int act, const float* resid, long ldr, void* stream) {
     SGA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sga_gemm: negative size");
-    SGA_CHECK_ARG(A && B && C, "sga_gemm: null pointer");
+    
     SGA_CHECK_ARG(act >= 0 && act <= 2, "sga_gemm_ex: act=%d (0 none, 1 relu, 2 leaky-relu 0.2)", act);
-    if (M == 0 || N == 0) return SGA_OK;
+    if (M == 0 || N == 0) return SGA_OK;                 // empty output (a zero-row shard): nothing to do, null pointers allowed
+    SGA_CHECK_ARG(C && (K == 0 || (A && B)), "sga_gemm: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = (M + 127) / 128, gy = (N + 127) / 128;
     // split K when the output grid cannot fill the chip (weight-gradient shape)
@@ -400,7 +401,7 @@ extern "C" int sga_gemm_ex(int transA, int transB, int M, int N, int K, const fl
 }
 
 extern "C" int sga_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream) {
-    SGA_CHECK_ARG(X && out && M >= 0 && N >= 0, "sga_colsum: bad argument");
+    SGA_CHECK_ARG((X || M == 0) && (out || N == 0) && M >= 0 && N >= 0, "sga_colsum: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N == 0) return SGA_OK;
     if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) { sga_set_error("sga_colsum: memset failed"); return SGA_ERR_HIP; }

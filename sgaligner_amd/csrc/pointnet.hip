@@ -197,7 +197,8 @@ extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1
                                 const float* b2, const float* w3, const float* b3, float* y,
                                 int32_t* argmax, int T, int P, int C3, void* stream) {
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_fwd: need T >= 0 and P >= 1 (got T=%d P=%d)", T, P);
-    SGA_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && y, "sga_pointnet_fwd: null pointer");
+    // a zero-object shard (T == 0: empty tensors carry null data pointers) is a valid no-op
+    SGA_CHECK_ARG((T == 0 || (x && y)) && w1 && b1 && w2 && b2 && w3 && b3, "sga_pointnet_fwd: null pointer");
     if (T == 0) return SGA_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (C3) {
@@ -457,7 +458,7 @@ extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const flo
                                 float* gb3, int T, int P, int C3, void* stream) {
     SGA_CHECK_ARG(C3 == 256, "sga_pointnet_bwd: out_size C3=%d unsupported (256 only)", C3);
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_bwd: bad sizes");
-    SGA_CHECK_ARG(x && argmax && y && gy && w1 && b1 && w2 && b2 && w3 && gw1 && gb1 && gw2 && gb2 && gw3 && gb3,
+    SGA_CHECK_ARG((T == 0 || (x && argmax && y && gy)) && w1 && b1 && w2 && b2 && w3 && gw1 && gb1 && gw2 && gb2 && gw3 && gb3,
                   "sga_pointnet_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipMemsetAsync(gw1, 0, 64 * 3 * sizeof(float), s);

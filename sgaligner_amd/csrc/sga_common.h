@@ -5,6 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 
+// The public C ABI: every translation unit sees the prototypes it implements, so a definition that drifts from
+// include/sgaligner_hip.h is a compile error (conflicting types for an extern "C" function).
+#include "../../include/sgaligner_hip.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -195,8 +195,10 @@ class EpochBasedTrainer:
             self.before_train_step(self.epoch, self.inner_iteration, data_dict)
             output_dict, result_dict = self.train_step(self.epoch, self.inner_iteration, data_dict)
             result_dict['loss'].backward()
-            if self.distributed:
-                # log_vars see the full (replicated) loss on every rank; everything else only this rank's rows
+            if self.distributed and self.inner_iteration % self.grad_acc_steps == 0:
+                # Reduce ONCE per optimiser step, on the locally accumulated gradients of all its micro-steps (reducing
+                # every micro-step in place would re-sum the already-reduced part: world*G1 + G2).  log_vars see the
+                # full (replicated) loss on every rank, everything else only this rank's rows -> pre-divide log_vars.
                 for p in list(self.steps.multi_loss_layer_ial.parameters()) + list(self.steps.multi_loss_layer_icl.parameters()):
                     if p.grad is not None:
                         p.grad /= self.world

@@ -126,9 +126,14 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         if not x.is_cuda:
             raise RuntimeError('sgaligner_amd.LinearFn: HIP device tensor required; there is no CPU path')
+        if x.dtype not in (torch.float32, torch.float64):
+            raise RuntimeError(f'sgaligner_amd.LinearFn: features must be float32 or float64 (the collated bag-of-words '
+                               f'tables), got {x.dtype}')
         x = x.contiguous()
         _req(weight, 'weight'); _req(bias, 'bias')
         t, k = x.shape
+        if x.dim() != 2 or k != weight.shape[1]:
+            raise RuntimeError(f'sgaligner_amd.LinearFn: x is {tuple(x.shape)} but weight is {tuple(weight.shape)}')
         y = gemm(x, weight, False, True, t, weight.shape[0], k, bias=bias)
         ctx.save_for_backward(x, weight)
         return y
@@ -200,29 +205,76 @@ def fusion(weight, embs):
 
 
 # ------------------------------------------------------------------------------------------ contrastive loss
+import os as _os
+import zlib as _zlib
+from collections import OrderedDict as _OrderedDict
+
 import numpy as _np
+
+
+def _fingerprint(arrays, extra=()):
+    """Content fingerprint of small host arrays: a cached device copy is reused only while the arrays a caller hands in
+    still hold the same values (the reference's tester shifts e1i/e2i IN PLACE between uses, inference_align_reg.py:119-120)."""
+    h = 1
+    shapes = []
+    for a in arrays:
+        a = _np.ascontiguousarray(a)
+        shapes.append((a.shape, a.dtype.str))
+        h = _zlib.adler32(a.reshape(-1).view(_np.uint8), h)
+    return (h, tuple(shapes), tuple(extra))
+
+
+class _SmallCache:
+    """Tiny LRU keyed by content fingerprints.  Lives HERE, never in the caller's data_dict: a dict that is reused with
+    different index arrays can not pick up a stale device copy."""
+
+    def __init__(self, n=4):
+        self.n, self.d = n, _OrderedDict()
+
+    def get(self, key, make):
+        v = self.d.get(key)
+        if v is None:
+            v = make()
+            self.d[key] = v
+            while len(self.d) > self.n:
+                self.d.popitem(last=False)
+        else:
+            self.d.move_to_end(key)
+        return v
+
+    def clear(self):
+        self.d.clear()
+
+
+VALIDATE = _os.environ.get('SGA_VALIDATE', '1') != '0'     # host-side range checks of index sets / edge lists, once per batch
 
 
 class IndexSets:
     """Device copy of the four host index arrays of a batch (reference scan3r.py:142-173 keeps them as
-    numpy int32 on the host): packed [e1i | e2i | e1j | e2j], converted once per batch."""
+    numpy int32 on the host): packed [e1i | e2i | e1j | e2j], converted once per batch.
+    `groups` (optional, loss_group=b): group id of every entry, same packing -- rows only interact within their group."""
 
-    def __init__(self, data_dict, device):
+    def __init__(self, data_dict, device, n_rows=None):
         arrs = [_np.ascontiguousarray(_np.asarray(data_dict[k]).astype(_np.int32)) for k in ('e1i', 'e2i', 'e1j', 'e2j')]
         if arrs[0].shape != arrs[1].shape:
             raise RuntimeError('sgaligner_amd: e1i and e2i must have the same length')
         self.A, self.J1, self.J2 = int(arrs[0].shape[0]), int(arrs[2].shape[0]), int(arrs[3].shape[0])
         self.R = 2 * self.A + self.J1 + self.J2
-        self.idx = torch.from_numpy(_np.concatenate(arrs)).to(device)
+        host = _np.concatenate(arrs)
+        if VALIDATE and host.size:
+            lo, hi = int(host.min()), int(host.max())
+            if lo < 0 or (n_rows is not None and hi >= n_rows):
+                raise RuntimeError(f'sgaligner_amd: e1i/e2i/e1j/e2j hold object indices in [{lo}, {hi}] but the embedding '
+                                   f'tables have {n_rows} rows')
+        self.idx = torch.from_numpy(host).to(device)
+
+    _cache = _SmallCache()
 
     @staticmethod
-    def of(data_dict, device):
-        c = data_dict.get('_sga_index_sets') if isinstance(data_dict, dict) else None
-        if c is None or c.idx.device != torch.device(device):
-            c = IndexSets(data_dict, device)
-            if isinstance(data_dict, dict):
-                data_dict['_sga_index_sets'] = c
-        return c
+    def of(data_dict, device, n_rows=None):
+        device = torch.device(device)
+        key = _fingerprint([_np.asarray(data_dict[k]) for k in ('e1i', 'e2i', 'e1j', 'e2j')], (str(device), n_rows))
+        return IndexSets._cache.get(key, lambda: IndexSets(data_dict, device, n_rows))
 
 
 FUSED_ANCHOR_BWD = True
@@ -315,7 +367,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
 
 
 def contrastive_terms(tables, data_dict, alpha=ALPHA):
-    s = IndexSets.of(data_dict, tables[0].device)
+    s = IndexSets.of(data_dict, tables[0].device, int(tables[0].shape[0]))
     return ContrastiveTermsFn.apply(s, alpha, *tables), s
 
 
@@ -325,7 +377,7 @@ class GraphBatch:
     src,ref,src,ref... order of reference sg_aligner.py:86-110, plus the int64 [sum E, 2] edge list
     (graph-local node ids, column 0 = source j, column 1 = target i) exactly as collated."""
 
-    def __init__(self, node_counts, edge_counts, edges):
+    def __init__(self, node_counts, edge_counts, edges, keep_edges=True):
         nc = _np.asarray(node_counts, dtype=_np.int64).reshape(-1)
         ec = _np.asarray(edge_counts, dtype=_np.int64).reshape(-1)
         if nc.shape != ec.shape:
@@ -337,19 +389,36 @@ class GraphBatch:
         dev = edges.device
         if edges.dtype != torch.int64:
             edges = edges.to(torch.int64)
-        self.edges = edges.contiguous()
-        if self.edges.shape[0] < self.E:
+        edges = edges.contiguous()
+        if edges.shape[0] < self.E:
             raise RuntimeError('sgaligner_amd: edge list shorter than graph_per_edge_count says')
+        if VALIDATE and self.E and edges.is_cuda:
+            # Node ids are graph-LOCAL (scan3r.py:99): anything outside [0, largest graph) can not be a node of any graph.
+            # The kernels drop out-of-range endpoints (PyG would raise an index error); catch the gross case here, once per batch.
+            mn, mx = torch.aminmax(edges[:self.E])
+            mn, mx = int(mn), int(mx)
+            if mn < 0 or mx >= self.nmax:
+                raise RuntimeError(f'sgaligner_amd: edge endpoints span [{mn}, {mx}] but the largest graph has {self.nmax} nodes '
+                                   f'(edges must hold graph-local node ids)')
+        self.edges = edges if keep_edges else None
         self.node_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(nc)]).astype(_np.int32)).to(dev)
         self.edge_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(ec)]).astype(_np.int32)).to(dev)
 
+    _cache = _SmallCache(2)
+
     @staticmethod
     def of(data_dict):
-        c = data_dict.get('_sga_graph_batch')
-        if c is None or c.edges.device != data_dict['edges'].device:
-            c = GraphBatch(data_dict['graph_per_obj_count'], data_dict['graph_per_edge_count'], data_dict['edges'])
-            data_dict['_sga_graph_batch'] = c
-        return c
+        """Offsets are cached by the CONTENT of the two host count arrays + the identity of the device edge list (nothing is
+        stored in the caller's dict).  The cached object keeps only the small offset arrays, never the edge tensor."""
+        edges = data_dict['edges']
+        key = _fingerprint([_np.asarray(data_dict['graph_per_obj_count']), _np.asarray(data_dict['graph_per_edge_count'])],
+                           (str(edges.device), edges.data_ptr(), tuple(edges.shape), str(edges.dtype)))
+        proto = GraphBatch._cache.get(key, lambda: GraphBatch(data_dict['graph_per_obj_count'], data_dict['graph_per_edge_count'],
+                                                              edges, keep_edges=False))
+        gb = GraphBatch.__new__(GraphBatch)
+        gb.__dict__.update(proto.__dict__)
+        gb.edges = edges if edges.dtype == torch.int64 and edges.is_contiguous() else edges.to(torch.int64).contiguous()
+        return gb
 
 
 def _attn_fwd(h, att_s, att_d, bias, gb):
@@ -383,6 +452,8 @@ class MultiGATFn(torch.autograd.Function):
     def forward(ctx, gb, x, w0, as0, ad0, b0, w1, as1, ad1, b1):
         if not x.is_cuda:
             raise RuntimeError('sgaligner_amd.MultiGATFn: HIP device tensor required; there is no CPU path')
+        if x.dtype not in (torch.float32, torch.float64):
+            raise RuntimeError(f'sgaligner_amd.MultiGATFn: tot_rel_pose must be float32 or float64, got {x.dtype}')
         x32 = cast_f32(x.contiguous())
         ps = [_req(t.contiguous(), n) for t, n in ((w0, 'gat0.lin'), (as0.reshape(-1), 'gat0.att_src'), (ad0.reshape(-1), 'gat0.att_dst'),
                                                    (b0, 'gat0.bias'), (w1, 'gat1.lin'), (as1.reshape(-1), 'gat1.att_src'),
@@ -590,7 +661,7 @@ class FusedContrastiveFn(torch.autograd.Function):
 def fused_contrastive_terms(tables, fusion_weight, data_dict, alpha=ALPHA, shard=None, reduce=None):
     """tables: the M modality tables the joint table was fused from; fusion_weight: the [M,1] parameter.
     shard / reduce: see FusedContrastiveFn (anchor range owned by this rank, in-place SUM all-reduce)."""
-    s = IndexSets.of(data_dict, tables[0].device)
+    s = IndexSets.of(data_dict, tables[0].device, int(tables[0].shape[0]))
     w = torch.softmax(fusion_weight.reshape(-1), dim=0)                # sg_aligner.py:32
     beta = (w * w) / (w * w).sum()
     return FusedContrastiveFn.apply(s, alpha, shard, reduce, beta, *tables), s

@@ -116,3 +116,31 @@ def test_synthetic_batch_schema():
     assert gb.G == 6 and gb.T == T and int(gb.edge_off[-1]) == dd['edges'].shape[0]
     s = ops.IndexSets.of(dd, 'cpu')
     assert s.R == T and s.idx.dtype == torch.int32
+
+
+def test_batch_caches_never_go_stale():
+    """The per-batch device copies (index sets, graph offsets) are cached by CONTENT, outside the caller's dict: a data_dict that
+    is reused with changed index arrays -- the reference's tester shifts e1i/e2i in place (inference_align_reg.py:119-120) -- must
+    get fresh copies, and nothing may be written into the caller's dict."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(2, 6, 8, seed=3)
+    keys = set(dd.keys())
+    T = int(dd['tot_obj_count'].sum())
+    s1 = ops.IndexSets.of(dd, 'cpu', T)
+    assert ops.IndexSets.of(dd, 'cpu', T) is s1                       # same content -> same device copy
+    dd['e1i'][0], dd['e1j'][0] = dd['e1j'][0], dd['e1i'][0]           # in-place edit, same array objects
+    s2 = ops.IndexSets.of(dd, 'cpu', T)
+    assert s2 is not s1 and int(s2.idx[0]) == int(dd['e1i'][0])
+    g1 = ops.GraphBatch.of(dd)
+    dd['graph_per_obj_count'] = dd['graph_per_obj_count'].copy()
+    dd['graph_per_obj_count'][0, 0] -= 1
+    dd['graph_per_obj_count'][0, 1] += 1
+    g2 = ops.GraphBatch.of(dd)
+    assert g2.node_off.tolist() != g1.node_off.tolist()
+    assert set(dd.keys()) == keys                                     # no `_sga_*` entries planted in the caller's dict
+    import pytest
+    dd['e2j'] = dd['e2j'].copy()
+    dd['e2j'][-1] = T                                                 # out of range: must raise, not read out of bounds
+    with pytest.raises(RuntimeError, match='object indices'):
+        ops.IndexSets.of(dd, 'cpu', T)

@@ -16,7 +16,7 @@ def _params(tr):
 
 def test_train_resume_and_snapshot_format(tmp_path):
     from sgaligner_amd.datasets import synthetic_scan3r as S
-    from sgaligner_amd.engine import Trainer
+    from sgaligner_amd.epoch_trainer import Trainer
     root = str(tmp_path / 'data')
     S.write_dataset(root, n_pairs=8, seed=3, resolutions=(64,))
     cfgA = S.make_cfg(root, max_epoch=3, output_dir=str(tmp_path / 'runA'))
@@ -62,7 +62,7 @@ def test_train_resume_and_snapshot_format(tmp_path):
 def test_one_optimizer_step_equals_oracle_plus_adam(tmp_path):
     from oracle import sga_oracle as O
     from sgaligner_amd.datasets import Scan3RDataset, synthetic_scan3r as S
-    from sgaligner_amd.engine import Trainer
+    from sgaligner_amd.epoch_trainer import Trainer
     root = str(tmp_path / 'data')
     S.write_dataset(root, n_pairs=4, seed=6, resolutions=(64,))
     cfg = S.make_cfg(root, max_epoch=1, batch_size=4, lr=1e-2, output_dir=str(tmp_path / 'run'))
@@ -103,7 +103,7 @@ def test_ground_truth_config_modules_train_end_to_end(tmp_path):
     """configs/scan3r/scan3r_ground_truth.yaml:5 -- modules ['pct', 'gat', 'rel', 'attr']: dataset -> epoch loop -> PCT
     object encoder (train-mode BatchNorm + Dropout) -> 4-table fused loss; two epochs run, stay finite and learn."""
     from sgaligner_amd.datasets import synthetic_scan3r as S
-    from sgaligner_amd.engine import Trainer
+    from sgaligner_amd.epoch_trainer import Trainer
     root = str(tmp_path / 'data')
     S.write_dataset(root, n_pairs=8, seed=12, resolutions=(64,))
     cfg = S.make_cfg(root, modules=('pct', 'gat', 'rel', 'attr'), max_epoch=3, batch_size=4, output_dir=str(tmp_path / 'run'))

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from sgaligner_amd.datasets import DeviceBatch, Scan3RDataset, synthetic_scan3r as S
-from sgaligner_amd.engine import Trainer
+from sgaligner_amd.epoch_trainer import Trainer
 
 mods = sys.argv[1].split(',') if len(sys.argv) > 1 else ['point', 'gat', 'rel', 'attr']
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 30
