@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: subscan-pairs/sec, fwd + bwd (encoder forward, OverallLoss forward, backward to all
 parameter gradients; optimiser step and data loading excluded; inputs resident in HBM) -- BASELINE.json
-metric, SURVEY.md 8(d).
+metric, SURVEY.md 8(d) -- plus the metric's second half, node-match Hits@1 against the oracle on a fixed
+val-style subsample.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W --config auto|c2|c3]      (N > 1: launched by torch.distributed.run)
 
-Workload (config.workload): BASELINE.json configs[1] per GPU -- 512 synthetic subscan pairs x 64 objects x
-512 points, modules point+gat+rel (P+S+R), batch-global loss.  For N > 1 every rank holds 512 pairs (weak
-scaling) and the loss is the global one over all 512*N pairs (tables all-gathered over RCCL).
+Workloads (config.workload):
+  c2 = BASELINE.json configs[1]: 512 synthetic subscan pairs PER GPU x 64 objects x 512 points, P+S+R, batch-global
+       loss over all 512*N pairs (weak scaling).  Default at N = 1.
+  c3 = BASELINE.json configs[2] / the north-star target: 4096 pairs x 128 objects x 512 points IN TOTAL, sharded
+       4096/N pairs per GPU, batch-global loss via the table all-gather (strong scaling; N = 1 runs the whole batch on
+       one GPU).  Default at N > 1.
 Prints ONE JSON line (rank 0)."""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,17 +28,23 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-# BASELINE.json configs[1] is P+S+R; SGA_BENCH_MODULES (e.g. point,gat,rel,attr) is for side experiments only
+# BASELINE.json configs[1]/[2] are P+S+R; SGA_BENCH_MODULES (e.g. point,gat,rel,attr) is for side experiments only
 MODULES = os.environ.get('SGA_BENCH_MODULES', 'point,gat,rel').split(',')
-PAIRS_PER_GPU, N_OBJ, N_PTS = 512, 64, 512
+CONFIGS = {
+    'c2': {'ref': 'BASELINE.json configs[1]', 'n_obj': 64, 'n_pts': 512, 'pairs_per_gpu': 512, 'scaling': 'weak'},
+    'c3': {'ref': 'BASELINE.json configs[2] (north-star target)', 'n_obj': 128, 'n_pts': 512, 'global_pairs': 4096,
+           'scaling': 'strong'},
+}
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) dense peak
 PEAK_HBM_GBS = 8000.0
+HITS_PAIRS = 8                   # fixed val-style subsample for the Hits@K half of the metric
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(n_obj, n_pts, seconds_budget=20.0):
     """The oracle (CPU restatement pinned to the reference by tests/golden) on this box's host cores:
     fwd + loss + bwd at the reference's native batch size b=2 (configs/scan3r/scan3r_ground_truth.yaml:27)
-    with the same (objects, points, modules) as the GPU workload."""
+    with the same (objects, points, modules) as the GPU workload.  Also returns the oracle's embeddings-based
+    Hits@K on the fixed val-style subsample (the checker for the metric's second half)."""
     from oracle import sga_oracle as O
     from sgaligner_amd.synthetic import make_batch
     # Thread count: on the 2 x 64-core EPYC 9575F GPU host a sweep over {4,8,16,32,64,128} threads (tools/cpu_threads.py)
@@ -41,7 +52,7 @@ def cpu_baseline(seconds_budget=20.0):
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     b = 2
-    dd = make_batch(b, N_OBJ, N_PTS, seed=43, device='cpu')
+    dd = make_batch(b, n_obj, n_pts, seed=43, device='cpu')
     params = O.init_params(MODULES, seed=42)
     O.train_step(params, dd, MODULES)                      # warm-up
     times = []
@@ -52,23 +63,62 @@ def cpu_baseline(seconds_budget=20.0):
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {'value': b / med, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle fwd+loss+bwd, b={b} pairs x {N_OBJ} obj x {N_PTS} pts, {"+".join(MODULES)}, '
+            'sample': f'oracle fwd+loss+bwd, b={b} pairs x {n_obj} obj x {n_pts} pts, {"+".join(MODULES)}, '
                       f'{len(times)} iterations, median {med*1e3:.1f} ms, torch {torch.__version__} CPU, {cores} threads '
                       f'(best of a thread-count sweep; host has {os.cpu_count()} hardware threads)'}
 
 
-def pmc_traffic_bytes(kernel_tag):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes of THIS workload
-    (profiles/r01_o_pmc_traffic.csv, written by tools/pmc_traffic.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of
-    bench.py, KiB per dispatch; gfx950 correction: FETCH_SIZE counts wide coalesced reads at half their size -> x2,
-    MI355X_MICROARCH.md, HBM)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_o_pmc_traffic.csv')
+def hits_at_k(steps, n_obj, n_pts, dev):
+    """BASELINE metric, second half: node-match Hits@K of the HIP path's embeddings vs the oracle's on identical inputs and
+    weights -- a fixed 8-pair val-style batch (every common object an anchor, scan3r.py:83-87), ranking arithmetic of
+    inference_align_reg.py:125-143 + utils/alignment.py on both sides.  Outside the timed region."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd.synthetic import make_batch, to_device
+    dd = make_batch(HITS_PAIRS, n_obj, n_pts, seed=1234, device='cpu', anchors='val')
+    params = {k: v.detach().cpu().clone() for k, v in steps.model.state_dict().items() if 'num_batches' not in k}
+    with torch.no_grad():
+        out_o = O.encoder_forward(params, dd, MODULES)
+    key = 'joint' if len(MODULES) > 1 else MODULES[0]
+    m_o = O.evaluate_batch(out_o[key].detach(), dd)
+    ddd = to_device(dd, dev)
+    out_g = steps.test_step(0, ddd)
+    m_g = steps.eval_step(0, ddd, out_g)
+    tot = m_g[1]['total']
+    emb_err = float((out_g[key].detach().cpu() - out_o[key].detach()).abs().max())
+    return {'gpu': m_g[1]['correct'] / max(1, tot), 'oracle': m_o['hits'][1][0] / max(1, m_o['hits'][1][1]),
+            'gpu_hits_1to5': [m_g[k]['correct'] for k in (1, 2, 3, 4, 5)],
+            'oracle_hits_1to5': [m_o['hits'][k][0] for k in (1, 2, 3, 4, 5)], 'anchors': tot,
+            'mrr_gpu': float(np.mean(m_g['mrr'])), 'mrr_oracle': float(np.mean(m_o['mrr'])),
+            'max_abs_embedding_err': emb_err,
+            'sample': f'{HITS_PAIRS} val-style pairs x {n_obj} obj x {n_pts} pts, random-init weights (seed 42), same inputs/weights both sides'}
+
+
+def _sha16(path):
+    try:
+        return hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def pmc_traffic_bytes(kernel_tag, workload_key, source):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.csv, written
+    by tools/pmc_traffic.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of THIS script; KiB per dispatch; gfx950
+    correction: FETCH_SIZE counts wide coalesced reads at half their size -> x2, MI355X_MICROARCH.md, HBM).
+    A row is used only if it was taken on the same workload (`workload_key`) AND the kernel's source file is unchanged
+    since (sha256 recorded by the tool): a stale measurement is reported as null, never as a number."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.csv')
+    sha = _sha16(os.path.join(ROOT, 'sgaligner_amd', 'csrc', source))
     try:
         f = w = None
         for line in open(path):
-            if line.startswith('#') or not line.startswith(kernel_tag + ','):
+            if line.startswith('#') or line.startswith('kernel,'):
                 continue
-            _, counter, value, _ = line.strip().rsplit(',', 3)
+            parts = line.strip().split(';')
+            if len(parts) != 6:
+                continue
+            k, wk, src_sha, counter, value, _ = parts
+            if k != kernel_tag or wk != workload_key or src_sha != sha:
+                continue
             if counter == 'FETCH_SIZE':
                 f = float(value)
             elif counter == 'WRITE_SIZE':
@@ -85,12 +135,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', choices=['auto', 'c2', 'c3'], default=os.environ.get('SGA_BENCH_CONFIG', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hits', action='store_true')
     args = ap.parse_args()
 
     from sgaligner_amd import dist as sdist
     from sgaligner_amd import ops
-    from sgaligner_amd.synthetic import make_batch
+    from sgaligner_amd.synthetic import make_batch_fast
     from sgaligner_amd.trainer import AlignerSteps
 
     rank, world, local = sdist.init_from_env()
@@ -99,9 +151,17 @@ def main():
     dev = torch.device('cuda', local)
     if world != args.gpus and rank == 0:
         print(f'[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+    cname = args.config if args.config != 'auto' else ('c2' if world == 1 else 'c3')
+    cfg = CONFIGS[cname]
+    n_obj, n_pts = cfg['n_obj'], cfg['n_pts']
+    if cfg['scaling'] == 'weak':
+        my_pairs, total_pairs = cfg['pairs_per_gpu'], cfg['pairs_per_gpu'] * world
+    else:
+        lo, hi = sdist.shard_range(cfg['global_pairs'], rank, world)
+        my_pairs, total_pairs = hi - lo, cfg['global_pairs']
 
     steps = AlignerSteps(MODULES, device=dev, seed=42)
-    dd = make_batch(PAIRS_PER_GPU, N_OBJ, N_PTS, seed=43 + rank, device=dev, gen_device=dev)
+    dd = make_batch_fast(my_pairs, n_obj, n_pts, seed=43 + rank, device=dev)
 
     def barrier():
         if world > 1:
@@ -112,21 +172,28 @@ def main():
         steps.forward_backward(dd)
     barrier()
     ops.KERNEL_EVENTS = {}
+    step_ev = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
         _, loss_dict = steps.forward_backward(dd)
+        e1.record()
+        step_ev.append((e0, e1))
     barrier()
     elapsed = time.perf_counter() - t0
     events = ops.KERNEL_EVENTS
     ops.KERNEL_EVENTS = None
+    step_ms = [a.elapsed_time(b) for a, b in step_ev]
+    med_ms = float(np.median(step_ms))
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, med_ms = float(t[0].item()), float(t[1].item())
     loss_val = float(loss_dict['loss'].item())
+    peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
 
     if rank == 0:
-        total_pairs = PAIRS_PER_GPU * world
         ms = elapsed / args.steps * 1e3
         # The two kernels that carry the step, each timed with HIP events on its launch stream; `roofline` is the
         # one with the larger per-step time, the other is reported under `roofline_other`.  Both are bound by the
@@ -143,9 +210,9 @@ def main():
             ach = alg / (avg_ms * 1e-3) / 1e12
             roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': round(ach / PEAK_F32_TFLOPS, 4),
-                          'traffic': pmc_traffic_bytes('pointnet_fwd_kernel') if world == 1 else None,
+                          'traffic': pmc_traffic_bytes('pointnet_fwd_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
                           'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object)',
-                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4),
+                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                           'algorithmic_flops_per_launch': alg})
         evs = events.get('loss_multi_grad', [])
         if evs:
@@ -155,32 +222,39 @@ def main():
             # = 2 x [ sum_tab 2*D_tab * 2A(J1+J2) ]  with sum_tab D_tab = 100*M + 100*M.
             d_sum = 100 * M + 100 * M
             alg = 2.0 * (2.0 * d_sum * 2.0 * ns * (J1 + J2))
-            # executed: two sweeps x M tables x (S with K = 100 + gradient GEMM with 112 columns); the joint table is derived
-            executed = 2.0 * (2.0 * ns * (J1 + J2)) * 2.0 * M * (100 + 112)
             avg_ms = float(np.mean(durs))
             ach = alg / (avg_ms * 1e-3) / 1e12
-            kname = f'sweep16_kernel<{M},true>'
+            info = ops.SWEEP_GRAD_INFO
+            executed = info['executed_flops'](ns, J1 + J2, M)
             roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                          'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': pmc_traffic_bytes(f'sweep16_kernel<{M},true>') if world == 1 else None,
-                          'kernel': f'{kname} (loss: negatives backward, all {M}+1 tables)',
-                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4),
+                          'frac': round(ach / PEAK_F32_TFLOPS, 4),
+                          'traffic': pmc_traffic_bytes(info['tag'] % M, f'ns={ns},A={A},J={J1 + J2}', 'contrastive.hip') if world == 1 else None,
+                          'kernel': f'{info["tag"] % M} ({info["what"]}, all {M}+1 tables)',
+                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                           'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed,
                           'executed_tflops': round(executed / (avg_ms * 1e-3) / 1e12, 2)})
-        roofs.sort(key=lambda r: -r['avg_launch_ms'])
+        roofs.sort(key=lambda r: -r['step_ms'])
         roof = roofs[0] if roofs else None
+        per = f'{my_pairs} pairs/GPU' if world > 1 else f'{my_pairs} pairs'
         line = {
-            'metric': 'subscan-pairs/sec (fwd+bwd)', 'value': round(total_pairs * args.steps / elapsed, 2), 'unit': 'pairs/s',
+            'metric': 'subscan-pairs/sec (fwd+bwd) + node-match Hits@1 vs reference',
+            'value': round(total_pairs * args.steps / elapsed, 2), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE.json configs[1]: {PAIRS_PER_GPU} synthetic subscan pairs/GPU x {N_OBJ} objects x '
-                                   f'{N_PTS} pts, modules {"+".join(MODULES)} (P+S+R), batch-global ICL/IAL loss over '
-                                   f'{total_pairs} pairs', 'global_pairs': total_pairs, 'objects_per_scene': N_OBJ,
-                       'points_per_object': N_PTS, 'modules': MODULES, 'parallelism': f'dp{world}', 'loss': loss_val},
+            'median_ms_per_step': round(med_ms, 3), 'value_median': round(total_pairs / (med_ms * 1e-3), 2),
+            'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{cfg["ref"]}: {total_pairs} synthetic subscan pairs ({per}) x {n_obj} objects x '
+                                   f'{n_pts} pts, modules {"+".join(MODULES)} (P+S+R), batch-global ICL/IAL loss over '
+                                   f'{total_pairs} pairs', 'name': cname, 'global_pairs': total_pairs, 'pairs_per_gpu': my_pairs,
+                       'objects_per_scene': n_obj, 'points_per_object': n_pts, 'modules': MODULES, 'parallelism': f'dp{world}',
+                       'loss': loss_val, 'peak_hbm_gib': round(peak_gib, 2)},
             'roofline': roof,
             'roofline_other': roofs[1:],
         }
+        if not args.no_hits:
+            line['hits_at_1'] = hits_at_k(steps, n_obj, n_pts, dev)
         if not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(n_obj, n_pts)
+            line['speedup_vs_cpu_baseline'] = round(line['value'] / line['cpu_baseline']['value'], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

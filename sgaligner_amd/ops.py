@@ -281,6 +281,29 @@ FUSED_ANCHOR_BWD = True
 FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
 KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel with HIP events on the launch stream
 
+STASH_BYTES = int(_os.environ.get('SGA_STASH_BYTES', str(4 << 30)))   # bound on the transposed dL/dS stashes of the A x A backward
+
+
+def _anchor_chunks(a_lo, a_hi, A, n_tables):
+    """Anchor-row blocks [c_lo, c_hi) of the anchors x anchors backward.  The coefficient stash of a block is
+    n_tables x [A, c_hi - c_lo] fp32; blocks are sized so that it never exceeds STASH_BYTES, which keeps the loss
+    backward O(A * D + STASH_BYTES) in memory whatever the batch (4096 pairs x 128 objects: A = 155 648, a full stash
+    would be 3 x 97 GB).  Block sizes are multiples of 32 rows (kernel tile) except the last."""
+    ns = a_hi - a_lo
+    if ns <= 0 or A <= 0:
+        return []
+    rows = max(32, (STASH_BYTES // (4 * A * max(1, n_tables))) // 32 * 32)
+    return [(c, min(c + rows, a_hi)) for c in range(a_lo, a_hi, rows)]
+
+
+# What sga_loss_multi_grad launches (bench.py's roofline line): two owner sweeps x M tables x (S with K = 100 + gradient
+# GEMM with 112 columns); the joint table is derived, never multiplied.
+SWEEP_GRAD_INFO = {
+    'tag': 'sweep16_kernel<%d,true>',
+    'what': 'loss: negatives backward',
+    'executed_flops': lambda ns, j, m: 2.0 * (2.0 * ns * j) * 2.0 * m * (100 + 112),
+}
+
 TAU_ICL = 0.1      # losses.py:39 (ctor argument ignored by the reference)
 TAU_IAL = 1.0      # losses.py:63
 ALPHA = 0.5        # losses.py:36,60 defaults
@@ -336,20 +359,26 @@ class ContrastiveTermsFn(torch.autograd.Function):
         st = _stream()
         coef = gout.contiguous().float()
         A = s.A
-        m1 = [torch.empty((A, A), device=dev, dtype=torch.float32) for _ in range(nt)]
-        gs = torch.empty((1 + L.sga_loss_slots(), nt, 8), device=dev, dtype=torch.float64)
+        slots = 1 + L.sga_loss_slots()
         dparr = (_ct.c_int * nt)(*dps)
-        _lib.check(L.sga_loss_anchor_bwd(_ptr_array(zs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
-                                         _ptr_array(m1), _p(gs), 0, A, st), 'sga_loss_anchor_bwd')
-        gs = gs[0]
+        dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for dp in dps]
+        gs = torch.zeros((nt, 8), device=dev, dtype=torch.float64)
+        chunks = _anchor_chunks(0, A, A, nt)
+        if chunks:
+            cmax = max(hi - lo for lo, hi in chunks)
+            m1 = [torch.empty((A * cmax,), device=dev, dtype=torch.float32) for _ in range(nt)]
+            gsc = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
+            for lo, hi in chunks:          # bounded stash: one anchor-row block at a time
+                _lib.check(L.sga_loss_anchor_bwd(_ptr_array(zs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
+                                                 _ptr_array(m1), _p(gsc), lo, hi, st), 'sga_loss_anchor_bwd')
+                gs += gsc[0]
+                for k in range(nt):
+                    # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]
+                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dps[k], _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
+            del m1
         grads = []
         for k in range(nt):
-            z, dp = zs[k], dps[k]
-            dz = torch.zeros((s.R, dp), device=dev, dtype=torch.float32)
-            if A > 0:
-                # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]
-                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(z), A, dp, _p(dz), 0, A, st), 'sga_loss_stash_grad')
-            m1[k] = None
+            z, dp, dz = zs[k], dps[k], dzs[k]
             ev = None
             if KERNEL_EVENTS is not None and dp <= 128:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -363,6 +392,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
             de = torch.zeros((t, d), device=dev, dtype=torch.float32)
             _lib.check(L.sga_loss_scatter(_p(dz), _p(z), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
             grads.append(de)
+            dzs[k] = None
         return (None, None, *grads)
 
 
@@ -607,37 +637,48 @@ class FusedContrastiveFn(torch.autograd.Function):
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for _ in range(M)]
         gam_neg = torch.empty((slots, M), device=dev, dtype=torch.float64)   # dL/dbeta via the negatives (zeroed by the callee)
         gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via the anchors x anchors terms
-        if M <= 4 and FUSED_ANCHOR_BWD:
-            # fused: M1[m] already holds dL/dS_m + beta_m dL/dS_J, dL/dbeta comes out directly; no joint operand / stash
-            m1 = [torch.empty((A, max(ns, 1)), device=dev, dtype=torch.float32) for _ in range(M)]
-            gs = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)     # + one block: float copy of 1/(sums+eps)
+        # The anchors x anchors backward runs one anchor-row block [lo, hi) at a time: the kernel writes the block's
+        # transposed coefficient stash M1[m] [A, hi-lo], two GEMMs turn it into dX1 / dX2, the next block reuses the
+        # buffers -- memory O(A*D + STASH_BYTES), never A x A (nothing of that size at configs[2]).
+        fused = M <= 4 and FUSED_ANCHOR_BWD
+        ntab = M if fused else nt
+        chunks = _anchor_chunks(a_lo, a_hi, A, ntab)
+        gs = torch.zeros((nt, 8), device=dev, dtype=torch.float64)
+        if fused:
+            gsc = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)     # + one block: float copy of 1/(sums+eps)
             gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
-            _lib.check(L.sga_loss_anchor_multi_bwd(_ptr_array(zs), M, _p(beta), A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
-                                                   _ptr_array(m1), _p(gs), _p(gam2), a_lo, a_hi, st), 'sga_loss_anchor_multi_bwd')
-            gs = _allreduce_sum(gs[0].contiguous(), ctx.reduce)
-            if A > 0 and ns > 0:
-                gam_anc = gam2[0]
-                for k in range(M):
-                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), a_lo, a_hi, st), 'sga_loss_stash_grad')
-                    m1[k] = None
+            gam_acc = torch.zeros((M,), device=dev, dtype=torch.float64)
         else:
-            m1 = [torch.empty((A, max(ns, 1)), device=dev, dtype=torch.float32) for _ in range(nt)]
-            gs = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
+            gsc = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
             dps = [dp] * M + [M * dp]
-            _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
-                                             TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gs), a_lo, a_hi, st), 'sga_loss_anchor_bwd')
-            gs = _allreduce_sum(gs[0].contiguous(), ctx.reduce)          # dL/d(global sums) needs every shard's tiles
-            if A > 0 and ns > 0:
-                for k in range(M):
-                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), a_lo, a_hi, st), 'sga_loss_stash_grad')
-                    m1[k] = None
-                dzj = torch.zeros((2 * A, M * dp), device=dev, dtype=torch.float32)
-                _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), a_lo, a_hi, st), 'sga_loss_stash_grad')
-                m1[M] = None
+            dzj = torch.zeros((2 * A, M * dp), device=dev, dtype=torch.float32) if chunks else None
+        if chunks:
+            cmax = max(hi - lo for lo, hi in chunks)
+            m1 = [torch.empty((A * cmax,), device=dev, dtype=torch.float32) for _ in range(ntab)]
+        for lo, hi in chunks:
+            if fused:
+                # M1[m] already holds dL/dS_m + beta_m dL/dS_J, dL/dbeta comes out directly; no joint operand / stash
+                _lib.check(L.sga_loss_anchor_multi_bwd(_ptr_array(zs), M, _p(beta), A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
+                                                       _ptr_array(m1), _p(gsc), _p(gam2), lo, hi, st), 'sga_loss_anchor_multi_bwd')
+                gam_acc += gam2[0]
+            else:
+                _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
+                                                 TAU_ICL, TAU_IAL, _p(coef), _ptr_array(m1), _p(gsc), lo, hi, st), 'sga_loss_anchor_bwd')
+                _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), lo, hi, st), 'sga_loss_stash_grad')
+            gs += gsc[0]
+            for k in range(M):
+                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
+        if chunks:
+            del m1
+            if fused:
+                gam_anc = gam_acc
+            else:
                 gam_sq = torch.zeros((M,), device=dev, dtype=torch.float64)
                 _lib.check(L.sga_loss_fold_joint(_ptr_array(zs), M, _p(beta), _p(dzj), 2 * A, _ptr_array(dzs), _p(gam_sq), st),
                            'sga_loss_fold_joint')
                 gam_anc = gam_sq / (2.0 * torch.sqrt(beta.double()))     # through sqrt(beta_m) in the anchor rows of ZJ
+                del dzj
+        gs = _allreduce_sum(gs, ctx.reduce)                              # dL/d(global sums) needs every shard's tiles
         ev = None
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -44,7 +44,8 @@ class AlignerSteps:
     val_step = train_step
 
     def test_step(self, iteration, data_dict):
-        return self.model(data_dict)
+        with torch.no_grad():                       # the reference's tester runs under set_eval_mode / no_grad (single_tester.py:52-63)
+            return self.model(data_dict)
 
     def eval_step(self, iteration, data_dict, output_dict, all_k=(1, 2, 3, 4, 5), reg_k=0):
         emb = output_dict['joint'] if len(self.modules) > 1 else output_dict[self.modules[0]]

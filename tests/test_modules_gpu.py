@@ -276,3 +276,35 @@ def test_train_step_other_embedding_widths(emb):
         if name in grads_o and p.grad is not None:
             ref = grads_o[name]
             assert (p.grad.cpu() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item()), name
+
+
+@pytest.mark.parametrize('mods', [['point', 'gat', 'rel'], ['point']])
+def test_backward_retain_graph_twice_like_the_reference_engine(mods):
+    """src/engine/epoch_based_trainer.py:93 calls `result_dict['loss'].backward(retain_graph=True)`: every saved buffer must
+    survive a backward (nothing saved is mutated or freed), so a second backward over the same graph doubles the gradients
+    exactly as autograd's accumulation semantics say, and a fresh forward/backward reproduces the first one."""
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    dd = to_device(make_batch(3, 10, 32, seed=9, ragged=True), 'cuda')
+    steps = AlignerSteps(mods, device='cuda', seed=1)
+    steps.zero_grad()
+    output_dict, result_dict = steps.train_step(0, 0, dd)
+    result_dict['loss'].backward(retain_graph=True)
+    torch.cuda.synchronize()
+    g1 = {n: p.grad.clone() for n, p in steps.model.named_parameters() if p.grad is not None}
+    assert g1 and all(torch.isfinite(g).all() for g in g1.values())
+    result_dict['loss'].backward(retain_graph=True)                       # second pass over the retained graph
+    torch.cuda.synchronize()
+    for n, p in steps.model.named_parameters():
+        if n in g1:
+            sc = g1[n].abs().max().item()
+            assert (p.grad - 2 * g1[n]).abs().max().item() <= 2e-5 * max(1.0, sc), n      # fp32 atomics reorder sums
+    steps.zero_grad()
+    _, r2 = steps.train_step(0, 0, dd)
+    r2['loss'].backward()
+    torch.cuda.synchronize()
+    assert abs(r2['loss'].item() - result_dict['loss'].item()) <= 1e-6 * abs(r2['loss'].item())
+    for n, p in steps.model.named_parameters():
+        if n in g1:
+            sc = g1[n].abs().max().item()
+            assert (p.grad - g1[n]).abs().max().item() <= 2e-5 * max(1.0, sc), n

@@ -1,27 +1,40 @@
 #!/bin/bash
 # HBM traffic of the two dominant kernels: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over
-# `python bench.py --steps 2 --warmup 1` (counters only, no trace domains).  usage: tools/pmc_traffic.sh <out.csv>
+# `python bench.py --config <c2|c3> --steps 2 --warmup 1` (counters only, no trace domains).
+# usage: tools/pmc_traffic.sh <c2|c3> <out.csv>   (rows are APPENDED; bench.py reads profiles/r02_pmc_traffic.csv)
+# row: kernel;workload_key;sha16(kernel source);counter;avg KiB per dispatch;launches  -- bench.py uses a row only when the
+# workload key matches what it runs and the source file is unchanged since the pass.
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=$1
-echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex 'sweep16_kernel<3, true>|pointnet_fwd_kernel'), bench.py --steps 2 --warmup 1" > $out
-echo "# unit: KiB per dispatch (average over the profiled launches); gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -> bytes = (2*FETCH + WRITE) * 1024" >> $out
-echo "kernel,counter,avg_kib_per_launch,launches" >> $out
+cfg=$1
+out=$2
+if [ ! -f "$out" ]; then
+  echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex 'sweep.*_kernel<3, true>|pointnet_fwd_kernel'), bench.py --config <cfg> --steps 2 --warmup 1" > $out
+  echo "# unit: KiB per dispatch (average over the profiled launches); gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -> bytes = (2*FETCH + WRITE) * 1024" >> $out
+  echo "kernel;workload_key;source_sha16;counter;avg_kib_per_launch;launches" >> $out
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-include-regex 'sweep16_kernel<3, true>|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_$c -- python bench.py --steps 2 --warmup 1 < /dev/null > gpurun_out/pmc_t_$c.log 2>&1
-  python - $c >> $out <<'PY'
-import csv, glob, sys, collections
-c = sys.argv[1]
+  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, true>|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
+  python - $c $cfg >> $out <<'PY'
+import csv, glob, sys, collections, hashlib
+c, cfg = sys.argv[1], sys.argv[2]
+sha = lambda f: hashlib.sha256(open('sgaligner_amd/csrc/' + f, 'rb').read()).hexdigest()[:16]
+keys = {'c2': ('T=65536,P=512', 'ns=9728,A=9728,J=46080'), 'c3': ('T=1048576,P=512', 'ns=155648,A=155648,J=737280')}[cfg]
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
-for f in glob.glob(f'gpurun_out/pmc_t_{c}/**/*counter_collection.csv', recursive=True):
+for f in glob.glob(f'gpurun_out/pmc_t_{cfg}_{c}/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != c:
             continue
-        k = 'pointnet_fwd_kernel' if 'pointnet_fwd' in r['Kernel_Name'] else 'sweep16_kernel<3,true>'
+        name = r['Kernel_Name']
+        if 'pointnet_fwd' in name:
+            k = ('pointnet_fwd_kernel', keys[0], sha('pointnet.hip'))
+        else:
+            base = name.split('(')[0].split('<')[0].split('::')[-1].split(' ')[-1]
+            k = (base + '<3,true>', keys[1], sha('contrastive.hip'))
         acc[k] += float(r['Counter_Value']); n[k] += 1
 for k in sorted(acc):
-    print(f'{k},{c},{acc[k] / n[k]:.4f},{n[k]}')
+    print(f'{k[0]};{k[1]};{k[2]};{c};{acc[k] / n[k]:.4f};{n[k]}')
 PY
 done
 cat $out
