@@ -35,10 +35,25 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _all_gather_flat(out, inp):
+    """out [world * n, ...] = cat of every rank's inp [n, ...].  RCCL: one all_gather_into_tensor; gloo (CPU and the
+    shared-GPU tests): the list form, which it supports for host and device tensors alike."""
+    if dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(out, inp)
+    else:
+        n = inp.shape[0]
+        dist.all_gather([out[r * n:(r + 1) * n] for r in range(dist.get_world_size())], inp)
+
+
+def _has_reduce_scatter():
+    return dist.get_backend() == 'nccl'          # RCCL; gloo (CPU / shared-GPU tests) has no reduce-scatter
+
+
 class AllGatherRows(torch.autograd.Function):
     """out = cat_r(x_r) along dim 0 (ranks may hold different row counts).  Backward: every rank holds
-    dL/d(out) of ITS OWN loss replica/shard; the gradient of the summed objective wrt x_r is the sum
-    over ranks of the corresponding row block -> all-reduce(sum) then slice (== reduce-scatter)."""
+    dL/d(out) of ITS OWN loss replica/shard; the gradient of the summed objective wrt x_r is the sum over ranks of
+    the corresponding row block -> ONE reduce-scatter (RCCL), each rank receiving only its own rows: half the bytes on
+    the wire of all-reduce + slice (2.5 GB -> 1.26 GB per rank at configs[2]).  gloo falls back to all-reduce + slice."""
 
     @staticmethod
     def forward(ctx, x, rows_per_rank, reduce_grad):
@@ -49,6 +64,10 @@ class AllGatherRows(torch.autograd.Function):
         pad = x
         if x.shape[0] < mx:
             pad = torch.cat([x, x.new_zeros((mx - x.shape[0],) + tuple(x.shape[1:]))])
+        if all(n == mx for n in ctx.rows):           # the usual case (equal shards): gather straight into the result
+            out = torch.empty((world * mx,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+            _all_gather_flat(out, pad.contiguous())
+            return out
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad.contiguous())
         return torch.cat([b[:n] for b, n in zip(bufs, ctx.rows)])
@@ -56,18 +75,74 @@ class AllGatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        if ctx.reduce_grad:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        lo = sum(ctx.rows[:ctx.rank])
-        return g[lo:lo + ctx.rows[ctx.rank]], None, None
+        rows, rank = ctx.rows, ctx.rank
+        lo = sum(rows[:rank])
+        if not ctx.reduce_grad:
+            return g[lo:lo + rows[rank]], None, None
+        if _has_reduce_scatter():
+            world, mx = len(rows), max(rows)
+            if all(n == mx for n in rows):
+                inp = g
+            else:                                    # ragged shards: blocks padded to the largest one
+                inp = g.new_zeros((world * mx,) + tuple(g.shape[1:]))
+                o = 0
+                for r, n in enumerate(rows):
+                    inp[r * mx:r * mx + n] = g[o:o + n]
+                    o += n
+            out = torch.empty((mx,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+            return out[:rows[rank]], None, None
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g[lo:lo + rows[rank]], None, None
 
 
 def gather_tables(output_dict, rows_per_rank, reduce_grad):
     return {k: AllGatherRows.apply(v, rows_per_rank, reduce_grad) for k, v in output_dict.items()}
 
 
+def gather_batch_layout(data_dict, device):
+    """ONE small integer all-gather per step: every rank's (object rows, |e1i|, |e1j|, |e2j|) -> [world, 4] on the host.
+    (Replaces two pickled all_gather_object calls; the read-back of 4*world integers is the step's only host sync.)"""
+    world = dist.get_world_size()
+    mine = torch.tensor([int(data_dict['tot_obj_pts'].shape[0]), len(data_dict['e1i']), len(data_dict['e1j']),
+                         len(data_dict['e2j'])], dtype=torch.int64, device=device)
+    if len(data_dict['e1i']) != len(data_dict['e2i']):
+        raise RuntimeError('sgaligner_amd: e1i and e2i must have the same length')
+    out = torch.empty((world * 4,), dtype=torch.int64, device=device)
+    _all_gather_flat(out, mine)
+    return out.view(world, 4).cpu().numpy()
+
+
+def gather_index_sets_device(data_dict, layout, device):
+    """Global packed index array [e1i | e2i | e1j | e2j] of ALL ranks, built on the device from one int32 all-gather of
+    the ranks' local packed arrays (offset by the ranks' object counts): what ops.IndexSets holds for the global batch.
+    Returns (idx int32 [R], A, J1, J2)."""
+    world = dist.get_world_size()
+    local = np.concatenate([np.asarray(data_dict[k]).astype(np.int32).reshape(-1) for k in ('e1i', 'e2i', 'e1j', 'e2j')])
+    lens = layout[:, 1] * 2 + layout[:, 2] + layout[:, 3]
+    mx = int(lens.max()) if world else 0
+    buf = torch.zeros((max(mx, 1),), dtype=torch.int32, device=device)
+    if local.size:
+        buf[:local.size] = torch.from_numpy(local).to(device)
+    allb = torch.empty((world * max(mx, 1),), dtype=torch.int32, device=device)
+    _all_gather_flat(allb, buf)
+    allb = allb.view(world, max(mx, 1))
+    offs = np.concatenate([[0], np.cumsum(layout[:, 0])])
+    parts = [[], [], [], []]
+    for r in range(world):
+        a, j1, j2 = int(layout[r, 1]), int(layout[r, 2]), int(layout[r, 3])
+        cuts = [0, a, 2 * a, 2 * a + j1, 2 * a + j1 + j2]
+        for q in range(4):
+            if cuts[q + 1] > cuts[q]:
+                parts[q].append(allb[r, cuts[q]:cuts[q + 1]] + int(offs[r]))
+    flat = [t for q in parts for t in q]
+    idx = torch.cat(flat) if flat else torch.zeros((0,), dtype=torch.int32, device=device)
+    return idx.contiguous(), int(layout[:, 1].sum()), int(layout[:, 2].sum()), int(layout[:, 3].sum())
+
+
 def gather_index_sets(data_dict, rows_per_rank):
-    """Global e1i/e2i/e1j/e2j (host numpy) from every rank's local ones, offset by the ranks' object counts."""
+    """Global e1i/e2i/e1j/e2j (host numpy) from every rank's local ones, offset by the ranks' object counts
+    (host-side variant for callers that need numpy arrays, e.g. the M == 1 replica path and the CPU tests)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     local = {k: np.asarray(data_dict[k]).astype(np.int64) for k in ('e1i', 'e2i', 'e1j', 'e2j')}
     gathered = [None] * world

@@ -271,7 +271,21 @@ class IndexSets:
     _cache = _SmallCache()
 
     @staticmethod
+    def from_device(idx, A, J1, J2):
+        """Wrap an already-packed device index array (the multi-GPU path gathers it on the device, dist.py)."""
+        s = IndexSets.__new__(IndexSets)
+        s.A, s.J1, s.J2 = int(A), int(J1), int(J2)
+        s.R = 2 * s.A + s.J1 + s.J2
+        if idx.dtype != torch.int32 or idx.numel() != s.R:
+            raise RuntimeError('sgaligner_amd: packed index array must be int32 of length 2A+J1+J2')
+        s.idx = idx.contiguous()
+        return s
+
+    @staticmethod
     def of(data_dict, device, n_rows=None):
+        pre = data_dict.get('_sga_index_sets') if isinstance(data_dict, dict) else None
+        if pre is not None:                          # set only by AlignerSteps._global_loss in its OWN dict
+            return pre
         device = torch.device(device)
         key = _fingerprint([_np.asarray(data_dict[k]) for k in ('e1i', 'e2i', 'e1j', 'e2j')], (str(device), n_rows))
         return IndexSets._cache.get(key, lambda: IndexSets(data_dict, device, n_rows))

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 
 from . import dist as sdist
+from . import ops
 from .aligner.losses import CustomMultiLossLayer, OverallLoss
 from .aligner.sg_aligner import MultiModalEncoder
 from .utils import alignment
@@ -77,13 +78,12 @@ class AlignerSteps:
         global loss value) and its share of dL/dE for all rows, summed over ranks in AllGatherRows.backward.
         M == 1: every rank evaluates the (small) global loss as a replica and keeps only its own rows' gradient."""
         world, rank = dist.get_world_size(), dist.get_rank()
-        t_local = int(data_dict['tot_obj_pts'].shape[0])
-        info = [None] * world
-        dist.all_gather_object(info, (t_local, int(len(data_dict['e1i']))))
-        rows = [i[0] for i in info]
-        anchors = [i[1] for i in info]
+        layout = sdist.gather_batch_layout(data_dict, self.device)          # [world, 4]: rows, |e1i|, |e1j|, |e2j|
+        rows = [int(v) for v in layout[:, 0]]
+        anchors = [int(v) for v in layout[:, 1]]
         sharded = len(self.modules) > 1
-        gdd = sdist.gather_index_sets(data_dict, rows)
+        idx, A, J1, J2 = sdist.gather_index_sets_device(data_dict, layout, self.device)
+        gdd = {'_sga_index_sets': ops.IndexSets.from_device(idx, A, J1, J2)}   # our own dict, never the caller's
         if sharded:
             # only the M modality tables travel: the fused loss derives every joint similarity from them (S_J = sum beta_m
             # S_m with the replicated fusion weight), so the 100*M-wide joint table is neither gathered nor reduced --

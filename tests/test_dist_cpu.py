@@ -44,6 +44,12 @@ def _worker(rank, world, port, out):
         gidx = sdist.gather_index_sets(local, rows)
         for k in ('e1i', 'e2i', 'e1j', 'e2j'):
             assert np.array_equal(gidx[k], full[k]), k
+        # (1b) the per-step variant: one int all-gather for the layout, one for the packed index arrays
+        layout = sdist.gather_batch_layout(local, 'cpu')
+        assert layout[:, 0].tolist() == rows and int(layout[:, 1].sum()) == len(full['e1i'])
+        idx, A, J1, J2 = sdist.gather_index_sets_device(local, layout, 'cpu')
+        assert (A, J1, J2) == (len(full['e1i']), len(full['e1j']), len(full['e2j']))
+        assert np.array_equal(idx.numpy(), np.concatenate([full[k] for k in ('e1i', 'e2i', 'e1j', 'e2j')]))
         # (2) table all-gather + loss replica + backward into own rows == single-process gradient
         torch.manual_seed(0)
         table = torch.randn(int(offs[-1]), 16, dtype=torch.float64)

@@ -1,0 +1,142 @@
+"""The REAL one-process-per-GPU path under the driver's GPU test tier: 2 ranks (torch.multiprocessing spawn, gloo backend,
+both on cuda:0 -- the box has one GPU; on a multi-GPU node the same code runs over RCCL) each take a contiguous block of the
+pairs of ONE global batch and run AlignerSteps.forward_backward: layout + index-set all-gathers, table all-gather,
+anchor-sharded global loss with its three scalar all-reduces, reduce of dL/dE to the owning rank, flat parameter-gradient
+all-reduce.  Loss and EVERY parameter gradient must equal the single-process result on the full batch (M = 3 and M = 1,
+even and uneven pair splits incl. a rank with zero pairs), and two accumulated micro-steps must equal their single-process
+sum (EpochBasedTrainer with grad_acc_steps = 2)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mods, n_pairs, cuts, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sgaligner_amd import dist as sdist
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda', 0)
+        full = to_device(make_batch(n_pairs, 14, 48, seed=21, ragged=True), dev)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        mine = sdist.shard_data_dict(full, lo, hi)
+        steps = AlignerSteps(mods, device=dev, seed=42)
+        _, loss = steps.forward_backward(mine)
+        torch.cuda.synchronize()
+        res = {'loss': float(loss['loss'].item())}
+        for n, p in steps.model.named_parameters():
+            if p.grad is not None:
+                res['g:' + n] = p.grad.detach().cpu()
+        for tag, layer in (('ial', steps.multi_loss_layer_ial), ('icl', steps.multi_loss_layer_icl)):
+            for p in layer.parameters():
+                if p.grad is not None:
+                    res['lv:' + tag] = p.grad.detach().cpu()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def _single(mods, n_pairs):
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    full = to_device(make_batch(n_pairs, 14, 48, seed=21, ragged=True), 'cuda')
+    ref = AlignerSteps(mods, device='cuda', seed=42)
+    _, loss = ref.forward_backward(full)
+    torch.cuda.synchronize()
+    return ref, loss
+
+
+@pytest.mark.parametrize('mods,n_pairs,cuts', [(['point', 'gat', 'rel'], 6, [0, 3, 6]), (['point', 'gat', 'rel'], 5, [0, 4, 5]),
+                                               (['point'], 6, [0, 3, 6]), (['point', 'gat', 'rel'], 4, [0, 4, 4])])
+def test_two_ranks_equal_single_process(mods, n_pairs, cuts):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), mods, n_pairs, cuts, out), nprocs=world, join=True)
+    ref, loss = _single(mods, n_pairs)
+    for rank in range(world):
+        r = out[rank]
+        assert abs(r['loss'] - loss['loss'].item()) <= 1e-5 * max(1.0, abs(loss['loss'].item())), (rank, r['loss'], loss['loss'].item())
+        seen = 0
+        for n, p in ref.model.named_parameters():
+            if p.grad is None:
+                continue
+            g = r['g:' + n]
+            sc = p.grad.abs().max().item()
+            assert (g - p.grad.cpu()).abs().max().item() <= 1e-4 * max(1.0, sc), (rank, n)
+            seen += 1
+        assert seen >= 8
+        if len(mods) > 1:
+            for tag, layer in (('ial', ref.multi_loss_layer_ial), ('icl', ref.multi_loss_layer_icl)):
+                a = next(layer.parameters()).grad.cpu()
+                assert (r['lv:' + tag] - a).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), (rank, tag)
+
+
+def _acc_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from sgaligner_amd.epoch_trainer import EpochBasedTrainer
+    from sgaligner_amd.synthetic import make_batch
+    from sgaligner_amd.trainer import AlignerSteps
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        steps = AlignerSteps(['point', 'gat', 'rel'], device='cuda', seed=42)
+        tr = EpochBasedTrainer(steps, output_dir=f'/tmp/sga_acc_{port}', max_epoch=1, lr=0.0, grad_acc_steps=2, log_steps=100)
+        batches = [make_batch(4, 10, 32, seed=50 + i) for i in range(2)]
+        grads = {}
+        tr._optimizer_step = lambda it: grads.update({n: p.grad.detach().cpu().clone() for n, p in steps.model.named_parameters()
+                                                      if p.grad is not None}) if it % 2 == 0 else None
+        tr.register_loader(batches, batches)
+        tr.train_epoch()
+        out[rank] = grads
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_accumulation_two_ranks_equals_single_process_sum():
+    """with grad_acc_steps = 2 under two ranks the gradient the optimiser sees must be G1 + G2 of the global
+    batches (one reduce per optimiser step), not world*G1 + G2."""
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_acc_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    ref = AlignerSteps(['point', 'gat', 'rel'], device='cuda', seed=42)
+    ref.zero_grad()
+    for i in range(2):
+        dd = to_device(make_batch(4, 10, 32, seed=50 + i), 'cuda')
+        o, l = ref.train_step(0, 0, dd)
+        l['loss'].backward()
+    torch.cuda.synchronize()
+    for rank in range(world):
+        g = out[rank]
+        assert g, 'optimizer step never reached'
+        for n, p in ref.model.named_parameters():
+            if p.grad is not None:
+                sc = p.grad.abs().max().item()
+                assert (g[n] - p.grad.cpu()).abs().max().item() <= 1e-4 * max(1.0, sc), (rank, n)
