@@ -120,6 +120,23 @@ int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const f
 /* *poison = NaN if any row norm is below F.normalize's eps (the identity above would not hold): fail loudly */
 int sga_loss_check_norms(const float* nrm, int n, float* poison, void* stream);
 
+/* ---- loss_group = b: the same loss on G independent groups of b consecutive pairs ------------------------
+ * replaces the reference trainer feeding b pairs per iteration (configs/scan3r/scan3r_ground_truth.yaml:27,
+ * src/engine/epoch_based_trainer.py:91-93 -> src/aligner/losses.py:114-152) for all B/b groups of a device batch at once:
+ * out[g] / gradients equal OverallLoss's raw terms evaluated on group g alone (its anchors against ITS negatives only).
+ * Z[m] [R, 104] packed normalised tables (sga_loss_gather, Dp = 104), rows X1 | X2 | N1 | N2; beta [M] as in the fused
+ * global path (NULL for M == 1: ICL only).  groups [G][8] int32 = {first anchor, #anchors, first N1 row, #N1, first N2
+ * row, #N2, 0, 0} (contiguous ranges inside [0,A) / [0,J1) / [0,J2)); s_off [G+1] int64 float offsets of the groups'
+ * similarity blocks [2 na, na+nj1+nj2] inside one table's slab of S [M][s_total].  sums [G][NT][8], out [G][NT+2M]
+ * (NT = M+1, or 1 and no IAL columns when M == 1).  bwd: coef [G][NT+2M] = dL/d(out); S (as left by fwd) is overwritten
+ * with dL/dS; dZ[m] += this batch's gradient (every packed row has one writer); gamma [G][M] = dL/dbeta per group. */
+int sga_group_loss_fwd(const float* const* Z, int M, const float* beta, int A, int J1, const int32_t* groups, int G,
+                       const int64_t* s_off, int64_t s_total, float alpha, float tau_icl, float tau_ial, float* S,
+                       double* sums, double* out, void* stream);
+int sga_group_loss_bwd(const float* const* Z, int M, const float* beta, int A, int J1, const int32_t* groups, int G,
+                       const int64_t* s_off, int64_t s_total, float alpha, float tau_icl, float tau_ial, float* S,
+                       const double* sums, const float* coef, float* const* dZ, double* gamma, void* stream);
+
 /* ---- per-pair similarity + ranking --------------------------------------------------------------------
  * replaces eval_step's emb/||emb||, sim = 1 - emb emb^T, argsort (src/inference/sgaligner/inference_align_reg.py:
  * 125-128) fused with the rank look-ups of utils/alignment.py:3-25,27-41,59-70.  For query object q_idx[q] of pair

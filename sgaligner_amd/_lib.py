@@ -58,6 +58,8 @@ SIGNATURES = {
     'sga_loss_anchor_multi_fwd': (I, [P, I, P, I, P, F, F, F, P, I, I, P]),
     'sga_loss_anchor_multi_bwd': (I, [P, I, P, I, P, F, F, F, P, P, P, P, I, I, P]),
     'sga_loss_stash_grad': (I, [P, P, I, I, P, I, I, P]),
+    'sga_group_loss_fwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, P]),
+    'sga_group_loss_bwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, P, P, P]),
     'sga_fusion_fwd': (I, [P, I, P, P, I, I, P]),
     'sga_fusion_bwd_workspace_bytes': (c_size_t, [I]),
     'sga_fusion_bwd': (I, [P, I, P, P, P, P, I, I, P, c_size_t, P]),

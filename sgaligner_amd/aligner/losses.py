@@ -54,6 +54,13 @@ class IALLoss(nn.Module):
 
 
 class OverallLoss(nn.Module):
+    """losses.py:99-152.  `loss_group` (metadata['loss_group'] or the attribute; default 'global') selects what "the batch"
+    of the loss is:
+      'global' -- one loss over all pairs of the batch (the reference's semantics applied to the whole device batch);
+      b (int)  -- the batch is cut into groups of b consecutive pairs and the reference's loss is evaluated on every group
+                  independently (its anchors against ITS negatives only); every returned value is the SUM over groups, i.e.
+                  exactly what the reference accumulates when it is fed b pairs per iteration (scan3r_ground_truth.yaml:27)."""
+
     def __init__(self, ial_loss_layer, icl_loss_layer, device, metadata):
         super().__init__()
         self.zoom = metadata['zoom']
@@ -61,22 +68,33 @@ class OverallLoss(nn.Module):
         self.modules = metadata['modules']
         self.weight_align_loss = metadata['wt_align_loss']            # stored, unused (as in the reference)
         self.weight_contrastive_loss = metadata['wt_contrastive_loss']
+        self.loss_group = metadata.get('loss_group', 'global')
         self.align_loss = IALLoss(device)
         self.contrastive_loss = ICLLoss(self.device)
         self.align_multi_loss_layer = ial_loss_layer
         self.contrastive_multi_loss_layer = icl_loss_layer
 
     def forward(self, output_dict, data_dict):
+        if self.loss_group not in (None, 'global'):
+            return self._forward_groups(output_dict, data_dict, int(self.loss_group))
+        return self._forward_global(output_dict, data_dict)
+
+    def _fusion_source(self, output_dict, mods):
+        m = len(mods)
+        tabs = [output_dict[k] for k in mods]
+        src = getattr(output_dict['joint'], '_sga_fusion', None)
+        fused = (src is not None and FUSED_JOINT and 2 <= m <= 4 and len(src[1]) == m
+                 and all(a is b for a, b in zip(src[1], tabs)) and all(t.shape[1] <= 104 for t in tabs))
+        return tabs, (src if fused else None)
+
+    def _forward_global(self, output_dict, data_dict):
         mods = list(self.modules)
         m = len(mods)
         if m > 1:
             # one fused pass over all M+1 tables: every similarity tile is computed once and shared by
             # ICL_m, ICL_joint and IAL_m (the reference recomputes the joint table's q's M times)
-            tabs = [output_dict[k] for k in mods]
-            src = getattr(output_dict['joint'], '_sga_fusion', None)
-            fused = (src is not None and FUSED_JOINT and 2 <= m <= 4 and len(src[1]) == m
-                     and all(a is b for a, b in zip(src[1], tabs)) and all(t.shape[1] <= 104 for t in tabs))
-            if fused:      # the joint table IS the fusion of these tables: never multiply the 100*M-d table
+            tabs, src = self._fusion_source(output_dict, mods)
+            if src is not None:      # the joint table IS the fusion of these tables: never multiply the 100*M-d table
                 sums, s = ops.fused_contrastive_terms(tabs, src[0], data_dict, alpha=self.contrastive_loss.alpha,
                                                       shard=data_dict.get('_sga_shard'), reduce=data_dict.get('_sga_reduce'))
             else:          # arbitrary joint table: treat it as an independent (M+1)-th table
@@ -96,5 +114,39 @@ class OverallLoss(nn.Module):
             total_align_loss = 0.0
             icl_multi = 0.0
             icl_uni = self.contrastive_loss(output_dict[mods[0]], data_dict)
+            loss = icl_uni
+        return {'loss': loss, 'icl_loss_unimodal': icl_uni, 'icl_loss_multimodal': icl_multi, 'ial_loss': total_align_loss}
+
+    def _forward_groups(self, output_dict, data_dict, b):
+        mods = list(self.modules)
+        m = len(mods)
+        if data_dict.get('_sga_shard') is not None:
+            raise RuntimeError('sgaligner_amd: loss_group=b groups never cross ranks; evaluate it on the local batch')
+        if m > 1:
+            tabs, src = self._fusion_source(output_dict, mods)
+            if src is None:
+                # arbitrary joint tensor: the reference's loop, literally -- one global-loss evaluation per group
+                tot = None
+                for gd in ops.group_data_dicts(data_dict, b):
+                    r = self._forward_global(output_dict, gd)
+                    tot = r if tot is None else {k: tot[k] + r[k] for k in r}
+                return tot
+            out, gr = ops.grouped_contrastive_terms(tabs, src[0], data_dict, b, alpha=self.contrastive_loss.alpha)
+            nt = m + 1
+            a2 = (gr.na * gr.na).unsqueeze(1)                                  # .mean() over each group's A_g x A_g matrix
+            icl = out[:, :nt] / a2
+            al = self.align_loss
+            ial = al.zoom * (al.alpha * out[:, nt:nt + m] + (1 - al.alpha) * out[:, nt + m:nt + 2 * m])
+            ml_a, ml_c = self.align_multi_loss_layer, self.contrastive_multi_loss_layer
+            # sum over groups of CustomMultiLossLayer: sum_m exp(-lv_m) * (sum_g x_gm) + G * lv_m
+            total_align_loss = ((torch.exp(-ml_a.log_vars) * ial.sum(0)).sum() + gr.G * ml_a.log_vars.sum()) * self.zoom
+            icl_uni = (torch.exp(-ml_c.log_vars) * icl[:, :m].sum(0)).sum() + gr.G * ml_c.log_vars.sum()
+            icl_multi = icl[:, m].sum()
+            loss = total_align_loss + icl_uni + icl_multi
+        else:
+            out, gr = ops.grouped_contrastive_terms([output_dict[mods[0]]], None, data_dict, b, alpha=self.contrastive_loss.alpha)
+            total_align_loss = 0.0
+            icl_multi = 0.0
+            icl_uni = (out[:, 0] / (gr.na * gr.na)).sum()
             loss = icl_uni
         return {'loss': loss, 'icl_loss_unimodal': icl_uni, 'icl_loss_multimodal': icl_multi, 'ial_loss': total_align_loss}

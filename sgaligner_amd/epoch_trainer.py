@@ -199,10 +199,7 @@ class EpochBasedTrainer:
                 # Reduce ONCE per optimiser step, on the locally accumulated gradients of all its micro-steps (reducing
                 # every micro-step in place would re-sum the already-reduced part: world*G1 + G2).  log_vars see the
                 # full (replicated) loss on every rank, everything else only this rank's rows -> pre-divide log_vars.
-                for p in list(self.steps.multi_loss_layer_ial.parameters()) + list(self.steps.multi_loss_layer_icl.parameters()):
-                    if p.grad is not None:
-                        p.grad /= self.world
-                sdist.allreduce_grads(self.steps.params)
+                self.steps.reduce_grads()
             self.after_backward(self.epoch, self.inner_iteration, data_dict, output_dict, result_dict)
             self.check_gradients(self.epoch, self.inner_iteration, data_dict, output_dict, result_dict)
             self._optimizer_step(self.inner_iteration)

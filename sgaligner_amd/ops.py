@@ -415,6 +415,145 @@ def contrastive_terms(tables, data_dict, alpha=ALPHA):
     return ContrastiveTermsFn.apply(s, alpha, *tables), s
 
 
+# ------------------------------------------------------------------------------------------ loss_group = b
+class LossGroups:
+    """Partition of a batch's pairs into groups of `b` consecutive pairs (the reference's training batches,
+    configs/scan3r/scan3r_ground_truth.yaml:27): per group the contiguous ranges it occupies in the packed
+    anchor / N1 / N2 row blocks, and the offsets of its similarity blocks.  Built from the per-pair counts the
+    collate provides (scan3r.py:142-173: e1i_count / e1j_count / e2j_count)."""
+
+    def __init__(self, data_dict, b, device):
+        ca = _np.asarray(data_dict['e1i_count']).reshape(-1).astype(_np.int64)
+        c1 = _np.asarray(data_dict['e1j_count']).reshape(-1).astype(_np.int64)
+        c2 = _np.asarray(data_dict['e2j_count']).reshape(-1).astype(_np.int64)
+        if not (len(ca) == len(c1) == len(c2)):
+            raise RuntimeError('sgaligner_amd: e1i_count / e1j_count / e2j_count disagree')
+        if int(b) < 1:
+            raise RuntimeError(f'sgaligner_amd: loss_group must be a positive number of pairs (got {b})')
+        B = len(ca)
+        cuts = list(range(0, B, int(b))) + [B]
+        oa, o1, o2 = (_np.concatenate([[0], _np.cumsum(c)]) for c in (ca, c1, c2))
+        g = _np.zeros((len(cuts) - 1, 8), dtype=_np.int32)
+        for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+            g[k, :6] = (oa[lo], oa[hi] - oa[lo], o1[lo], o1[hi] - o1[lo], o2[lo], o2[hi] - o2[lo])
+        size = 2 * g[:, 1].astype(_np.int64) * (g[:, 1].astype(_np.int64) + g[:, 3] + g[:, 5])
+        soff = _np.concatenate([[0], _np.cumsum(size)]).astype(_np.int64)
+        self.G, self.b = int(g.shape[0]), int(b)
+        self.host = g
+        self.s_total = int(soff[-1])
+        self.groups = torch.from_numpy(g).to(device)
+        self.soff = torch.from_numpy(soff).to(device)
+        self.na = torch.from_numpy(g[:, 1].astype(_np.float32)).to(device)
+        self.totals = (int(oa[-1]), int(o1[-1]), int(o2[-1]))
+
+    _cache = _SmallCache()
+
+    @staticmethod
+    def of(data_dict, b, device):
+        device = torch.device(device)
+        key = _fingerprint([_np.asarray(data_dict[k]) for k in ('e1i_count', 'e1j_count', 'e2j_count')], (str(device), int(b)))
+        return LossGroups._cache.get(key, lambda: LossGroups(data_dict, b, device))
+
+
+class GroupedContrastiveFn(torch.autograd.Function):
+    """Raw loss terms of every loss group: out [G, NT + 2M] = [ICL_k sums | IALa_m | IALb_m] (NT = M+1 with the joint
+    table derived from the M modality tables through beta; M == 1 -> ICL of the single table only, beta None).
+    csrc/grouploss.hip: similarity blocks materialised per group (they are reference-sized), one set of launches."""
+
+    @staticmethod
+    def forward(ctx, index_sets, groups, alpha, beta, *tables):
+        L = _lib.lib()
+        M = len(tables)
+        nt = M + 1 if M > 1 else 1
+        no = nt + (2 * M if M > 1 else 0)
+        tables = [_req(t.contiguous(), f'table[{i}]') for i, t in enumerate(tables)]
+        dev = tables[0].device
+        s, gr = index_sets, groups
+        if (s.A, s.J1, s.J2) != gr.totals:
+            raise RuntimeError('sgaligner_amd: per-pair counts (e1i_count/e1j_count/e2j_count) do not add up to the index sets')
+        st = _stream()
+        dp = 104
+        T = tables[0].shape[0]
+        zs, nrms = [], []
+        poison = torch.zeros((1,), device=dev, dtype=torch.float32)
+        for e in tables:
+            d = e.shape[1]
+            if d > dp:
+                raise RuntimeError('sgaligner_amd: loss_group needs emb_dim <= 104')
+            z = torch.empty((max(s.R, 1), dp), device=dev, dtype=torch.float32)
+            nrm = torch.empty((max(s.R, 1),), device=dev, dtype=torch.float32)
+            _lib.check(L.sga_loss_gather(_p(e), T, d, _p(s.idx), s.R, _p(z), dp, _p(nrm), st), 'sga_loss_gather')
+            _lib.check(L.sga_loss_check_norms(_p(nrm), s.R, _p(poison), st), 'sga_loss_check_norms')
+            zs.append(z); nrms.append(nrm)
+        if beta is not None:
+            beta = _req(beta.contiguous(), 'beta')
+        S = torch.empty((M * max(gr.s_total, 1),), device=dev, dtype=torch.float32)
+        sums = torch.empty((max(gr.G, 1), nt, 8), device=dev, dtype=torch.float64)
+        out = torch.zeros((max(gr.G, 1), no), device=dev, dtype=torch.float64)
+        _lib.check(L.sga_group_loss_fwd(_ptr_array(zs), M, _p(beta), s.A, s.J1, _p(gr.groups), gr.G, _p(gr.soff), gr.s_total,
+                                        float(alpha), TAU_ICL, TAU_IAL, _p(S), _p(sums), _p(out), st), 'sga_group_loss_fwd')
+        ctx.s, ctx.gr, ctx.alpha, ctx.M = s, gr, float(alpha), M
+        ctx.shapes = [tuple(t.shape) for t in tables]
+        ctx.has_beta = beta is not None
+        ctx.save_for_backward(S, sums, *( [beta] if beta is not None else []), *zs, *nrms)
+        return out[:gr.G].float() + poison
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        s, gr, M = ctx.s, ctx.gr, ctx.M
+        saved = list(ctx.saved_tensors)
+        S, sums = saved[0], saved[1]
+        beta = saved[2] if ctx.has_beta else None
+        rest = saved[3:] if ctx.has_beta else saved[2:]
+        zs, nrms = rest[:M], rest[M:]
+        dev = S.device
+        st = _stream()
+        dp = 104
+        coef = gout.contiguous().float()
+        C = S.clone()                         # the backward overwrites the similarity blocks: keep the saved ones (retain_graph)
+        dzs = [torch.zeros((max(s.R, 1), dp), device=dev, dtype=torch.float32) for _ in range(M)]
+        gamma = torch.zeros((max(gr.G, 1), M), device=dev, dtype=torch.float64)
+        _lib.check(L.sga_group_loss_bwd(_ptr_array(zs), M, _p(beta), s.A, s.J1, _p(gr.groups), gr.G, _p(gr.soff), gr.s_total,
+                                        ctx.alpha, TAU_ICL, TAU_IAL, _p(C), _p(sums), _p(coef), _ptr_array(dzs), _p(gamma), st),
+                   'sga_group_loss_bwd')
+        grads = []
+        for k in range(M):
+            t, d = ctx.shapes[k]
+            de = torch.zeros((t, d), device=dev, dtype=torch.float32)
+            _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
+            grads.append(de)
+        gbeta = gamma[:gr.G].sum(0).float() if ctx.has_beta else None
+        return (None, None, None, gbeta, *grads)
+
+
+def grouped_contrastive_terms(tables, fusion_weight, data_dict, b, alpha=ALPHA):
+    """tables: the M modality tables (M >= 2: the joint is their fusion with `fusion_weight` [M,1]; M == 1: pass None).
+    Returns (out [G, NT+2M], LossGroups)."""
+    dev = tables[0].device
+    s = IndexSets.of(data_dict, dev, int(tables[0].shape[0]))
+    gr = LossGroups.of(data_dict, b, dev)
+    beta = None
+    if len(tables) > 1:
+        w = torch.softmax(fusion_weight.reshape(-1), dim=0)            # sg_aligner.py:32
+        beta = (w * w) / (w * w).sum()
+    return GroupedContrastiveFn.apply(s, gr, alpha, beta, *tables), gr
+
+
+def group_data_dicts(data_dict, b):
+    """The index sets of every loss group as stand-alone dicts (global object indices kept): what the reference's loss
+    would be handed for that group.  Used by the general (arbitrary joint table) loss_group path and by the tests."""
+    ca, c1, c2 = (_np.asarray(data_dict[k]).reshape(-1) for k in ('e1i_count', 'e1j_count', 'e2j_count'))
+    oa, o1, o2 = (_np.concatenate([[0], _np.cumsum(c)]) for c in (ca, c1, c2))
+    B = len(ca)
+    out = []
+    for lo in range(0, B, int(b)):
+        hi = min(B, lo + int(b))
+        out.append({'e1i': _np.asarray(data_dict['e1i'])[oa[lo]:oa[hi]], 'e2i': _np.asarray(data_dict['e2i'])[oa[lo]:oa[hi]],
+                    'e1j': _np.asarray(data_dict['e1j'])[o1[lo]:o1[hi]], 'e2j': _np.asarray(data_dict['e2j'])[o2[lo]:o2[hi]]})
+    return out
+
+
 # ------------------------------------------------------------------------------------------ GAT
 class GraphBatch:
     """Device-side CSR-style description of the 2B scene graphs of a batch: node/edge offsets in the

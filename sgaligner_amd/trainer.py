@@ -17,7 +17,7 @@ from .utils import alignment
 
 
 class AlignerSteps:
-    def __init__(self, modules, rel_dim=41, attr_dim=164, zoom=0.1, device='cuda', seed=42):
+    def __init__(self, modules, rel_dim=41, attr_dim=164, zoom=0.1, device='cuda', seed=42, loss_group='global'):
         if not torch.cuda.is_available() and str(device).startswith('cuda'):
             raise RuntimeError('sgaligner_amd.AlignerSteps: no HIP device; the product path has no CPU fallback')
         self.modules = list(modules)
@@ -27,7 +27,9 @@ class AlignerSteps:
         m = len(self.modules)
         self.multi_loss_layer_icl = CustomMultiLossLayer(loss_num=m, device=self.device).to(self.device)
         self.multi_loss_layer_ial = CustomMultiLossLayer(loss_num=m, device=self.device).to(self.device)
-        meta = {'zoom': zoom, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': self.modules}
+        # loss_group: 'global' (one loss over the whole batch, all-gathered across ranks) or b = reference-sized groups of b pairs
+        self.loss_group = loss_group
+        meta = {'zoom': zoom, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': self.modules, 'loss_group': loss_group}
         self.loss_func = OverallLoss(self.multi_loss_layer_ial, self.multi_loss_layer_icl, self.device, meta)
         self.params = list(self.model.parameters())
         if m > 1:
@@ -36,7 +38,7 @@ class AlignerSteps:
     # -- reference hook names ---------------------------------------------------------------------
     def train_step(self, epoch, iteration, data_dict):
         output_dict = self.model(data_dict)
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized() and dist.get_world_size() > 1 and self.loss_group in (None, 'global'):
             loss_dict = self._global_loss(output_dict, data_dict)
         else:
             loss_dict = self.loss_func(output_dict, data_dict)
@@ -62,13 +64,19 @@ class AlignerSteps:
         output_dict, loss_dict = self.train_step(0, 0, data_dict)
         loss_dict['loss'].backward()
         if dist.is_initialized() and dist.get_world_size() > 1:
-            # log_vars see the full (replicated) loss on every rank; everything else sees only this rank's rows
+            self.reduce_grads()
+        return output_dict, loss_dict
+
+    def reduce_grads(self):
+        """One flat SUM all-reduce of the parameter gradients.  With the batch-global loss the log_vars see the full
+        (replicated) loss value on every rank -- pre-divide them; everything else (and everything under loss_group=b, where
+        each rank's loss is the sum over ITS groups) holds this rank's share only."""
+        if self.loss_group in (None, 'global'):
             w = dist.get_world_size()
             for p in list(self.multi_loss_layer_ial.parameters()) + list(self.multi_loss_layer_icl.parameters()):
                 if p.grad is not None:
                     p.grad /= w
-            sdist.allreduce_grads(self.params)
-        return output_dict, loss_dict
+        sdist.allreduce_grads(self.params)
 
     # -- batch-global loss across ranks -------------------------------------------------------------
     def _global_loss(self, output_dict, data_dict):
