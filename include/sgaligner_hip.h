@@ -139,12 +139,21 @@ int sga_group_loss_bwd(const float* const* Z, int M, const float* beta, int A, i
 
 /* ---- per-pair similarity + ranking --------------------------------------------------------------------
  * replaces eval_step's emb/||emb||, sim = 1 - emb emb^T, argsort (src/inference/sgaligner/inference_align_reg.py:
- * 125-128) fused with the rank look-ups of utils/alignment.py:3-25,27-41,59-70.  For query object q_idx[q] of pair
- * q_pair[q]: rank[q] = 1-based rank of q_tgt[q] among the pair's other objects; topk_*[q,:K] nearest others. */
+ * 125-128) fused with the rank look-ups of utils/alignment.py:3-25,27-41,59-70.  The per-pair E E^T blocks run on the
+ * matrix cores (exact fp32 MFMA; f16 != 0: fp16 inputs / fp32 accumulate on the normalised rows -- BASELINE.json
+ * configs[4]).  pair_off [B+1] object offsets of the pairs; blk_off [B+1] prefix sum of ceil(n_b / 64) (one workgroup per
+ * 64 objects of a pair), n_blocks = blk_off[B].  For query object q_idx[q] (each object at most once): rank[q] = 1-based
+ * rank of q_tgt[q] among its pair's other objects (q_tgt NULL or out of the pair: -1); topk_*[q,:K] its K nearest
+ * others (pair-local index, distance), ascending, ties by index.  K <= 8, <= 512 objects per pair. */
 size_t sga_simrank_workspace_bytes(int T);
-int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, int B, int max_pair_objects,
-                const int32_t* q_pair, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
-                int32_t* topk_idx, float* topk_sim, void* workspace, size_t workspace_bytes, void* stream);
+int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_off, int n_blocks, int B,
+                int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
+                int32_t* topk_idx, float* topk_sim, int f16, void* workspace, size_t workspace_bytes, void* stream);
+/* per pair b (queries pair_q_off[b]..pair_q_off[b+1], in sga_simrank's order): out[b][0..4] = Hits@1..5 counts,
+ * [5] = #queries, [6] = sum 1/rank, [7..9] = SGAR for modes '2', '50', '100' (utils/alignment.py:13-25,3-11,27-57);
+ * topk_* with leading dimension K >= 1 (column 0 = the top-1 prediction).  out [B][12] floats. */
+int sga_pair_metrics(const int32_t* rank, const int32_t* topk_idx, const float* topk_sim, int K, const int32_t* q_tgt,
+                     const int32_t* pair_off, const int32_t* pair_q_off, int B, float* out, void* stream);
 
 /* ---- Point-Cloud-Transformer object encoder, inference path ('pct' module) ---------
  * sga_gemm_ex: C = act(op(A) op(B) + bias) (+ resid), act 0 none / 1 ReLU / 2 LeakyReLU(0.2): the conv1d(k=1) +

@@ -7,14 +7,27 @@
 // value, alignment.py:7,18) and its K nearest other objects with their distances.  The full n x n
 // sort and the seven device->host copies of the rank list (alignment.py:4,14,29) disappear.
 // Ties: broken by object index (a stable ascending sort); the reference's sort is unstable there.
-// One wave per query: lanes span the pair's objects, the rank is a ballot/popcount-style wave sum,
-// the top-K a K-step wave arg-min.  Byte-bound: each query streams its pair's table once from L2.
+//
+// simrank_mfma_kernel: the per-pair E E^T blocks on the matrix cores.  A workgroup = 4 waves = 64 consecutive objects
+// of one pair (its "query rows"); a wave holds its 16 rows as the MFMA A operand in registers (D <= 320) and walks the pair's
+// objects in 16-column tiles whose B fragments come straight from global memory as 64-byte row segments (4 lanes x 16 B per
+// row -- every byte of a fetched line is used; the round-1 kernel walked one row per lane with stride-D scalar reads).  The
+// wave's 16 x n similarity strip lands in LDS; ranking is then per query row with lanes across the pair's objects: the rank
+// is a wave sum of "closer than the target", the top-K a K-step wave arg-min.  Row blocks without a query skip everything.
+//   fp32: v_mfma_f32_16x16x4_f32 (exact fp32 products, the headline path);
+//   f16 : v_mfma_f32_16x16x16_f16 on the L2-normalised rows converted to half, fp32 accumulate (BASELINE.json configs[4]:
+//         "MFMA similarity GEMM at fp16"; |sim error| ~1e-3, tolerance 1e-2).
+// pair_metrics_kernel: Hits@1..5 counts and the three SGAR flags per pair on the device (one wave per pair), so the host
+// only formats the reference's meter dict.
 #include "sga_common.h"
 
 namespace {
 
 constexpr int SR_MAXK = 8;
 constexpr int SR_MAXPER = 8;          // objects per lane -> up to 512 objects per pair
+constexpr int SR_ROWS = 64;           // query rows per workgroup (4 waves x 16)
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __global__ void row_inv_norm_kernel(const float* __restrict__ E, int T, int D, float* __restrict__ inv) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
@@ -26,39 +39,118 @@ __global__ void row_inv_norm_kernel(const float* __restrict__ E, int T, int D, f
     }
 }
 
-__global__ void simrank_kernel(const float* __restrict__ E, const float* __restrict__ inv, int D,
-                               const int* __restrict__ pair_off, const int* __restrict__ q_pair,
-                               const int* __restrict__ q_idx, const int* __restrict__ q_tgt, int Q, int K,
-                               int* __restrict__ rank, int* __restrict__ topk_idx, float* __restrict__ topk_sim) {
-    extern __shared__ float qrow[];                        // [waves][D]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    float* myq = qrow + (size_t)wave * D;
-    for (int q = blockIdx.x * wpb + wave; q < Q; q += gridDim.x * wpb) {
-        const int b = q_pair[q];
-        const int o0 = pair_off[b], n = pair_off[b + 1] - o0;
-        const int a = q_idx[q];                            // global object index of the query
-        const float ia = inv[a];
-        for (int d = lane; d < D; d += 64) myq[d] = E[(size_t)a * D + d] * ia;
-        __builtin_amdgcn_wave_barrier();
+__global__ void fill_int_kernel(int* __restrict__ p, int n, int v) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void scatter_query_kernel(const int* __restrict__ q_idx, int Q, int* __restrict__ obj_query) {
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) obj_query[q_idx[q]] = q;
+}
+
+struct SimArgs {
+    const float* E; const float* inv; int D, B;
+    const int* pair_off;              // [B+1] object offsets
+    const int* blk_off;               // [B+1] workgroup offsets (ceil(n_b / 64) per pair)
+    const int* obj_query;             // [T] query id of an object or -1
+    const int* q_tgt;                 // [Q] or null
+    int K;
+    int* rank; int* topk_idx; float* topk_sim;
+    int npad_max;                     // LDS strip width (largest pair, padded to 16) + 1
+};
+
+// 16-float K group `q` of row `row`: this lane's 4 values k = 16 q + 4 g4 + r, zero past D, scaled
+__device__ __forceinline__ f32x4 load_kgroup(const float* __restrict__ row, int D, int q, int g4, float scale) {
+    const int k = 16 * q + 4 * g4;
+    f32x4 v;
+    if (k + 4 <= D && (D & 3) == 0) v = *reinterpret_cast<const f32x4*>(row + k);
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = k + r < D ? row[k + r] : 0.f;
+    }
+    return v * scale;
+}
+
+template <int KQ, bool F16>
+__global__ __launch_bounds__(256) void simrank_mfma_kernel(SimArgs a) {
+    extern __shared__ float strip[];                       // [4 waves][16][npad_max]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = lane >> 4, l15 = lane & 15;
+    // which pair does this workgroup belong to
+    int lo = 0, hi = a.B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.blk_off[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+    const int b = lo;
+    const int o0 = a.pair_off[b], n = a.pair_off[b + 1] - o0;
+    const int row0 = ((int)blockIdx.x - a.blk_off[b]) * SR_ROWS + wave * 16;      // pair-local first row of this wave
+    if (row0 >= n) return;
+    // any query among this wave's rows?  (wave-uniform)
+    const int my_row = row0 + l15;
+    const int my_q = (my_row < n && g4 == 0) ? a.obj_query[o0 + my_row] : -1;
+    if (__ballot(my_q >= 0) == 0ull) return;
+
+    const int NP = a.npad_max;
+    float* S = strip + (size_t)wave * 16 * NP;
+    const int D = a.D, nkq = (D + 15) / 16;
+    // ---- A operand: the wave's 16 query rows, pre-scaled by their inverse norms (emb /= ||emb||, :126)
+    const int arow = o0 + min(my_row, n - 1);
+    const float ia = a.inv[arow];
+    const float* __restrict__ ap = a.E + (size_t)arow * D;
+    f32x4 areg[KQ > 0 ? KQ : 1];
+    if (KQ > 0) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) areg[q] = q < nkq ? load_kgroup(ap, D, q, g4, ia) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- similarity strip: 16 rows x n columns, one 16-column tile at a time
+    for (int j0 = 0; j0 < n; j0 += 16) {
+        const int brow = o0 + min(j0 + l15, n - 1);
+        const float ib = a.inv[brow];
+        const float* __restrict__ bp = a.E + (size_t)brow * D;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (KQ > 0) {
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (q < nkq) {
+                    const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
+                    if (F16) {
+                        const f16x4 ah = {(_Float16)areg[q][0], (_Float16)areg[q][1], (_Float16)areg[q][2], (_Float16)areg[q][3]};
+                        const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[q][r], bv[r], acc, 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            for (int q = 0; q < nkq; ++q) {
+                const f32x4 av = load_kgroup(ap, D, q, g4, ia);
+                const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
+                if (F16) {
+                    const f16x4 ah = {(_Float16)av[0], (_Float16)av[1], (_Float16)av[2], (_Float16)av[3]};
+                    const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc, 0, 0, 0);
+                }
+            }
+        }
+        // D layout: lane&15 = column (object j0 + l15), rows 4 g4 + r.  sim = 1 - dot (dot scaled by the column's inverse norm)
+        const float cs = F16 ? 1.f : ib;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(4 * g4 + r) * NP + j0 + l15] = 1.f - acc[r] * cs;
+    }
+    __builtin_amdgcn_wave_barrier();                       // the strip is written and read by this wave only (DS ops of a wave are ordered)
+
+    // ---- ranking, one query row at a time, lanes across the pair's objects
+    for (int rr = 0; rr < 16; ++rr) {
+        const int q = __shfl(my_q, rr, 64);                // lanes 0..15 (g4 == 0) hold the rows' query ids
+        if (q < 0) continue;
+        const float* srow = S + rr * NP;
+        const int al = row0 + rr;                          // pair-local self index
         float sim[SR_MAXPER];
 #pragma unroll
-        for (int u = 0; u < SR_MAXPER; ++u) {
-            const int j = lane + 64 * u;
-            float dot = 0.f;
-            if (j < n) {
-                const float* r = E + (size_t)(o0 + j) * D;
-                for (int d = 0; d < D; ++d) dot = fmaf(myq[d], r[d], dot);
-                dot *= inv[o0 + j];
-            }
-            sim[u] = j < n ? 1.f - dot : INFINITY;
-        }
-        const int al = a - o0;                             // pair-local self index
-        // ---- rank of the target among the others
-        const int tg = q_tgt ? q_tgt[q] - o0 : -1;
+        for (int u = 0; u < SR_MAXPER; ++u) { const int j = lane + 64 * u; sim[u] = j < n ? srow[j] : INFINITY; }
+        const int tg = a.q_tgt ? a.q_tgt[q] - o0 : -1;
         if (tg >= 0 && tg < n) {
-            float st = 0.f;
-#pragma unroll
-            for (int u = 0; u < SR_MAXPER; ++u) { const float v = __shfl(sim[u], tg & 63, 64); if ((tg >> 6) == u) st = v; }
+            const float st = srow[tg];
             int cnt = 0;
 #pragma unroll
             for (int u = 0; u < SR_MAXPER; ++u) {
@@ -67,14 +159,13 @@ __global__ void simrank_kernel(const float* __restrict__ E, const float* __restr
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-            if (lane == 0) rank[q] = cnt + 1;
-        } else if (lane == 0 && rank) {
-            rank[q] = -1;
+            if (lane == 0) a.rank[q] = cnt + 1;
+        } else if (lane == 0) {
+            a.rank[q] = -1;
         }
-        // ---- K nearest others (ascending distance, index tie-break)
 #pragma unroll
         for (int u = 0; u < SR_MAXPER; ++u) if (lane + 64 * u == al) sim[u] = INFINITY;
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < a.K; ++k) {
             float bv = INFINITY; int bj = 0x7fffffff;
 #pragma unroll
             for (int u = 0; u < SR_MAXPER; ++u) { const int j = lane + 64 * u; if (sim[u] < bv) { bv = sim[u]; bj = j; } }
@@ -83,35 +174,116 @@ __global__ void simrank_kernel(const float* __restrict__ E, const float* __restr
                 const float ov = __shfl_xor(bv, o, 64); const int oj = __shfl_xor(bj, o, 64);
                 if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
             }
-            if (lane == 0) { topk_idx[(size_t)q * K + k] = bv < INFINITY ? bj : -1; topk_sim[(size_t)q * K + k] = bv; }
+            if (lane == 0) { a.topk_idx[(size_t)q * a.K + k] = bv < INFINITY ? bj : -1; a.topk_sim[(size_t)q * a.K + k] = bv; }
 #pragma unroll
             for (int u = 0; u < SR_MAXPER; ++u) if (lane + 64 * u == bj) sim[u] = INFINITY;
         }
-        __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Per pair (one wave): Hits@1..5 counts, sum of reciprocal ranks, and SGAR for the modes '2', '50', '100'
+// (utils/alignment.py:13-25,27-57): the anchors' top-1 predictions are ordered by ascending distance (stable), and a mode is
+// satisfied when all of the first 2 / first half / all of them are correct.
+__global__ void pair_metrics_kernel(const int* __restrict__ rank, const int* __restrict__ top1, const float* __restrict__ top1_sim,
+                                    int ldk, const int* __restrict__ q_tgt, const int* __restrict__ pair_off,
+                                    const int* __restrict__ pair_q_off, int B, float* __restrict__ out /* [B][12] */) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
+        const int q0 = pair_q_off[b], na = pair_q_off[b + 1] - q0, o0 = pair_off[b];
+        int hits[5] = {0, 0, 0, 0, 0};
+        float rr = 0.f;
+        int bad2 = 0, bad50 = 0, bad100 = 0;
+        for (int i = lane; i < na; i += 64) {
+            const int r = rank[q0 + i];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) hits[k] += (r >= 1 && r <= k + 1) ? 1 : 0;
+            rr += r >= 1 ? 1.f / (float)r : 0.f;
+            // position of this anchor's top-1 distance among the pair's anchors (stable ascending)
+            const float s = top1_sim[(size_t)(q0 + i) * ldk];
+            int pos = 0;
+            for (int j = 0; j < na; ++j) {
+                const float sj = top1_sim[(size_t)(q0 + j) * ldk];
+                pos += (sj < s || (sj == s && j < i)) ? 1 : 0;
+            }
+            const bool wrong = top1[(size_t)(q0 + i) * ldk] != q_tgt[q0 + i] - o0;
+            if (wrong) { bad100 = 1; if (pos < 2) bad2 = 1; if (pos < na / 2) bad50 = 1; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) hits[k] += __shfl_xor(hits[k], o, 64);
+            rr += __shfl_xor(rr, o, 64);
+            bad2 |= __shfl_xor(bad2, o, 64); bad50 |= __shfl_xor(bad50, o, 64); bad100 |= __shfl_xor(bad100, o, 64);
+        }
+        if (lane == 0) {
+            float* o = out + (size_t)b * 12;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] = (float)hits[k];
+            o[5] = (float)na; o[6] = rr;
+            o[7] = bad2 ? 0.f : 1.f; o[8] = bad50 ? 0.f : 1.f; o[9] = bad100 ? 0.f : 1.f;
+            o[10] = 0.f; o[11] = 0.f;
+        }
+    }
+}
+
+template <bool F16>
+int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_off, int n_blocks, int B,
+                   int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank, int32_t* topk_idx,
+                   float* topk_sim, void* workspace, size_t workspace_bytes, hipStream_t s, const char* who) {
+    SGA_CHECK_ARG(T >= 0 && D >= 1 && B >= 0 && Q >= 0, "%s: bad sizes", who);
+    SGA_CHECK_ARG(K >= 0 && K <= SR_MAXK, "%s: K=%d outside [0,%d]", who, K, SR_MAXK);
+    SGA_CHECK_ARG(max_pair_objects <= 64 * SR_MAXPER, "%s: a pair has %d objects; at most %d are supported", who, max_pair_objects, 64 * SR_MAXPER);
+    if (Q == 0 || T == 0 || B == 0) return SGA_OK;
+    SGA_CHECK_ARG(E && pair_off && blk_off && q_idx && rank && topk_idx && topk_sim, "%s: null pointer", who);
+    if (!workspace || workspace_bytes < sga_simrank_workspace_bytes(T)) { sga_set_error("%s: workspace too small", who); return SGA_ERR_WORKSPACE; }
+    float* inv = static_cast<float*>(workspace);
+    int* obj_query = reinterpret_cast<int*>(inv + T);
+    int g = (T + 3) / 4; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(g), dim3(256), 0, s, E, T, D, inv);
+    hipLaunchKernelGGL(fill_int_kernel, dim3((T + 255) / 256 > 2048 ? 2048 : (T + 255) / 256), dim3(256), 0, s, obj_query, T, -1);
+    hipLaunchKernelGGL(scatter_query_kernel, dim3((Q + 255) / 256 > 2048 ? 2048 : (Q + 255) / 256), dim3(256), 0, s, q_idx, Q, obj_query);
+    SimArgs a{};
+    a.E = E; a.inv = inv; a.D = D; a.B = B; a.pair_off = pair_off; a.blk_off = blk_off; a.obj_query = obj_query; a.q_tgt = q_tgt; a.K = K;
+    a.rank = rank; a.topk_idx = topk_idx; a.topk_sim = topk_sim;
+    a.npad_max = ((max_pair_objects + 15) / 16) * 16 + 1;
+    const size_t lds = (size_t)4 * 16 * a.npad_max * sizeof(float);
+    const int nkq = (D + 15) / 16;
+    auto launch = [&](auto kern) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, a);
+    };
+    if (nkq <= 7) launch(simrank_mfma_kernel<7, F16>);            // emb_dim 100 (single modality)
+    else if (nkq <= 13) launch(simrank_mfma_kernel<13, F16>);     // 200
+    else if (nkq <= 20) launch(simrank_mfma_kernel<20, F16>);     // 300 (P+S+R joint)
+    else if (nkq <= 26) launch(simrank_mfma_kernel<26, F16>);     // 400 (P+S+R+A joint)
+    else launch(simrank_mfma_kernel<0, F16>);                     // wider: both operands streamed
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { sga_set_error("%s: launch failed: %s", who, hipGetErrorString(e_)); return SGA_ERR_HIP; }
+    return SGA_OK;
 }
 
 }  // namespace
 
-extern "C" size_t sga_simrank_workspace_bytes(int T) { return sizeof(float) * (size_t)(T > 0 ? T : 1); }
+extern "C" size_t sga_simrank_workspace_bytes(int T) { return (sizeof(float) + sizeof(int)) * (size_t)(T > 0 ? T : 1); }
 
-extern "C" int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, int B, int max_pair_objects,
-                           const int32_t* q_pair, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K,
-                           int32_t* rank, int32_t* topk_idx, float* topk_sim, void* workspace, size_t workspace_bytes,
-                           void* stream) {
-    SGA_CHECK_ARG(E && pair_off && q_pair && q_idx && rank && topk_idx && topk_sim && T >= 0 && D >= 1 && B >= 0 && Q >= 0,
-                  "sga_simrank: bad argument");
-    SGA_CHECK_ARG(K >= 0 && K <= SR_MAXK, "sga_simrank: K=%d outside [0,%d]", K, SR_MAXK);
-    SGA_CHECK_ARG(max_pair_objects <= 64 * SR_MAXPER, "sga_simrank: a pair has %d objects; at most %d are supported", max_pair_objects, 64 * SR_MAXPER);
-    if (!workspace || workspace_bytes < sga_simrank_workspace_bytes(T)) { sga_set_error("sga_simrank: workspace too small"); return SGA_ERR_WORKSPACE; }
-    if (Q == 0 || T == 0) return SGA_OK;
+extern "C" int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_off, int n_blocks, int B,
+                           int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
+                           int32_t* topk_idx, float* topk_sim, int f16, void* workspace, size_t workspace_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    float* inv = static_cast<float*>(workspace);
-    int g = (T + 3) / 4; if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(g), dim3(256), 0, s, E, T, D, inv);
-    int gq = (Q + 3) / 4; if (gq > 8192) gq = 8192;
-    hipLaunchKernelGGL(simrank_kernel, dim3(gq), dim3(256), 4 * (size_t)D * sizeof(float), s, E, inv, D, pair_off, q_pair, q_idx,
-                       q_tgt, Q, K, rank, topk_idx, topk_sim);
-    SGA_CHECK_LAUNCH("sga_simrank");
+    if (f16) return simrank_launch<true>(E, T, D, pair_off, blk_off, n_blocks, B, max_pair_objects, q_idx, q_tgt, Q, K, rank, topk_idx,
+                                         topk_sim, workspace, workspace_bytes, s, "sga_simrank(f16)");
+    return simrank_launch<false>(E, T, D, pair_off, blk_off, n_blocks, B, max_pair_objects, q_idx, q_tgt, Q, K, rank, topk_idx, topk_sim,
+                                 workspace, workspace_bytes, s, "sga_simrank");
+}
+
+extern "C" int sga_pair_metrics(const int32_t* rank, const int32_t* topk_idx, const float* topk_sim, int K, const int32_t* q_tgt,
+                                const int32_t* pair_off, const int32_t* pair_q_off, int B, float* out, void* stream) {
+    SGA_CHECK_ARG(B >= 0 && K >= 1, "sga_pair_metrics: bad sizes (K >= 1: the top-1 prediction is needed)");
+    if (B == 0) return SGA_OK;
+    SGA_CHECK_ARG(rank && topk_idx && topk_sim && q_tgt && pair_off && pair_q_off && out, "sga_pair_metrics: null pointer");
+    int g = (B + 3) / 4; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pair_metrics_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), rank, topk_idx, topk_sim, K, q_tgt,
+                       pair_off, pair_q_off, B, out);
+    SGA_CHECK_LAUNCH("sga_pair_metrics");
     return SGA_OK;
 }

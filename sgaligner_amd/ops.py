@@ -682,28 +682,69 @@ def multi_gat(gb, x, layer0, layer1):
 
 
 # ------------------------------------------------------------------------------------------ similarity + ranking
-def simrank(emb, pair_counts, q_pair, q_idx, q_tgt, k: int):
+class PairLayout:
+    """Device offsets of the pairs of a batch for the similarity kernels: object offsets and the workgroup prefix
+    (one workgroup per 64 objects of a pair).  Cached by content (small host arrays)."""
+
+    def __init__(self, pair_counts, device):
+        pc = _np.asarray(pair_counts, dtype=_np.int64).reshape(-1)
+        self.B = int(len(pc))
+        self.nmax = int(pc.max()) if self.B else 0
+        self.T = int(pc.sum())
+        self.off_host = _np.concatenate([[0], _np.cumsum(pc)])
+        blk = _np.concatenate([[0], _np.cumsum((pc + 63) // 64)])
+        self.n_blocks = int(blk[-1])
+        self.pair_off = torch.from_numpy(self.off_host.astype(_np.int32)).to(device)
+        self.blk_off = torch.from_numpy(blk.astype(_np.int32)).to(device)
+
+    _cache = _SmallCache()
+
+    @staticmethod
+    def of(pair_counts, device):
+        device = torch.device(device)
+        return PairLayout._cache.get(_fingerprint([_np.asarray(pair_counts)], (str(device),)), lambda: PairLayout(pair_counts, device))
+
+
+SIMRANK_F16 = False      # opt-in: fp16-input MFMA similarity (BASELINE.json configs[4]); the default is exact fp32 MFMA
+
+
+def simrank(emb, pair_counts, q_idx, q_tgt, k: int, f16=None):
     """For each query object: rank of its target and the k nearest other objects of its pair.
     emb [T,D] fp32 (un-normalised: the kernel applies emb/||emb|| as inference_align_reg.py:126 does);
-    pair_counts [B] objects per pair; q_* host int arrays (global object indices; q_tgt may be None).
-    Returns (rank [Q] int32, topk_idx [Q,k] int32 pair-local, topk_sim [Q,k] fp32) on the device."""
+    pair_counts [B] objects per pair; q_idx / q_tgt host int arrays or device int32 tensors of global object indices
+    (q_tgt may be None; each object may be queried once).
+    Returns (rank [Q] int32, topk_idx [Q,k] int32 pair-local, topk_sim [Q,k] fp32, layout) on the device."""
     emb = _req(emb.contiguous(), 'embedding')
     dev = emb.device
     T, D = emb.shape
-    pc = _np.asarray(pair_counts, dtype=_np.int64).reshape(-1)
-    pair_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(pc)]).astype(_np.int32)).to(dev)
-    Q = int(len(q_idx))
-    f = lambda a: torch.from_numpy(_np.ascontiguousarray(_np.asarray(a, dtype=_np.int32))).to(dev)
-    qp, qi = f(q_pair), f(q_idx)
+    lay = PairLayout.of(pair_counts, dev)
+    f = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(_np.ascontiguousarray(_np.asarray(a, dtype=_np.int32))).to(dev)
+    qi = f(q_idx)
     qt = f(q_tgt) if q_tgt is not None else None
+    Q = int(qi.numel())
     rank = torch.empty((max(Q, 1),), device=dev, dtype=torch.int32)
     tk = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.int32)
     ts = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.float32)
     nb = _lib.lib().sga_simrank_workspace_bytes(T)
     ws = torch.empty((nb,), device=dev, dtype=torch.uint8)
-    _lib.check(_lib.lib().sga_simrank(_p(emb), T, D, _p(pair_off), len(pc), int(pc.max()) if len(pc) else 0, _p(qp), _p(qi),
-                                      _p(qt), Q, k, _p(rank), _p(tk), _p(ts), _p(ws), nb, _stream()), 'sga_simrank')
-    return rank[:Q], tk[:Q, :k], ts[:Q, :k]
+    use16 = SIMRANK_F16 if f16 is None else bool(f16)
+    _lib.check(_lib.lib().sga_simrank(_p(emb), T, D, _p(lay.pair_off), _p(lay.blk_off), lay.n_blocks, lay.B, lay.nmax, _p(qi), _p(qt),
+                                      Q, k, _p(rank), _p(tk), _p(ts), int(use16), _p(ws), nb, _stream()), 'sga_simrank')
+    return rank[:Q], tk[:Q, :k], ts[:Q, :k], lay
+
+
+def pair_metrics(rank, topk_idx, topk_sim, q_tgt, layout, pair_q_counts):
+    """Per-pair Hits@1..5 counts, #queries, sum of reciprocal ranks and SGAR('2','50','100') on the device: [B,12] fp32."""
+    dev = rank.device
+    qc = _np.asarray(pair_q_counts, dtype=_np.int64).reshape(-1)
+    qoff = torch.from_numpy(_np.concatenate([[0], _np.cumsum(qc)]).astype(_np.int32)).to(dev)
+    out = torch.zeros((max(layout.B, 1), 12), device=dev, dtype=torch.float32)
+    qt = q_tgt if isinstance(q_tgt, torch.Tensor) else torch.from_numpy(_np.ascontiguousarray(_np.asarray(q_tgt, dtype=_np.int32))).to(dev)
+    tki = topk_idx.contiguous()
+    tks = topk_sim.contiguous()
+    _lib.check(_lib.lib().sga_pair_metrics(_p(rank.contiguous()), _p(tki), _p(tks), int(tki.shape[1]), _p(qt), _p(layout.pair_off),
+                                           _p(qoff), layout.B, _p(out), _stream()), 'sga_pair_metrics')
+    return out[:layout.B]
 
 
 def _allreduce_sum(t, group_reduce):

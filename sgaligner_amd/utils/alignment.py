@@ -66,45 +66,47 @@ def compute_alignment_score(rank_list, src_objects_count, ref_objects_count):
 
 # ---- fused device path ------------------------------------------------------------------------------
 def evaluate_batch(embedding, data_dict, all_k=(1, 2, 3, 4, 5), recall_modes=('2', '50', '100'), reg_k=0):
-    """The alignment block of AlignerRegTester.eval_step for a whole batch in two kernel launches.
+    """The alignment block of AlignerRegTester.eval_step for a whole batch: the per-pair E E^T blocks on the matrix cores
+    with rank / top-K in the epilogue (sga_simrank), Hits@K counts and SGAR per pair on the device (sga_pair_metrics), ONE
+    device->host copy of the small result arrays, and vectorised formatting -- no per-pair host loop.
     Returns the reference's meter dict: {'mrr': [...], k: {'correct','total'}, 'sgar': {mode: [...]}}
     (+ 'node_corrs': per-pair list of (src, ref) pair-local index tuples when reg_k > 0)."""
     counts = np.asarray(data_dict['tot_obj_count']).reshape(-1)
     e1c = np.asarray(data_dict['e1i_count']).reshape(-1)
-    q_pair = np.repeat(np.arange(len(counts)), e1c)
     e1i = np.asarray(data_dict['e1i'])
     e2i = np.asarray(data_dict['e2i'])
-    rank, tki, tks = ops.simrank(embedding, counts, q_pair, e1i, e2i, 1)
-    rank = rank.cpu().numpy()
-    top1 = tki.cpu().numpy()[:, 0] if len(rank) else np.zeros(0, dtype=np.int64)
-    top1s = tks.cpu().numpy()[:, 0] if len(rank) else np.zeros(0)
-    offs = np.concatenate([[0], np.cumsum(counts)])
     res = {'mrr': [], 'sgar': {m: [] for m in recall_modes}}
     for k in all_k:
         res[k] = {'correct': 0, 'total': 0}
-    a0 = 0
-    for b, na in enumerate(e1c):
-        if na:
-            r = rank[a0:a0 + na]
-            res['mrr'] += [1.0 / int(x) for x in r]
-            for k in all_k:
-                res[k]['correct'] += int((r <= k).sum())
-                res[k]['total'] += int(na)
-            gt = (e2i[a0:a0 + na] - offs[b]).tolist()
-            sg = _sgar_from(top1[a0:a0 + na].tolist(), top1s[a0:a0 + na].tolist(), gt, recall_modes)
-            for m in recall_modes:
-                res['sgar'][m].append(sg[m])
-        a0 += na
+    if len(e1i):
+        rank, tki, tks, lay = ops.simrank(embedding, counts, e1i, e2i, 1)
+        pm = ops.pair_metrics(rank, tki, tks, e2i, lay, e1c)
+        host = torch.cat([rank.float(), pm.reshape(-1)]).cpu().numpy()          # one read-back
+        rk, pm = host[:len(e1i)], host[len(e1i):].reshape(-1, 12)
+        res['mrr'] = (1.0 / rk).tolist()
+        has = e1c > 0
+        for k in all_k:
+            res[k]['correct'] = int(pm[:, k - 1].sum()) if 1 <= k <= 5 else int((rk <= k).sum())
+            res[k]['total'] = int(e1c.sum())
+        col = {'2': 7, '50': 8, '100': 9}
+        for m in recall_modes:
+            res['sgar'][m] = pm[has, col[m]].astype(float).tolist()
     if reg_k > 0:
         gpc = np.asarray(data_dict['graph_per_obj_count'])
-        qp = np.repeat(np.arange(len(counts)), gpc[:, 0])
-        qi = np.concatenate([np.arange(offs[b], offs[b] + gpc[b, 0]) for b in range(len(counts))]) if len(counts) else np.zeros(0)
-        _, tk, _ = ops.simrank(embedding, counts, qp, qi, None, reg_k)
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        ns_all = gpc[:, 0].astype(np.int64)
+        # src objects of every pair: offs[b] + arange(ns_b), vectorised
+        rep = np.repeat(np.arange(len(counts)), ns_all)
+        loc = np.arange(int(ns_all.sum())) - np.repeat(np.concatenate([[0], np.cumsum(ns_all)])[:-1], ns_all)
+        qi = (offs[rep] + loc).astype(np.int32)
+        _, tk, _, _ = ops.simrank(embedding, counts, qi, None, reg_k)
         tk = tk.cpu().numpy()
+        keep = tk >= ns_all[rep][:, None]                                        # top-k non-self entries in the ref half (:68)
         res['node_corrs'] = []
         p = 0
         for b in range(len(counts)):
-            ns = int(gpc[b, 0])
-            res['node_corrs'].append([(i, int(j)) for i in range(ns) for j in tk[p + i] if j >= ns])
+            ns = int(ns_all[b])
+            rows, cols = np.nonzero(keep[p:p + ns])
+            res['node_corrs'].append(list(zip(rows.tolist(), tk[p:p + ns][rows, cols].tolist())))
             p += ns
     return res

@@ -30,7 +30,8 @@ for f in glob.glob(f'gpurun_out/pmc_t_{cfg}_{c}/**/*counter_collection.csv', rec
         if 'pointnet_fwd' in name:
             k = ('pointnet_fwd_kernel', keys[0], sha('pointnet.hip'))
         else:
-            base = name.split('(')[0].split('<')[0].split('::')[-1].split(' ')[-1]
+            import re
+            base = re.search(r'(\w+_kernel)<', name).group(1)
             k = (base + '<3,true>', keys[1], sha('contrastive.hip'))
         acc[k] += float(r['Counter_Value']); n[k] += 1
 for k in sorted(acc):
