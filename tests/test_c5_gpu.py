@@ -1,0 +1,99 @@
+"""BASELINE.json configs[4] (stress shape): 256 objects per scene x 2048 points per object, 1024-d embeddings.  One pair of that
+shape through the drop-in encoder + OverallLoss against the oracle (embeddings, loss terms, every parameter gradient), the
+batch-global loss on wide tables (general per-table kernels: D = 1024 modality tables + the 3072-d joint), and the fp16-input
+MFMA similarity for Hits@K at its relaxed tolerance (the fp32 similarity stays the default)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def test_c5_shape_train_step_vs_oracle():
+    from oracle import sga_oracle as O
+    from sgaligner_amd.aligner.losses import CustomMultiLossLayer, OverallLoss
+    from sgaligner_amd.aligner.sg_aligner import MultiModalEncoder
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.utils import alignment
+    mods = ['point', 'gat', 'rel']
+    dd = make_batch(1, 256, 2048, seed=4)
+    assert dd['tot_obj_pts'].shape == (512, 2048, 3) and len(dd['e1i']) == 76             # A = int(0.3 * 256)
+    torch.manual_seed(2)
+    model = MultiModalEncoder(modules=mods, rel_dim=41, attr_dim=164, emb_dim=1024)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if 'num_batches' not in k}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    out_o, loss_o, grads_o = O.train_step(params, dd, mods)
+    model = model.cuda()
+    ddd = to_device(dd, 'cuda')
+    loss_fn = OverallLoss(CustomMultiLossLayer(3).cuda(), CustomMultiLossLayer(3).cuda(), 'cuda',
+                          {'zoom': 0.1, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': mods})
+    out = model(ddd)
+    assert out['joint'].shape == (512, 3072)
+    res = loss_fn(out, ddd)
+    res['loss'].backward()
+    torch.cuda.synchronize()
+    for k in out_o:
+        assert (out[k].detach().cpu() - out_o[k].detach()).abs().max() < TOL, k
+    for key in ('loss', 'icl_loss_unimodal', 'icl_loss_multimodal', 'ial_loss'):
+        r = float(loss_o[key])
+        assert abs(float(res[key]) - r) < TOL * max(1.0, abs(r)), (key, float(res[key]), r)
+    seen = 0
+    for name, p in model.named_parameters():
+        if name in grads_o and p.grad is not None:
+            ref = grads_o[name]
+            err = (p.grad.cpu() - ref).abs().max().item()
+            assert err < TOL * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
+            seen += 1
+    assert seen >= 15
+    # Hits@K on the 3072-d joint table of 512-object pairs: exact-fp32 MFMA == oracle; fp16-input MFMA within its tolerance
+    ddv = make_batch(1, 256, 2048, seed=4, anchors='val')
+    mo = O.evaluate_batch(out_o['joint'].detach().double(), ddv)
+    mg = alignment.evaluate_batch(out['joint'].detach(), ddv)
+    assert [mg[k]['correct'] for k in (1, 2, 3, 4, 5)] == [mo['hits'][k][0] for k in (1, 2, 3, 4, 5)]
+    from sgaligner_amd import ops
+    r32, k32, s32, _ = ops.simrank(out['joint'].detach(), ddv['tot_obj_count'], ddv['e1i'], ddv['e2i'], 2, f16=False)
+    r16, k16, s16, _ = ops.simrank(out['joint'].detach(), ddv['tot_obj_count'], ddv['e1i'], ddv['e2i'], 2, f16=True)
+    assert (s32 - s16).abs().max().item() < 1e-2
+    gap = (s32[:, 1] - s32[:, 0]).cpu().numpy()
+    assert (k32[:, 0] == k16[:, 0]).cpu().numpy()[gap > 2e-2].all()
+
+
+@pytest.mark.parametrize('D', [256, 1024])
+def test_wide_table_loss_vs_fp64_oracle(D):
+    """Batch-global loss on tables wider than the fused path's 104 columns (emb_dim 256 / 1024 -> joint 768 / 3072 wide)."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd.aligner import losses as L
+    from sgaligner_amd.aligner.sg_aligner import MultiModalFusion
+    from sgaligner_amd.synthetic import make_batch
+    mods = ['point', 'gat', 'rel']
+    dd = make_batch(6, 40, 1, seed=D, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    torch.manual_seed(D)
+    base = {k: torch.randn(T, D, dtype=torch.float64) for k in mods}
+    w0 = torch.tensor([[0.4], [1.3], [-0.2]], dtype=torch.float64)
+    lv1, lv2 = 0.2 * torch.randn(3, dtype=torch.float64), 0.2 * torch.randn(3, dtype=torch.float64)
+    eo = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    wo = w0.clone().requires_grad_(True)
+    l1, l2 = lv1.clone().requires_grad_(True), lv2.clone().requires_grad_(True)
+    out_o = dict(eo)
+    out_o['joint'] = O.fusion([eo[k] for k in mods], wo)
+    ref = O.overall_loss(out_o, dd, mods, l1, l2)
+    ref['loss'].backward()
+    e = {k: base[k].float().cuda().requires_grad_(True) for k in mods}
+    fus = MultiModalFusion(3).cuda()
+    ial, icl = L.CustomMultiLossLayer(3).cuda(), L.CustomMultiLossLayer(3).cuda()
+    with torch.no_grad():
+        fus.weight.copy_(w0.float()); ial.log_vars.copy_(lv1.float()); icl.log_vars.copy_(lv2.float())
+    out = dict(e)
+    out['joint'] = fus([e[k] for k in mods])
+    fn = L.OverallLoss(ial, icl, 'cuda', {'zoom': 0.1, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': mods})
+    res = fn(out, dd)
+    res['loss'].backward()
+    torch.cuda.synchronize()
+    assert abs(float(res['loss']) - float(ref['loss'])) < 1e-4 * max(1.0, abs(float(ref['loss'])))
+    for k in mods:
+        gref = eo[k].grad
+        err = (e[k].grad.cpu().double() - gref).abs().max().item()
+        assert err < 1e-3 * max(1e-6, gref.abs().max().item()), (k, err, gref.abs().max().item())
+    assert (fus.weight.grad.cpu().double() - wo.grad).abs().max().item() < 1e-3 * max(1e-3, wo.grad.abs().max().item())
