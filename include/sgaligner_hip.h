@@ -61,7 +61,11 @@ int sga_fusion_bwd(const float* const* embs, int M, const float* weight, const f
  * for ALL graphs of a batch in one launch (sg_aligner.py:86-110 issues 2B sequential calls):
  * H [T,256] = x W^T (2 heads x 128), att_src/att_dst/bias [256]; edges [sumE,2] int64 graph-local (col 0 source,
  * col 1 target); node_off/edge_off [G+1] int32 prefix sums; nmax = max nodes per graph (<= 256; up to 128 the features stay in LDS).
- * out[i] = sum_j softmax_j(leaky_relu(a_s[j]+a_d[i], 0.2)) H[j] + bias, self loops normalised as PyG does. */
+ * out[i] = sum_j softmax_j(leaky_relu(a_s[j]+a_d[i], 0.2)) H[j] + bias, self loops normalised as PyG does.
+ * Limits the CALLER must respect (the Python wrapper checks the first two on the host once per batch): node ids are
+ * graph-local in [0, nodes of that graph) -- an endpoint outside that range is DROPPED by the kernels, where PyG would raise;
+ * duplicate edges count with their multiplicity (as PyG's scatter does) up to 255 copies of one (source, target) pair -- the
+ * multiplicity matrix is 8-bit and saturates there. */
 int sga_gat_attn_fwd(const float* H, const float* att_src, const float* att_dst, const float* bias,
                      const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G, int nmax,
                      float* out, void* stream);

@@ -9,20 +9,18 @@ pytestmark = pytest.mark.gpu
 
 
 def _overall(out, dd, mods, lv_ial, lv_icl):
-    """OverallLoss arithmetic on top of ops.contrastive_terms (same wiring as sgaligner_amd.aligner.losses)."""
-    from sgaligner_amd import ops
-    tabs = [out[m] for m in mods] + ([out['joint']] if len(mods) > 1 else [])
-    sums, s = ops.contrastive_terms(tabs, dd)
-    nt, m = len(tabs), len(mods) if len(mods) > 1 else 0
-    a2 = float(s.A) ** 2
-    icl = sums[:nt] / a2
-    if m == 0:
-        return {'loss': icl[0], 'icl_loss_unimodal': icl[0]}
-    ial = 0.1 * (0.5 * sums[nt:nt + m] + 0.5 * sums[nt + m:nt + 2 * m])
-    tot_ial = (torch.exp(-lv_ial) * ial + lv_ial).sum() * 0.1
-    icl_uni = (torch.exp(-lv_icl) * icl[:m] + lv_icl).sum()
-    return {'loss': tot_ial + icl_uni + icl[m], 'ial_loss': tot_ial, 'icl_loss_unimodal': icl_uni,
-            'icl_loss_multimodal': icl[m]}
+    """The PRODUCT class on arbitrary tables: sgaligner_amd.aligner.losses.OverallLoss with the given log_vars.  The joint table of
+    the goldens is an independent random tensor (not a fusion output), so this is the general per-table kernel path."""
+    from sgaligner_amd.aligner.losses import CustomMultiLossLayer, OverallLoss
+    m = len(mods)
+    ial, icl = CustomMultiLossLayer(m).cuda(), CustomMultiLossLayer(m).cuda()
+    if lv_ial is not None:
+        ial.log_vars = torch.nn.Parameter(lv_ial)           # the test owns the leaves it reads gradients from
+        icl.log_vars = torch.nn.Parameter(lv_icl)
+    fn = OverallLoss(ial, icl, 'cuda', {'zoom': 0.1, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': list(mods)})
+    res = fn(out, dd)
+    res['_lv'] = (ial.log_vars, icl.log_vars)
+    return res
 
 
 @pytest.mark.parametrize('tag', ['b1', 'b2', 'b4'])
@@ -36,6 +34,7 @@ def test_loss_golden(tag):
     res = _overall(out, dd, mods, lv_ial, lv_icl)
     res['loss'].backward()
     torch.cuda.synchronize()
+    lv_ial, lv_icl = res['_lv']
     assert abs(res['loss'].item() - float(g['loss'])) < 1e-3 * max(1, abs(float(g['loss'])))
     assert abs(res['ial_loss'].item() - float(g['ial'])) < 1e-4 * max(1, abs(float(g['ial'])))
     assert abs(res['icl_loss_unimodal'].item() - float(g['icl_uni'])) < 1e-4 * max(1, abs(float(g['icl_uni'])))
@@ -79,6 +78,9 @@ def test_loss_vs_oracle_fp64(B, N, mods):
     res = _overall(out, dd, mods, l1, l2)
     res['loss'].backward()
     torch.cuda.synchronize()
+    l1, l2 = res['_lv']
+    if m > 1:
+        assert torch.allclose(l1.grad.cpu().double(), lv1.grad, rtol=1e-3, atol=1e-5) and torch.allclose(l2.grad.cpu().double(), lv2.grad, rtol=1e-3, atol=1e-5)
     assert abs(res['loss'].item() - ref['loss'].item()) < 1e-3 * max(1, abs(ref['loss'].item()))
     for k in out:
         gref = out64[k].grad
