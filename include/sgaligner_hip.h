@@ -23,6 +23,12 @@ extern "C" {
 int sga_version(void);                 /* 100 * major + minor */
 const char* sga_last_error(void);
 int sga_device_cus(void);
+/* Arithmetic of the MFMA kernels that have a split-precision variant (sga_pointnet_fwd): 0 = exact fp32 (default; every
+ * headline number), 1 = split-bf16 x3 (each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product into an fp32
+ * accumulator; relative error ~1e-5).  Returns the previous mode (-1 on a bad argument).  SGA_MFMA_MODE=bf16x3 in the
+ * environment selects mode 1 at first use. */
+int sga_set_mfma_mode(int mode);
+int sga_get_mfma_mode(void);
 
 /* ---- PointNet object encoder ------------------------------------------------------------------------
  * replaces PointNetfeat.forward, src/aligner/networks/pointnet.py:120-175 (called sg_aligner.py:115):

@@ -21,6 +21,8 @@ SIGNATURES = {
     'sga_version': (I, []),
     'sga_last_error': (c_char_p, []),
     'sga_device_cus': (I, []),
+    'sga_set_mfma_mode': (I, [I]),
+    'sga_get_mfma_mode': (I, []),
     'sga_pointnet_fwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
     'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, P]),
     'sga_gat_attn_fwd': (I, [P, P, P, P, P, P, P, I, I, P, P]),

@@ -171,6 +171,189 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Opt-in split-bf16 x3 form of the forward (sga_set_mfma_mode(1); the default and every headline number stay exact fp32).
+//
+// fp32 MFMA runs at 1/16 of the bf16 rate.  Each fp32 operand is split into two bf16 terms, v = hi + lo with hi = bf16(v),
+// lo = bf16(v - hi) (16 significand bits together), and a product becomes three bf16 MFMAs into the same fp32 accumulator:
+// hi*hi + hi*lo + lo*hi (the dropped lo*lo term is ~2^-18 relative).  Same geometry as pointnet_fwd_kernel -- one wave per
+// object, the 3 -> 64 -> 128 -> C3 chain of a 32-point tile in registers, layer 2's accumulators are layer 3's A operand --
+// on v_mfma_f32_32x32x16_bf16 (K = 16 per instruction, 8 k-slots per lane): layer 3 is 8 K-steps x 3 MFMAs of 32 cycles per
+// 32-channel block instead of 64 fp32 MFMAs of 64 cycles.  Weights are split once per workgroup into hi / lo planes in LDS in
+// per-lane operand order (W2 2 x 16 KiB, W3 2 x 64 KiB: the same 160 KiB as the fp32 layout); activations are split in
+// registers with v_cvt_pk_bf16_f32 (6 VALU per value pair).  Measured error vs the fp32 kernel: DESIGN.md 3d.
+// -------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 floats -> packed bf16 hi / lo (4 dwords each; element 2p in the low half of dword p)
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const bf16x2 h = __builtin_convertvector(f32x2{v[2 * p], v[2 * p + 1]}, bf16x2);
+        const unsigned hp = __builtin_bit_cast(unsigned, h);
+        const float b0 = __builtin_bit_cast(float, hp << 16), b1 = __builtin_bit_cast(float, hp & 0xffff0000u);
+        const bf16x2 l = __builtin_convertvector(f32x2{v[2 * p] - b0, v[2 * p + 1] - b1}, bf16x2);
+        hi[p] = hp;
+        lo[p] = __builtin_bit_cast(unsigned, l);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int C3, bool WITH_ARGMAX>
+__global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ y,
+    int* __restrict__ argmax, int T, int P) {
+    constexpr int NB3 = C3 / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];
+    u32x4* w2hi = reinterpret_cast<u32x4*>(ldsu);            // [4 cb2][4 ks][64 lane]   16 KiB
+    u32x4* w2lo = w2hi + 16 * 64;                            //                            16 KiB
+    u32x4* w3hi = w2lo + 16 * 64;                            // [NB3 cb3][8 ks3][64 lane] C3/4 KiB
+    u32x4* w3lo = w3hi + NB3 * 8 * 64;
+
+    const int tid = threadIdx.x;
+    // ---- split the weights into bf16 hi / lo planes in operand order (once per persistent workgroup)
+    for (int d = tid; d < 16 * 64; d += PN_THREADS) {       // W2 as layer-2 A operand: row = out channel, k-slots = in channels 16 ks + 8 h + j
+        const int ln = d & 63, ks = (d >> 6) & 3, cb = d >> 8;
+        const float* src = w2 + (cb * 32 + (ln & 31)) * 64 + 16 * ks + 8 * (ln >> 5);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j];
+        split8(v, w2hi[d], w2lo[d]);
+    }
+    for (int d = tid; d < NB3 * 8 * 64; d += PN_THREADS) {  // W3 as layer-3 B operand: column = out channel, k-slots follow layer 2's C layout
+        const int ln = d & 63, ks3 = (d >> 6) & 7, cb = d >> 9;
+        const int cb2 = ks3 >> 1, half8 = ks3 & 1, hh = ln >> 5;
+        const float* src = w3 + (cb * 32 + (ln & 31)) * 128 + cb2 * 32 + 16 * half8 + 4 * hh;   // channel (j&3) + 8 (2 half8 + (j>>2)) + 4 h
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(j & 3) + 8 * (j >> 2)];
+        split8(v, w3hi[d], w3lo[d]);
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, pt = lane & 31;
+    const int n_tiles = (P + 31) >> 5;
+
+    for (int t = blockIdx.x * PN_WAVES + wave; t < T; t += gridDim.x * PN_WAVES) {
+        const float* xt = x + (size_t)t * P * 3;
+        float best[NB3];
+        int bidx[NB3];
+#pragma unroll
+        for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
+
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int p0 = tile * 32;
+            int lane_o = lane, h_o = h;                       // opaque copies: keep the weight reads inside the tile loop
+            asm volatile("" : "+v"(lane_o), "+v"(h_o));
+            const int pi = min(p0 + pt, P - 1);
+            const float x0 = xt[pi * 3 + 0], x1 = xt[pi * 3 + 1], x2 = xt[pi * 3 + 2];
+
+            // ---- layer 1 (VALU, fp32): this lane's 32 channels k = 16 ks + 8 h + j, split for the MFMA B operand
+            u32x4 h1hi[4], h1lo[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 16 * ks + 8 * h_o;
+                float v[8];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int kk = k + 4 * half;
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w1 + kk * 3);
+                    const f32x4 wb = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 4);
+                    const f32x4 wc = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 8);
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + kk);
+                    v[4 * half + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
+                    v[4 * half + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
+                    v[4 * half + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
+                    v[4 * half + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
+                }
+                split8(v, h1hi[ks], h1lo[ks]);
+            }
+
+            // ---- layer 2: H2^T = W2 H1^T (A = W2 planes from LDS, B = H1 split), accumulators start at the bias
+            u32x4 h2hi[8], h2lo[8];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * g + 4 * h_o);
+                    acc[g * 4 + 0] = bb[0]; acc[g * 4 + 1] = bb[1]; acc[g * 4 + 2] = bb[2]; acc[g * 4 + 3] = bb[3];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 wh = w2hi[(cb * 4 + ks) * 64 + lane_o], wl = w2lo[(cb * 4 + ks) * 64 + lane_o];
+                    acc = mfma_bf16(wh, h1hi[ks], acc);
+                    acc = mfma_bf16(wh, h1lo[ks], acc);
+                    acc = mfma_bf16(wl, h1hi[ks], acc);
+                }
+#pragma unroll
+                for (int half8 = 0; half8 < 2; ++half8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[half8 * 8 + j], 0.f);
+                    split8(v, h2hi[cb * 2 + half8], h2lo[cb * 2 + half8]);
+                }
+            }
+
+            // ---- layer 3: Z3 = H2 W3^T (A = H2 split, straight from layer 2's accumulators; B = W3 planes), running max over points
+#pragma unroll
+            for (int cb = 0; cb < NB3; ++cb) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks3 = 0; ks3 < 8; ++ks3) {
+                    const u32x4 wh = w3hi[(cb * 8 + ks3) * 64 + lane_o], wl = w3lo[(cb * 8 + ks3) * 64 + lane_o];
+                    acc = mfma_bf16(h2hi[ks3], wh, acc);
+                    acc = mfma_bf16(h2hi[ks3], wl, acc);
+                    acc = mfma_bf16(h2lo[ks3], wh, acc);
+                }
+                if (WITH_ARGMAX) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool gt = acc[r] > best[cb];
+                        best[cb] = gt ? acc[r] : best[cb];
+                        bidx[cb] = gt ? (p0 + mfma32_row(r, h)) : bidx[cb];
+                    }
+                } else {
+                    float m = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                    best[cb] = fmaxf(best[cb], m);
+                }
+            }
+        }
+
+#pragma unroll
+        for (int cb = 0; cb < NB3; ++cb) {
+            const float ov = __shfl_xor(best[cb], 32, 64);
+            float v = best[cb];
+            int bi = bidx[cb];
+            if (WITH_ARGMAX) {
+                const int oi = __shfl_xor(bidx[cb], 32, 64);
+                const bool take = (ov > v) || (ov == v && oi < bi);
+                v = take ? ov : v;
+                bi = take ? oi : bi;
+                bi = min(bi, P - 1);
+            } else {
+                v = fmaxf(v, ov);
+            }
+            if (h == 0) {
+                const int c = cb * 32 + pt;
+                y[(size_t)t * C3 + c] = fmaxf(v + b3[c], 0.f);
+                if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
+            }
+        }
+    }
+}
+
 template <int C3>
 int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                const float* w3, const float* b3, float* y, int* argmax, int T, int P, hipStream_t stream) {
@@ -178,7 +361,17 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     int grid = (T + PN_WAVES - 1) / PN_WAVES;
     const int ncu = sga_num_cus();
     if (grid > ncu) grid = ncu;
-    if (argmax) {
+    if (sga_mfma_mode() == 1) {
+        if (argmax) {
+            auto k = pointnet_fwd_bf16x3_kernel<C3, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+        } else {
+            auto k = pointnet_fwd_bf16x3_kernel<C3, false>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+        }
+    } else if (argmax) {
         auto k = pointnet_fwd_kernel<C3, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);

@@ -32,6 +32,23 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+MFMA_MODES = {'f32': 0, 'bf16x3': 1}
+
+
+def set_mfma_mode(mode: str) -> str:
+    """Arithmetic of the MFMA kernels that have a split-precision variant: 'f32' (exact fp32 MFMA: the default and every
+    headline number) or 'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate;
+    ~1e-5 relative error).  Returns the previous mode.  SGA_MFMA_MODE=bf16x3 in the environment sets the initial mode."""
+    if mode not in MFMA_MODES:
+        raise ValueError(f"sgaligner_amd: mfma mode must be one of {sorted(MFMA_MODES)} (got {mode!r})")
+    old = _lib.lib().sga_set_mfma_mode(MFMA_MODES[mode])
+    return 'bf16x3' if old == 1 else 'f32'
+
+
+def get_mfma_mode() -> str:
+    return 'bf16x3' if _lib.lib().sga_get_mfma_mode() == 1 else 'f32'
+
+
 # ------------------------------------------------------------------------------------------ PointNet
 def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     """x_tp3 [T,P,3] (point-major, as in data_dict['tot_obj_pts']).  Returns (y [T,C3], argmax|None)."""

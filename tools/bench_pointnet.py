@@ -1,26 +1,40 @@
-"""Micro-benchmark of the PointNet forward kernel (HIP events on the launch stream)."""
+"""Micro-benchmark of the PointNet forward kernel (HIP events on the launch stream): exact fp32 and the opt-in split-bf16 x3 mode,
+with the latter's error against the former."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from sgaligner_amd import ops
+from sgaligner_amd import _lib, ops
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 torch.manual_seed(0)
 x = torch.randn(T, P, 3, device='cuda')
-w = [torch.randn(64, 3, device='cuda') * 0.2, torch.zeros(64, device='cuda'),
-     torch.randn(128, 64, device='cuda') * 0.1, torch.zeros(128, device='cuda'),
-     torch.randn(256, 128, device='cuda') * 0.1, torch.zeros(256, device='cuda')]
-for am in (False, True):
-    for _ in range(2):
-        ops.pointnet_forward(x, *w, want_argmax=am)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    n = 5
-    for _ in range(n):
-        ops.pointnet_forward(x, *w, want_argmax=am)
-    e.record(); torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / n
-    fl = 82304.0 * T * P
-    print(f'pointnet_fwd argmax={am} T={T} P={P}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.1f}% of fp32 peak)')
+w = [torch.randn(64, 3, device='cuda') * 0.2, torch.randn(64, device='cuda') * 0.1,
+     torch.randn(128, 64, device='cuda') * 0.1, torch.randn(128, device='cuda') * 0.1,
+     torch.randn(256, 128, device='cuda') * 0.1, torch.randn(256, device='cuda') * 0.1]
+ref = None
+for mode in (0, 1):
+    _lib.lib().sga_set_mfma_mode(mode)
+    for am in (False, True):
+        for _ in range(2):
+            y, a = ops.pointnet_forward(x, *w, want_argmax=am)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        n = 5
+        for _ in range(n):
+            y, a = ops.pointnet_forward(x, *w, want_argmax=am)
+        e.record(); torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / n
+        fl = 82304.0 * T * P
+        extra = ''
+        if mode == 0 and am:
+            ref = (y.clone(), a.clone())
+        if mode == 1 and am:
+            err = (y - ref[0]).abs().max().item()
+            rel = err / ref[0].abs().max().item()
+            same = (a == ref[1]).float().mean().item()
+            extra = f'  max|y - y_fp32| {err:.3e} (rel {rel:.2e}), same arg-max point {same * 100:.3f} %'
+        print(f'pointnet_fwd mode={"bf16x3" if mode else "fp32"} argmax={am} T={T} P={P}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s algorithmic '
+              f'({fl/ms/1e9/157.3*100:.1f}% of the fp32 MFMA peak){extra}')
+_lib.lib().sga_set_mfma_mode(0)
