@@ -130,6 +130,18 @@ int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const f
 /* *poison = NaN if any row norm is below F.normalize's eps (the identity above would not hold): fail loudly */
 int sga_loss_check_norms(const float* nrm, int n, float* poison, void* stream);
 
+/* ---- opt-in split-bf16 x3 form of the two fused sweeps above (sga_set_mfma_mode(1); sweepb.hip) ----------------------
+ * sga_loss_split_tables: packed fp32 table Z [R(+32), 104] (sga_loss_gather, Dp = 104) -> Zb, 32-row blocks of four bf16 planes
+ * (row-major hi/lo + transposed hi/lo; segments X1 | X2 | N1 | N2 each padded to whole blocks), sga_loss_split_bytes bytes.
+ * sga_loss_multi_sums_bf16x3 / _grad_bf16x3: same arguments and outputs as sga_loss_multi_sums / sga_loss_multi_grad with the
+ * M tables given as Zb; every similarity / gradient product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi) into fp32. M in {2,3}. */
+size_t sga_loss_split_bytes(int A, int J1, int J2);
+int sga_loss_split_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
+int sga_loss_multi_sums_bf16x3(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                               double* sums, int a_lo, int a_hi, void* stream);
+int sga_loss_multi_grad_bf16x3(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                               const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
+
 /* ---- loss_group = b: the same loss on G independent groups of b consecutive pairs ------------------------
  * replaces the reference trainer feeding b pairs per iteration (configs/scan3r/scan3r_ground_truth.yaml:27,
  * src/engine/epoch_based_trainer.py:91-93 -> src/aligner/losses.py:114-152) for all B/b groups of a device batch at once:

@@ -33,29 +33,6 @@ namespace {
 
 constexpr int CT_THREADS = 256;
 constexpr int CT_MAXT = 9;            // modalities (<= 8) + joint
-// Global scalar accumulators (loss sums, dL/d(sums), Gamma) are hit by every wave of every workgroup; a single
-// set of addresses serialises in L2 (measured: ~10 of the 15 ms of the anchors backward).  Each accumulator therefore
-// has SGA_SLOTS copies, a wave adds to copy (wave id mod SGA_SLOTS), and reduce_slots_kernel folds them into copy 0's
-// final location.  Buffers passed to the C ABI hold (1 + SGA_SLOTS) * n doubles: [result n | slots].
-constexpr int SGA_SLOTS = 128;
-__device__ __forceinline__ int my_slot() {
-    return (int)((blockIdx.x * gridDim.y + blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)) % SGA_SLOTS;
-}
-__global__ void reduce_slots_kernel(double* __restrict__ buf, int n) {      // buf[0..n) = sum_s buf[n + s*n + i]
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double v = 0.0;
-    for (int sl = 0; sl < SGA_SLOTS; ++sl) v += buf[n + (size_t)sl * n + i];
-    buf[i] = v;
-}
-static int zero_slots(double* buf, int n, hipStream_t s, const char* who) {
-    if (hipMemsetAsync(buf, 0, (size_t)(1 + SGA_SLOTS) * n * sizeof(double), s) != hipSuccess) { sga_set_error("%s: memset failed", who); return SGA_ERR_HIP; }
-    return SGA_OK;
-}
-static void fold_slots(double* buf, int n, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slots_kernel, dim3((n + 63) / 64), dim3(64), 0, s, buf, n);
-}
-
 // ------------------------------------------------------------------------------------------------
 // gather + normalise:  Z[r, :] = E[idx[r], :] / max(||.||, 1e-12), zero padded to Dp; nrm[r] = ||.||
 // (F.normalize(emb, dim=1) then emb[data_dict[...]]: losses.py:44-48, :73-79, :84-87)

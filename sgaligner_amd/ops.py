@@ -811,8 +811,19 @@ class FusedContrastiveFn(torch.autograd.Function):
         slots = 1 + L.sga_loss_slots()
         sums = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
         dmax = max(e.shape[1] for e in tables)          # real width: the K step that only covers zero padding is skipped
-        _lib.check(L.sga_loss_multi_sums(zarr, M, dmax, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), a_lo, a_hi, st),
-                   'sga_loss_multi_sums')
+        # opt-in split-bf16 x3 sweeps: the tables additionally as blocked bf16 hi/lo planes (sweepb.hip)
+        zbs = []
+        if M <= 3 and get_mfma_mode() == 'bf16x3':
+            nb = L.sga_loss_split_bytes(s.A, s.J1, s.J2)
+            for z in zs:
+                zb = torch.empty((nb,), device=dev, dtype=torch.uint8)
+                _lib.check(L.sga_loss_split_tables(_p(z), s.A, s.J1, s.J2, _p(zb), st), 'sga_loss_split_tables')
+                zbs.append(zb)
+            _lib.check(L.sga_loss_multi_sums_bf16x3(_ptr_array(zbs), M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums),
+                                                    a_lo, a_hi, st), 'sga_loss_multi_sums_bf16x3')
+        else:
+            _lib.check(L.sga_loss_multi_sums(zarr, M, dmax, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), a_lo, a_hi, st),
+                       'sga_loss_multi_sums')
         sums = _allreduce_sum(sums[0].contiguous(), reduce)
         zj = torch.empty((2 * s.A, M * dp), device=dev, dtype=torch.float32)
         _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')
@@ -827,7 +838,8 @@ class FusedContrastiveFn(torch.autograd.Function):
         out = _allreduce_sum(out[:nt + 2 * M].contiguous(), reduce)
         ctx.s, ctx.alpha, ctx.M, ctx.shard, ctx.reduce = s, float(alpha), M, (a_lo, a_hi), reduce
         ctx.shapes = [tuple(t.shape) for t in tables]
-        ctx.save_for_backward(sums, beta, zj, *zs, *nrms)
+        ctx.n_zb = len(zbs)
+        ctx.save_for_backward(sums, beta, zj, *zs, *nrms, *zbs)
         return out.float() + poison
 
     @staticmethod
@@ -838,7 +850,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         ns = a_hi - a_lo
         nt = M + 1
         sums, beta, zj, *rest = ctx.saved_tensors
-        zs, nrms = rest[:M], rest[M:]
+        zs, nrms, zbs = rest[:M], rest[M:2 * M], rest[2 * M:]
         dev = sums.device
         st = _stream()
         dp = 104
@@ -894,8 +906,12 @@ class FusedContrastiveFn(torch.autograd.Function):
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _lib.check(L.sga_loss_multi_grad(_ptr_array(zs), M, max(d for _, d in ctx.shapes), _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
-                                         _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad')
+        if ctx.n_zb:          # the forward ran in bf16x3 mode: its blocked bf16 planes are there
+            _lib.check(L.sga_loss_multi_grad_bf16x3(_ptr_array(zbs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
+                                                    _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad_bf16x3')
+        else:
+            _lib.check(L.sga_loss_multi_grad(_ptr_array(zs), M, max(d for _, d in ctx.shapes), _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
+                                             _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad')
         if ev is not None:
             ev[1].record()
             KERNEL_EVENTS.setdefault('loss_multi_grad', []).append(ev + ((ns, A, s.J1, s.J2, M),))

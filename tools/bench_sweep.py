@@ -23,3 +23,21 @@ ms = [a.elapsed_time(b) for a, b, _ in ev]
 ns, A, J1, J2, M = ev[0][2]
 alg = 2.0 * (2.0 * 600 * 2.0 * ns * (J1 + J2))
 print(f'sweep grad: median {np.median(ms):.3f} ms (min {min(ms):.3f})  A={A} J={J1 + J2}  algorithmic {alg / np.median(ms) / 1e9:.1f} TFLOP/s = {alg / np.median(ms) / 1e9 / 157.3:.3f} of fp32 MFMA peak; grad checksum {float(tabs[0].grad.abs().sum()):.6e}')
+# accuracy of the opt-in mode against the exact-fp32 sweeps on the same inputs (run with SGA_BENCH_SWEEP_COMPARE=1)
+if os.environ.get('SGA_BENCH_SWEEP_COMPARE'):
+    res = {}
+    for mode in ('f32', 'bf16x3'):
+        ops.set_mfma_mode(mode)
+        for t in tabs:
+            t.grad = None
+        w.grad = None
+        sums, s = ops.fused_contrastive_terms(tabs, w, dd)
+        sums.sum().backward()
+        torch.cuda.synchronize()
+        res[mode] = (sums.detach().clone(), [t.grad.clone() for t in tabs], w.grad.clone())
+    ops.set_mfma_mode('f32')
+    a, b = res['f32'], res['bf16x3']
+    print('loss terms rel err', ((a[0] - b[0]).abs() / a[0].abs().clamp_min(1e-30)).max().item())
+    for k in range(3):
+        print(f'dE[{k}] max abs err {(a[1][k] - b[1][k]).abs().max().item():.3e} / max |dE| {a[1][k].abs().max().item():.3e}')
+    print('dw max abs err', (a[2] - b[2]).abs().max().item(), '/', a[2].abs().max().item())
