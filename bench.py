@@ -138,6 +138,7 @@ def main():
     ap.add_argument('--config', choices=['auto', 'c2', 'c3'], default=os.environ.get('SGA_BENCH_CONFIG', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hits', action='store_true')
+    ap.add_argument('--no-bf16x3', action='store_true', help='skip the extra (opt-in split-bf16 x3 MFMA mode) measurement')
     args = ap.parse_args()
 
     from sgaligner_amd import dist as sdist
@@ -192,6 +193,35 @@ def main():
         elapsed, med_ms = float(t[0].item()), float(t[1].item())
     loss_val = float(loss_dict['loss'].item())
     peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
+
+    # ---- extra, NOT the headline: the same steps in the opt-in split-bf16 x3 MFMA mode (ops.set_mfma_mode), with its error against
+    # the exact-fp32 step on the same batch and weights.  `value` above is always exact fp32.
+    extra = None
+    if not args.no_bf16x3:
+        ref_grads = {n: p.grad.detach().clone() for n, p in steps.model.named_parameters() if p.grad is not None}
+        ops.set_mfma_mode('bf16x3')
+        try:
+            for _ in range(min(2, args.warmup)):
+                steps.forward_backward(dd)
+            barrier()
+            n_x = max(2, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(n_x):
+                _, ld_x = steps.forward_backward(dd)
+            barrier()
+            el_x = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([el_x], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el_x = float(t.item())
+            gerr = max(((p.grad - ref_grads[n]).abs().max() / ref_grads[n].abs().max().clamp_min(1e-30)).item()
+                       for n, p in steps.model.named_parameters() if p.grad is not None and n in ref_grads)
+            extra = {'mode': 'bf16x3 (opt-in): PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate',
+                     'value': round(total_pairs * n_x / el_x, 2), 'unit': 'pairs/s', 'ms_per_step': round(el_x / n_x * 1e3, 3), 'steps': n_x,
+                     'loss_rel_err_vs_f32': abs(float(ld_x['loss'].item()) - loss_val) / max(1e-30, abs(loss_val)),
+                     'max_param_grad_rel_err_vs_f32': gerr}
+        finally:
+            ops.set_mfma_mode('f32')
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -250,6 +280,8 @@ def main():
             'roofline': roof,
             'roofline_other': roofs[1:],
         }
+        if extra is not None:
+            line['extra_bf16x3'] = extra
         if not args.no_hits:
             line['hits_at_1'] = hits_at_k(steps, n_obj, n_pts, dev)
         if not args.no_cpu_baseline:

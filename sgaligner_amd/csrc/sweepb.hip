@@ -8,16 +8,22 @@
 // epilogue becomes the larger part.
 //
 // Data layout.  sga_loss_split_tables turns a packed fp32 table Z [X1 | X2 | N1 | N2] into 32-row BLOCKS, each segment padded
-// to whole blocks; a block holds four bf16 planes, 26 624 B contiguous:
-//     R hi | R lo   [32 rows][104 cols]    row-major: the S product's operands (8 consecutive k per lane = one 16-byte read)
-//     T hi | T lo   [104 cols][32 rows]    transposed: the gradient GEMM's B operand (8 consecutive "other" rows of a column)
-// so a tile of "other" rows is ONE contiguous 26 KiB copy per table (26 global_load_lds DMA chunks), double-buffered in LDS
-// (3 tables: 2 x 78 KiB = 156 KiB: one 8-wave workgroup per CU, 128 owner rows).
+// to whole blocks; a block holds two bf16 planes (hi | lo) of 6 656 B, 13 312 B contiguous, stored in the S product's MFMA OPERAND
+// ORDER, so that its LDS reads are lane-linear (lane L reads 16 B at base + 16 L: ds_read_b128 conflict-free by construction):
+//     [K step q (3)][half jh (2)][lane = 16 g4 + i][8 bf16] = columns 32 q + 8 g4 .. + 7 of row 8 (i>>2) + 4 jh + (i&3),
+//     then the K = 16 tail [jh][g4 < 2][i][4 bf16] = columns 96 + 4 g4 .. + 3.
+// A tile of "other" rows is ONE contiguous 13 KiB copy per table (13 global_load_lds DMA chunks; the LDS-DMA path sustains only
+// ~18 B/clk per CU, which is why there is no second, transposed copy of the tile), double-buffered in LDS (3 tables: 78 KiB).
+// The gradient GEMM's B operand -- 8 consecutive "other" rows of one column per lane, i.e. the TRANSPOSE of how a row is stored --
+// comes from the same planes through gfx950's LDS transpose read: ds_read_b64_tr_b16 hands lane c of a 16-lane group element
+// (c & 3) of the 8-byte pieces addressed by lanes 4 j + (c >> 2), j = 0..3 (tools/micro/tr16_probe.hip), so with lane i pointing at
+// (row r0 + (i >> 2), columns col0 + 4 (i & 3) ..) lane c receives rows r0 .. r0 + 3 of column col0 + c: two such reads per plane
+// are one 16x16x32 B operand.
 // MFMA bookkeeping (v_mfma_f32_16x16x32_bf16; A: lane&15 = row, B: lane&15 = column, lane>>4 = k group of 8 slots):
 //   S^T tile: A = other rows from LDS, B = owner rows (registers).  Half jh of a 32-row tile uses A row i <-> other row
 //   8 (i>>2) + 4 jh + (i&3), so that a lane's 8 accumulator values (2 halves x 4) are the 8 CONSECUTIVE other rows 8 g4 .. 8 g4+7:
 //   exactly the k slots of the gradient MFMA  dZ[own] += C[own, other] Z[other, cols]  whose A operand is therefore the
-//   coefficient registers (split into bf16 hi/lo, 6 VALU per pair) and whose B operand is one ds_read_b128 of the T plane.
+//   coefficient registers (split into bf16 hi/lo, 6 VALU per pair) and whose B operand comes from the transpose reads above.
 #include "loss_math.h"
 
 namespace {
@@ -30,10 +36,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SB_WAVES = 8, SB_THREADS = SB_WAVES * 64, SB_OWN = SB_WAVES * 16;
+#ifndef SB_NBUF
+#define SB_NBUF 2
+#endif
 constexpr int SB_DP = 104;
 constexpr int SB_ROWB = SB_DP * 2;               // bytes of a row in an R plane
 constexpr int SB_PLANE = 32 * SB_ROWB;           // 6656 B
-constexpr int SB_BLOCK = 4 * SB_PLANE;           // 26624 B: R hi | R lo | T hi | T lo
+constexpr int SB_BLOCK = 2 * SB_PLANE;           // 13312 B: hi | lo
 
 __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
     const bf16x2 h = __builtin_convertvector(f32x2{v0, v1}, bf16x2);
@@ -43,6 +52,10 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
 }
 __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {     // ds_read_b64_tr_b16
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p)));
 }
 __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, a), __builtin_bit_cast(bf16x4, b), c, 0, 0, 0);
@@ -66,17 +79,22 @@ __global__ __launch_bounds__(256) void split_tables_kernel(const float* __restri
     __syncthreads();
     unsigned* out = reinterpret_cast<unsigned*>(Zb + (size_t)blockIdx.x * SB_BLOCK);
     constexpr int PD = SB_PLANE / 4;                  // dwords per plane
-    for (int e = threadIdx.x; e < 32 * 52; e += 256) {             // R planes: dword (row w, column pair p)
-        const int w = e / 52, p = e - w * 52;
+    // main part: dword (q, jh, g4, i, pair p of 4): columns 32 q + 8 g4 + 2 p, +1 of row 8 (i>>2) + 4 jh + (i&3)
+    for (int e = threadIdx.x; e < 3 * 2 * 64 * 4; e += 256) {
+        const int p = e & 3, ln = (e >> 2) & 63, jh = (e >> 8) & 1, q = e >> 9;
+        const int i = ln & 15, g4 = ln >> 4;
+        const int row = 8 * (i >> 2) + 4 * jh + (i & 3), col = 32 * q + 8 * g4 + 2 * p;
         unsigned hi, lo;
-        split_pair(tile[w * SB_DP + 2 * p], tile[w * SB_DP + 2 * p + 1], hi, lo);
+        split_pair(tile[row * SB_DP + col], tile[row * SB_DP + col + 1], hi, lo);
         out[e] = hi; out[PD + e] = lo;
     }
-    for (int e = threadIdx.x; e < SB_DP * 16; e += 256) {          // T planes: dword (column c, row pair q)
-        const int c = e >> 4, q = e & 15;
+    // K = 16 tail: dword (jh, g4 < 2, i, pair p of 2): columns 96 + 4 g4 + 2 p, +1
+    for (int e = threadIdx.x; e < 2 * 2 * 16 * 2; e += 256) {
+        const int p = e & 1, i = (e >> 1) & 15, g4 = (e >> 5) & 1, jh = e >> 6;
+        const int row = 8 * (i >> 2) + 4 * jh + (i & 3), col = 96 + 4 * g4 + 2 * p;
         unsigned hi, lo;
-        split_pair(tile[(2 * q) * SB_DP + c], tile[(2 * q + 1) * SB_DP + c], hi, lo);
-        out[2 * PD + e] = hi; out[3 * PD + e] = lo;
+        split_pair(tile[row * SB_DP + col], tile[row * SB_DP + col + 1], hi, lo);
+        out[1536 + e] = hi; out[PD + 1536 + e] = lo;
     }
 }
 
@@ -95,9 +113,10 @@ struct BArgs {
 template <int M, bool GRAD>
 __global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
     constexpr int NCT = 7;
-    constexpr int TBYTES = GRAD ? SB_BLOCK : 2 * SB_PLANE;          // the sums pass only needs the R planes
+    constexpr int TBYTES = SB_BLOCK;
     constexpr int BUF = M * TBYTES, NCH = TBYTES / 1024, NCHUNK = M * NCH;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];      // [2][M][TBYTES]
+    constexpr int NBUF = SB_NBUF;                                             // ring depth: tiles it+1 .. it+NBUF-1 are in flight
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];      // [NBUF][M][TBYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
     int g = 0;
@@ -117,19 +136,20 @@ __global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
     float beta[M];
     {
         const int rel = (iv ? my_i : own0) - grp.own_old0;
-        const size_t off = (size_t)(grp.own_blk0 + (rel >> 5)) * SB_BLOCK + (size_t)(rel & 31) * SB_ROWB;
+        const int o = rel & 31, oi = 4 * (o >> 3) + (o & 3), ojh = (o >> 2) & 1;       // row o sits at (half ojh, operand row oi) of its block
+        const size_t off = (size_t)(grp.own_blk0 + (rel >> 5)) * SB_BLOCK;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const unsigned char* base = a.Zb[m] + off;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                ohi[m][q] = *reinterpret_cast<const u32x4*>(base + (32 * q + 8 * g4) * 2);
-                olo[m][q] = *reinterpret_cast<const u32x4*>(base + SB_PLANE + (32 * q + 8 * g4) * 2);
+                ohi[m][q] = *reinterpret_cast<const u32x4*>(base + ((q * 2 + ojh) * 64 + g4 * 16 + oi) * 16);
+                olo[m][q] = *reinterpret_cast<const u32x4*>(base + SB_PLANE + ((q * 2 + ojh) * 64 + g4 * 16 + oi) * 16);
                 if (!iv) { ohi[m][q] = u32x4{0, 0, 0, 0}; olo[m][q] = u32x4{0, 0, 0, 0}; }
             }
             const bool tv = iv && g4 < 2;                      // columns 96..103 only: the k slots of lanes 32..63 multiply zeros
-            othi[m] = tv ? *reinterpret_cast<const u32x2*>(base + (96 + 4 * g4) * 2) : u32x2{0, 0};
-            otlo[m] = tv ? *reinterpret_cast<const u32x2*>(base + SB_PLANE + (96 + 4 * g4) * 2) : u32x2{0, 0};
+            othi[m] = tv ? *reinterpret_cast<const u32x2*>(base + 6144 + ((ojh * 2 + (g4 & 1)) * 16 + oi) * 8) : u32x2{0, 0};
+            otlo[m] = tv ? *reinterpret_cast<const u32x2*>(base + SB_PLANE + 6144 + ((ojh * 2 + (g4 & 1)) * 16 + oi) * 8) : u32x2{0, 0};
             beta[m] = a.beta[m];
         }
     }
@@ -142,6 +162,10 @@ __global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
 #pragma unroll
     for (int m = 0; m < M; ++m) gam[m] = 0.f;
 
+    // transposed-read piece of this lane (see the header): operand row i_o = 4 g4 + (l15 >> 2), column sub-piece l15 & 3
+    const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
+    const int tr_main = (tr_cs >> 1) * 256 + tr_io * 16 + (tr_cs & 1) * 8;        // + (ct >> 1) * 2048 + (ct & 1) * 512 + rd * 1024
+    const int tr_tail = 6144 + (tr_cs & 1) * 128 + tr_io * 8;                    // + rd * 256  (columns 96..103; sub-pieces 2, 3 alias 0, 1)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
     auto issue = [&](int blk, unsigned char* buf) {
 #pragma unroll
@@ -170,39 +194,64 @@ __global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
         for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
 
         __syncthreads();
-        if (seg.jt_lo + split < seg.jt_hi) issue(seg.blk0 + seg.jt_lo + split, ldsb);
+#pragma unroll
+        for (int d = 0; d < NBUF - 1; ++d)
+            if (seg.jt_lo + split + d * nsplit < seg.jt_hi) issue(seg.blk0 + seg.jt_lo + split + d * nsplit, ldsb + d * BUF);
         int it = 0;
 #pragma unroll 1
         for (int jt = seg.jt_lo + split; jt < seg.jt_hi; jt += nsplit, ++it) {
-            unsigned char* buf = ldsb + (it & 1) * BUF;
+            unsigned char* buf = ldsb + (it % NBUF) * BUF;
             const int j0 = seg.old0 + 32 * jt;                 // old row of the tile's first row
-            __syncthreads();                                   // tile `it` landed / other buffer free
-            if (jt + nsplit < seg.jt_hi) issue(seg.blk0 + jt + nsplit, ldsb + ((it + 1) & 1) * BUF);
+            // tile `it` must have landed: all but the NBUF-2 most recently issued tiles of this wave are complete (a wave's DMA
+            // chunks return in order), then the barrier publishes every wave's chunks; it also frees buffer (it-1) % NBUF
+            if (NBUF == 2) {
+                __syncthreads();
+            } else {
+                constexpr int keep = (NCHUNK / SB_WAVES) * (NBUF - 2);      // every wave issues >= NCHUNK / 8 chunks per tile
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (jt + (NBUF - 1) * nsplit < seg.jt_hi) issue(seg.blk0 + jt + (NBUF - 1) * nsplit, ldsb + ((it + NBUF - 1) % NBUF) * BUF);
 
-            // ---- S^T tiles: sacc[m][jh][r] = S_m[own = lane&15, other = 8 g4 + 4 jh + r]
+            // ---- S^T tiles: sacc[m][jh][r] = S_m[own = lane&15, other = 8 g4 + 4 jh + r].  Per half, the M main chains and the M
+            // tail chains are interleaved (a dependent MFMA is M issues away) and a K step's operands are read for all tables first.
             f32x4 sacc[M][2];
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
-                const int rowi = 8 * (l15 >> 2) + 4 * jh + (l15 & 3);
+                const unsigned char* ar = buf + (jh * 64 + lane) * 16;          // lane-linear: [q][jh][lane][16 B]
+                f32x4 acc[M], tacc[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; tacc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                // tail K = 16: only lanes g4 < 2 carry columns 96..103; lanes 32..63 multiply the owner's zeros and re-read the same
+                // (finite) data.  It runs in its OWN accumulator chain: chaining v_mfma_*_16x16x16 onto an accumulator that a
+                // v_mfma_*_16x16x32 has just written gave schedule-dependent wrong sums on gfx950 (mixed-type SrcC forwarding).
+                const unsigned char* at = buf + 6144 + ((jh * 2 + (g4 & 1)) * 16 + l15) * 8;
+                u32x2 th[M], tl[M];
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const unsigned char* ar = buf + m * TBYTES + rowi * SB_ROWB;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const u32x4 ah = *reinterpret_cast<const u32x4*>(ar + (32 * q + 8 * g4) * 2);
-                        const u32x4 al = *reinterpret_cast<const u32x4*>(ar + SB_PLANE + (32 * q + 8 * g4) * 2);
-                        acc = mfma32(ah, ohi[m][q], acc);
-                        acc = mfma32(ah, olo[m][q], acc);
-                        acc = mfma32(al, ohi[m][q], acc);
-                    }
-                    const u32x2 th = *reinterpret_cast<const u32x2*>(ar + (96 + 4 * g4) * 2);
-                    const u32x2 tl = *reinterpret_cast<const u32x2*>(ar + SB_PLANE + (96 + 4 * g4) * 2);
-                    acc = mfma16(th, othi[m], acc);
-                    acc = mfma16(th, otlo[m], acc);
-                    acc = mfma16(tl, othi[m], acc);
-                    sacc[m][jh] = acc;
+                    th[m] = *reinterpret_cast<const u32x2*>(at + m * TBYTES);
+                    tl[m] = *reinterpret_cast<const u32x2*>(at + m * TBYTES + SB_PLANE);
                 }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    u32x4 ah[M], al[M];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        ah[m] = *reinterpret_cast<const u32x4*>(ar + m * TBYTES + q * 2048);
+                        al[m] = *reinterpret_cast<const u32x4*>(ar + m * TBYTES + SB_PLANE + q * 2048);
+                    }
+#pragma unroll
+                    for (int m = 0; m < M; ++m) acc[m] = mfma32(ah[m], ohi[m][q], acc[m]);
+#pragma unroll
+                    for (int m = 0; m < M; ++m) tacc[m] = q == 0 ? mfma16(th[m], othi[m], tacc[m]) : (q == 1 ? mfma16(th[m], otlo[m], tacc[m]) : mfma16(tl[m], othi[m], tacc[m]));
+#pragma unroll
+                    for (int m = 0; m < M; ++m) acc[m] = mfma32(ah[m], olo[m][q], acc[m]);
+#pragma unroll
+                    for (int m = 0; m < M; ++m) acc[m] = mfma32(al[m], ohi[m][q], acc[m]);
+                }
+#pragma unroll
+                for (int m = 0; m < M; ++m) sacc[m][jh] = acc[m] + tacc[m];
             }
 
             float okf[2][4];
@@ -245,14 +294,6 @@ __global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
                         for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][jh][r], sj);
                         cj[jh][r] = okf[jh][r] * (c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1));
                     }
-                if (g < 2) {                                   // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
-#pragma unroll
-                    for (int m = 0; m < M; ++m)
-#pragma unroll
-                        for (int jh = 0; jh < 2; ++jh)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[jh][r], sacc[m][jh][r], gam[m]);
-                }
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     // c_m for this lane's 8 consecutive other rows (k slot j = 4 jh + r), split into bf16 hi / lo: the A operand
@@ -267,17 +308,40 @@ __global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
                         split_pair(v0, v1, hi, lo);
                         chi[p] = hi; clo[p] = lo;
                     }
-                    const unsigned char* tb = buf + m * TBYTES + 2 * SB_PLANE + l15 * 64 + g4 * 16;   // T plane: [column][32 others]
+                    // B operand (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes: lane i
+                    // of a 16-lane group addresses the 8-byte piece (row 8 g4 + 4 rd + (i >> 2), columns 16 ct + 4 (i & 3) ..)
+                    const unsigned char* tb = buf + m * TBYTES + tr_main;
+                    const unsigned char* tb6 = buf + m * TBYTES + tr_tail;
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const u32x4 bh = *reinterpret_cast<const u32x4*>(tb + ct * 16 * 64);
-                        const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + SB_PLANE + ct * 16 * 64);
-                        f32x4 acc = gacc[GRAD ? m : 0][ct];
-                        acc = mfma32(chi, bh, acc);
-                        acc = mfma32(chi, bl, acc);
-                        acc = mfma32(clo, bh, acc);
-                        gacc[GRAD ? m : 0][ct] = acc;
+                    for (int c0t = 0; c0t < NCT; c0t += 4) {
+                        u32x4 bh[4], bl[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int ct = c0t + u;
+                            if (ct < NCT) {
+                                const unsigned char* p0 = ct < 6 ? tb + (ct >> 1) * 2048 + (ct & 1) * 512 : tb6;
+                                const int rstep = ct < 6 ? 1024 : 256;                      // rd = 1: the other half (jh) of the operand-order image
+                                const u32x2 h0 = tr_read(p0), h1 = tr_read(p0 + rstep);
+                                const u32x2 l0 = tr_read(p0 + SB_PLANE), l1 = tr_read(p0 + SB_PLANE + rstep);
+                                bh[u] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                                bl[u] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(chi, bh[u], gacc[GRAD ? m : 0][c0t + u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(chi, bl[u], gacc[GRAD ? m : 0][c0t + u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(clo, bh[u], gacc[GRAD ? m : 0][c0t + u]);
                     }
+                }
+                if (g < 2) {                                   // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[jh][r], sacc[m][jh][r], gam[m]);
                 }
 #pragma unroll
                 for (int m = 0; m < M; ++m) asm volatile("" : "+v"(gam[m]));
@@ -354,7 +418,11 @@ int fill_b(BArgs& a, const void* const* Zb, int M, const float* beta, int A, int
         BGroup& G = a.grp[i];
         int steps = 0;
         for (int sg = 0; sg < G.nseg; ++sg) steps += G.seg[sg].jt_hi - G.seg[sg].jt_lo;
-        int nsp = (steps + 159) / 160;
+        // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  With nsplit a multiple of 8 (and every group's
+        // first workgroup therefore too) the 32 co-resident workgroups of an XCD share `split`, i.e. they walk the SAME other tiles
+        // at the same time for different owner blocks: a tile comes from HBM/MALL once per XCD and 31 more times from its L2.
+        int nsp = ((steps + 159) / 160 + 7) / 8 * 8;
+        if (nsp > steps) nsp = (steps + 7) / 8 * 8;
         if (nsp < 1) nsp = 1;
         G.nsplit = nsp;
         G.blk0 = nwg;
@@ -365,7 +433,7 @@ int fill_b(BArgs& a, const void* const* Zb, int M, const float* beta, int A, int
 
 template <int M, bool GRAD>
 void launch_b(const BArgs& a, int nwg, hipStream_t s) {
-    const size_t lds = (size_t)2 * M * (GRAD ? SB_BLOCK : 2 * SB_PLANE);
+    const size_t lds = (size_t)SB_NBUF * M * SB_BLOCK;
     auto k = sweepb_kernel<M, GRAD>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(nwg), dim3(SB_THREADS), lds, s, a);
