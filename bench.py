@@ -214,12 +214,23 @@ def main():
                 t = torch.tensor([el_x], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el_x = float(t.item())
-            gerr = max(((p.grad - ref_grads[n]).abs().max() / ref_grads[n].abs().max().clamp_min(1e-30)).item()
-                       for n, p in steps.model.named_parameters() if p.grad is not None and n in ref_grads)
+            gmax = max(float(g.abs().max()) for g in ref_grads.values())
+            worst, worst_name, worst_glob = 0.0, None, 0.0
+            for n, p in steps.model.named_parameters():
+                if p.grad is None or n not in ref_grads:
+                    continue
+                err = float((p.grad - ref_grads[n]).abs().max())
+                own = err / max(1e-30, float(ref_grads[n].abs().max()))
+                worst_glob = max(worst_glob, err / max(1e-30, gmax))
+                if own > worst:
+                    worst, worst_name = own, n
             extra = {'mode': 'bf16x3 (opt-in): PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate',
                      'value': round(total_pairs * n_x / el_x, 2), 'unit': 'pairs/s', 'ms_per_step': round(el_x / n_x * 1e3, 3), 'steps': n_x,
                      'loss_rel_err_vs_f32': abs(float(ld_x['loss'].item()) - loss_val) / max(1e-30, abs(loss_val)),
-                     'max_param_grad_rel_err_vs_f32': gerr}
+                     # gradient error against the exact-fp32 step on the same batch: relative to the largest gradient entry of the
+                     # whole model, and -- worst case -- relative to the parameter's own largest entry (dominated by parameters whose
+                     # gradient is a small difference of large sums, and by arg-max ties of the max-pool flipping between points)
+                     'max_grad_err_rel_to_global_max': worst_glob, 'max_grad_err_rel_to_own_max': worst, 'worst_param': worst_name}
         finally:
             ops.set_mfma_mode('f32')
 
