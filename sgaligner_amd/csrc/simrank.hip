@@ -104,10 +104,14 @@ __global__ __launch_bounds__(256) void simrank_mfma_kernel(SimArgs a) {
         const float* __restrict__ bp = a.E + (size_t)brow * D;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (KQ > 0) {
+            // all B fragments of the tile first (one memory latency per tile, not one per K group), then the MFMAs
+            f32x4 bvs[KQ];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) bvs[q] = q < nkq ? load_kgroup(bp, D, q, g4, F16 ? ib : 1.f) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 if (q < nkq) {
-                    const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
+                    const f32x4 bv = bvs[q];
                     if (F16) {
                         const f16x4 ah = {(_Float16)areg[q][0], (_Float16)areg[q][1], (_Float16)areg[q][2], (_Float16)areg[q][3]};
                         const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
