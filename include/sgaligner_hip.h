@@ -163,12 +163,13 @@ int sga_group_loss_bwd(const float* const* Z, int M, const float* beta, int A, i
  * replaces eval_step's emb/||emb||, sim = 1 - emb emb^T, argsort (src/inference/sgaligner/inference_align_reg.py:
  * 125-128) fused with the rank look-ups of utils/alignment.py:3-25,27-41,59-70.  The per-pair E E^T blocks run on the
  * matrix cores (exact fp32 MFMA; f16 != 0: fp16 inputs / fp32 accumulate on the normalised rows -- BASELINE.json
- * configs[4]).  pair_off [B+1] object offsets of the pairs; blk_off [B+1] prefix sum of ceil(n_b / 64) (one workgroup per
- * 64 objects of a pair), n_blocks = blk_off[B].  For query object q_idx[q] (each object at most once): rank[q] = 1-based
+ * configs[4]).  pair_off [B+1] object offsets of the pairs; blk_pair / blk_row [n_blocks]: the (pair, 64-row block) of every
+ * workgroup -- list exactly the blocks that contain a query object (any order; the caller knows q_idx), so that no workgroup is
+ * launched for nothing and the work spreads over all XCDs.  For query object q_idx[q] (each object at most once): rank[q] = 1-based
  * rank of q_tgt[q] among its pair's other objects (q_tgt NULL or out of the pair: -1); topk_*[q,:K] its K nearest
  * others (pair-local index, distance), ascending, ties by index.  K <= 8, <= 512 objects per pair. */
 size_t sga_simrank_workspace_bytes(int T);
-int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_off, int n_blocks, int B,
+int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_pair, const int32_t* blk_row, int n_blocks, int B,
                 int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
                 int32_t* topk_idx, float* topk_sim, int f16, void* workspace, size_t workspace_bytes, void* stream);
 /* per pair b (queries pair_q_off[b]..pair_q_off[b+1], in sga_simrank's order): out[b][0..4] = Hits@1..5 counts,

@@ -49,7 +49,8 @@ __global__ void scatter_query_kernel(const int* __restrict__ q_idx, int Q, int* 
 struct SimArgs {
     const float* E; const float* inv; int D, B;
     const int* pair_off;              // [B+1] object offsets
-    const int* blk_off;               // [B+1] workgroup offsets (ceil(n_b / 64) per pair)
+    const int* blk_pair;              // [n_blocks] pair of each workgroup: only 64-row blocks that hold a query are launched,
+    const int* blk_row;               // [n_blocks] its row block inside the pair      so the work spreads over all XCDs
     const int* obj_query;             // [T] query id of an object or -1
     const int* q_tgt;                 // [Q] or null
     int K;
@@ -69,81 +70,9 @@ __device__ __forceinline__ f32x4 load_kgroup(const float* __restrict__ row, int 
     return v * scale;
 }
 
-template <int KQ, bool F16>
-__global__ __launch_bounds__(256) void simrank_mfma_kernel(SimArgs a) {
-    extern __shared__ float strip[];                       // [4 waves][16][npad_max]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = lane >> 4, l15 = lane & 15;
-    // which pair does this workgroup belong to
-    int lo = 0, hi = a.B;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.blk_off[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
-    const int b = lo;
-    const int o0 = a.pair_off[b], n = a.pair_off[b + 1] - o0;
-    const int row0 = ((int)blockIdx.x - a.blk_off[b]) * SR_ROWS + wave * 16;      // pair-local first row of this wave
-    if (row0 >= n) return;
-    // any query among this wave's rows?  (wave-uniform)
-    const int my_row = row0 + l15;
-    const int my_q = (my_row < n && g4 == 0) ? a.obj_query[o0 + my_row] : -1;
-    if (__ballot(my_q >= 0) == 0ull) return;
-
-    const int NP = a.npad_max;
-    float* S = strip + (size_t)wave * 16 * NP;
-    const int D = a.D, nkq = (D + 15) / 16;
-    // ---- A operand: the wave's 16 query rows, pre-scaled by their inverse norms (emb /= ||emb||, :126)
-    const int arow = o0 + min(my_row, n - 1);
-    const float ia = a.inv[arow];
-    const float* __restrict__ ap = a.E + (size_t)arow * D;
-    f32x4 areg[KQ > 0 ? KQ : 1];
-    if (KQ > 0) {
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) areg[q] = q < nkq ? load_kgroup(ap, D, q, g4, ia) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // ---- similarity strip: 16 rows x n columns, one 16-column tile at a time
-    for (int j0 = 0; j0 < n; j0 += 16) {
-        const int brow = o0 + min(j0 + l15, n - 1);
-        const float ib = a.inv[brow];
-        const float* __restrict__ bp = a.E + (size_t)brow * D;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (KQ > 0) {
-            // all B fragments of the tile first (one memory latency per tile, not one per K group), then the MFMAs
-            f32x4 bvs[KQ];
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) bvs[q] = q < nkq ? load_kgroup(bp, D, q, g4, F16 ? ib : 1.f) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                if (q < nkq) {
-                    const f32x4 bv = bvs[q];
-                    if (F16) {
-                        const f16x4 ah = {(_Float16)areg[q][0], (_Float16)areg[q][1], (_Float16)areg[q][2], (_Float16)areg[q][3]};
-                        const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
-                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[q][r], bv[r], acc, 0, 0, 0);
-                    }
-                }
-            }
-        } else {
-            for (int q = 0; q < nkq; ++q) {
-                const f32x4 av = load_kgroup(ap, D, q, g4, ia);
-                const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
-                if (F16) {
-                    const f16x4 ah = {(_Float16)av[0], (_Float16)av[1], (_Float16)av[2], (_Float16)av[3]};
-                    const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc, 0, 0, 0);
-                }
-            }
-        }
-        // D layout: lane&15 = column (object j0 + l15), rows 4 g4 + r.  sim = 1 - dot (dot scaled by the column's inverse norm)
-        const float cs = F16 ? 1.f : ib;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(4 * g4 + r) * NP + j0 + l15] = 1.f - acc[r] * cs;
-    }
-    __builtin_amdgcn_wave_barrier();                       // the strip is written and read by this wave only (DS ops of a wave are ordered)
-
-    // ---- ranking, one query row at a time, lanes across the pair's objects
+// ranking of one wave's 16 x n similarity strip S (LDS, written by this wave only), one query row at a time with lanes across the
+// pair's objects: rank = wave sum of "closer than the target", top-K = K-step wave arg-min
+__device__ __forceinline__ void rank_strip(const SimArgs& a, const float* S, int NP, int my_q, int row0, int o0, int n, int lane) {
     for (int rr = 0; rr < 16; ++rr) {
         const int q = __shfl(my_q, rr, 64);                // lanes 0..15 (g4 == 0) hold the rows' query ids
         if (q < 0) continue;
@@ -183,6 +112,163 @@ __global__ __launch_bounds__(256) void simrank_mfma_kernel(SimArgs a) {
             for (int u = 0; u < SR_MAXPER; ++u) if (lane + 64 * u == bj) sim[u] = INFINITY;
         }
     }
+}
+
+// Staged form (D <= 16 KQ, i.e. the 100 / 200 / 300 / 400-wide tables of the path): the workgroup's 4 waves SHARE every 16-column
+// tile of the pair's table.  It is fetched once per workgroup with coalesced 16-byte loads into registers one tile ahead (the loads
+// fly under the current tile's MFMAs), parked in an LDS tile [16][RS] and read back as MFMA B fragments (ds_read_b128).  The
+// streaming form below made every wave fetch every tile itself, one K group at a time: latency-bound at 5-7 TFLOP/s.
+template <int KQ, bool F16>
+__global__ __launch_bounds__(256) void simrank_staged_kernel(SimArgs a) {
+    constexpr int RS = KQ * 16 + 4;                        // LDS row stride of the B tile (floats): 16-byte aligned, rows 4 slots apart
+    constexpr int NLD = (KQ * 16 + 63) / 64;               // float4 loads per thread and tile (16 threads per row)
+    extern __shared__ float strip[];                       // [4 waves][16][npad_max] | B tile [16][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int b = a.blk_pair[blockIdx.x];
+    const int o0 = a.pair_off[b], n = a.pair_off[b + 1] - o0;
+    const int row0 = a.blk_row[blockIdx.x] * SR_ROWS + wave * 16;                 // pair-local first row of this wave
+    const int my_row = row0 + l15;
+    const int my_q = (row0 < n && my_row < n && g4 == 0) ? a.obj_query[o0 + my_row] : -1;
+    const bool wave_has = __ballot(my_q >= 0) != 0ull;
+    if (!__syncthreads_or(wave_has ? 1 : 0)) return;       // no query in these 64 rows: nothing to do (uniform per workgroup)
+
+    const int NP = a.npad_max;
+    float* S = strip + (size_t)wave * 16 * NP;
+    float* sB = strip + (size_t)4 * 16 * NP;
+    const int D = a.D, nkq = (D + 15) / 16;
+    const int arow = o0 + min(my_row, n - 1);
+    const float ia = a.inv[arow];
+    const float* __restrict__ ap = a.E + (size_t)arow * D;
+    f32x4 areg[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) areg[q] = (wave_has && q < nkq) ? load_kgroup(ap, D, q, g4, ia) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging role of this thread: row sr of the tile, float4 column groups sc, sc + 16, ...
+    const int sr = tid >> 4, sc = tid & 15;
+    f32x4 stg[NLD];
+    auto fetch = [&](int j0) {
+        const float* __restrict__ rp = a.E + (size_t)(o0 + min(j0 + sr, n - 1)) * D;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = (sc + 16 * i) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c + 4 <= D && (D & 3) == 0) v = *reinterpret_cast<const f32x4*>(rp + c);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (c + r < D) v[r] = rp[c + r];
+            }
+            stg[i] = v;
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = (sc + 16 * i) * 4;
+            if (c < KQ * 16) *reinterpret_cast<f32x4*>(sB + sr * RS + c) = stg[i];
+        }
+    };
+    fetch(0);
+    park();
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 16) {
+        if (j0 + 16 < n) fetch(j0 + 16);                   // next tile's loads fly under this tile's MFMAs
+        if (wave_has) {
+            const float ib = a.inv[o0 + min(j0 + l15, n - 1)];
+            const float* bp = sB + l15 * RS + 4 * g4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (q < nkq) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 16 * q) * (F16 ? ib : 1.f);
+                    if (F16) {
+                        const f16x4 ah = {(_Float16)areg[q][0], (_Float16)areg[q][1], (_Float16)areg[q][2], (_Float16)areg[q][3]};
+                        const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[q][r], bv[r], acc, 0, 0, 0);
+                    }
+                }
+            }
+            const float cs = F16 ? 1.f : ib;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(4 * g4 + r) * NP + j0 + l15] = 1.f - acc[r] * cs;
+        }
+        __syncthreads();                                   // everyone is done with the tile
+        if (j0 + 16 < n) park();
+        __syncthreads();
+    }
+    if (wave_has) rank_strip(a, S, NP, my_q, row0, o0, n, lane);
+}
+
+template <int KQ, bool F16>
+__global__ __launch_bounds__(256) void simrank_mfma_kernel(SimArgs a) {
+    extern __shared__ float strip[];                       // [4 waves][16][npad_max]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int b = a.blk_pair[blockIdx.x];
+    const int o0 = a.pair_off[b], n = a.pair_off[b + 1] - o0;
+    const int row0 = a.blk_row[blockIdx.x] * SR_ROWS + wave * 16;                 // pair-local first row of this wave
+    if (row0 >= n) return;
+    // any query among this wave's rows?  (wave-uniform)
+    const int my_row = row0 + l15;
+    const int my_q = (my_row < n && g4 == 0) ? a.obj_query[o0 + my_row] : -1;
+    if (__ballot(my_q >= 0) == 0ull) return;
+
+    const int NP = a.npad_max;
+    float* S = strip + (size_t)wave * 16 * NP;
+    const int D = a.D, nkq = (D + 15) / 16;
+    // ---- A operand: the wave's 16 query rows, pre-scaled by their inverse norms (emb /= ||emb||, :126)
+    const int arow = o0 + min(my_row, n - 1);
+    const float ia = a.inv[arow];
+    const float* __restrict__ ap = a.E + (size_t)arow * D;
+    f32x4 areg[KQ > 0 ? KQ : 1];
+    if (KQ > 0) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) areg[q] = q < nkq ? load_kgroup(ap, D, q, g4, ia) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- similarity strip: 16 rows x n columns, one 16-column tile at a time
+    for (int j0 = 0; j0 < n; j0 += 16) {
+        const int brow = o0 + min(j0 + l15, n - 1);
+        const float ib = a.inv[brow];
+        const float* __restrict__ bp = a.E + (size_t)brow * D;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (KQ > 0) {
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (q < nkq) {
+                    const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
+                    if (F16) {
+                        const f16x4 ah = {(_Float16)areg[q][0], (_Float16)areg[q][1], (_Float16)areg[q][2], (_Float16)areg[q][3]};
+                        const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[q][r], bv[r], acc, 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            for (int q = 0; q < nkq; ++q) {
+                const f32x4 av = load_kgroup(ap, D, q, g4, ia);
+                const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
+                if (F16) {
+                    const f16x4 ah = {(_Float16)av[0], (_Float16)av[1], (_Float16)av[2], (_Float16)av[3]};
+                    const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc, 0, 0, 0);
+                }
+            }
+        }
+        // D layout: lane&15 = column (object j0 + l15), rows 4 g4 + r.  sim = 1 - dot (dot scaled by the column's inverse norm)
+        const float cs = F16 ? 1.f : ib;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(4 * g4 + r) * NP + j0 + l15] = 1.f - acc[r] * cs;
+    }
+    __builtin_amdgcn_wave_barrier();                       // the strip is written and read by this wave only (DS ops of a wave are ordered)
+
+    rank_strip(a, S, NP, my_q, row0, o0, n, lane);
 }
 
 // Per pair (one wave): Hits@1..5 counts, sum of reciprocal ranks, and SGAR for the modes '2', '50', '100'
@@ -231,14 +317,14 @@ __global__ void pair_metrics_kernel(const int* __restrict__ rank, const int* __r
 }
 
 template <bool F16>
-int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_off, int n_blocks, int B,
+int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_pair, const int32_t* blk_row, int n_blocks, int B,
                    int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank, int32_t* topk_idx,
                    float* topk_sim, void* workspace, size_t workspace_bytes, hipStream_t s, const char* who) {
     SGA_CHECK_ARG(T >= 0 && D >= 1 && B >= 0 && Q >= 0, "%s: bad sizes", who);
     SGA_CHECK_ARG(K >= 0 && K <= SR_MAXK, "%s: K=%d outside [0,%d]", who, K, SR_MAXK);
     SGA_CHECK_ARG(max_pair_objects <= 64 * SR_MAXPER, "%s: a pair has %d objects; at most %d are supported", who, max_pair_objects, 64 * SR_MAXPER);
-    if (Q == 0 || T == 0 || B == 0) return SGA_OK;
-    SGA_CHECK_ARG(E && pair_off && blk_off && q_idx && rank && topk_idx && topk_sim, "%s: null pointer", who);
+    if (Q == 0 || T == 0 || B == 0 || n_blocks == 0) return SGA_OK;
+    SGA_CHECK_ARG(E && pair_off && blk_pair && blk_row && q_idx && rank && topk_idx && topk_sim, "%s: null pointer", who);
     if (!workspace || workspace_bytes < sga_simrank_workspace_bytes(T)) { sga_set_error("%s: workspace too small", who); return SGA_ERR_WORKSPACE; }
     float* inv = static_cast<float*>(workspace);
     int* obj_query = reinterpret_cast<int*>(inv + T);
@@ -247,20 +333,21 @@ int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const 
     hipLaunchKernelGGL(fill_int_kernel, dim3((T + 255) / 256 > 2048 ? 2048 : (T + 255) / 256), dim3(256), 0, s, obj_query, T, -1);
     hipLaunchKernelGGL(scatter_query_kernel, dim3((Q + 255) / 256 > 2048 ? 2048 : (Q + 255) / 256), dim3(256), 0, s, q_idx, Q, obj_query);
     SimArgs a{};
-    a.E = E; a.inv = inv; a.D = D; a.B = B; a.pair_off = pair_off; a.blk_off = blk_off; a.obj_query = obj_query; a.q_tgt = q_tgt; a.K = K;
+    a.E = E; a.inv = inv; a.D = D; a.B = B; a.pair_off = pair_off; a.blk_pair = blk_pair; a.blk_row = blk_row; a.obj_query = obj_query; a.q_tgt = q_tgt; a.K = K;
     a.rank = rank; a.topk_idx = topk_idx; a.topk_sim = topk_sim;
     a.npad_max = ((max_pair_objects + 15) / 16) * 16 + 1;
-    const size_t lds = (size_t)4 * 16 * a.npad_max * sizeof(float);
     const int nkq = (D + 15) / 16;
-    auto launch = [&](auto kern) {
+    auto launch = [&](auto kern, size_t lds) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, a);
     };
-    if (nkq <= 7) launch(simrank_mfma_kernel<7, F16>);            // emb_dim 100 (single modality)
-    else if (nkq <= 13) launch(simrank_mfma_kernel<13, F16>);     // 200
-    else if (nkq <= 20) launch(simrank_mfma_kernel<20, F16>);     // 300 (P+S+R joint)
-    else if (nkq <= 26) launch(simrank_mfma_kernel<26, F16>);     // 400 (P+S+R+A joint)
-    else launch(simrank_mfma_kernel<0, F16>);                     // wider: both operands streamed
+    const size_t strip_b = (size_t)4 * 16 * a.npad_max * sizeof(float);
+    auto tile_b = [](int kq) { return (size_t)16 * (kq * 16 + 4) * sizeof(float); };
+    if (nkq <= 7) launch(simrank_staged_kernel<7, F16>, strip_b + tile_b(7));            // emb_dim 100 (single modality)
+    else if (nkq <= 13) launch(simrank_staged_kernel<13, F16>, strip_b + tile_b(13));    // 200
+    else if (nkq <= 20) launch(simrank_staged_kernel<20, F16>, strip_b + tile_b(20));    // 300 (P+S+R joint)
+    else if (nkq <= 26) launch(simrank_staged_kernel<26, F16>, strip_b + tile_b(26));    // 400 (P+S+R+A joint)
+    else launch(simrank_mfma_kernel<0, F16>, strip_b);                                   // wider: both operands streamed per wave
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { sga_set_error("%s: launch failed: %s", who, hipGetErrorString(e_)); return SGA_ERR_HIP; }
     return SGA_OK;
@@ -270,13 +357,13 @@ int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const 
 
 extern "C" size_t sga_simrank_workspace_bytes(int T) { return (sizeof(float) + sizeof(int)) * (size_t)(T > 0 ? T : 1); }
 
-extern "C" int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_off, int n_blocks, int B,
+extern "C" int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_pair, const int32_t* blk_row, int n_blocks, int B,
                            int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
                            int32_t* topk_idx, float* topk_sim, int f16, void* workspace, size_t workspace_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (f16) return simrank_launch<true>(E, T, D, pair_off, blk_off, n_blocks, B, max_pair_objects, q_idx, q_tgt, Q, K, rank, topk_idx,
+    if (f16) return simrank_launch<true>(E, T, D, pair_off, blk_pair, blk_row, n_blocks, B, max_pair_objects, q_idx, q_tgt, Q, K, rank, topk_idx,
                                          topk_sim, workspace, workspace_bytes, s, "sga_simrank(f16)");
-    return simrank_launch<false>(E, T, D, pair_off, blk_off, n_blocks, B, max_pair_objects, q_idx, q_tgt, Q, K, rank, topk_idx, topk_sim,
+    return simrank_launch<false>(E, T, D, pair_off, blk_pair, blk_row, n_blocks, B, max_pair_objects, q_idx, q_tgt, Q, K, rank, topk_idx, topk_sim,
                                  workspace, workspace_bytes, s, "sga_simrank");
 }
 

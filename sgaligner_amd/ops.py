@@ -700,8 +700,7 @@ def multi_gat(gb, x, layer0, layer1):
 
 # ------------------------------------------------------------------------------------------ similarity + ranking
 class PairLayout:
-    """Device offsets of the pairs of a batch for the similarity kernels: object offsets and the workgroup prefix
-    (one workgroup per 64 objects of a pair).  Cached by content (small host arrays)."""
+    """Device offsets of the pairs of a batch for the similarity kernels.  Cached by content (small host arrays)."""
 
     def __init__(self, pair_counts, device):
         pc = _np.asarray(pair_counts, dtype=_np.int64).reshape(-1)
@@ -709,10 +708,7 @@ class PairLayout:
         self.nmax = int(pc.max()) if self.B else 0
         self.T = int(pc.sum())
         self.off_host = _np.concatenate([[0], _np.cumsum(pc)])
-        blk = _np.concatenate([[0], _np.cumsum((pc + 63) // 64)])
-        self.n_blocks = int(blk[-1])
         self.pair_off = torch.from_numpy(self.off_host.astype(_np.int32)).to(device)
-        self.blk_off = torch.from_numpy(blk.astype(_np.int32)).to(device)
 
     _cache = _SmallCache()
 
@@ -722,31 +718,63 @@ class PairLayout:
         return PairLayout._cache.get(_fingerprint([_np.asarray(pair_counts)], (str(device),)), lambda: PairLayout(pair_counts, device))
 
 
+class QueryBlocks:
+    """The (pair, 64-row block) list of the blocks that hold a query object, + the device copies of the query arrays: the
+    similarity kernel launches one workgroup per listed block (nothing for blocks without a query, work spread over all XCDs)."""
+
+    def __init__(self, layout, q_idx, q_tgt, device):
+        qi = _np.ascontiguousarray(_np.asarray(q_idx, dtype=_np.int32).reshape(-1))
+        if VALIDATE and qi.size and (int(qi.min()) < 0 or int(qi.max()) >= layout.T):
+            raise RuntimeError(f'sgaligner_amd: query object indices must lie in [0, {layout.T})')
+        pair = _np.searchsorted(layout.off_host, qi, side='right') - 1
+        rb = (qi - layout.off_host[pair]) // 64
+        nrb = (layout.nmax + 63) // 64 if layout.nmax else 1
+        key = _np.unique(pair.astype(_np.int64) * nrb + rb)
+        self.n_blocks = int(key.size)
+        self.blk_pair = torch.from_numpy((key // nrb).astype(_np.int32)).to(device)
+        self.blk_row = torch.from_numpy((key % nrb).astype(_np.int32)).to(device)
+        self.q_idx = torch.from_numpy(qi).to(device)
+        self.q_tgt = None if q_tgt is None else torch.from_numpy(_np.ascontiguousarray(_np.asarray(q_tgt, dtype=_np.int32).reshape(-1))).to(device)
+        self.Q = int(qi.size)
+
+    _cache = _SmallCache()
+
+    @staticmethod
+    def of(layout, pair_counts, q_idx, q_tgt, device):
+        arrs = [_np.asarray(pair_counts), _np.asarray(q_idx)] + ([_np.asarray(q_tgt)] if q_tgt is not None else [])
+        return QueryBlocks._cache.get(_fingerprint(arrs, (str(device), q_tgt is None)), lambda: QueryBlocks(layout, q_idx, q_tgt, device))
+
+
 SIMRANK_F16 = False      # opt-in: fp16-input MFMA similarity (BASELINE.json configs[4]); the default is exact fp32 MFMA
 
 
 def simrank(emb, pair_counts, q_idx, q_tgt, k: int, f16=None):
     """For each query object: rank of its target and the k nearest other objects of its pair.
     emb [T,D] fp32 (un-normalised: the kernel applies emb/||emb|| as inference_align_reg.py:126 does);
-    pair_counts [B] objects per pair; q_idx / q_tgt host int arrays or device int32 tensors of global object indices
-    (q_tgt may be None; each object may be queried once).
+    pair_counts [B] objects per pair; q_idx / q_tgt host int arrays of global object indices (q_tgt may be None; each object
+    may be queried once).
     Returns (rank [Q] int32, topk_idx [Q,k] int32 pair-local, topk_sim [Q,k] fp32, layout) on the device."""
     emb = _req(emb.contiguous(), 'embedding')
     dev = emb.device
     T, D = emb.shape
+    if isinstance(q_idx, torch.Tensor):
+        q_idx = q_idx.cpu().numpy()
+    if isinstance(q_tgt, torch.Tensor):
+        q_tgt = q_tgt.cpu().numpy()
     lay = PairLayout.of(pair_counts, dev)
-    f = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(_np.ascontiguousarray(_np.asarray(a, dtype=_np.int32))).to(dev)
-    qi = f(q_idx)
-    qt = f(q_tgt) if q_tgt is not None else None
-    Q = int(qi.numel())
+    if lay.T != T:
+        raise RuntimeError(f'sgaligner_amd: the pairs hold {lay.T} objects but the embedding table has {T} rows')
+    qb = QueryBlocks.of(lay, pair_counts, q_idx, q_tgt, dev)
+    Q = qb.Q
     rank = torch.empty((max(Q, 1),), device=dev, dtype=torch.int32)
     tk = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.int32)
     ts = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.float32)
     nb = _lib.lib().sga_simrank_workspace_bytes(T)
     ws = torch.empty((nb,), device=dev, dtype=torch.uint8)
     use16 = SIMRANK_F16 if f16 is None else bool(f16)
-    _lib.check(_lib.lib().sga_simrank(_p(emb), T, D, _p(lay.pair_off), _p(lay.blk_off), lay.n_blocks, lay.B, lay.nmax, _p(qi), _p(qt),
-                                      Q, k, _p(rank), _p(tk), _p(ts), int(use16), _p(ws), nb, _stream()), 'sga_simrank')
+    _lib.check(_lib.lib().sga_simrank(_p(emb), T, D, _p(lay.pair_off), _p(qb.blk_pair), _p(qb.blk_row), qb.n_blocks, lay.B, lay.nmax,
+                                      _p(qb.q_idx), _p(qb.q_tgt), Q, k, _p(rank), _p(tk), _p(ts), int(use16), _p(ws), nb, _stream()),
+               'sga_simrank')
     return rank[:Q], tk[:Q, :k], ts[:Q, :k], lay
 
 
