@@ -225,6 +225,14 @@ int sga_fps(const float* pts, const int32_t* offsets, int n_obj, const int32_t* 
             const int32_t* work_small, int n_small, const int32_t* work_mid, int n_mid,
             const int32_t* work_large, int n_large, int32_t* out_idx, float* scratch, void* stream);
 
+/* ---- convex-hull candidate filter (the other half of the step in front of the path) ----------
+ * serves preprocessing/scan3r/preprocess.py:93-96 (hull = ConvexHull(obj_pcl); barycentre = mean of the hull vertices):
+ * keep[i] = 0 for points that are provably interior to their object's hull (strictly inside the convex hull of the object's 26
+ * directional support points, by 1e-5 of its extent), 1 otherwise -- the hull of the kept points IS the object's hull, so the
+ * host's Qhull call sees a few per cent of the points and returns the same vertices.  pts [sum N,3] f32 packed per object,
+ * offsets [n_obj+1]; n_planes [n_obj] (nullable): facets of the filter polytope, 0 = object kept whole (degenerate). */
+int sga_hull_candidates(const float* pts, const int32_t* offsets, int n_obj, unsigned char* keep, int32_t* n_planes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

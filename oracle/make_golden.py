@@ -355,6 +355,34 @@ def gen_fps():
     npz('fps_cases', n_cases=np.int32(k + 1), **cases)
 
 
+def gen_hull():
+    """Per-object convex-hull barycentre (preprocessing/scan3r/preprocess.py:93-96).  The four lines live
+    inside process_scan and cannot be imported; they are scipy.spatial.ConvexHull + three np.mean calls, restated in
+    oracle/hull_oracle.py and evaluated here on the objects of the reference's own example scan (as preprocess.py selects
+    them: objects with >= min_obj_points = 50 points, :90) plus synthetic shapes with coplanar / collinear structure."""
+    from oracle import hull_oracle
+    real = np.load(os.path.join(REF, 'example_data', 'scene_1', 'data.npy'))
+    ids, cnt = np.unique(real['objectId'], return_counts=True)
+    ids = ids[cnt >= 50]
+    cases = {}
+    k = 0
+    for oid in ids[:6]:
+        obj = real[real['objectId'] == oid]
+        pts = np.stack([obj['x'], obj['y'], obj['z']], 1)
+        bc, verts = hull_oracle.hull_barycenter(pts)
+        cases[f'pts{k}'] = pts; cases[f'bc{k}'] = bc; cases[f'verts{k}'] = verts.astype(np.int32)
+        k += 1
+    rng = np.random.default_rng(11)
+    cube = rng.integers(0, 4, size=(400, 3)).astype(np.float64)                    # lattice cube: coplanar and collinear points
+    sphere = rng.standard_normal((3000, 3)); sphere /= np.linalg.norm(sphere, axis=1, keepdims=True)
+    blob = rng.standard_normal((4000, 3)) * np.array([2.0, 1.0, 0.3])
+    for pts in (cube, sphere, blob, blob[:5]):
+        bc, verts = hull_oracle.hull_barycenter(pts)
+        cases[f'pts{k}'] = pts; cases[f'bc{k}'] = bc; cases[f'verts{k}'] = verts.astype(np.int32)
+        k += 1
+    npz('hull_cases', n_cases=np.int32(k), **cases)
+
+
 def gen_dataset():
     """Dataset/collate: the reference's Scan3RDataset (src/datasets/scan3r.py) run on a synthetic
     on-disk dataset written by sgaligner_amd.datasets.synthetic_scan3r (deterministic in its seed; the test re-writes the
@@ -463,6 +491,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'pct':
         gen_pct()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'hull':
+        gen_hull()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'fps':
         gen_fps()
         return
@@ -471,6 +502,7 @@ def main():
         return
     losses, pointnet, sg_aligner, alignment = import_reference()
     gen_fps()
+    gen_hull()
     gen_dataset()
     gen_pct()
     gen_pointnet(pointnet)

@@ -62,3 +62,48 @@ def pcl_farthest_sample(point, npoint, return_idxs=False):
     if return_idxs:
         return point[idx], idx
     return point[idx]
+
+
+# ---- convex-hull barycentre (preprocessing/scan3r/preprocess.py:93-96) ---------------------------------------------------
+def hull_candidate_mask_batch(points, offsets):
+    """points [sum N, 3] float32 CUDA tensor (objects packed back to back), offsets [n_obj+1] host ints.  Returns
+    (keep [sum N] bool CUDA tensor, n_planes [n_obj] int32 CUDA tensor): points that can be hull vertices (csrc/hull.hip)."""
+    if not (isinstance(points, torch.Tensor) and points.is_cuda and points.dtype == torch.float32):
+        raise RuntimeError('hull_candidate_mask_batch: points must be a float32 CUDA tensor (no CPU fallback)')
+    pts = points.contiguous()
+    off = np.asarray(offsets, dtype=np.int64)
+    n_obj = len(off) - 1
+    if n_obj < 0 or off[0] != 0 or off[-1] != pts.shape[0] or (np.diff(off) < 0).any():
+        raise ValueError('offsets must be a monotone prefix array covering all points')
+    d_off = torch.from_numpy(off.astype(np.int32)).to(pts.device)
+    keep = torch.empty((max(int(pts.shape[0]), 1),), device=pts.device, dtype=torch.uint8)
+    npl = torch.zeros((max(n_obj, 1),), device=pts.device, dtype=torch.int32)
+    _lib.check(_lib.lib().sga_hull_candidates(_p(pts), _p(d_off), n_obj, _p(keep), _p(npl), _stream()), 'sga_hull_candidates')
+    return keep[:pts.shape[0]].bool(), npl[:n_obj]
+
+
+def convex_hull_barycenters_batch(point_list):
+    """Barycentre of the convex-hull vertices of every object (list of [N_i, 3] numpy arrays), as preprocess.py:93-96 computes
+    it per object: cx, cy, cz = mean of hull.points[hull.vertices, 0 / 1 / 2].  One kernel launch filters all objects down to
+    their hull candidates; Qhull (scipy, the reference's own dependency) then runs on those only and finds the same vertices."""
+    from scipy.spatial import ConvexHull
+    sizes = [int(p.shape[0]) for p in point_list]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    if off[-1] == 0:
+        return np.zeros((len(point_list), 3))
+    flat = np.concatenate([np.asarray(p)[:, :3] for p in point_list]).astype(np.float32, copy=False)
+    keep, _ = hull_candidate_mask_batch(torch.from_numpy(np.ascontiguousarray(flat)).cuda(), off)
+    keep = keep.cpu().numpy()
+    out = np.zeros((len(point_list), 3))
+    for i, p in enumerate(point_list):
+        cand = np.asarray(p)[keep[off[i]:off[i + 1]]]          # candidates in the object's own dtype / values
+        hull = ConvexHull(cand)
+        v = hull.points[hull.vertices]
+        out[i] = (np.mean(v[:, 0]), np.mean(v[:, 1]), np.mean(v[:, 2]))
+    return out
+
+
+def convex_hull_barycenter(obj_pcl):
+    """Single-object form: (cx, cy, cz) exactly as preprocess.py:93-96 binds them."""
+    c = convex_hull_barycenters_batch([obj_pcl])[0]
+    return float(c[0]), float(c[1]), float(c[2])

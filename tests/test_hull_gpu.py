@@ -1,0 +1,57 @@
+"""GPU: the hull-candidate filter (csrc/hull.hip) + Qhull on the survivors must give exactly the reference's hull vertices and
+barycentre (preprocess.py:93-96), on the reference's example-scan objects, on shapes with coplanar / collinear points, on
+degenerate (flat, tiny) objects -- and it must actually discard most interior points of bulky objects."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _verts_of_candidates(pts, keep):
+    from scipy.spatial import ConvexHull
+    idx = np.nonzero(keep)[0]
+    hull = ConvexHull(pts[idx])
+    return np.sort(idx[hull.vertices])
+
+
+def test_golden_objects_same_vertices_and_barycentre():
+    from sgaligner_amd.utils import point_cloud
+    g = load_golden('hull_cases')
+    n = int(g['n_cases'])
+    objs = [g[f'pts{k}'] for k in range(n)]
+    bcs = point_cloud.convex_hull_barycenters_batch(objs)
+    off = np.concatenate([[0], np.cumsum([len(o) for o in objs])])
+    flat = torch.from_numpy(np.concatenate(objs).astype(np.float32)).cuda()
+    keep, npl = point_cloud.hull_candidate_mask_batch(flat, off)
+    keep, npl = keep.cpu().numpy(), npl.cpu().numpy()
+    for k in range(n):
+        assert np.allclose(bcs[k], g[f'bc{k}'], rtol=0, atol=1e-9), (k, bcs[k], g[f'bc{k}'])
+        kk = keep[off[k]:off[k + 1]]
+        assert kk[g[f'verts{k}']].all(), k                         # no hull vertex is ever discarded
+        if len(objs[k]) >= 4:
+            assert np.array_equal(_verts_of_candidates(objs[k], kk), g[f'verts{k}']), k
+    # the 4000-point Gaussian blob: most of it is interior
+    k = n - 2
+    assert npl[k] >= 4 and keep[off[k]:off[k + 1]].mean() < 0.35, (npl[k], keep[off[k]:off[k + 1]].mean())
+    cx, cy, cz = point_cloud.convex_hull_barycenter(objs[0])
+    assert np.allclose([cx, cy, cz], g['bc0'], atol=1e-9)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_random_objects_vs_oracle(seed):
+    from oracle import hull_oracle
+    from sgaligner_amd.utils import point_cloud
+    rng = np.random.default_rng(seed)
+    objs = []
+    for n in (4, 7, 60, 500, 3000, 30000):
+        objs.append(rng.standard_normal((n, 3)) * rng.uniform(0.2, 3.0, size=3) + rng.uniform(-3, 3, size=3))
+    objs.append(np.c_[rng.standard_normal((300, 2)), np.zeros(300)] @ np.linalg.qr(rng.standard_normal((3, 3)))[0] + 1e-9 * rng.standard_normal((300, 3)))  # nearly flat
+    objs.append(np.round(rng.standard_normal((2000, 3)) * 3) / 3)                       # lattice: many coplanar points
+    objs.append((rng.random((5000, 3)) - 0.5) * np.array([4.0, 0.5, 0.1]))             # thin box
+    bcs = point_cloud.convex_hull_barycenters_batch(objs)
+    for k, o in enumerate(objs):
+        bc, verts = hull_oracle.hull_barycenter(o)
+        assert np.allclose(bcs[k], bc, rtol=0, atol=1e-9 * max(1.0, np.abs(o).max())), (k, bcs[k], bc)
