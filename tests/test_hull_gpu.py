@@ -32,7 +32,10 @@ def test_golden_objects_same_vertices_and_barycentre():
         kk = keep[off[k]:off[k + 1]]
         assert kk[g[f'verts{k}']].all(), k                         # no hull vertex is ever discarded
         if len(objs[k]) >= 4:
-            assert np.array_equal(_verts_of_candidates(objs[k], kk), g[f'verts{k}']), k
+            # same vertex COORDINATES (scans hold exact duplicate points: Qhull then names one of the copies, which one depends on the input)
+            a = np.unique(objs[k][_verts_of_candidates(objs[k], kk)], axis=0)
+            b = np.unique(objs[k][g[f'verts{k}']], axis=0)
+            assert a.shape == b.shape and np.array_equal(a, b), k
     # the 4000-point Gaussian blob: most of it is interior
     k = n - 2
     assert npl[k] >= 4 and keep[off[k]:off[k + 1]].mean() < 0.35, (npl[k], keep[off[k]:off[k + 1]].mean())
