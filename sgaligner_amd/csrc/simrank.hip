@@ -8,12 +8,11 @@
 // sort and the seven device->host copies of the rank list (alignment.py:4,14,29) disappear.
 // Ties: broken by object index (a stable ascending sort); the reference's sort is unstable there.
 //
-// simrank_mfma_kernel: the per-pair E E^T blocks on the matrix cores.  A workgroup = 4 waves = 64 consecutive objects
-// of one pair (its "query rows"); a wave holds its 16 rows as the MFMA A operand in registers (D <= 320) and walks the pair's
-// objects in 16-column tiles whose B fragments come straight from global memory as 64-byte row segments (4 lanes x 16 B per
-// row -- every byte of a fetched line is used; the round-1 kernel walked one row per lane with stride-D scalar reads).  The
-// wave's 16 x n similarity strip lands in LDS; ranking is then per query row with lanes across the pair's objects: the rank
-// is a wave sum of "closer than the target", the top-K a K-step wave arg-min.  Row blocks without a query skip everything.
+// simrank_staged_kernel / simrank_stream_kernel: the per-pair E E^T blocks on the matrix cores.  A workgroup = 4 waves = 64
+// consecutive objects of one pair (its "query rows"); only blocks that hold a query are launched (blk_pair / blk_row), so the work
+// spreads over all XCDs whatever the query pattern.  A wave holds its 16 rows as the MFMA A operand in registers and walks the
+// pair's objects in 16-column tiles; the 16 x n similarity strip lands in LDS and ranking is per query row with lanes across the
+// pair's objects: the rank is a wave sum of "closer than the target", the top-K a K-step wave arg-min.
 //   fp32: v_mfma_f32_16x16x4_f32 (exact fp32 products, the headline path);
 //   f16 : v_mfma_f32_16x16x16_f16 on the L2-normalised rows converted to half, fp32 accumulate (BASELINE.json configs[4]:
 //         "MFMA similarity GEMM at fp16"; |sim error| ~1e-3, tolerance 1e-2).
@@ -201,64 +200,41 @@ __global__ __launch_bounds__(256) void simrank_staged_kernel(SimArgs a) {
     if (wave_has) rank_strip(a, S, NP, my_q, row0, o0, n, lane);
 }
 
-template <int KQ, bool F16>
-__global__ __launch_bounds__(256) void simrank_mfma_kernel(SimArgs a) {
+// Streaming form for tables wider than 416 columns (BASELINE.json configs[4]: 1024-d embeddings, 3072-d joint): a wave's A operand
+// no longer fits its registers, so both operands are read from global memory one K group at a time.
+template <bool F16>
+__global__ __launch_bounds__(256) void simrank_stream_kernel(SimArgs a) {
     extern __shared__ float strip[];                       // [4 waves][16][npad_max]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = lane >> 4, l15 = lane & 15;
     const int b = a.blk_pair[blockIdx.x];
     const int o0 = a.pair_off[b], n = a.pair_off[b + 1] - o0;
     const int row0 = a.blk_row[blockIdx.x] * SR_ROWS + wave * 16;                 // pair-local first row of this wave
     if (row0 >= n) return;
-    // any query among this wave's rows?  (wave-uniform)
     const int my_row = row0 + l15;
     const int my_q = (my_row < n && g4 == 0) ? a.obj_query[o0 + my_row] : -1;
-    if (__ballot(my_q >= 0) == 0ull) return;
+    if (__ballot(my_q >= 0) == 0ull) return;               // no query among this wave's rows (wave-uniform)
 
     const int NP = a.npad_max;
     float* S = strip + (size_t)wave * 16 * NP;
     const int D = a.D, nkq = (D + 15) / 16;
-    // ---- A operand: the wave's 16 query rows, pre-scaled by their inverse norms (emb /= ||emb||, :126)
     const int arow = o0 + min(my_row, n - 1);
-    const float ia = a.inv[arow];
+    const float ia = a.inv[arow];                          // query rows pre-scaled by their inverse norms (emb /= ||emb||, :126)
     const float* __restrict__ ap = a.E + (size_t)arow * D;
-    f32x4 areg[KQ > 0 ? KQ : 1];
-    if (KQ > 0) {
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) areg[q] = q < nkq ? load_kgroup(ap, D, q, g4, ia) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // ---- similarity strip: 16 rows x n columns, one 16-column tile at a time
     for (int j0 = 0; j0 < n; j0 += 16) {
         const int brow = o0 + min(j0 + l15, n - 1);
         const float ib = a.inv[brow];
         const float* __restrict__ bp = a.E + (size_t)brow * D;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (KQ > 0) {
+        for (int q = 0; q < nkq; ++q) {
+            const f32x4 av = load_kgroup(ap, D, q, g4, ia);
+            const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
+            if (F16) {
+                const f16x4 ah = {(_Float16)av[0], (_Float16)av[1], (_Float16)av[2], (_Float16)av[3]};
+                const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                if (q < nkq) {
-                    const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
-                    if (F16) {
-                        const f16x4 ah = {(_Float16)areg[q][0], (_Float16)areg[q][1], (_Float16)areg[q][2], (_Float16)areg[q][3]};
-                        const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
-                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[q][r], bv[r], acc, 0, 0, 0);
-                    }
-                }
-            }
-        } else {
-            for (int q = 0; q < nkq; ++q) {
-                const f32x4 av = load_kgroup(ap, D, q, g4, ia);
-                const f32x4 bv = load_kgroup(bp, D, q, g4, F16 ? ib : 1.f);
-                if (F16) {
-                    const f16x4 ah = {(_Float16)av[0], (_Float16)av[1], (_Float16)av[2], (_Float16)av[3]};
-                    const f16x4 bh = {(_Float16)bv[0], (_Float16)bv[1], (_Float16)bv[2], (_Float16)bv[3]};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc, 0, 0, 0);
-                }
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc, 0, 0, 0);
             }
         }
         // D layout: lane&15 = column (object j0 + l15), rows 4 g4 + r.  sim = 1 - dot (dot scaled by the column's inverse norm)
@@ -267,7 +243,6 @@ __global__ __launch_bounds__(256) void simrank_mfma_kernel(SimArgs a) {
         for (int r = 0; r < 4; ++r) S[(4 * g4 + r) * NP + j0 + l15] = 1.f - acc[r] * cs;
     }
     __builtin_amdgcn_wave_barrier();                       // the strip is written and read by this wave only (DS ops of a wave are ordered)
-
     rank_strip(a, S, NP, my_q, row0, o0, n, lane);
 }
 
@@ -347,7 +322,7 @@ int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const 
     else if (nkq <= 13) launch(simrank_staged_kernel<13, F16>, strip_b + tile_b(13));    // 200
     else if (nkq <= 20) launch(simrank_staged_kernel<20, F16>, strip_b + tile_b(20));    // 300 (P+S+R joint)
     else if (nkq <= 26) launch(simrank_staged_kernel<26, F16>, strip_b + tile_b(26));    // 400 (P+S+R+A joint)
-    else launch(simrank_mfma_kernel<0, F16>, strip_b);                                   // wider: both operands streamed per wave
+    else launch(simrank_stream_kernel<F16>, strip_b);                                    // wider: both operands streamed per wave
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { sga_set_error("%s: launch failed: %s", who, hipGetErrorString(e_)); return SGA_ERR_HIP; }
     return SGA_OK;

@@ -94,3 +94,44 @@ def test_train_step_vs_oracle(bf16x3):
     mo = O.evaluate_batch(out_o['joint'].detach(), ddv)
     mg = steps.eval_step(0, ddv, out)
     assert [mg[k]['correct'] for k in (1, 2, 3, 4, 5)] == [mo['hits'][k][0] for k in (1, 2, 3, 4, 5)]
+
+
+@pytest.mark.parametrize('M,emb', [(3, 100), (2, 100), (3, 64)])
+def test_sweeps_vs_fp32_sweeps_and_anchor_shards(bf16x3, M, emb):
+    """The bf16x3 loss sweeps against the exact-fp32 sweeps on the same tables (loss terms, dE, d fusion weight), unsharded and as
+    the sum of 3 anchor shards with cuts that are NOT multiples of the 32-row blocks (what ranks of a multi-GPU job own)."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    from test_c3_gpu import _replay_sharded
+    dd = make_batch(9, 30, 4, seed=40 + M, ragged=True, anchors='val')
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(M)
+    base = [torch.randn(T, emb, device='cuda', generator=g) for _ in range(M)]
+    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')[:M].contiguous()
+    cot = torch.randn(M + 1 + 2 * M, device='cuda', generator=g)
+
+    def run():
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        w = w0.clone().requires_grad_(True)
+        sums, s = ops.fused_contrastive_terms(tabs, w, dd)
+        (sums * cot).sum().backward()
+        torch.cuda.synchronize()
+        return sums.detach(), [t.grad for t in tabs], w.grad, s
+    sb, gb, wb, s = run()
+    ops.set_mfma_mode('f32')
+    sf, gf, wf, _ = run()
+    ops.set_mfma_mode('bf16x3')
+    assert torch.allclose(sb, sf, rtol=2e-5, atol=1e-6)
+    for m in range(M):
+        sc = gf[m].abs().max().item()
+        assert (gb[m] - gf[m]).abs().max().item() < 1e-4 * sc, (m, (gb[m] - gf[m]).abs().max().item(), sc)
+    assert (wb - wf).abs().max().item() < 1e-4 * max(1e-3, wf.abs().max().item())
+    A = s.A
+    cuts = [0, A // 3 + 5, 2 * A // 3 - 3, A]
+    _, gs, gw, all_sums = _replay_sharded(base, w0, cot, dd, cuts)
+    for sr in all_sums:
+        assert torch.allclose(sr, sb, rtol=1e-4, atol=1e-5)
+    for m in range(M):
+        sc = gb[m].abs().max().item()
+        assert (gs[m] - gb[m]).abs().max().item() < 2e-4 * sc, m
+    assert (gw - wb).abs().max().item() < 2e-4 * max(1e-3, wb.abs().max().item())
