@@ -231,6 +231,8 @@ def main():
                      # whole model, and -- worst case -- relative to the parameter's own largest entry (dominated by parameters whose
                      # gradient is a small difference of large sums, and by arg-max ties of the max-pool flipping between points)
                      'max_grad_err_rel_to_global_max': worst_glob, 'max_grad_err_rel_to_own_max': worst, 'worst_param': worst_name}
+        except Exception as e:           # the opt-in measurement must never cost the headline line
+            extra = {'mode': 'bf16x3 (opt-in)', 'error': f'{type(e).__name__}: {e}'}
         finally:
             ops.set_mfma_mode('f32')
 
