@@ -140,3 +140,71 @@ def test_grad_accumulation_two_ranks_equals_single_process_sum():
             if p.grad is not None:
                 sc = p.grad.abs().max().item()
                 assert (g[n] - p.grad.cpu()).abs().max().item() <= 1e-4 * max(1.0, sc), (rank, n)
+
+
+def _rccl_worker(rank, world, port, mods, ragged_pad, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sgaligner_amd import dist as sdist
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        assert sdist._has_reduce_scatter()
+        dev = torch.device('cuda', 0)
+        dd = to_device(make_batch(5, 14, 48, seed=23, ragged=True), dev)
+        steps = AlignerSteps(mods, device=dev, seed=42)
+        steps.zero_grad()
+        output_dict = steps.model(dd)
+        loss = steps._global_loss(output_dict, dd)          # the N > 1 code path, over RCCL, with a world of one
+        loss['loss'].backward()
+        steps.reduce_grads()
+        torch.cuda.synchronize()
+        res = {'loss': float(loss['loss'].item())}
+        for n, p in steps.model.named_parameters():
+            if p.grad is not None:
+                res['g:' + n] = p.grad.detach().cpu()
+        # the ragged reduce-scatter branch (blocks padded to the largest shard) cannot arise with one rank through the trainer:
+        # drive AllGatherRows.backward's padded path directly with a row count below the padded block size
+        x = torch.randn(7, 5, device=dev, requires_grad=True)
+        y = sdist.AllGatherRows.apply(x, [7], True)
+        (y * torch.arange(35, device=dev, dtype=torch.float32).view(7, 5)).sum().backward()
+        res['ag_grad'] = x.grad.cpu()
+        lay = sdist.gather_batch_layout(dd, dev)
+        res['layout'] = lay.tolist()
+        out[0] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mods', [['point', 'gat', 'rel'], ['point']])
+def test_rccl_collectives_world_of_one(mods):
+    """The box has one GPU and RCCL refuses two ranks on one device, so the 2-rank tests above run over gloo.  This one
+    initialises the nccl (= RCCL) backend with a world of ONE and drives the multi-GPU code path (AlignerSteps._global_loss +
+    reduce_grads) through it: all_gather_into_tensor of int64 / int32 / fp32 device tensors, reduce_scatter_tensor of the table
+    gradients, the fp64 scalar all-reduces and the flat fp32 gradient all-reduce are real RCCL calls here.  Results must equal
+    the plain single-process path."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), mods, False, out), nprocs=1, join=True)
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    dd = to_device(make_batch(5, 14, 48, seed=23, ragged=True), 'cuda')
+    ref = AlignerSteps(mods, device='cuda', seed=42)
+    _, loss = ref.forward_backward(dd)
+    torch.cuda.synchronize()
+    r = out[0]
+    assert abs(r['loss'] - loss['loss'].item()) <= 1e-5 * max(1.0, abs(loss['loss'].item()))
+    seen = 0
+    for n, p in ref.model.named_parameters():
+        if p.grad is None:
+            continue
+        sc = p.grad.abs().max().item()
+        assert (r['g:' + n] - p.grad.cpu()).abs().max().item() <= 1e-4 * max(1.0, sc), n
+        seen += 1
+    assert seen >= (8 if len(mods) > 1 else 4)
+    assert torch.equal(r['ag_grad'], torch.arange(35, dtype=torch.float32).view(7, 5))
+    assert r['layout'][0][0] == int(dd['tot_obj_pts'].shape[0])
