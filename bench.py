@@ -138,6 +138,7 @@ def main():
     ap.add_argument('--config', choices=['auto', 'c2', 'c3'], default=os.environ.get('SGA_BENCH_CONFIG', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hits', action='store_true')
+    ap.add_argument('--no-scale-ref', action='store_true', help='skip the extra configs[2]-on-one-GPU measurement (N = 1, --config auto)')
     ap.add_argument('--no-bf16x3', action='store_true', help='skip the extra (opt-in split-bf16 x3 MFMA mode) measurement')
     args = ap.parse_args()
 
@@ -236,6 +237,32 @@ def main():
         finally:
             ops.set_mfma_mode('f32')
 
+    # ---- extra at N = 1 under --config auto: configs[2] (the workload the N > 1 lines run, strong scaling at a fixed 4096-pair
+    # global batch) on THIS one GPU, so that a 1/2/4/8 series of lines carries its own same-workload single-GPU point.
+    scale_ref = None
+    if world == 1 and args.config == 'auto' and not args.no_scale_ref:
+        try:
+            c3 = CONFIGS['c3']
+            del dd
+            torch.cuda.empty_cache()
+            dd3 = make_batch_fast(c3['global_pairs'], c3['n_obj'], c3['n_pts'], seed=43, device=dev)
+            steps.forward_backward(dd3)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            n3 = 2
+            for _ in range(n3):
+                steps.forward_backward(dd3)
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t2
+            scale_ref = {'workload': f'{c3["ref"]}: {c3["global_pairs"]} pairs x {c3["n_obj"]} objects x {c3["n_pts"]} pts on one GPU (what the '
+                                     f'n_gpus > 1 lines run, sharded)', 'value': round(c3['global_pairs'] * n3 / el3, 2), 'unit': 'pairs/s',
+                         'ms_per_step': round(el3 / n3 * 1e3, 1), 'steps': n3, 'warmup': 1, 'dtype': 'f32',
+                         'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+            del dd3
+            torch.cuda.empty_cache()
+        except Exception as e:
+            scale_ref = {'error': f'{type(e).__name__}: {e}'}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         # The two kernels that carry the step, each timed with HIP events on its launch stream; `roofline` is the
@@ -295,6 +322,8 @@ def main():
         }
         if extra is not None:
             line['extra_bf16x3'] = extra
+        if scale_ref is not None:
+            line['strong_scaling_one_gpu'] = scale_ref
         if not args.no_hits:
             line['hits_at_1'] = hits_at_k(steps, n_obj, n_pts, dev)
         if not args.no_cpu_baseline:
