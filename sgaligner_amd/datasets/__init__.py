@@ -10,4 +10,4 @@ if __name__ == 'datasets':
     from sgaligner_amd._dropin import alias as _alias
     _alias('datasets', ['scan3r'], ours_first=False)
 else:
-    from .scan3r import Scan3RDataset, DeviceBatch  # noqa: F401
+    from .scan3r import Scan3RDataset, DeviceBatch, DevicePrefetcher  # noqa: F401

@@ -15,7 +15,8 @@ Same as the reference:
 Different on purpose (the hygiene list of SURVEY.md 8(f) rank 3):
   * no `retain_graph=True`, no per-iteration `torch.cuda.empty_cache()`, no per-iteration `.item()` syncs: running loss
     sums stay on the device and are read back once per `log_steps`;
-  * batches go to the GPU through `datasets.DeviceBatch` (pinned, non-blocking), index sets stay on the host;
+  * batches go to the GPU through `datasets.DevicePrefetcher` (pinned, non-blocking, one batch ahead on a second HIP stream:
+    the upload of batch i+1 overlaps the step of batch i), index sets stay on the host;
   * the two `log_vars` vectors are saved too (key 'loss_layers'; the reference loses them on resume);
   * multi-GPU is real: under torchrun every rank owns a contiguous shard of each batch's pairs, the loss is the
     batch-GLOBAL loss (AlignerSteps._global_loss over RCCL) and parameter gradients are all-reduced;
@@ -34,7 +35,7 @@ import torch
 import torch.distributed as dist
 
 from . import dist as sdist
-from .datasets import DeviceBatch
+from .datasets import DeviceBatch, DevicePrefetcher
 from .trainer import AlignerSteps
 
 
@@ -149,11 +150,18 @@ class EpochBasedTrainer:
         return {'missing': sorted(want - have), 'unexpected': sorted(have - want)}
 
     # ---- one process per GPU: this rank's pairs of a collated batch ----------------------------------------
-    def _to_device(self, data_dict):
+    def _shard(self, data_dict):
         if self.distributed:
             lo, hi = sdist.shard_range(int(data_dict['batch_size']), self.rank, self.world)
             data_dict = sdist.shard_data_dict(data_dict, lo, hi)
-        return DeviceBatch(data_dict, self.device)
+        return data_dict
+
+    def _to_device(self, data_dict):
+        return DeviceBatch(self._shard(data_dict), self.device)
+
+    def _device_batches(self, loader):
+        """The loader's batches, sharded for this rank and uploaded one batch ahead on a second HIP stream."""
+        return DevicePrefetcher(loader, self.device, prepare=self._shard)
 
     def check_gradients(self, epoch, iteration, data_dict, output_dict, result_dict):
         """NaN / Inf scan of every gradient (one device-side reduction; the reference dumps data/model and drops into ipdb,
@@ -188,10 +196,9 @@ class EpochBasedTrainer:
         keys, acc, n_acc = None, None, 0
         ep_sum, ep_n = None, 0
         t0 = time.time()
-        for iteration, data_dict in enumerate(self.train_loader):
+        for iteration, data_dict in enumerate(self._device_batches(self.train_loader)):
             self.inner_iteration = iteration + 1
             self.iteration += 1
-            data_dict = self._to_device(data_dict)
             self.before_train_step(self.epoch, self.inner_iteration, data_dict)
             output_dict, result_dict = self.train_step(self.epoch, self.inner_iteration, data_dict)
             result_dict['loss'].backward()
@@ -235,9 +242,8 @@ class EpochBasedTrainer:
         self.before_val_epoch(self.epoch)
         keys, acc, n = None, None, 0
         last_loss = None
-        for iteration, data_dict in enumerate(self.val_loader):
+        for iteration, data_dict in enumerate(self._device_batches(self.val_loader)):
             self.inner_iteration = iteration + 1
-            data_dict = self._to_device(data_dict)
             self.before_val_step(self.epoch, self.inner_iteration, data_dict)
             output_dict, result_dict = self.val_step(self.epoch, self.inner_iteration, data_dict)
             self.after_val_step(self.epoch, self.inner_iteration, data_dict, output_dict, result_dict)

@@ -51,3 +51,28 @@ def test_dataset_batch_through_the_hot_path(tmp_path):
     mg = alignment.evaluate_batch(ev, ddv)
     assert [mg[k]['correct'] for k in (1, 2, 3, 4, 5)] == [mo['hits'][k][0] for k in (1, 2, 3, 4, 5)]
     assert np.allclose(mg['mrr'], mo['mrr'])
+
+
+def test_device_prefetcher_matches_device_batch():
+    """DevicePrefetcher (upload of batch i+1 on a second stream under the step of batch i) hands out the same batches, in
+    order, as DeviceBatch; the step results are identical; `prepare` sees the host batch."""
+    import torch
+    from sgaligner_amd.datasets import DeviceBatch, DevicePrefetcher
+    from sgaligner_amd.synthetic import make_batch
+    from sgaligner_amd.trainer import AlignerSteps
+    host = [make_batch(3, 10, 32, seed=70 + i) for i in range(4)]
+    steps = AlignerSteps(['point', 'gat', 'rel'], device='cuda', seed=42)
+    want = []
+    for dd in host:
+        _, l = steps.forward_backward(DeviceBatch(dd))
+        want.append(float(l['loss'].item()))
+    seen = []
+    got = []
+    for i, dd in enumerate(DevicePrefetcher(host, 'cuda', prepare=lambda d: (seen.append(id(d)), d)[1])):
+        assert all(v.is_cuda for v in dd.values() if isinstance(v, torch.Tensor))
+        assert torch.equal(dd['tot_obj_pts'].cpu(), host[i]['tot_obj_pts'])
+        _, l = steps.forward_backward(dd)
+        got.append(float(l['loss'].item()))
+    assert seen == [id(d) for d in host]
+    assert got == want
+    assert len(DevicePrefetcher(host, 'cuda')) == 4
