@@ -400,9 +400,17 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
     const SweepGroup& grp = a.grp[g];
+    // XCD-aware work order.  Workgroup b is dispatched to XCD b % 8 (its own 4 MiB L2); a group's work list, ordered (split major,
+    // owner block minor), is cut into 8 contiguous chunks, one per XCD: the ~64 workgroups resident on an XCD at any time are
+    // consecutive owner blocks of the SAME split, i.e. they stream the same "other" tiles in the same order and share them in that
+    // XCD's L2 (owner-block-major order put every split on every XCD: 7.1 GB of L2 misses per launch at configs[1]).
+    // plan_multi pads every group to a multiple of 8 workgroups (blk0 % 8 == 0); the padding workgroups exit here.
     const int wg_in_grp = (int)blockIdx.x - grp.blk0;
-    const int nsplit = grp.nsplit, split = wg_in_grp % nsplit;
-    const int own0 = grp.own0 + (wg_in_grp / nsplit) * S16_OWN;
+    const int nsplit = grp.nsplit, n_ob = (grp.nown + S16_OWN - 1) / S16_OWN, n_units = n_ob * nsplit;
+    const int unit = (wg_in_grp & 7) * ((n_units + 7) >> 3) + (wg_in_grp >> 3);
+    if ((wg_in_grp >> 3) >= ((n_units + 7) >> 3) || unit >= n_units) return;
+    const int split = unit / n_ob;
+    const int own0 = grp.own0 + (unit - split * n_ob) * S16_OWN;
     const int own_end = grp.own0 + grp.nown;
     const int my_i = own0 + wave * 16 + l15;
     const bool iv = my_i < own_end;
@@ -1427,7 +1435,7 @@ static int plan_multi(MultiArgs& a, int target_steps, int own_rows = 128) {
         if (ns < 1) ns = 1;
         G.nsplit = ns;
         G.blk0 = nwg;
-        nwg += ((G.nown + own_rows - 1) / own_rows) * ns;
+        nwg += ((((G.nown + own_rows - 1) / own_rows) * ns + 7) / 8) * 8;      // 8 per-XCD chunks (sweep16_kernel's work order)
     }
     return nwg;
 }
