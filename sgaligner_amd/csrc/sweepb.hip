@@ -123,9 +123,14 @@ __global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
     const BGroup& grp = a.grp[g];
+    // XCD-aware work order, as in contrastive.hip's sweep16_kernel: the group's (split major, owner block minor) work list in 8
+    // contiguous per-XCD chunks; groups are padded to a multiple of 8 workgroups, the padding exits here.
     const int wg_in_grp = (int)blockIdx.x - grp.blk0;
-    const int nsplit = grp.nsplit, split = wg_in_grp % nsplit;
-    const int own0 = grp.own0 + (wg_in_grp / nsplit) * SB_OWN;
+    const int nsplit = grp.nsplit, n_ob = (grp.nown + SB_OWN - 1) / SB_OWN, n_units = n_ob * nsplit;
+    const int unit = (wg_in_grp & 7) * ((n_units + 7) >> 3) + (wg_in_grp >> 3);
+    if ((wg_in_grp >> 3) >= ((n_units + 7) >> 3) || unit >= n_units) return;
+    const int split = unit / n_ob;
+    const int own0 = grp.own0 + (unit - split * n_ob) * SB_OWN;
     const int own_end = grp.own0 + grp.nown;
     const int my_i = own0 + wave * 16 + l15;
     const bool iv = my_i < own_end;
@@ -418,15 +423,15 @@ int fill_b(BArgs& a, const void* const* Zb, int M, const float* beta, int A, int
         BGroup& G = a.grp[i];
         int steps = 0;
         for (int sg = 0; sg < G.nseg; ++sg) steps += G.seg[sg].jt_hi - G.seg[sg].jt_lo;
-        // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  With nsplit a multiple of 8 (and every group's
-        // first workgroup therefore too) the 32 co-resident workgroups of an XCD share `split`, i.e. they walk the SAME other tiles
-        // at the same time for different owner blocks: a tile comes from HBM/MALL once per XCD and 31 more times from its L2.
-        int nsp = ((steps + 159) / 160 + 7) / 8 * 8;
-        if (nsp > steps) nsp = (steps + 7) / 8 * 8;
+        // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); the kernel maps workgroup -> (split, owner block)
+        // so that the 32 co-resident workgroups of an XCD share `split`, i.e. they walk the SAME other tiles at the same time for
+        // different owner blocks: a tile comes from HBM/MALL once per XCD and 31 more times from its L2.
+        int nsp = (steps + 159) / 160;
+        if (nsp > steps) nsp = steps;
         if (nsp < 1) nsp = 1;
         G.nsplit = nsp;
         G.blk0 = nwg;
-        nwg += ((G.nown + SB_OWN - 1) / SB_OWN) * nsp;
+        nwg += (((G.nown + SB_OWN - 1) / SB_OWN) * nsp + 7) / 8 * 8;
     }
     return -nwg;                                                    // negative: number of workgroups (0 is a valid "nothing to do")
 }
