@@ -326,7 +326,7 @@ def main():
             line['strong_scaling_one_gpu'] = scale_ref
         if not args.no_hits:
             line['hits_at_1'] = hits_at_k(steps, n_obj, n_pts, dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # the CPU leg runs on rank 0 of a one-GPU run only
             line['cpu_baseline'] = cpu_baseline(n_obj, n_pts)
             line['speedup_vs_cpu_baseline'] = round(line['value'] / line['cpu_baseline']['value'], 1)
         print(json.dumps(line), flush=True)
