@@ -299,7 +299,7 @@ def main():
             roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': round(ach / PEAK_F32_TFLOPS, 4),
                           'traffic': pmc_traffic_bytes(info['tag'] % M, f'ns={ns},A={A},J={J1 + J2}', 'contrastive.hip') if world == 1 else None,
-                          'kernel': f'{info["tag"] % M} ({info["what"]}, all {M}+1 tables)',
+                          'kernel': f'{info["tag"] % M if M != 4 else "sweep16x2_kernel<true>"} ({info["what"]}, all {M}+1 tables)',
                           'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                           'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed,
                           'executed_tflops': round(executed / (avg_ms * 1e-3) / 1e12, 2)})

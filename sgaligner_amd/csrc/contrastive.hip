@@ -654,6 +654,291 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// M = 4 (point + gat + rel + attr: the module list of every config the reference ships) on PAIRED waves.
+//
+// sweep16_kernel<4> needs 104 owner-operand + 112 gradient-accumulator + 32 S-tile registers per lane: one wave per SIMD, so
+// nothing runs under a wave's epilogue or barrier wait (0.61 of the MFMA peak against 0.72 for M = 3 with two waves per SIMD).
+// Here a workgroup still owns 64 rows but runs 8 waves: wave (rg, th) owns row group rg (16 rows) and TABLES {2 th, 2 th + 1} only --
+// half of the operands, S tiles and accumulators (~200 registers: two waves per SIMD again).  The joint similarity needs all four
+// S tiles of an element, so the two waves of a row group swap their halves through LDS once per tile (16 values per lane each way,
+// one extra workgroup barrier -- a pairwise LDS-flag hand-over instead measured 2 % slower: the spinning wave takes issue slots);
+// the joint coefficient is then computed by both (the only duplicated work, ~100 VALU per tile) and
+// each wave forms the coefficients and gradient GEMMs of its own two tables.  Same work units, XCD order and DMA ring as sweep16_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int S4_THREADS = 512;
+template <bool GRAD>
+__global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
+    constexpr int M = 4, MT = 2, DP = 104, OT = 32, NCT = 7;
+    constexpr int TILE_F = OT * DP, BUF_F = M * TILE_F, NCHUNK = M * 13;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][M][OT][DP] + 32 slack + exchange [8 waves][16][64]
+    float* xbuf = lds + 2 * BUF_F + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int rg = wave & 3, th = wave >> 2;                        // row group, table half
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
+    const SweepGroup& grp = a.grp[g];
+    const int wg_in_grp = (int)blockIdx.x - grp.blk0;
+    const int nsplit = grp.nsplit, n_ob = (grp.nown + S16_OWN - 1) / S16_OWN, n_units = n_ob * nsplit;
+    const int unit = (wg_in_grp & 7) * ((n_units + 7) >> 3) + (wg_in_grp >> 3);     // XCD-aware order, see sweep16_kernel
+    if ((wg_in_grp >> 3) >= ((n_units + 7) >> 3) || unit >= n_units) return;
+    const int split = unit / n_ob;
+    const int own0 = grp.own0 + (unit - split * n_ob) * S16_OWN;
+    const int own_end = grp.own0 + grp.nown;
+    const int my_i = own0 + rg * 16 + l15;
+    const bool iv = my_i < own_end;
+
+    f32x4 own[MT][6];
+    float ownt[MT][2], bm[MT], bp[MT];                             // beta of this wave's tables / of its partner's
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const float* src = a.Z[2 * th + m] + (size_t)(iv ? my_i : own0) * DP;
+        const float msk = iv ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 16 * q + 4 * g4) * msk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ownt[m][t] = src[96 + 4 * t + g4] * msk;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { bm[m] = a.beta[2 * th + m]; bp[m] = a.beta[2 * (1 - th) + m]; }
+    f32x4 gacc[GRAD ? MT : 1][NCT];
+#pragma unroll
+    for (int m = 0; m < (GRAD ? MT : 1); ++m)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) gacc[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gam[MT] = {0.f, 0.f};
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue = [&](int j0, float* buf) {
+#pragma unroll
+        for (int c0 = 0; c0 < NCHUNK; c0 += 8) {
+            const int c = c0 + wave_u;
+            if (c >= NCHUNK) break;
+            const int m = c / 13, cc = c - m * 13;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(a.Z[m] + (size_t)j0 * DP + cc * 256 + lane * 4),
+                (__attribute__((address_space(3))) void*)(buf + m * TILE_F + cc * 256), 16, 0, 0);
+        }
+    };
+    int jrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) jrow[r] = s16_pi(4 * g4 + r);
+    const int arow = s16_pi(l15);
+    float* xmine = xbuf + ((rg * 2 + th) * 16) * 64 + lane;
+    const float* xpart = xbuf + ((rg * 2 + (1 - th)) * 16) * 64 + lane;
+
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        if (sg >= grp.nseg) break;
+        const SweepSeg seg = grp.seg[sg];
+        const int ntile = (seg.n + OT - 1) / OT;
+        const int j_end = seg.row0 + seg.n;
+        float c0[MT + 1], c1[MT + 1];                              // this wave's two tables, then the joint table
+#pragma unroll
+        for (int m = 0; m <= MT; ++m) {
+            const int tab = m == MT ? M : 2 * th + m;
+            c0[m] = GRAD ? (float)(a.gs[tab * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
+            c1[m] = GRAD ? (float)(a.gs[tab * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
+        }
+        double dsum[MT + 1][2];                                    // own two tables (+ the joint table: th == 0 only)
+#pragma unroll
+        for (int m = 0; m <= MT; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
+
+        __syncthreads();
+        if (split < ntile) issue(seg.row0 + split * OT, lds);
+        int it = 0;
+        for (int jt = split; jt < ntile; jt += nsplit, ++it) {
+            float* buf = lds + (it & 1) * BUF_F;
+            const int j0 = seg.row0 + jt * OT;
+            __syncthreads();                               // tile `it` landed / other buffer free / exchange buffer free
+            if (jt + nsplit < ntile) issue(seg.row0 + (jt + nsplit) * OT, lds + ((it + 1) & 1) * BUF_F);
+
+            // ---- S^T tiles of this wave's two tables
+            f32x4 mine[MT][2], part[MT][2];
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                const float* ap = buf + (2 * th) * TILE_F + (jh * 16 + arow) * DP + 4 * g4;
+                const float* at = buf + (2 * th) * TILE_F + (jh * 16 + arow) * DP + 96 + g4;
+                f32x4 sacc[MT], avA[MT], avB[MT];
+                float tl[MT][2];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    sacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    avA[m] = *reinterpret_cast<const f32x4*>(ap + m * TILE_F);
+                    avB[m] = avA[m];
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    if (q < 5) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            if (q & 1) avA[m] = *reinterpret_cast<const f32x4*>(ap + m * TILE_F + 16 * (q + 1));
+                            else avB[m] = *reinterpret_cast<const f32x4*>(ap + m * TILE_F + 16 * (q + 1));
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) { tl[m][0] = at[m * TILE_F]; tl[m][1] = at[m * TILE_F + 4]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            sacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32((q & 1) ? avB[m][r] : avA[m][r], own[m][q][r], sacc[m], 0, 0, 0);
+                    if (q < 5) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (t >= a.ktail) break;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        sacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[m][t], ownt[m][t], sacc[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xmine[((m * 2 + jh) * 4 + r) * 64] = sacc[m][r];
+                    mine[m][jh] = sacc[m];
+                }
+            }
+            __syncthreads();                               // both halves of every row group are in the exchange buffer
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = xpart[((m * 2 + jh) * 4 + r) * 64];
+                    part[m][jh] = v;
+                }
+
+            if (!GRAD) {
+                float p0[MT + 1], p1[MT + 1];
+#pragma unroll
+                for (int m = 0; m <= MT; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float okf = (iv && (j0 + jh * 16 + jrow[r] < j_end)) ? 1.f : 0.f;
+                        float sj = 0.f;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) sj = fmaf(bm[m], mine[m][jh][r], fmaf(bp[m], part[m][jh][r], sj));
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const float sv = mine[m][jh][r];
+                            p0[m] = fmaf(okf, fexp2(sv * a.k0), p0[m]);
+                            p1[m] = fmaf(okf, fexp2(sv * a.k1), p1[m]);
+                        }
+                        if (th == 0) {                              // wave-uniform: the joint table's sums are taken once per row group
+                            p0[MT] = fmaf(okf, fexp2(sj * a.k0), p0[MT]);
+                            p1[MT] = fmaf(okf, fexp2(sj * a.k1), p1[MT]);
+                        }
+                    }
+#pragma unroll
+                for (int m = 0; m <= MT; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
+            } else {
+                float cj[2][4], okf[2][4];
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        okf[jh][r] = (iv && (j0 + jh * 16 + jrow[r] < j_end)) ? 1.f : 0.f;
+                        float sj = 0.f;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) sj = fmaf(bm[m], mine[m][jh][r], fmaf(bp[m], part[m][jh][r], sj));
+                        cj[jh][r] = okf[jh][r] * (c0[MT] * fexp2(sj * a.k0) + c1[MT] * fexp2(sj * a.k1));
+                    }
+                if (g < 2) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[jh][r], mine[m][jh][r], gam[m]);
+                }
+                float cmv[2], bv[2][NCT];
+                auto coef = [&](int e) {
+                    const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
+                    const float sv = mine[m][jh][r];
+                    return okf[jh][r] * fmaf(bm[m], cj[jh][r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1));
+                };
+                auto bload = [&](int e, float* dst) {
+                    const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
+                    const float* bb = buf + (2 * th + m) * TILE_F + (jh * 16 + jrow[r]) * DP + l15;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) dst[ct] = bb[ct * 16];
+                };
+                cmv[0] = coef(0);
+                bload(0, bv[0]);
+#pragma unroll
+                for (int e = 0; e < MT * 8; ++e) {
+                    if (e + 1 < MT * 8) { cmv[(e + 1) & 1] = coef(e + 1); bload(e + 1, bv[(e + 1) & 1]); }
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        gacc[GRAD ? (e >> 3) : 0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmv[e & 1], bv[e & 1][ct], gacc[GRAD ? (e >> 3) : 0][ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(gam[m]));
+            }
+        }
+        if (!GRAD) {
+#pragma unroll
+            for (int m = 0; m <= MT; ++m) {
+                if (m == MT && th != 0) break;
+                const int tab = m == MT ? M : 2 * th + m;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const double v = wave_sum_d(dsum[m][tt]);
+                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + (M + 1) * 8 * (1 + my_slot()) + tab * 8 + seg.fam * 2 + tt, v);
+                }
+            }
+        }
+    }
+    if (GRAD) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float* dz = a.dZ[2 * th + m];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int d = ct * 16 + l15;
+                if (d < DP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = own0 + rg * 16 + 4 * g4 + r;
+                        if (i < own_end) atomicAdd(dz + (size_t)i * DP + d, gacc[GRAD ? m : 0][ct][r]);
+                    }
+                }
+            }
+        }
+        if (g < 2) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float v = wave_sum(gam[m]);
+                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + 2 * th + m, (double)v);
+            }
+        }
+    }
+}
+
+template <bool GRAD>
+static void launch_sweep16x2(const MultiArgs& a, int nwg, hipStream_t s) {
+    const size_t lds = ((size_t)2 * 4 * 32 * 104 + 32 + 8 * 16 * 64) * sizeof(float);
+    auto k = sweep16x2_kernel<GRAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(S4_THREADS), lds, s, a);
+}
+
 template <int M, bool GRAD>
 static void launch_sweep16(const MultiArgs& a, int nwg, hipStream_t s) {
     const size_t lds = ((size_t)2 * M * 32 * 104 + 32) * sizeof(float);
@@ -1453,7 +1738,7 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, int D, const fl
     const int nwg = plan_multi(a, 160, S16_OWN);
     if (M == 2) launch_sweep16<2, false>(a, nwg, s);
     else if (M == 3) launch_sweep16<3, false>(a, nwg, s);
-    else launch_sweep16<4, false>(a, nwg, s);
+    else launch_sweep16x2<false>(a, nwg, s);
     fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums");
     return SGA_OK;
@@ -1474,7 +1759,7 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, int D, const fl
     const int nwg = plan_multi(a, 160, S16_OWN);
     if (M == 2) launch_sweep16<2, true>(a, nwg, s);
     else if (M == 3) launch_sweep16<3, true>(a, nwg, s);
-    else launch_sweep16<4, true>(a, nwg, s);          // one workgroup per CU (104 KiB ring, ~300 registers per lane)
+    else launch_sweep16x2<true>(a, nwg, s);            // paired waves: two tables per wave, 8 waves per workgroup
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad");
     return SGA_OK;

@@ -330,7 +330,7 @@ def _anchor_chunks(a_lo, a_hi, A, n_tables):
 # What sga_loss_multi_grad launches (bench.py's roofline line): two owner sweeps x M tables x (S with K = 100 + gradient
 # GEMM with 112 columns); the joint table is derived, never multiplied.
 SWEEP_GRAD_INFO = {
-    'tag': 'sweep16_kernel<%d,true>',
+    'tag': 'sweep16_kernel<%d,true>',           # M = 4 launches sweep16x2_kernel<true> (paired waves, two tables each)
     'what': 'loss: negatives backward',
     'executed_flops': lambda ns, j, m: 2.0 * (2.0 * ns * j) * 2.0 * m * (100 + 112),
 }
