@@ -138,6 +138,7 @@ def main():
     ap.add_argument('--config', choices=['auto', 'c2', 'c3'], default=os.environ.get('SGA_BENCH_CONFIG', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hits', action='store_true')
+    ap.add_argument('--no-attr', action='store_true', help='skip the extra point+gat+rel+attr (M = 4) measurement (N = 1)')
     ap.add_argument('--no-scale-ref', action='store_true', help='skip the extra configs[2]-on-one-GPU measurement (N = 1, --config auto)')
     ap.add_argument('--no-bf16x3', action='store_true', help='skip the extra (opt-in split-bf16 x3 MFMA mode) measurement')
     args = ap.parse_args()
@@ -237,6 +238,28 @@ def main():
         finally:
             ops.set_mfma_mode('f32')
 
+    # ---- extra at N = 1: the same batch with the reference's full module list (point+gat+rel+attr, M = 4: what every yaml the
+    # reference ships trains; SURVEY.md 8(d) "also report +'attr'").  Exact fp32, same step definition; never the headline.
+    extra_attr = None
+    if world == 1 and not args.no_attr and 'attr' not in MODULES:
+        try:
+            mods4 = MODULES + ['attr']
+            steps4 = AlignerSteps(mods4, device=dev, seed=42)
+            for _ in range(2):
+                steps4.forward_backward(dd)
+            torch.cuda.synchronize()
+            n4 = max(3, min(args.steps, 10))
+            t4 = time.perf_counter()
+            for _ in range(n4):
+                steps4.forward_backward(dd)
+            torch.cuda.synchronize()
+            el4 = time.perf_counter() - t4
+            extra_attr = {'modules': mods4, 'value': round(total_pairs * n4 / el4, 2), 'unit': 'pairs/s',
+                          'ms_per_step': round(el4 / n4 * 1e3, 3), 'steps': n4, 'warmup': 2, 'dtype': 'f32'}
+            del steps4
+        except Exception as e:
+            extra_attr = {'error': f'{type(e).__name__}: {e}'}
+
     # ---- extra at N = 1 under --config auto: configs[2] (the workload the N > 1 lines run, strong scaling at a fixed 4096-pair
     # global batch) on THIS one GPU, so that a 1/2/4/8 series of lines carries its own same-workload single-GPU point.
     scale_ref = None
@@ -322,6 +345,8 @@ def main():
         }
         if extra is not None:
             line['extra_bf16x3'] = extra
+        if extra_attr is not None:
+            line['extra_full_module_list'] = extra_attr
         if scale_ref is not None:
             line['strong_scaling_one_gpu'] = scale_ref
         if not args.no_hits:
