@@ -1365,25 +1365,27 @@ __global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restri
     if (i < n) inv[i] = (float)(1.0 / (sums[i] + 1e-9));
 }
 
-template <int M>
-__global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
-    constexpr int DP = 104, NT = M + 1;
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][32][DP] own rows
+// RB = anchor rows staged per workgroup: 32 (two wave pairs, each walking its own J tiles) for M <= 3; 16 for M = 4, where 32 rows of
+// four tables are 106 KiB of LDS = one workgroup per CU (all four waves then share the 16 rows and split the J tiles four ways).
+template <int M, int RB = (M <= 3 ? 32 : 16)>
+__global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
+    constexpr int DP = 104, NT = M + 1, NSUB = RB / 16, TW = 4 / NSUB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][RB][DP] own rows
     // the (M+1)*8 sum coefficients are read from global memory at uniform addresses: s_load -> SGPRs.  As LDS reads
     // each of the 32 values cost an address VGPR + a data VGPR and pushed the kernel into scratch.
     const float* __restrict__ inv_s = a.inv;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int A = a.A, ns = a.i_hi - a.i_lo;
     const int ib = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
-    const int i0 = a.i_lo + ib * 32;
-    const int ih = wave & 1;                                         // which 16 anchor rows of the block
+    const int i0 = a.i_lo + ib * RB;
+    const int ih = wave % NSUB, tw = wave / NSUB;                    // which 16 anchor rows of the block / which share of the J tiles
     const int my_i = i0 + ih * 16 + l15;
     const bool iv = my_i < a.i_hi;
 
-    for (int e = tid; e < M * 2 * 32 * (DP / 4); e += CT_THREADS) {
-        const int c = (e % (DP / 4)) * 4, r = (e / (DP / 4)) % 32, side = (e / (DP / 4) / 32) % 2, m = e / (DP / 4) / 64;
+    for (int e = tid; e < M * 2 * RB * (DP / 4); e += CT_THREADS) {
+        const int c = (e % (DP / 4)) * 4, r = (e / (DP / 4)) % RB, side = (e / (DP / 4) / RB) % 2, m = e / (DP / 4) / (2 * RB);
         const int row = min(i0 + r, a.i_hi - 1) + side * A;
-        *reinterpret_cast<f32x4*>(lds + ((m * 2 + side) * 32 + r) * DP + c) = *reinterpret_cast<const f32x4*>(a.Z[m] + (size_t)row * DP + c);
+        *reinterpret_cast<f32x4*>(lds + ((m * 2 + side) * RB + r) * DP + c) = *reinterpret_cast<const f32x4*>(a.Z[m] + (size_t)row * DP + c);
     }
     __syncthreads();
     float beta[M];
@@ -1401,7 +1403,7 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_bwd16
 
     const int ntile = (A + 15) / 16;
 #pragma unroll 1
-    for (int jt = split * 2 + (wave >> 1); jt < ntile; jt += a.nsplit * 2) {
+    for (int jt = split * TW + tw; jt < ntile; jt += a.nsplit * TW) {
         const int j0 = jt * 16;
         const int jrow = min(j0 + l15, A - 1);
         // The anchor-row operands are loop invariant; left alone, LICM parks all M*2*26 of them in registers
@@ -1416,8 +1418,8 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_bwd16
             Q[m] = P[m];
             const float* gp = a.Z[m] + (size_t)(A + jrow) * DP;              // X2[j] for P
             const float* gq = a.Z[m] + (size_t)jrow * DP;                    // X1[j] for Q
-            const float* bp = lds + lofs + ((m * 2 + 0) * 32 + ih * 16 + l15) * DP;   // X1[i]
-            const float* bq = lds + lofs + ((m * 2 + 1) * 32 + ih * 16 + l15) * DP;   // X2[i]
+            const float* bp = lds + lofs + ((m * 2 + 0) * RB + ih * 16 + l15) * DP;   // X1[i]
+            const float* bq = lds + lofs + ((m * 2 + 1) * RB + ih * 16 + l15) * DP;   // X2[i]
 #pragma unroll
             for (int q = 0; q < 6; ++q) {                                    // k = 16q + 4g + r
                 const f32x4 ap = *reinterpret_cast<const f32x4*>(gp + 16 * q + 4 * g);
@@ -1903,10 +1905,11 @@ extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const flo
     a.inv = inv;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(M1[m], "sga_loss_anchor_multi_bwd: null stash"); a.M1[m] = M1[m]; }
     {
-        const size_t lds = (size_t)(M * 2 * 32 * 104 + (M + 1) * 8) * sizeof(float);
-        const int nib = (a.i_hi - a.i_lo + 31) / 32, ntile16 = (A + 15) / 16;
+        const int RB = M <= 3 ? 32 : 16, TW = M <= 3 ? 2 : 4;
+        const size_t lds = (size_t)(M * 2 * RB * 104 + (M + 1) * 8) * sizeof(float);
+        const int nib = (a.i_hi - a.i_lo + RB - 1) / RB, ntile16 = (A + 15) / 16;
         int nsp = (6 * sga_num_cus() + nib - 1) / (nib > 0 ? nib : 1);
-        if (nsp > (ntile16 + 1) / 2) nsp = (ntile16 + 1) / 2;
+        if (nsp > (ntile16 + TW - 1) / TW) nsp = (ntile16 + TW - 1) / TW;
         if (nsp < 1) nsp = 1;
         a.nsplit = nsp;
         if (M == 2) {
