@@ -742,7 +742,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
             c0[m] = GRAD ? (float)(a.gs[tab * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
             c1[m] = GRAD ? (float)(a.gs[tab * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
         }
-        double dsum[MT + 1][2];                                    // own two tables (+ the joint table: th == 0 only)
+        double dsum[MT + 1][2];                                    // own two tables + this wave's half of the joint table
 #pragma unroll
         for (int m = 0; m <= MT; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
 
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
                             p0[m] = fmaf(okf, fexp2(sv * a.k0), p0[m]);
                             p1[m] = fmaf(okf, fexp2(sv * a.k1), p1[m]);
                         }
-                        if (th == 0) {                              // wave-uniform: the joint table's sums are taken once per row group
+                        if (jh == th) {                             // wave-uniform: the joint table's sums, one 16-row half per partner
                             p0[MT] = fmaf(okf, fexp2(sj * a.k0), p0[MT]);
                             p1[MT] = fmaf(okf, fexp2(sj * a.k1), p1[MT]);
                         }
@@ -895,7 +895,6 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
         if (!GRAD) {
 #pragma unroll
             for (int m = 0; m <= MT; ++m) {
-                if (m == MT && th != 0) break;
                 const int tab = m == MT ? M : 2 * th + m;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
