@@ -196,7 +196,8 @@ def test_fused_path_fails_loudly_on_zero_rows():
     assert torch.isnan(fn(out, dd)['loss']).item()
 
 
-def test_anchor_sharded_loss_equals_unsharded():
+@pytest.mark.parametrize('M', [3, 4])
+def test_anchor_sharded_loss_equals_unsharded(M):
     """Multi-GPU loss sharding, simulated on one GPU: R 'ranks' each own a contiguous anchor range; the all-reduces
     inside ops.FusedContrastiveFn (2 in forward, 1 in backward) are replayed deterministically: round n supplies the
     totals of reduce #0..n-1 recorded in earlier rounds and records the partials of reduce #n.  Summed over ranks, the
@@ -205,10 +206,10 @@ def test_anchor_sharded_loss_equals_unsharded():
     from sgaligner_amd.synthetic import make_batch
     dd = make_batch(5, 24, 8, seed=11, ragged=True, anchors='val')
     T = int(dd['tot_obj_count'].sum())
-    M, R = 3, 3
+    R = 3
     torch.manual_seed(0)
     base = [torch.randn(T, 100, device='cuda') for _ in range(M)]
-    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')
+    w0 = torch.tensor([[0.3], [1.1], [-0.4], [0.7]], device='cuda')[:M]
     cot = torch.randn(M + 1 + 2 * M, device='cuda')
 
     def run(shard, reduce):
@@ -248,6 +249,40 @@ def test_anchor_sharded_loss_equals_unsharded():
         assert (g - ref_grads[m]).abs().max() < 1e-4 * max(1.0, ref_grads[m].abs().max().item()), m
     gw = sum(results[r][2] for r in range(R))
     assert (gw - ref_w).abs().max() < 1e-4 * max(1.0, ref_w.abs().max().item())
+
+
+@pytest.mark.parametrize('M', [3, 4])
+def test_fused_sweeps_many_splits_equal_per_table_kernels(M):
+    """Enough rows for several splits per owner block (> 160 other tiles) and many owner blocks: the fused multi-table sweeps
+    (M = 3: sweep16_kernel, M = 4: the paired-wave sweep16x2_kernel, both in the XCD-chunked work order) against the general
+    per-table kernels that sweep the joint table as an independent table -- sums and every gradient."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.aligner import losses as L
+    from sgaligner_amd.synthetic import make_batch_fast
+    dd = make_batch_fast(96, 64, 4, seed=5, device='cuda')           # A = 1824, J = 4320 per family: 135 + 135 tiles per owner block
+    T = int(dd['tot_obj_pts'].shape[0])
+    torch.manual_seed(4)
+    base = [torch.nn.functional.normalize(torch.randn(T, 100, device='cuda'), dim=1) for _ in range(M)]
+    w0 = torch.tensor([[0.3], [1.1], [-0.4], [0.7]], device='cuda')[:M]
+    cot = torch.rand(M + 1 + 2 * M, device='cuda') + 0.5
+    res = {}
+    for fused in (True, False):
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        w = w0.clone().requires_grad_(True)
+        if fused:
+            sums, _ = ops.fused_contrastive_terms(tabs, w, dict(dd))
+        else:
+            ws = torch.softmax(w, dim=0)
+            joint = torch.cat([ws[m] * torch.nn.functional.normalize(tabs[m], dim=1) for m in range(M)], dim=1)
+            sums, _ = ops.contrastive_terms(tabs + [joint], dict(dd))
+        (sums * cot).sum().backward()
+        torch.cuda.synchronize()
+        res[fused] = (sums.detach(), [t.grad for t in tabs], w.grad)
+    a, b = res[True], res[False]
+    assert torch.allclose(a[0], b[0], rtol=2e-4, atol=1e-5), (a[0], b[0])
+    for m in range(M):
+        assert (a[1][m] - b[1][m]).abs().max() < 2e-4 * max(1.0, b[1][m].abs().max().item()), m
+    assert (a[2] - b[2]).abs().max() < 2e-4 * max(1.0, b[2].abs().max().item())
 
 
 @pytest.mark.parametrize('emb', [64, 104, 128])
