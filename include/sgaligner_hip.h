@@ -38,6 +38,14 @@ int sga_get_mfma_mode(void);
 int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                      const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
                      void* stream);
+/* Same, with a caller-owned workspace of sga_pointnet_fwd_ws_bytes(T, C3) bytes: when the batch has few objects (the reference's
+ * own batch sizes, single-pair inference: T < 4 x CUs) every object is split over the 8 waves of a workgroup and the partial
+ * (max, arg-max) pairs are folded by a second small kernel -- identical results, per-object latency / 8.  workspace may be NULL
+ * (then this is sga_pointnet_fwd). */
+size_t sga_pointnet_fwd_ws_bytes(int T, int C3);
+int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
+                        void* workspace, size_t ws_bytes, void* stream);
 /* autograd of the above wrt the six parameters (sparse through the max-pool); gy [T,C3]; C3 == 256. */
 int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy, const float* w1,
                      const float* b1, const float* w2, const float* b2, const float* w3, float* gw1, float* gb1,

@@ -24,6 +24,8 @@ SIGNATURES = {
     'sga_set_mfma_mode': (I, [I]),
     'sga_get_mfma_mode': (I, []),
     'sga_pointnet_fwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    'sga_pointnet_fwd_ws_bytes': (c_size_t, [I, I]),
+    'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, P]),
     'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, P]),
     'sga_gat_attn_fwd': (I, [P, P, P, P, P, P, P, I, I, P, P]),
     'sga_gat_attn_bwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),

@@ -28,7 +28,11 @@ namespace {
 constexpr int PN_WAVES = 8;
 constexpr int PN_THREADS = PN_WAVES * 64;
 
-template <int C3, bool WITH_ARGMAX>
+// SPLIT (few objects: the reference's own batch sizes, single-pair inference): a workgroup takes ONE object at a time and its 8
+// waves share the object's 32-point tiles (tile = wave, wave + 8, ...); each wave leaves its running (max, arg-max) in `part`
+// [T][8][C3] (value, index) and pointnet_combine_kernel folds the 8 partials.  With one wave per object, T = 320 objects keep 40 of
+// the 256 CUs busy for 16 tiles each (0.63 ms); split, every CU works and an object takes 2 tiles per wave.
+template <int C3, bool WITH_ARGMAX, bool SPLIT = false>
 __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     const float* __restrict__ x,   // [T, P, 3]
     const float* __restrict__ w1,  // [64, 3]
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     const float* __restrict__ b3,  // [C3]
     float* __restrict__ y,         // [T, C3]
     int* __restrict__ argmax,      // [T, C3] or nullptr
-    int T, int P) {
+    int T, int P, float2* __restrict__ part) {             // part: SPLIT only, [T][PN_WAVES][C3] (value, index as float bits)
     constexpr int NB3 = C3 / 32;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w2s = lds;             // [4 cb][8 q][64 lane][4]        = 8192 floats
@@ -63,14 +67,14 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     const int h = lane >> 5, pt = lane & 31;
     const int n_tiles = (P + 31) >> 5;
 
-    for (int t = blockIdx.x * PN_WAVES + wave; t < T; t += gridDim.x * PN_WAVES) {
+    for (int t = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * PN_WAVES + wave; t < T; t += SPLIT ? (int)gridDim.x : (int)gridDim.x * PN_WAVES) {
         const float* xt = x + (size_t)t * P * 3;
         float best[NB3];
         int bidx[NB3];
 #pragma unroll
         for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
 
-        for (int tile = 0; tile < n_tiles; ++tile) {
+        for (int tile = SPLIT ? wave : 0; tile < n_tiles; tile += SPLIT ? PN_WAVES : 1) {
             const int p0 = tile * 32;
             // Opaque per-tile copies of the lane ids: the weight reads below are loop-invariant, and
             // without this LICM hoists ~900 registers of them out of the tile loop (-> scratch spills).
@@ -164,11 +168,33 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
             }
             if (h == 0) {
                 const int c = cb * 32 + pt;
-                y[(size_t)t * C3 + c] = fmaxf(v + b3[c], 0.f);
-                if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
+                if (SPLIT) {
+                    part[((size_t)t * PN_WAVES + wave) * C3 + c] = float2{v, __int_as_float(bi)};
+                } else {
+                    y[(size_t)t * C3 + c] = fmaxf(v + b3[c], 0.f);
+                    if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
+                }
             }
         }
     }
+}
+
+// fold the PN_WAVES partial (max, arg-max) pairs of the SPLIT forward: larger value wins, equal values -> smaller point index (the
+// first maximum, as in the unsplit kernel); then bias + ReLU
+__global__ void pointnet_combine_kernel(const float2* __restrict__ part, const float* __restrict__ b3, float* __restrict__ y,
+                                        int* __restrict__ argmax, int T, int C3, int P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * C3) return;
+    const int t = i / C3, c = i - t * C3;
+    float v = -INFINITY;
+    int bi = 0;
+    for (int w = 0; w < PN_WAVES; ++w) {
+        const float2 pv = part[((size_t)t * PN_WAVES + w) * C3 + c];
+        const int oi = __float_as_int(pv.y);
+        if (pv.x > v || (pv.x == v && oi < bi) || w == 0) { v = pv.x; bi = oi; }
+    }
+    y[i] = fmaxf(v + b3[c], 0.f);
+    if (argmax) argmax[i] = min(bi, P - 1);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -356,11 +382,29 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
 
 template <int C3>
 int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-               const float* w3, const float* b3, float* y, int* argmax, int T, int P, hipStream_t stream) {
+               const float* w3, const float* b3, float* y, int* argmax, int T, int P, hipStream_t stream,
+               void* workspace = nullptr, size_t ws_bytes = 0) {
     const size_t lds_bytes = (size_t)(8192 + C3 * 128) * sizeof(float);
     int grid = (T + PN_WAVES - 1) / PN_WAVES;
     const int ncu = sga_num_cus();
     if (grid > ncu) grid = ncu;
+    // few objects: one object per workgroup, its tiles dealt to the 8 waves (exact fp32 kernel only; needs the partials workspace)
+    if (sga_mfma_mode() == 0 && workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32) {
+        float2* part = static_cast<float2*>(workspace);
+        const int g2 = T < ncu ? T : ncu;
+        if (argmax) {
+            auto k = pointnet_fwd_kernel<C3, true, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part);
+        } else {
+            auto k = pointnet_fwd_kernel<C3, false, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part);
+        }
+        hipLaunchKernelGGL(pointnet_combine_kernel, dim3((T * C3 + 255) / 256), dim3(256), 0, stream, part, b3, y, argmax, T, C3, P);
+        SGA_CHECK_LAUNCH("sga_pointnet_fwd");
+        return SGA_OK;
+    }
     if (sga_mfma_mode() == 1) {
         if (argmax) {
             auto k = pointnet_fwd_bf16x3_kernel<C3, true>;
@@ -374,11 +418,11 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     } else if (argmax) {
         auto k = pointnet_fwd_kernel<C3, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr));
     } else {
         auto k = pointnet_fwd_kernel<C3, false>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr));
     }
     SGA_CHECK_LAUNCH("sga_pointnet_fwd");
     return SGA_OK;
@@ -386,18 +430,36 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
 
 }  // namespace
 
+extern "C" size_t sga_pointnet_fwd_ws_bytes(int T, int C3) { return (size_t)(T > 0 ? T : 0) * PN_WAVES * (C3 > 0 ? C3 : 0) * sizeof(float2); }
+
+static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                             const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,
+                             void* stream);
+
+extern "C" int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
+                                   void* workspace, size_t ws_bytes, void* stream) {
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, stream);
+}
+
 extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* w3, const float* b3, float* y,
                                 int32_t* argmax, int T, int P, int C3, void* stream) {
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, nullptr, 0, stream);
+}
+
+static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                             const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,
+                             void* stream) {
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_fwd: need T >= 0 and P >= 1 (got T=%d P=%d)", T, P);
     // a zero-object shard (T == 0: empty tensors carry null data pointers) is a valid no-op
     SGA_CHECK_ARG((T == 0 || (x && y)) && w1 && b1 && w2 && b2 && w3 && b3, "sga_pointnet_fwd: null pointer");
     if (T == 0) return SGA_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (C3) {
-        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s);
-        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s);
-        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s);
+        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes);
+        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes);
+        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes);
         default:
             sga_set_error("sga_pointnet_fwd: out_size C3=%d unsupported (64, 128 or 256: W3 must fit the 160 KiB LDS)", C3);
             return SGA_ERR_ARG;

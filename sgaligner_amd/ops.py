@@ -50,6 +50,7 @@ def get_mfma_mode() -> str:
 
 
 # ------------------------------------------------------------------------------------------ PointNet
+POINTNET_SPLIT_MAX_OBJECTS = 1023      # the library uses the split form below 4 x CUs objects; above that a workspace is not allocated
 def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     """x_tp3 [T,P,3] (point-major, as in data_dict['tot_obj_pts']).  Returns (y [T,C3], argmax|None)."""
     T, P, _ = x_tp3.shape
@@ -60,8 +61,13 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     if KERNEL_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    rc = _lib.lib().sga_pointnet_fwd(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
-                                     T, P, C3, _stream())
+    L = _lib.lib()
+    ws, ws_bytes = None, 0
+    if 0 < T <= POINTNET_SPLIT_MAX_OBJECTS:      # few objects: split every object over a workgroup's 8 waves (needs a partials buffer)
+        ws_bytes = int(L.sga_pointnet_fwd_ws_bytes(T, C3))
+        ws = torch.empty((ws_bytes,), device=x_tp3.device, dtype=torch.uint8)
+    rc = L.sga_pointnet_fwd_ws(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
+                               T, P, C3, _p(ws), ws_bytes, _stream())
     _lib.check(rc, 'sga_pointnet_fwd')
     if ev is not None:
         ev[1].record()
