@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 
 from . import dist as sdist
+from . import ops
 from .datasets import DeviceBatch, DevicePrefetcher
 from .trainer import AlignerSteps
 
@@ -230,6 +231,7 @@ class EpochBasedTrainer:
                                      self.inner_iteration / max(1e-9, time.time() - t0))
                 acc.zero_()
                 n_acc = 0
+        ops.DEFERRED_CHECKS.flush()                      # deferred range checks of the epoch's last batches
         self.after_train_epoch(self.epoch)
         if self.scheduler is not None:
             self.scheduler.step()

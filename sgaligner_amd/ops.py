@@ -269,7 +269,60 @@ class _SmallCache:
         self.d.clear()
 
 
+def _h2d(host_array, device):
+    """Small per-batch host array -> device without stalling the host: a pageable `tensor.to(device)` is a blocking copy that
+    waits for everything queued on the stream (the previous step's backward); from a pinned staging tensor the copy is
+    asynchronous and the host runs on.  CPU 'devices' (unit tests) take the plain path."""
+    t = torch.from_numpy(_np.ascontiguousarray(host_array))
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 VALIDATE = _os.environ.get('SGA_VALIDATE', '1') != '0'     # host-side range checks of index sets / edge lists, once per batch
+
+
+class _DeferredChecks:
+    """Range checks whose operands live on the device (the collated edge list): reading the answer back at once would stall the
+    host on everything already queued -- once per batch, i.e. once per training step.  The [min, max] pair is reduced on the
+    device, copied to a pinned host slot without blocking, and examined when its event has fired: at the next batch's check (by
+    then it has) or at `flush()` (blocking; trainers call it at epoch ends, tests directly).  A bad batch therefore raises at the
+    latest one step after it was used; the kernels themselves never read out of bounds (they drop such endpoints)."""
+
+    def __init__(self):
+        self.pending = []          # (event, pinned host tensor, upper bound, message)
+        self.free = []
+
+    def submit(self, minmax_dev, upper, what):
+        host = self.free.pop() if self.free else torch.empty((2,), dtype=torch.int64).pin_memory()
+        host.copy_(minmax_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, host, int(upper), what))
+
+    def poll(self, wait=False):
+        keep = []
+        err = None
+        for ev, host, upper, what in self.pending:
+            if wait:
+                ev.synchronize()
+            if wait or ev.query():
+                mn, mx = int(host[0]), int(host[1])
+                self.free.append(host)
+                if (mn < 0 or mx >= upper) and err is None:
+                    err = what % (mn, mx, upper)
+            else:
+                keep.append((ev, host, upper, what))
+        self.pending = keep
+        if err is not None:
+            raise RuntimeError(err)
+
+    def flush(self):
+        self.poll(wait=True)
+
+
+DEFERRED_CHECKS = _DeferredChecks()
 
 
 class IndexSets:
@@ -289,7 +342,7 @@ class IndexSets:
             if lo < 0 or (n_rows is not None and hi >= n_rows):
                 raise RuntimeError(f'sgaligner_amd: e1i/e2i/e1j/e2j hold object indices in [{lo}, {hi}] but the embedding '
                                    f'tables have {n_rows} rows')
-        self.idx = torch.from_numpy(host).to(device)
+        self.idx = _h2d(host, device)
 
     _cache = _SmallCache()
 
@@ -601,14 +654,13 @@ class GraphBatch:
         if VALIDATE and self.E and edges.is_cuda:
             # Node ids are graph-LOCAL (scan3r.py:99): anything outside [0, largest graph) can not be a node of any graph.
             # The kernels drop out-of-range endpoints (PyG would raise an index error); catch the gross case here, once per batch.
-            mn, mx = torch.aminmax(edges[:self.E])
-            mn, mx = int(mn), int(mx)
-            if mn < 0 or mx >= self.nmax:
-                raise RuntimeError(f'sgaligner_amd: edge endpoints span [{mn}, {mx}] but the largest graph has {self.nmax} nodes '
-                                   f'(edges must hold graph-local node ids)')
+            DEFERRED_CHECKS.poll()                                   # earlier batches' answers (no waiting)
+            DEFERRED_CHECKS.submit(torch.stack(torch.aminmax(edges[:self.E])), self.nmax,
+                                   'sgaligner_amd: edge endpoints span [%d, %d] but the largest graph has %d nodes '
+                                   '(edges must hold graph-local node ids)')
         self.edges = edges if keep_edges else None
-        self.node_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(nc)]).astype(_np.int32)).to(dev)
-        self.edge_off = torch.from_numpy(_np.concatenate([[0], _np.cumsum(ec)]).astype(_np.int32)).to(dev)
+        self.node_off = _h2d(_np.concatenate([[0], _np.cumsum(nc)]).astype(_np.int32), dev)
+        self.edge_off = _h2d(_np.concatenate([[0], _np.cumsum(ec)]).astype(_np.int32), dev)
 
     _cache = _SmallCache(2)
 

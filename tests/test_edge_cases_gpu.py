@@ -63,3 +63,25 @@ def test_degenerate_batches_vs_oracle(name):
     mo = O.evaluate_batch(out_o['joint'].detach(), dd)
     mg = alignment.evaluate_batch(out['joint'].detach(), dd)
     assert [mg[k]['correct'] for k in (1, 2, 3, 4, 5)] == [mo['hits'][k][0] for k in (1, 2, 3, 4, 5)]
+
+
+def test_edge_list_range_check_is_deferred_but_raises():
+    """Edge endpoints outside every graph (global instead of graph-local node ids) must raise -- without a device read-back
+    stalling every step: the check is queued, and fires at the next batch or at ops.DEFERRED_CHECKS.flush()."""
+    import pytest
+    import torch
+    from sgaligner_amd import ops
+    from sgaligner_amd.aligner.sg_aligner import MultiModalEncoder
+    from sgaligner_amd.synthetic import make_batch, to_device
+    ops.DEFERRED_CHECKS.flush()
+    dd = to_device(make_batch(2, 9, 16, seed=3), 'cuda')
+    model = MultiModalEncoder(modules=['point', 'gat'], rel_dim=41, attr_dim=164).cuda()
+    model(dd)
+    ops.DEFERRED_CHECKS.flush()                                   # a good batch passes
+    bad = dict(dd)
+    bad['edges'] = dd['edges'].clone()
+    bad['edges'][0, 0] = 1000
+    model(bad)                                                    # the kernels drop the endpoint; the check is pending
+    with pytest.raises(RuntimeError, match='graph-local'):
+        ops.DEFERRED_CHECKS.flush()
+    ops.DEFERRED_CHECKS.flush()                                   # reported once
