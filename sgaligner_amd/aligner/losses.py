@@ -19,12 +19,13 @@ class CustomMultiLossLayer(nn.Module):
         self.log_vars = nn.Parameter(torch.zeros(self.loss_num, ), requires_grad=True)
 
     def forward(self, loss_list):
-        assert len(loss_list) == self.loss_num
-        precision = torch.exp(-self.log_vars)
-        loss = 0
-        for i in range(self.loss_num):
-            loss += precision[i] * loss_list[i] + self.log_vars[i]
-        return loss
+        """sum_i exp(-log_vars[i]) * L_i + log_vars[i]  (reference losses.py:28-34), as four tensor ops instead of 3 per term:
+        at the reference's own batch sizes the step is bound by the number of launches, not by their size.  `loss_list` may be
+        a list of 0-d tensors or one [loss_num] tensor."""
+        terms = loss_list if isinstance(loss_list, torch.Tensor) else torch.stack([t.reshape(()) for t in loss_list])
+        assert terms.shape[0] == self.loss_num
+        lv = self.log_vars.to(terms.dtype)
+        return (torch.exp(-lv) * terms + lv).sum()
 
 
 class ICLLoss(nn.Module):
@@ -106,8 +107,8 @@ class OverallLoss(nn.Module):
             icl = sums[:nt] / a2
             al = self.align_loss
             ial = al.zoom * (al.alpha * sums[nt:nt + m] + (1 - al.alpha) * sums[nt + m:nt + 2 * m])
-            total_align_loss = self.align_multi_loss_layer([ial[i] for i in range(m)]) * self.zoom
-            icl_uni = self.contrastive_multi_loss_layer([icl[i] for i in range(m)])
+            total_align_loss = self.align_multi_loss_layer(ial) * self.zoom          # [m] tensors: no per-term slicing launches
+            icl_uni = self.contrastive_multi_loss_layer(icl[:m])
             icl_multi = icl[m]
             loss = total_align_loss + icl_uni + icl_multi
         else:
