@@ -11,7 +11,14 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device.  The raw getter is ~20x cheaper than building a
+    torch.cuda.Stream object (13 launches per step: 0.17 ms of a 2.5 ms step at the reference's batch sizes)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -659,8 +666,8 @@ class GraphBatch:
                                    'sgaligner_amd: edge endpoints span [%d, %d] but the largest graph has %d nodes '
                                    '(edges must hold graph-local node ids)')
         self.edges = edges if keep_edges else None
-        self.node_off = _h2d(_np.concatenate([[0], _np.cumsum(nc)]).astype(_np.int32), dev)
-        self.edge_off = _h2d(_np.concatenate([[0], _np.cumsum(ec)]).astype(_np.int32), dev)
+        offs = _h2d(_np.concatenate([[0], _np.cumsum(nc), [0], _np.cumsum(ec)]).astype(_np.int32), dev)     # one upload
+        self.node_off, self.edge_off = offs[:self.G + 1], offs[self.G + 1:]
 
     _cache = _SmallCache(2)
 
