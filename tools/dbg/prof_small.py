@@ -15,4 +15,4 @@ for i in range(100):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(45)
+st.sort_stats('tottime').print_stats(40)
