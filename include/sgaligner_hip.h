@@ -241,6 +241,17 @@ int sga_fps(const float* pts, const int32_t* offsets, int n_obj, const int32_t* 
  * offsets [n_obj+1]; n_planes [n_obj] (nullable): facets of the filter polytope, 0 = object kept whole (degenerate). */
 int sga_hull_candidates(const float* pts, const int32_t* offsets, int n_obj, unsigned char* keep, int32_t* n_planes, void* stream);
 
+/* ---- scalar head of OverallLoss -----------------------------------------------------------------------
+ * replaces the one-element arithmetic of src/aligner/losses.py:114-152 + CustomMultiLossLayer.forward :28-34 on the raw terms
+ * sums = [S_icl[M+1] | S_ial_a[M] | S_ial_b[M]] (doubles) returned by the loss kernels:
+ *   out = [loss, icl_loss_unimodal, icl_loss_multimodal, ial_loss]   (doubles);  inv_a2 = 1 / A^2, z_ial / alpha = IALLoss zoom / alpha,
+ *   zoom = cfg.loss.zoom.  bwd: gout[4] = dL/d(out) -> dsums [3M+1] (type of sums), dlv_ial / dlv_icl [M] floats (the two log_vars). */
+int sga_loss_head_fwd(const void* sums, int sums_f64, const float* lv_ial, const float* lv_icl, int M, double inv_a2,
+                      double z_ial, double alpha, double zoom, double* out, void* stream);
+int sga_loss_head_bwd(const double* gout, const void* sums, int sums_f64, const float* lv_ial, const float* lv_icl, int M,
+                      double inv_a2, double z_ial, double alpha, double zoom, void* dsums, float* dlv_ial, float* dlv_icl,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ from .. import ops
 
 
 FUSED_JOINT = True     # tests flip this to cross-check the fused path against the independent-table path
+FUSED_HEAD = True      # the scalar loss head as one launch (ops.LossHeadFn); False: the same arithmetic as torch ops
 
 
 class CustomMultiLossLayer(nn.Module):
@@ -103,14 +104,20 @@ class OverallLoss(nn.Module):
                     raise RuntimeError('sgaligner_amd: anchor sharding is implemented for the fused joint path only')
                 sums, s = ops.contrastive_terms(tabs + [output_dict['joint']], data_dict, alpha=self.contrastive_loss.alpha)
             nt = m + 1
-            a2 = float(s.A * s.A)
-            icl = sums[:nt] / a2
             al = self.align_loss
-            ial = al.zoom * (al.alpha * sums[nt:nt + m] + (1 - al.alpha) * sums[nt + m:nt + 2 * m])
-            total_align_loss = self.align_multi_loss_layer(ial) * self.zoom          # [m] tensors: no per-term slicing launches
-            icl_uni = self.contrastive_multi_loss_layer(icl[:m])
-            icl_multi = icl[m]
-            loss = total_align_loss + icl_uni + icl_multi
+            ml_a, ml_c = self.align_multi_loss_layer, self.contrastive_multi_loss_layer
+            if FUSED_HEAD and sums.is_cuda and type(ml_a) is CustomMultiLossLayer and type(ml_c) is CustomMultiLossLayer:
+                # losses.py:114-152 + the two multi-loss layers as one launch (ops.LossHeadFn)
+                loss, icl_uni, icl_multi, total_align_loss = ops.LossHeadFn.apply(
+                    sums, ml_a.log_vars, ml_c.log_vars, s.A, al.zoom, al.alpha, self.zoom).unbind(0)
+            else:
+                a2 = float(s.A * s.A)
+                icl = sums[:nt] / a2
+                ial = al.zoom * (al.alpha * sums[nt:nt + m] + (1 - al.alpha) * sums[nt + m:nt + 2 * m])
+                total_align_loss = ml_a(ial) * self.zoom
+                icl_uni = ml_c(icl[:m])
+                icl_multi = icl[m]
+                loss = total_align_loss + icl_uni + icl_multi
         else:
             total_align_loss = 0.0
             icl_multi = 0.0

@@ -498,6 +498,37 @@ def contrastive_terms(tables, data_dict, alpha=ALPHA):
     return ContrastiveTermsFn.apply(s, alpha, *tables), s
 
 
+class LossHeadFn(torch.autograd.Function):
+    """[loss, icl_unimodal, icl_multimodal, ial] from the raw loss terms and the two log_vars vectors: reference
+    losses.py:114-152 + CustomMultiLossLayer.forward :28-34 as ONE launch forward and ONE backward (csrc/losshead.hip) instead of
+    ~60 one-element torch kernels -- a fifth of all launches of a step at the reference's batch sizes."""
+
+    @staticmethod
+    def forward(ctx, sums, lv_ial, lv_icl, n_anchors, z_ial, alpha_ial, zoom):
+        M = int(lv_ial.numel())
+        if sums.dtype not in (torch.float32, torch.float64) or sums.numel() != 3 * M + 1 or lv_icl.numel() != M:
+            raise RuntimeError('sgaligner_amd: LossHeadFn takes the 3M+1 loss terms (float32/float64) and two [M] log_vars vectors')
+        sums = sums.contiguous()
+        la, lc = _req(lv_ial.detach(), 'log_vars (ial)'), _req(lv_icl.detach(), 'log_vars (icl)')
+        out = torch.empty((4,), device=sums.device, dtype=torch.float64)
+        ctx.consts = (M, 1.0 / float(n_anchors * n_anchors), float(z_ial), float(alpha_ial), float(zoom))
+        ctx.f64 = int(sums.dtype == torch.float64)
+        _lib.check(_lib.lib().sga_loss_head_fwd(_p(sums), ctx.f64, _p(la), _p(lc), *ctx.consts, _p(out), _stream()), 'sga_loss_head_fwd')
+        ctx.save_for_backward(sums, la, lc)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sums, la, lc = ctx.saved_tensors
+        M = ctx.consts[0]
+        gout = gout.to(torch.float64).contiguous()
+        dsums = torch.empty_like(sums)
+        dla, dlc = torch.empty_like(la), torch.empty_like(lc)
+        _lib.check(_lib.lib().sga_loss_head_bwd(_p(gout), _p(sums), ctx.f64, _p(la), _p(lc), *ctx.consts, _p(dsums), _p(dla), _p(dlc),
+                                                _stream()), 'sga_loss_head_bwd')
+        return dsums, dla, dlc, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------ loss_group = b
 class LossGroups:
     """Partition of a batch's pairs into groups of `b` consecutive pairs (the reference's training batches,

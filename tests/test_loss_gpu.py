@@ -86,3 +86,45 @@ def test_loss_vs_oracle_fp64(B, N, mods):
         gref = out64[k].grad
         err = (out[k].grad.cpu().double() - gref).abs().max().item()
         assert err < 1e-3 * max(1e-3, gref.abs().max().item()) + 1e-6, (k, err, gref.abs().max().item())
+
+
+@pytest.mark.parametrize('m', [2, 3, 4])
+def test_fused_loss_head_equals_torch_arithmetic(m):
+    """ops.LossHeadFn (one launch forward, one backward) against the same arithmetic written as torch ops (losses.FUSED_HEAD =
+    False): the four returned values and the gradients of every table, the fusion weight and both log_vars vectors; also with a
+    cotangent on the logged values, not only on `loss`."""
+    from sgaligner_amd.aligner import losses as L
+    from sgaligner_amd.aligner.sg_aligner import MultiModalFusion
+    from sgaligner_amd.synthetic import make_batch
+    mods = ['point', 'gat', 'rel', 'attr'][:m]
+    dd = make_batch(3, 17, 8, seed=5, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    torch.manual_seed(2)
+    base = {k: torch.randn(T, 100, device='cuda') for k in mods}
+    lv1, lv2 = 0.3 * torch.randn(m, device='cuda'), 0.3 * torch.randn(m, device='cuda')
+    cot = torch.tensor([1.0, 0.3, -0.2, 0.7], device='cuda', dtype=torch.float64)
+    res = {}
+    for fused in (True, False):
+        L.FUSED_HEAD = fused
+        try:
+            e = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            fus = MultiModalFusion(m).cuda()
+            ial, icl = L.CustomMultiLossLayer(m).cuda(), L.CustomMultiLossLayer(m).cuda()
+            with torch.no_grad():
+                ial.log_vars.copy_(lv1); icl.log_vars.copy_(lv2)
+            out = dict(e)
+            out['joint'] = fus([e[k] for k in mods])
+            fn = L.OverallLoss(ial, icl, 'cuda', {'zoom': 0.1, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': mods})
+            r = fn(out, dd)
+            vals = torch.stack([r['loss'], r['icl_loss_unimodal'], r['icl_loss_multimodal'], r['ial_loss']]).double()
+            (vals * cot).sum().backward()
+            torch.cuda.synchronize()
+            res[fused] = (vals.detach(), [e[k].grad for k in mods], fus.weight.grad, ial.log_vars.grad, icl.log_vars.grad)
+        finally:
+            L.FUSED_HEAD = True
+    a, b = res[True], res[False]
+    assert torch.allclose(a[0], b[0], rtol=1e-6, atol=1e-9), (a[0], b[0])
+    for x, y in zip(a[1], b[1]):
+        assert (x - y).abs().max() <= 1e-5 * max(1.0, y.abs().max().item())
+    for x, y in zip(a[2:], b[2:]):
+        assert (x - y).abs().max() <= 1e-5 * max(1.0, y.abs().max().item()), (x, y)
