@@ -368,8 +368,12 @@ extern "C" int sga_gat_attn_bwd(const float* H, const float* dO, const float* at
     if (rc) return rc;
     SGA_CHECK_ARG(((G == 0 || nmax == 0) || (H && dO && node_off && edge_off && dH)) && att_src && att_dst && d_att_src && d_att_dst, "sga_gat_attn_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipMemsetAsync(d_att_src, 0, GAT_H * GAT_C * sizeof(float), s);
-    hipMemsetAsync(d_att_dst, 0, GAT_H * GAT_C * sizeof(float), s);
+    if (d_att_dst == d_att_src + GAT_H * GAT_C) {                     // one flat buffer (ops.py): one launch
+        hipMemsetAsync(d_att_src, 0, 2 * GAT_H * GAT_C * sizeof(float), s);
+    } else {
+        hipMemsetAsync(d_att_src, 0, GAT_H * GAT_C * sizeof(float), s);
+        hipMemsetAsync(d_att_dst, 0, GAT_H * GAT_C * sizeof(float), s);
+    }
     if (G == 0 || nmax == 0) return SGA_OK;
     if (nmax <= GAT_MAXN) {
         const size_t lds = gat_lds_bytes(nmax, true, 2, true);

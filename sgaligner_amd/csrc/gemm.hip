@@ -297,7 +297,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nn_kernel(const float* __rest
 }
 
 // column sums: out[n] (+)= sum_m X[m*ld + n]   (bias gradients)
-__global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float* __restrict__ out) {
+__global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float* __restrict__ out, int accumulate) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rw = threadIdx.x >> 6;                 // 4 row-walkers per block
     float s = 0.f;
@@ -306,7 +306,11 @@ __global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N
     __shared__ float red[4][64];
     red[rw][threadIdx.x & 63] = s;
     __syncthreads();
-    if (rw == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rw == 0 && n < N) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (gridDim.y == 1) out[n] = accumulate ? out[n] + v : v;        // short inputs: plain store, no zeroing launch before
+        else atomicAdd(out + n, v);
+    }
 }
 
 __global__ void cast_f64_f32_kernel(const double* __restrict__ in, float* __restrict__ out, size_t n) {
@@ -409,11 +413,11 @@ extern "C" int sga_colsum(const float* X, long ld, int M, int N, float* out, int
     SGA_CHECK_ARG((X || M == 0) && (out || N == 0) && M >= 0 && N >= 0, "sga_colsum: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N == 0) return SGA_OK;
-    if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) { sga_set_error("sga_colsum: memset failed"); return SGA_ERR_HIP; }
-    if (M == 0) return SGA_OK;
-    int gy = (M + 255) / 256;
+    int gy = M <= 2048 ? 1 : (M + 255) / 256;                             // up to 2048 rows: one workgroup per 64 columns walks them all
     if (gy > 512) gy = 512;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, s, X, ld, M, N, out);
+    if (!accumulate && (gy > 1 || M == 0) && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) { sga_set_error("sga_colsum: memset failed"); return SGA_ERR_HIP; }
+    if (M == 0) return SGA_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, s, X, ld, M, N, out, accumulate);
     SGA_CHECK_LAUNCH("sga_colsum");
     return SGA_OK;
 }

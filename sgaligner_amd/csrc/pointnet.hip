@@ -716,12 +716,16 @@ extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const flo
     SGA_CHECK_ARG((T == 0 || (x && argmax && y && gy)) && w1 && b1 && w2 && b2 && w3 && gw1 && gb1 && gw2 && gb2 && gw3 && gb3,
                   "sga_pointnet_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipMemsetAsync(gw1, 0, 64 * 3 * sizeof(float), s);
-    hipMemsetAsync(gb1, 0, 64 * sizeof(float), s);
-    hipMemsetAsync(gw2, 0, 128 * 64 * sizeof(float), s);
-    hipMemsetAsync(gb2, 0, 128 * sizeof(float), s);
-    hipMemsetAsync(gw3, 0, 256 * 128 * sizeof(float), s);
-    hipMemsetAsync(gb3, 0, 256 * sizeof(float), s);
+    if (gb1 == gw1 + 192 && gw2 == gb1 + 64 && gb2 == gw2 + 8192 && gw3 == gb2 + 128 && gb3 == gw3 + 32768) {
+        hipMemsetAsync(gw1, 0, (192 + 64 + 8192 + 128 + 32768 + 256) * sizeof(float), s);      // one flat buffer (ops.py): one launch
+    } else {
+        hipMemsetAsync(gw1, 0, 64 * 3 * sizeof(float), s);
+        hipMemsetAsync(gb1, 0, 64 * sizeof(float), s);
+        hipMemsetAsync(gw2, 0, 128 * 64 * sizeof(float), s);
+        hipMemsetAsync(gb2, 0, 128 * sizeof(float), s);
+        hipMemsetAsync(gw3, 0, 256 * 128 * sizeof(float), s);
+        hipMemsetAsync(gb3, 0, 256 * sizeof(float), s);
+    }
     if (T == 0) return SGA_OK;
     {
         const size_t lds_f = (3 * 8192 + 384) * sizeof(float);

@@ -104,7 +104,12 @@ class PointNetFn(torch.autograd.Function):
         T, P, _ = x.shape
         C3 = w3.shape[0]
         gy = gy.contiguous()
-        g = [torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3)]
+        ps = (w1, b1, w2, b2, w3, b3)
+        flat = torch.empty((sum(t.numel() for t in ps),), device=x.device, dtype=torch.float32)   # adjacent: the library zeroes it in one launch
+        g, o = [], 0
+        for t in ps:
+            g.append(flat[o:o + t.numel()].view(t.shape))
+            o += t.numel()
         rc = _lib.lib().sga_pointnet_bwd(_p(x), _p(am), _p(y), _p(gy), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3),
                                          _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]), T, P, C3, _stream())
         _lib.check(rc, 'sga_pointnet_bwd')
@@ -726,8 +731,8 @@ def _attn_fwd(h, att_s, att_d, bias, gb):
 
 def _attn_bwd(h, d_o, att_s, att_d, gb):
     dh = torch.empty_like(h)
-    das = torch.empty_like(att_s)
-    dad = torch.empty_like(att_d)
+    dboth = torch.empty((2,) + tuple(att_s.shape), device=att_s.device, dtype=att_s.dtype)      # adjacent: zeroed in one launch
+    das, dad = dboth[0], dboth[1]
     _lib.check(_lib.lib().sga_gat_attn_bwd(_p(h), _p(d_o), _p(att_s), _p(att_d), _p(gb.edges), _p(gb.node_off),
                                            _p(gb.edge_off), gb.G, gb.nmax, _p(dh), _p(das), _p(dad), _stream()),
                'sga_gat_attn_bwd')
@@ -981,7 +986,8 @@ class FusedContrastiveFn(torch.autograd.Function):
         A = s.A
         coef = gout.contiguous().float()
         slots = 1 + L.sga_loss_slots()
-        dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for _ in range(M)]
+        dz_all = torch.zeros((M, s.R, dp), device=dev, dtype=torch.float32)      # one fill for the M accumulation targets
+        dzs = [dz_all[k] for k in range(M)]
         gam_neg = torch.empty((slots, M), device=dev, dtype=torch.float64)   # dL/dbeta via the negatives (zeroed by the callee)
         gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via the anchors x anchors terms
         # The anchors x anchors backward runs one anchor-row block [lo, hi) at a time: the kernel writes the block's
@@ -990,11 +996,12 @@ class FusedContrastiveFn(torch.autograd.Function):
         fused = M <= 4 and FUSED_ANCHOR_BWD
         ntab = M if fused else nt
         chunks = _anchor_chunks(a_lo, a_hi, A, ntab)
-        gs = torch.zeros((nt, 8), device=dev, dtype=torch.float64)
+        zz = torch.zeros((nt * 8 + M,), device=dev, dtype=torch.float64)              # gs and gam_acc: one fill
+        gs = zz[:nt * 8].view(nt, 8)
         if fused:
             gsc = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)     # + one block: float copy of 1/(sums+eps)
             gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
-            gam_acc = torch.zeros((M,), device=dev, dtype=torch.float64)
+            gam_acc = zz[nt * 8:]
         else:
             gsc = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
             dps = [dp] * M + [M * dp]
@@ -1040,9 +1047,11 @@ class FusedContrastiveFn(torch.autograd.Function):
             ev[1].record()
             KERNEL_EVENTS.setdefault('loss_multi_grad', []).append(ev + ((ns, A, s.J1, s.J2, M),))
         grads = []
+        same = all(sh == ctx.shapes[0] for sh in ctx.shapes)
+        de_all = torch.zeros((M,) + tuple(ctx.shapes[0]), device=dev, dtype=torch.float32) if same else None   # one fill
         for k in range(M):
             t, d = ctx.shapes[k]
-            de = torch.zeros((t, d), device=dev, dtype=torch.float32)
+            de = de_all[k] if same else torch.zeros((t, d), device=dev, dtype=torch.float32)
             _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
             grads.append(de)
         # d/dbeta_m: through the negatives (gamma) + through sqrt(beta_m) in the anchor rows of ZJ
