@@ -62,7 +62,13 @@ def cpu_baseline(n_obj, n_pts, seconds_budget=20.0):
         O.train_step(params, dd, MODULES)
         times.append(time.time() - t0)
     med = float(np.median(times))
-    return {'value': b / med, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+    cpu_model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), 'unknown')
+    except OSError:
+        pass
+    return {'value': b / med, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model,
             'sample': f'oracle fwd+loss+bwd, b={b} pairs x {n_obj} obj x {n_pts} pts, {"+".join(MODULES)}, '
                       f'{len(times)} iterations, median {med*1e3:.1f} ms, torch {torch.__version__} CPU, {cores} threads '
                       f'(best of a thread-count sweep; host has {os.cpu_count()} hardware threads)'}
