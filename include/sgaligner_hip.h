@@ -241,6 +241,13 @@ int sga_fps(const float* pts, const int32_t* offsets, int n_obj, const int32_t* 
  * offsets [n_obj+1]; n_planes [n_obj] (nullable): facets of the filter polytope, 0 = object kept whole (degenerate). */
 int sga_hull_candidates(const float* pts, const int32_t* offsets, int n_obj, unsigned char* keep, int32_t* n_planes, void* stream);
 
+/* Wide tables (Dp > 128) of sga_loss_neg_grad: one anchor-owner sweep writes c_ij = dL/dS_ij to a caller-owned stash (anchor-row blocks
+ * sized to stash_floats; sga_loss_neg_grad_wide_floats() = everything in one block), both gradients are GEMMs on it: the K = Dp
+ * similarity tile is computed once instead of 2 x ceil(Dp / 320) times.  Same results as sga_loss_neg_grad up to fp32 summation order. */
+size_t sga_loss_neg_grad_wide_floats(int A, int J1, int J2);
+int sga_loss_neg_grad_wide(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8, float* dZ,
+                           float* stash, size_t stash_floats, void* stream);
+
 /* ---- scalar head of OverallLoss -----------------------------------------------------------------------
  * replaces the one-element arithmetic of src/aligner/losses.py:114-152 + CustomMultiLossLayer.forward :28-34 on the raw terms
  * sums = [S_icl[M+1] | S_ial_a[M] | S_ial_b[M]] (doubles) returned by the loss kernels:

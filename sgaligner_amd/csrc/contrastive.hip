@@ -195,6 +195,64 @@ __global__ __launch_bounds__(CT_THREADS) void sweep_kernel(SweepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wide tables (Dp > 128: 1024-d modality tables, 300-/3072-d joint tables on the general path).  sweep_kernel<.,10,true> covers 320
+// gradient columns per pass and recomputes the K = Dp similarity tile in every pass (Dp = 3072: 10 passes, 5.5x the necessary FLOPs;
+// 293 of the 340 ms of a BASELINE configs[4]-shaped step).  For wide rows S is the expensive part, so the trade of the 100-d path
+// is reversed: ONE anchor-owner sweep computes S and the coefficient c_ij = dL/dS_ij and writes it, transposed, to a stash
+// Ct[g][j - n1][i - own0] (lane = anchor: 128-byte stores); both gradients are then plain GEMMs on the stash,
+//   dZ[anchors] += Ct^T Z[negatives]   (gemm_tn)        dZ[negatives] += Ct Z[anchors]   (gemm_nn),
+// so S is computed once instead of 2 x passes times.  The stash is bounded by the caller's workspace: anchor-row blocks.
+// ------------------------------------------------------------------------------------------------
+struct CoefArgs {
+    const float* Z; int Dp; SweepGroup grp[2];
+    float k0, k1, it0, it1;
+    const double* gs;               // [8] dL/d(sums)
+    float* stash[2];                // per anchor group: [J1 + J2][ld] (negative-major)
+    int ld, n1;                     // stash row length (anchors in this block), first negative row of the packed table
+};
+
+template <int NJT>
+__global__ __launch_bounds__(CT_THREADS) void sweep_coef_kernel(CoefArgs a) {
+    constexpr int OT = NJT * 32;
+    __shared__ __attribute__((aligned(16))) float own_s[128 * SGA_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float oth_s[OT * SGA_LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int g = ((int)blockIdx.x >= a.grp[1].blk0 && a.grp[1].nown > 0) ? 1 : 0;
+    const SweepGroup& grp = a.grp[g];
+    const int own0 = grp.own0 + ((int)blockIdx.x - grp.blk0) * 128;
+    const int own_end = grp.own0 + grp.nown;
+    const int my_i = own0 + wave * 32 + (lane & 31);
+    float* __restrict__ st = a.stash[g];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        const SweepSeg seg = grp.seg[sg];
+        const float c0 = (float)(a.gs[seg.fam * 2 + 0] * (double)a.it0), c1 = (float)(a.gs[seg.fam * 2 + 1] * (double)a.it1);
+        const int ntile = (seg.n + OT - 1) / OT;
+        for (int jt = blockIdx.y; jt < ntile; jt += gridDim.y) {
+            const int j0 = seg.row0 + jt * OT, j_end = seg.row0 + seg.n;
+            f32x16 sacc[NJT];
+            zero_acc<NJT>(sacc);
+            for (int k0 = 0; k0 < a.Dp; k0 += SGA_KC) {
+                __syncthreads();
+                lds_load_rows<128, CT_THREADS>(own_s, a.Z, a.Dp, own0, own_end, k0, a.Dp, tid);
+                lds_load_rows<OT, CT_THREADS>(oth_s, a.Z, a.Dp, j0, j_end, k0, a.Dp, tid);
+                __syncthreads();
+                mfma_chunk<NJT>(sacc, oth_s, own_s + (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE, lane);
+            }
+            if (my_i < own_end) {
+#pragma unroll
+                for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = j0 + t * 32 + mfma32_row(r, h);
+                        if (j < j_end) st[(size_t)(j - a.n1) * a.ld + (my_i - grp.own0)] = c0 * fexp2(sacc[t][r] * a.k0) + c1 * fexp2(sacc[t][r] * a.k1);
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fast path of the sweeps for Dp <= 128 (emb_dim = 100 -> Dp = 104): the wave's 32 owner rows live in
 // registers for the whole sweep (NQ float4 per lane = the MFMA B operand of every S tile), and each
 // 128-row "other" tile is staged ONCE into LDS as full rows and serves both the S tiles (ds_read_b128
@@ -1642,6 +1700,50 @@ extern "C" int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, 
         }
     }
     SGA_CHECK_LAUNCH("sga_loss_neg_grad");
+    return SGA_OK;
+}
+
+extern "C" size_t sga_loss_neg_grad_wide_floats(int A, int J1, int J2) {
+    return (size_t)2 * (size_t)(J1 + J2) * (size_t)((A + 31) / 32 * 32);       // the whole batch in one block; less is allowed
+}
+
+extern "C" int sga_loss_neg_grad_wide(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
+                                      float* dZ, float* stash, size_t stash_floats, void* stream) {
+    SGA_CHECK_ARG(Z && gs8 && dZ && stash && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_neg_grad_wide: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int J = J1 + J2;
+    if (A == 0 || J == 0) return SGA_OK;
+    size_t rows = stash_floats / ((size_t)2 * J);
+    if (rows >= (size_t)A) rows = A; else rows = rows / 32 * 32;
+    SGA_CHECK_ARG(rows >= 32 || rows == (size_t)A, "sga_loss_neg_grad_wide: workspace holds fewer than 32 anchor rows (%zu floats for J = %d)", stash_floats, J);
+    const int n1 = 2 * A, n2 = 2 * A + J1;
+    for (int lo = 0; lo < A; lo += (int)rows) {
+        const int hi = lo + (int)rows < A ? lo + (int)rows : A, ns = hi - lo;
+        CoefArgs a{};
+        a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1; a.gs = gs8;
+        a.ld = ns; a.n1 = n1;
+        a.stash[0] = stash; a.stash[1] = stash + (size_t)J * ns;
+        const int nb = (ns + 127) / 128;
+        a.grp[0] = SweepGroup{lo, ns, 0, 2, {SweepSeg{n1, J1, 0}, SweepSeg{n2, J2, 1}}, 1};            // X1 anchors: s11, s12
+        a.grp[1] = SweepGroup{A + lo, ns, nb, 2, {SweepSeg{n2, J2, 2}, SweepSeg{n1, J1, 3}}, 1};       // X2 anchors: s22, s21
+        const int mx = J1 > J2 ? J1 : J2;
+        int gy = (6 * sga_num_cus() + 2 * nb - 1) / (2 * nb);
+        const int jt = (mx + 63) / 64;
+        if (gy > jt) gy = jt;
+        if (gy < 1) gy = 1;
+        hipLaunchKernelGGL(sweep_coef_kernel<2>, dim3(2 * nb, gy), dim3(CT_THREADS), 0, s, a);
+        SGA_CHECK_LAUNCH("sga_loss_neg_grad_wide");
+        for (int g = 0; g < 2; ++g) {
+            const float* C = a.stash[g];
+            const size_t own_row = (size_t)(g == 0 ? lo : A + lo);
+            // dZ[anchors of the block] += Ct^T Z[negatives]
+            int rc = sga_gemm(1, 0, ns, Dp, J, C, ns, 0, Z + (size_t)n1 * Dp, Dp, dZ + own_row * Dp, Dp, nullptr, 1, stream);
+            if (rc) return rc;
+            // dZ[negatives] += Ct Z[anchors of the block]
+            rc = sga_gemm(0, 0, J, Dp, ns, C, ns, 0, Z + own_row * Dp, Dp, dZ + (size_t)n1 * Dp, Dp, nullptr, 1, stream);
+            if (rc) return rc;
+        }
+    }
     return SGA_OK;
 }
 

@@ -380,6 +380,7 @@ class IndexSets:
 
 
 FUSED_ANCHOR_BWD = True
+WIDE_STASH = True         # tables wider than 128 columns: coefficient stash + GEMMs instead of the multi-pass gradient sweep (tests flip it)
 FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
 KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel with HIP events on the launch stream
 
@@ -485,8 +486,17 @@ class ContrastiveTermsFn(torch.autograd.Function):
             if KERNEL_EVENTS is not None and dp <= 128:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            _lib.check(L.sga_loss_neg_grad(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), st),
-                       'sga_loss_neg_grad')
+            if dp > 128 and WIDE_STASH:
+                # wide rows: S is the expensive part -> coefficient stash + GEMMs, S computed once (csrc/contrastive.hip, sweep_coef_kernel)
+                need = int(L.sga_loss_neg_grad_wide_floats(A, s.J1, s.J2))
+                have = max(min(need, STASH_BYTES // 4), 2 * (s.J1 + s.J2) * min(A, 32))
+                stash = torch.empty((have,), device=dev, dtype=torch.float32)
+                _lib.check(L.sga_loss_neg_grad_wide(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), _p(stash), have, st),
+                           'sga_loss_neg_grad_wide')
+                del stash
+            else:
+                _lib.check(L.sga_loss_neg_grad(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), st),
+                           'sga_loss_neg_grad')
             if ev is not None:
                 ev[1].record()
                 KERNEL_EVENTS.setdefault('sweep_kernel<4,4,grad>', []).append(ev + ((A, s.J1, s.J2, dp),))

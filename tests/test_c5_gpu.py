@@ -97,3 +97,36 @@ def test_wide_table_loss_vs_fp64_oracle(D):
         err = (e[k].grad.cpu().double() - gref).abs().max().item()
         assert err < 1e-3 * max(1e-6, gref.abs().max().item()), (k, err, gref.abs().max().item())
     assert (fus.weight.grad.cpu().double() - wo.grad).abs().max().item() < 1e-3 * max(1e-3, wo.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('D,stash_rows', [(304, None), (1024, None), (1024, 64), (520, 32)])
+def test_wide_table_stash_gradient_equals_multipass_sweep(D, stash_rows):
+    """Tables wider than 128 columns: the coefficient-stash + GEMM gradient of the negatives' terms (one similarity computation)
+    against the multi-pass gradient sweep it replaces, with the whole batch in one stash block and with a workspace that only
+    holds 64 / 32 anchor rows (several blocks); terms identical, gradients to fp32 summation order."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(7, 23, 4, seed=9, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    torch.manual_seed(D)
+    base = [torch.randn(T, D, device='cuda'), torch.randn(T, D, device='cuda')]
+    cot = torch.rand(2 + 2, device='cuda') + 0.5
+    res = {}
+    keep = ops.STASH_BYTES
+    for wide in (True, False):
+        ops.WIDE_STASH = wide
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        try:
+            if wide and stash_rows is not None:
+                s0 = ops.IndexSets.of(dd, 'cuda', T)
+                ops.STASH_BYTES = 4 * 2 * (s0.J1 + s0.J2) * stash_rows
+            sums, s = ops.contrastive_terms(tabs, dict(dd))
+            (sums * cot).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.WIDE_STASH = True
+            ops.STASH_BYTES = keep
+        res[wide] = (sums.detach(), [t.grad for t in tabs])
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a - b).abs().max() <= 2e-5 * max(1.0, b.abs().max().item())
