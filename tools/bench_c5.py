@@ -36,7 +36,7 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f'configs[4] shape, {B} pairs x 256 objects x 2048 pts, D = 1024, P+S+R: {dt * 1e3:.1f} ms/step = {B / dt:.1f} pairs/s, '
-      f'peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB, loss {float(res["loss"]):.4e}')
+      f'peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB, loss {float(res["loss"].detach()):.4e}')
 ddv = make_batch_fast(B, 256, 8, seed=4, device='cuda', anchors='val')
 with torch.no_grad():
     emb = model({**ddv, 'tot_obj_pts': dd['tot_obj_pts']})['joint']
