@@ -17,7 +17,16 @@
 //   group_grad_kernel  dL/dSg, Z    -> dZ rows of the group (every packed row belongs to exactly one group: plain stores)
 // All arithmetic fp32 (fp64 only for the per-group scalar sums), VALU: the total work is O(B/b * b^2), three orders of
 // magnitude below the batch-global loss, so these kernels are written for clarity, not for the MFMA roofline.
+#include <stdlib.h>
+
 #include "loss_math.h"
+#include "mfma_tiles.h"
+
+static int g_group_grad_valu = -1;
+static int sga_group_grad_valu() {
+    if (g_group_grad_valu < 0) { const char* e = getenv("SGA_GROUP_GRAD_VALU"); g_group_grad_valu = (e && e[0] == '1') ? 1 : 0; }
+    return g_group_grad_valu;
+}
 
 namespace {
 
@@ -361,6 +370,119 @@ int fill_group_args(GroupArgs& a, const float* const* Z, int M, const float* bet
     return SGA_OK;
 }
 
+// group_sim on the matrix cores (15.6 ms per step for the VALU kernel at b = 16 on a 512-pair batch): a wave owns a 32 x 32 tile of a
+// group's Sg (top and bottom halves tiled separately: their first na columns meet different anchor sets), both operands are Z rows
+// read as float4 straight from L2 (k = 8q + 4h + r: one b128 per operand feeds 4 MFMAs), rows of Sg are stored 128 bytes at a time.
+__global__ __launch_bounds__(GL_THREADS) void group_sim_mfma_kernel(GroupArgs a) {
+    const int gi = blockIdx.x, m = blockIdx.y;
+    const Grp g = load_grp(a.grp + gi * 8);
+    const float* __restrict__ Z = a.Z[m];
+    float* __restrict__ S = a.S + (size_t)m * a.stot + a.soff[gi];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
+    const int na = g.na, W = g.W;
+    const int tR = (na + 31) >> 5, tC = (W + 31) >> 5, ntile = 2 * tR * tC;
+    for (int tile = blockIdx.z * (GL_THREADS / 64) + wave; tile < ntile; tile += gridDim.z * (GL_THREADS / 64)) {
+        const int half = tile >= tR * tC, t2 = tile - half * tR * tC;
+        const int r0 = (t2 / tC) * 32, c0 = (t2 % tC) * 32;
+        const int ri = min(r0 + l31, na - 1), cj = min(c0 + l31, W - 1);               // clamped: rows / columns past the end are not stored
+        const float* __restrict__ zr = Z + (size_t)row_z(g, a.A, half * na + ri) * GL_DP + 4 * h;
+        const float* __restrict__ zc = Z + (size_t)col_z(g, a.A, a.J1, half, cj) * GL_DP + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < GL_DP / 8; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(zr + 8 * q);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(zc + 8 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[r], acc, 0, 0, 0);
+        }
+        if (c0 + l31 < W) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = r0 + mfma32_row(r, h);
+                if (i < na) S[(size_t)(half * na + i) * W + c0 + l31] = acc[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// group_grad on the matrix cores.  The VALU kernel above walks every (row, column) of a group's dL/dSg with one thread per embedding
+// column: fine for b = 2 (it was written for that), 13 ms per step at b = 4 and 62 ms at b = 8 on a 512-pair batch -- more than the
+// whole batch-global loss.  Here a wave owns a 32-row tile of the group's output rows and accumulates its 32 x 104 block of dZ in
+// four 32x32 MFMA accumulators; the coefficient is the A operand straight from the dL/dSg block (row-major for the "row role" of the
+// anchors, transposed -- lane = output row, coalesced -- for the "column role" of X2 and of the negatives), the gathered Z rows are
+// the B operand (lane = embedding column: 128-byte reads).  No LDS, everything comes from L2: a group's blocks are <= ~1 MB.
+//   X1 tile (rows i):      dX1_i  = sum_c G[i, c] Zcol_top(c)                                   c in [0, W)
+//   X2 tile (rows i):      dX2_i  = sum_{c >= na} G[na + i, c] Zcol_bot(c)  +  sum_r G[r, i] X1_r   r in [0, na)
+//   negatives tile (c):    dN_c   = sum_r G[r, na + c] Zrow(r)                                   r in [0, 2 na)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GL_THREADS) void group_grad_mfma_kernel(GroupArgs a) {
+    const int gi = blockIdx.x, m = blockIdx.y;
+    const Grp g = load_grp(a.grp + gi * 8);
+    const float* __restrict__ Z = a.Z[m];
+    const float* __restrict__ C = a.S + (size_t)m * a.stot + a.soff[gi];
+    float* __restrict__ dZ = a.dZ[m];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
+    const int na = g.na, W = g.W, nneg = g.nj1 + g.nj2;
+    const int tA = (na + 31) >> 5, tN = (nneg + 31) >> 5, ntile = 2 * tA + tN;
+    for (int tile = blockIdx.z * (GL_THREADS / 64) + wave; tile < ntile; tile += gridDim.z * (GL_THREADS / 64)) {
+        f32x16 acc[4];
+        zero_acc<4>(acc);
+        const int cls = tile < tA ? 0 : (tile < 2 * tA ? 1 : 2);
+        const int o0 = cls == 0 ? tile * 32 : (cls == 1 ? (tile - tA) * 32 : (tile - 2 * tA) * 32);   // first row of the tile within its class
+        const int nvalid = (cls == 2 ? nneg : na) - o0;                                                  // rows of the tile that exist (>= 1)
+        const bool rv = l31 < nvalid;
+        // ---- row-role segment (A row-major: lane's row of G, k along the row)
+        if (cls <= 1) {
+            const int grow = (cls == 0 ? 0 : na) + o0 + (rv ? l31 : 0);
+            const float* __restrict__ crow = C + (size_t)grow * W;
+            for (int k0 = cls == 0 ? 0 : na; k0 < W; k0 += 2) {
+                const int k = k0 + h;
+                const bool kv = k < W;
+                const float av = (rv && kv) ? crow[k] : 0.f;
+                const float* __restrict__ zr = Z + (size_t)col_z(g, a.A, a.J1, cls, kv ? k : W - 1) * GL_DP;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int d = ct * 32 + l31;
+                    const float bv = (kv && d < GL_DP) ? zr[d] : 0.f;
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ct], 0, 0, 0);
+                }
+            }
+        }
+        // ---- column-role segment (A transposed: k = a row r of G, lane = this tile's column)
+        if (cls >= 1) {
+            const int gcol = (cls == 1 ? 0 : na) + o0 + (rv ? l31 : 0);
+            const int kend = cls == 1 ? na : 2 * na;
+            for (int k0 = 0; k0 < kend; k0 += 2) {
+                const int r = k0 + h;
+                const bool kv = r < kend;
+                const float av = (rv && kv) ? C[(size_t)r * W + gcol] : 0.f;
+                const float* __restrict__ zr = Z + (size_t)row_z(g, a.A, kv ? r : 0) * GL_DP;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int d = ct * 32 + l31;
+                    const float bv = (kv && d < GL_DP) ? zr[d] : 0.f;
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ct], 0, 0, 0);
+                }
+            }
+        }
+        // ---- store: acc[ct][r] = dZ[row(r,h) of the tile][ct*32 + lane&31]; every packed row belongs to exactly one tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = mfma32_row(r, h);
+            if (i >= nvalid) continue;
+            const int zrow = cls == 0 ? g.a0 + o0 + i : (cls == 1 ? a.A + g.a0 + o0 + i : col_z(g, a.A, a.J1, 0, na + o0 + i));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int d = ct * 32 + l31;
+                if (d < GL_DP) dZ[(size_t)zrow * GL_DP + d] += acc[ct][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sga_group_loss_fwd(const float* const* Z, int M, const float* beta, int A, int J1, const int32_t* groups, int G,
@@ -372,7 +494,14 @@ extern "C" int sga_group_loss_fwd(const float* const* Z, int M, const float* bet
     SGA_CHECK_ARG(sums && out, "sga_group_loss_fwd: null output");
     a.sums = sums; a.out = out;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(group_sim_kernel, dim3(G, M), dim3(GL_THREADS), 0, s, a);
+    if (sga_group_grad_valu()) {
+        hipLaunchKernelGGL(group_sim_kernel, dim3(G, M), dim3(GL_THREADS), 0, s, a);
+    } else {
+        int gz = (8 * sga_num_cus()) / (G * M > 0 ? G * M : 1);
+        if (gz < 1) gz = 1;
+        if (gz > 16) gz = 16;
+        hipLaunchKernelGGL(group_sim_mfma_kernel, dim3(G, M, gz), dim3(GL_THREADS), 0, s, a);
+    }
     if (M == 1) hipLaunchKernelGGL(group_fwd_kernel<1>, dim3(G), dim3(GL_THREADS), 0, s, a);
     else if (M == 2) hipLaunchKernelGGL(group_fwd_kernel<2>, dim3(G), dim3(GL_THREADS), 0, s, a);
     else if (M == 3) hipLaunchKernelGGL(group_fwd_kernel<3>, dim3(G), dim3(GL_THREADS), 0, s, a);
@@ -395,7 +524,14 @@ extern "C" int sga_group_loss_bwd(const float* const* Z, int M, const float* bet
     else if (M == 2) hipLaunchKernelGGL(group_bwd_kernel<2>, dim3(G), dim3(GL_THREADS), 0, s, a);
     else if (M == 3) hipLaunchKernelGGL(group_bwd_kernel<3>, dim3(G), dim3(GL_THREADS), 0, s, a);
     else hipLaunchKernelGGL(group_bwd_kernel<4>, dim3(G), dim3(GL_THREADS), 0, s, a);
-    hipLaunchKernelGGL(group_grad_kernel, dim3(G, M), dim3(GL_THREADS), 0, s, a);
+    if (sga_group_grad_valu()) {
+        hipLaunchKernelGGL(group_grad_kernel, dim3(G, M), dim3(GL_THREADS), 0, s, a);
+    } else {
+        int gz = (8 * sga_num_cus()) / (G * M > 0 ? G * M : 1);          // tiles of a group are spread over gz workgroups of 4 waves
+        if (gz < 1) gz = 1;
+        if (gz > 16) gz = 16;
+        hipLaunchKernelGGL(group_grad_mfma_kernel, dim3(G, M, gz), dim3(GL_THREADS), 0, s, a);
+    }
     SGA_CHECK_LAUNCH("sga_group_loss_bwd");
     return SGA_OK;
 }
