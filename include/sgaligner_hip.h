@@ -241,6 +241,9 @@ int sga_fps(const float* pts, const int32_t* offsets, int n_obj, const int32_t* 
  * offsets [n_obj+1]; n_planes [n_obj] (nullable): facets of the filter polytope, 0 = object kept whole (degenerate). */
 int sga_hull_candidates(const float* pts, const int32_t* offsets, int n_obj, unsigned char* keep, int32_t* n_planes, void* stream);
 
+/* loss_group kernels: 1 = the VALU forms of the similarity / gradient kernels (kept for cross-checks), 0 = MFMA (default); returns the old value. */
+int sga_set_group_valu(int on);
+
 /* Wide tables (Dp > 128) of sga_loss_neg_grad: one anchor-owner sweep writes c_ij = dL/dS_ij to a caller-owned stash (anchor-row blocks
  * sized to stash_floats; sga_loss_neg_grad_wide_floats() = everything in one block), both gradients are GEMMs on it: the K = Dp
  * similarity tile is computed once instead of 2 x ceil(Dp / 320) times.  Same results as sga_loss_neg_grad up to fp32 summation order. */

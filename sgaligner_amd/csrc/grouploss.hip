@@ -28,6 +28,12 @@ static int sga_group_grad_valu() {
     return g_group_grad_valu;
 }
 
+extern "C" int sga_set_group_valu(int on) {          // 1: the VALU forms of group_sim / group_grad (cross-checks); returns the old value
+    const int old = sga_group_grad_valu();
+    g_group_grad_valu = on ? 1 : 0;
+    return old;
+}
+
 namespace {
 
 constexpr int GL_THREADS = 256;
