@@ -292,6 +292,32 @@ def main():
         except Exception as e:
             scale_ref = {'error': f'{type(e).__name__}: {e}'}
 
+    # ---- extra at N > 1 under --config auto: the weak-scaling point (BASELINE configs[1] per GPU: 512 pairs x 64 objects on every
+    # rank, batch-global loss over 512 N pairs) next to the strong-scaling headline of the same line.
+    weak_ref = None
+    if world > 1 and args.config == 'auto' and not args.no_scale_ref:
+        try:
+            c2 = CONFIGS['c2']
+            ddw = make_batch_fast(c2['pairs_per_gpu'], c2['n_obj'], c2['n_pts'], seed=143 + rank, device=dev)
+            steps.forward_backward(ddw)
+            barrier()
+            tw = time.perf_counter()
+            nw = 3
+            for _ in range(nw):
+                steps.forward_backward(ddw)
+            barrier()
+            elw = time.perf_counter() - tw
+            t = torch.tensor([elw], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elw = float(t.item())
+            weak_ref = {'workload': f'{c2["ref"]} per GPU: {c2["pairs_per_gpu"]} pairs x {c2["n_obj"]} objects x {c2["n_pts"]} pts on each of {world} '
+                                    f'GPUs, batch-global loss over {c2["pairs_per_gpu"] * world} pairs', 'scaling': 'weak',
+                        'value': round(c2['pairs_per_gpu'] * world * nw / elw, 2), 'unit': 'pairs/s', 'ms_per_step': round(elw / nw * 1e3, 2),
+                        'steps': nw, 'warmup': 1, 'dtype': 'f32'}
+            del ddw
+        except Exception as e:
+            weak_ref = {'error': f'{type(e).__name__}: {e}'}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         # The two kernels that carry the step, each timed with HIP events on its launch stream; `roofline` is the
@@ -355,6 +381,8 @@ def main():
             line['extra_full_module_list'] = extra_attr
         if scale_ref is not None:
             line['strong_scaling_one_gpu'] = scale_ref
+        if weak_ref is not None:
+            line['weak_scaling_point'] = weak_ref
         if not args.no_hits:
             line['hits_at_1'] = hits_at_k(steps, n_obj, n_pts, dev)
         if not args.no_cpu_baseline and world == 1:         # the CPU leg runs on rank 0 of a one-GPU run only
