@@ -212,6 +212,12 @@ int sga_segment_max_bwd(const float* dG, const int32_t* argmax, int T, int N, in
  *   sga_bn_bwd_stats: sums = [sum_r g | sum_r g * xhat],  g = dY * act'(X * scale + shift)    (= dbeta | dgamma)
  *   sga_bn_bwd_apply: dX = scale * (g - mean_g - xhat * mean_gx)   (mean_g / mean_gx NULL: eval-mode BN, dX = scale * g) */
 int sga_bn_stats(const float* X, long ldx, int R, int C, double* sums, void* stream);
+/* per-channel arithmetic between the passes as one launch each: out = [scale | shift | mean | rstd] (4C floats), running statistics and
+ * num_batches_tracked (int64, may be NULL) updated like nn.BatchNorm1d when training != 0 (eval: the running statistics, sums unused);
+ * backward: out = [dbeta | dgamma | mean_g | mean_gx] from the sums of sga_bn_bwd_stats. */
+int sga_bn_finalize(const double* sums, int R, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    long long* num_batches_tracked, float momentum, float eps, int training, float* out, void* stream);
+int sga_bn_bwd_finalize(const double* sums, int R, int C, float* out, void* stream);
 int sga_bn_apply(const float* X, long ldx, int R, int C, const float* scale, const float* shift, int act,
                  const float* resid, long ldr, float* Y, long ldy, void* stream);
 int sga_bn_bwd_stats(const float* X, long ldx, const float* dY, long ldd, int R, int C, const float* scale,

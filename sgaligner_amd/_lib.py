@@ -45,6 +45,8 @@ SIGNATURES = {
     'sga_segment_max': (I, [P, c_long, I, I, I, P, P, P]),
     'sga_segment_max_bwd': (I, [P, P, I, I, I, P, c_long, P]),
     'sga_bn_stats': (I, [P, c_long, I, I, P, P]),
+    'sga_bn_finalize': (I, [P, I, I, P, P, P, P, P, c_float, c_float, I, P, P]),
+    'sga_bn_bwd_finalize': (I, [P, I, I, P, P]),
     'sga_bn_apply': (I, [P, c_long, I, I, P, P, I, P, c_long, P, c_long, P]),
     'sga_bn_bwd_stats': (I, [P, c_long, P, c_long, I, I, P, P, P, P, I, P, P]),
     'sga_bn_bwd_apply': (I, [P, c_long, P, c_long, I, I, P, P, P, P, P, P, I, P, c_long, P]),

@@ -94,6 +94,42 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ X, long ldx, const
     }
 }
 
+// per-channel arithmetic between the statistics pass and the apply pass, as ONE launch (it was ~20 one-element-per-channel torch ops
+// per BatchNorm call: the PCT encoder has 9 of them per step and its small-batch step is bound by launch count).
+//   training: mean = s1 / R, var = max(s2 / R - mean^2, 0) (biased, what BN normalises with); running_mean / running_var updated
+//   with `momentum` like nn.BatchNorm1d (unbiased running variance), num_batches_tracked += 1;  eval: the running statistics.
+//   out[0..C) = scale = gamma * rstd, out[C..2C) = shift = beta - mean * scale, out[2C..3C) = mean, out[3C..4C) = rstd
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int R, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches, float momentum, float eps, int training, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && training && num_batches) num_batches[0] += 1;
+    if (c >= C) return;
+    float mean, rstd;
+    if (training) {
+        const double m = sums[c] / (double)R;
+        double v = sums[C + c] / (double)R - m * m;
+        if (v < 0.0) v = 0.0;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v * ((double)R / (double)(R > 1 ? R - 1 : 1)));
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(v + (double)eps));
+    } else {
+        mean = running_mean[c];
+        rstd = rsqrtf(running_var[c] + eps);
+    }
+    const float sc = gamma[c] * rstd;
+    out[c] = sc; out[C + c] = beta[c] - mean * sc; out[2 * C + c] = mean; out[3 * C + c] = rstd;
+}
+
+// backward counterpart: sums = [sum g | sum g xhat] (doubles) -> out = [dbeta | dgamma | mean_g | mean_gx] floats
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int R, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double a = sums[c], b = sums[C + c];
+    out[c] = (float)a; out[C + c] = (float)b; out[2 * C + c] = (float)(a / (double)R); out[3 * C + c] = (float)(b / (double)R);
+}
+
 inline dim3 bn_grid(int R, int C) {
     int gy = (R + 255) / 256;
     if (gy > 1024) gy = 1024;
@@ -110,6 +146,23 @@ extern "C" int sga_bn_stats(const float* X, long ldx, int R, int C, double* sums
     if (R == 0) return SGA_OK;
     hipLaunchKernelGGL(bn_stats_kernel, bn_grid(R, C), dim3(BN_THREADS), 0, s, X, ldx, R, C, sums);
     SGA_CHECK_LAUNCH("sga_bn_stats");
+    return SGA_OK;
+}
+
+extern "C" int sga_bn_finalize(const double* sums, int R, int C, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float momentum, float eps, int training, float* out,
+                               void* stream) {
+    SGA_CHECK_ARG((sums || !training) && gamma && beta && running_mean && running_var && out && C >= 1 && R >= 0, "sga_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), sums, R, C, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, momentum, eps, training, out);
+    SGA_CHECK_LAUNCH("sga_bn_finalize");
+    return SGA_OK;
+}
+
+extern "C" int sga_bn_bwd_finalize(const double* sums, int R, int C, float* out, void* stream) {
+    SGA_CHECK_ARG(sums && out && C >= 1 && R >= 1, "sga_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), sums, R, C, out);
+    SGA_CHECK_LAUNCH("sga_bn_bwd_finalize");
     return SGA_OK;
 }
 

@@ -22,47 +22,46 @@ class BatchNormActFn(torch.autograd.Function):
         R, C = x.shape
         dev = x.device
         L = _lib.lib()
+        st = _stream()
+        sums = None
         if training:
             sums = torch.empty((2 * C,), device=dev, dtype=torch.float64)
-            _chk(L.sga_bn_stats(_p(x), x.stride(0), R, C, _p(sums), _stream()), 'sga_bn_stats')
-            mean64 = sums[:C] / R
-            var64 = (sums[C:] / R - mean64 * mean64).clamp_min_(0.0)          # biased, as BN normalises with
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean64.float(), alpha=momentum)
-                running_var.mul_(1 - momentum).add_((var64 * (R / max(R - 1, 1))).float(), alpha=momentum)
-                if num_batches_tracked is not None:
-                    num_batches_tracked.add_(1)
-            mean = mean64.float()
-            rstd = torch.rsqrt(var64 + eps).float()
-        else:
-            mean = running_mean.float()
-            rstd = torch.rsqrt(running_var.float() + eps)
-        scale = (gamma * rstd).contiguous()
-        shift = (beta - mean * scale).contiguous()
+            _chk(L.sga_bn_stats(_p(x), x.stride(0), R, C, _p(sums), st), 'sga_bn_stats')
+        # scale | shift | mean | rstd and the running-statistics update: one launch (csrc/bn.hip, bn_finalize_kernel)
+        fin = torch.empty((4, C), device=dev, dtype=torch.float32)
+        nbt = num_batches_tracked if (num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64) else None
+        g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
+        b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
+        _chk(L.sga_bn_finalize(_p(sums), R, C, _p(g32.contiguous()), _p(b32.contiguous()), _p(running_mean), _p(running_var), _p(nbt),
+                               float(momentum), float(eps), int(bool(training)), _p(fin), st), 'sga_bn_finalize')
+        if training and num_batches_tracked is not None and nbt is None:
+            num_batches_tracked.add_(1)
+        scale, shift, mean, rstd = fin[0], fin[1], fin[2], fin[3]
         y = out if out is not None else torch.empty((R, C), device=dev, dtype=torch.float32)
         _chk(L.sga_bn_apply(_p(x), x.stride(0), R, C, _p(scale), _p(shift), act, _p(resid), resid.stride(0) if resid is not None else 0,
-                            _p(y), y.stride(0), _stream()), 'sga_bn_apply')
-        ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous())
+                            _p(y), y.stride(0), st), 'sga_bn_apply')
+        ctx.save_for_backward(x, fin)
         ctx.act, ctx.training, ctx.has_resid = act, training, resid is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, scale, shift, mean, rstd = ctx.saved_tensors
+        x, fin = ctx.saved_tensors
+        scale, shift, mean, rstd = fin[0], fin[1], fin[2], fin[3]
         R, C = x.shape
         L = _lib.lib()
+        st = _stream()
         dyc = dy if dy.stride(1) == 1 else dy.contiguous()
         sums = torch.empty((2 * C,), device=x.device, dtype=torch.float64)
         _chk(L.sga_bn_bwd_stats(_p(x), x.stride(0), _p(dyc), dyc.stride(0), R, C, _p(scale), _p(shift), _p(mean), _p(rstd), ctx.act,
-                                _p(sums), _stream()), 'sga_bn_bwd_stats')
-        dbeta, dgamma = sums[:C].float(), sums[C:].float()
+                                _p(sums), st), 'sga_bn_bwd_stats')
+        bf = torch.empty((4, C), device=x.device, dtype=torch.float32)          # dbeta | dgamma | mean_g | mean_gx: one launch
+        _chk(L.sga_bn_bwd_finalize(_p(sums), R, C, _p(bf), st), 'sga_bn_bwd_finalize')
+        dbeta, dgamma = bf[0], bf[1]
+        mg, mgx = (bf[2], bf[3]) if ctx.training else (None, None)
         dx = torch.empty((R, C), device=x.device, dtype=torch.float32)
-        if ctx.training:
-            mg, mgx = (sums[:C] / R).float().contiguous(), (sums[C:] / R).float().contiguous()
-        else:
-            mg = mgx = None
         _chk(L.sga_bn_bwd_apply(_p(x), x.stride(0), _p(dyc), dyc.stride(0), R, C, _p(scale), _p(shift), _p(mean), _p(rstd), _p(mg), _p(mgx),
-                                ctx.act, _p(dx), dx.stride(0), _stream()), 'sga_bn_bwd_apply')
+                                ctx.act, _p(dx), dx.stride(0), st), 'sga_bn_bwd_apply')
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, (dy if ctx.has_resid else None), None
 
 
