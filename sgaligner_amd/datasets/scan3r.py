@@ -39,8 +39,13 @@ def _load_pkl(path):
 
 
 class Scan3RDataset(data.Dataset):
-    def __init__(self, cfg, split):
+    def __init__(self, cfg, split, cache=True):
+        """cache (beyond the reference, which re-reads both files of both scans for every item): keep each scan's centroid (all that
+        is used of data.npy) and its unpickled graph dict in memory after the first read -- same values, same np.random draws;
+        17 of the 43 ms per iteration of the end-to-end loop at 16 pairs were these reads.  Per DataLoader worker when workers are used."""
         self.split = split
+        self.cache = bool(cache)
+        self._centroids, self._pkls = {}, {}
         self.pc_resolution = cfg.val.pc_res if split == 'val' else cfg.train.pc_res
         self.anchor_type_name = cfg.preprocess.anchor_type_name
         self.model_name = cfg.model_name
@@ -72,15 +77,13 @@ class Scan3RDataset(data.Dataset):
 
         # centring (scan3r.py:66-77): train draws which scan's centroid to use -- one np.random.rand(1) per item, after
         # BOTH point clouds were loaded (the RNG stream position is part of the contract)
-        src_pts = _load_points(osp.join(self.scans_scenes_dir, '{}/data.npy'.format(src_id)))
-        ref_pts = _load_points(osp.join(self.scans_scenes_dir, '{}/data.npy'.format(ref_id)))
+        src_c, ref_c = self._centroid(src_id), self._centroid(ref_id)
         if self.split == 'train':
-            center = np.mean(src_pts, axis=0) if np.random.rand(1)[0] > 0.5 else np.mean(ref_pts, axis=0)
+            center = src_c if np.random.rand(1)[0] > 0.5 else ref_c
         else:
-            center = np.mean(src_pts, axis=0)
+            center = src_c
 
-        src = _load_pkl(osp.join(self.scans_files_dir, '{}/data/{}.pkl'.format(self.mode, src_id)))
-        ref = _load_pkl(osp.join(self.scans_files_dir, '{}/data/{}.pkl'.format(self.mode, ref_id)))
+        src, ref = self._graph(src_id), self._graph(ref_id)
         src_ids, ref_ids = src['objects_id'], ref['objects_id']
 
         # anchors (scan3r.py:85-93): listed anchors that are non-zero and present on both sides, in list order;
@@ -122,6 +125,23 @@ class Scan3RDataset(data.Dataset):
             'overlap': overlap,
         }
 
+    def _centroid(self, scan_id):
+        """np.mean over all vertices of the scan (scan3r.py:66-77 uses nothing else of data.npy)."""
+        c = self._centroids.get(scan_id) if self.cache else None
+        if c is None:
+            c = np.mean(_load_points(osp.join(self.scans_scenes_dir, '{}/data.npy'.format(scan_id))), axis=0)
+            if self.cache:
+                self._centroids[scan_id] = c
+        return c
+
+    def _graph(self, scan_id):
+        d = self._pkls.get(scan_id) if self.cache else None
+        if d is None:
+            d = _load_pkl(osp.join(self.scans_files_dir, '{}/data/{}.pkl'.format(self.mode, scan_id)))
+            if self.cache:
+                self._pkls[scan_id] = d
+        return d
+
     @staticmethod
     def _collate_entity_idxs(batch):
         """Batch-global index sets (scan3r.py:142-173): every pair's four sets shifted by the objects before it."""
@@ -158,12 +178,24 @@ class DeviceBatch(dict):
     """A collated batch resident on one GPU: tensors moved once (non_blocking from pinned memory when available), numpy
     entries left on the host exactly as the reference's `to_cuda` leaves them (utils/torch_util.py:26-36)."""
 
-    def __init__(self, data_dict, device='cuda', pin=True):
+    def __init__(self, data_dict, device='cuda', pin=True, staging=None):
+        """staging: a dict of reusable pinned host buffers (DevicePrefetcher owns two such sets): `tensor.pin_memory()` registers
+        fresh memory for every tensor of every batch (1.1 ms each: 8 of the 43 ms per iteration of the end-to-end loop); copying into
+        a pinned buffer that already exists is a memcpy."""
         super().__init__()
         for k, v in data_dict.items():
             if isinstance(v, torch.Tensor):
                 if pin and v.device.type == 'cpu' and torch.cuda.is_available() and not v.is_pinned():
-                    v = v.pin_memory()
+                    if staging is not None:
+                        buf = staging.get(k)
+                        if buf is None or buf.dtype != v.dtype or buf.numel() < v.numel():
+                            buf = torch.empty((max(v.numel(), 1) * 5 // 4,), dtype=v.dtype).pin_memory()     # head-room: batches vary in size
+                            staging[k] = buf
+                        pv = buf[:v.numel()].view(v.shape)
+                        np.copyto(pv.numpy(), v.contiguous().numpy())        # plain memcpy (Tensor.copy_ into pinned memory goes through the runtime: ~2 ms)
+                        v = pv
+                    else:
+                        v = v.pin_memory()
                 self[k] = v.to(device, non_blocking=True)
             else:
                 self[k] = v
@@ -180,6 +212,9 @@ class DevicePrefetcher:
     def __init__(self, loader, device='cuda', prepare=None):
         self.loader, self.device, self.prepare = loader, torch.device(device), prepare
         self.stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+        self._staging = [{}, {}]                 # two sets of reusable pinned buffers, used alternately
+        self._staging_ev = [None, None]          # the upload event that last read each set
+        self._n = 0
 
     def __len__(self):
         return len(self.loader)
@@ -191,10 +226,15 @@ class DevicePrefetcher:
             data_dict = self.prepare(data_dict)
         if self.stream is None:
             return DeviceBatch(data_dict, self.device, pin=False), None
+        slot = self._n & 1
+        self._n += 1
+        if self._staging_ev[slot] is not None:
+            self._staging_ev[slot].synchronize()             # the copy that read this staging set two batches ago (long done)
         with torch.cuda.stream(self.stream):
-            batch = DeviceBatch(data_dict, self.device)
+            batch = DeviceBatch(data_dict, self.device, staging=self._staging[slot])
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._staging_ev[slot] = ev
         return batch, ev
 
     def __iter__(self):
