@@ -281,15 +281,35 @@ class _SmallCache:
         self.d.clear()
 
 
+_H2D_RING = {'n': 0, 'bufs': [None] * 8, 'evs': [None] * 8}
+
+
 def _h2d(host_array, device):
     """Small per-batch host array -> device without stalling the host: a pageable `tensor.to(device)` is a blocking copy that
     waits for everything queued on the stream (the previous step's backward); from a pinned staging tensor the copy is
     asynchronous and the host runs on.  CPU 'devices' (unit tests) take the plain path."""
-    t = torch.from_numpy(_np.ascontiguousarray(host_array))
+    arr = _np.ascontiguousarray(host_array)
+    t = torch.from_numpy(arr)
     device = torch.device(device)
     if device.type != 'cuda':
         return t.to(device)
-    return t.pin_memory().to(device, non_blocking=True)
+    # a ring of reusable pinned byte buffers (Tensor.pin_memory() registers fresh memory on every call: ~1 ms, twice per batch)
+    slot = _H2D_RING['n'] % len(_H2D_RING['bufs'])
+    _H2D_RING['n'] += 1
+    buf, ev = _H2D_RING['bufs'][slot], _H2D_RING['evs'][slot]
+    if ev is not None:
+        ev.synchronize()                                   # the copy that last read this buffer, several uploads ago
+    nbytes = arr.nbytes
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(nbytes * 2, 4096),), dtype=torch.uint8).pin_memory()
+        _H2D_RING['bufs'][slot] = buf
+    if nbytes:
+        _np.copyto(buf.numpy()[:nbytes], arr.reshape(-1).view(_np.uint8))
+    out = buf[:nbytes].view(t.dtype).view(t.shape).to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _H2D_RING['evs'][slot] = ev
+    return out
 
 
 VALIDATE = _os.environ.get('SGA_VALIDATE', '1') != '0'     # host-side range checks of index sets / edge lists, once per batch
