@@ -305,6 +305,7 @@ class Trainer(EpochBasedTrainer):
         self._shuffle_gen, self._shuffle_seed = g, getattr(cfg, 'seed', 42)
         self.register_loader(
             torch.utils.data.DataLoader(train_ds, batch_size=cfg.train.batch_size, shuffle=True, generator=g,
-                                        num_workers=nw, collate_fn=train_ds.collate_fn, drop_last=True),
+                                        num_workers=nw, collate_fn=train_ds.collate_fn, drop_last=True,
+                                        persistent_workers=nw > 0),        # workers (and their scan caches) live across epochs
             torch.utils.data.DataLoader(val_ds, batch_size=cfg.val.batch_size, shuffle=False, num_workers=nw,
-                                        collate_fn=val_ds.collate_fn, drop_last=False))
+                                        collate_fn=val_ds.collate_fn, drop_last=False, persistent_workers=nw > 0))
