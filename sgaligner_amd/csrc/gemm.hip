@@ -105,6 +105,61 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(const TA* __restrict__
     }
 }
 
+// Small outputs with layouts the fast kernels do not take (K = 3 / 41: not a multiple of 4, float64 bag-of-words inputs, transposed
+// operands at K = a few hundred objects): the generic kernel above gives such a problem to one or two workgroups that walk K in
+// barrier-separated chunks (30-45 us for a 320 x 100 x 164 product: 7 launches and 0.24 ms of a 1.6 ms step at the reference's batch
+// sizes).  Here a workgroup owns ONE 32 x 32 output tile and its 4 waves split K between them (wave w takes k = 8 i + 2 w, + 1);
+// operands come straight from global memory / L2 by element (any stride, any K, fp64 A converted on load), the four partial tiles
+// are added through LDS.  No K chunking, no staging barriers.
+template <typename TA>
+__global__ __launch_bounds__(GM_THREADS) void gemm_small_kernel(const TA* __restrict__ A, long lda, int transA, const float* __restrict__ B,
+                                                                long ldb, int transB, float* __restrict__ C, long ldc,
+                                                                const float* __restrict__ bias, int M, int N, int K, int accumulate,
+                                                                int act, const float* __restrict__ resid, long ldr) {
+    __shared__ float red[3][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int m = m0 + l31, n = n0 + l31;
+    const bool mv = m < M, nv = n < N;
+    const long am = transA ? (long)(mv ? m : 0) : (long)(mv ? m : 0) * lda;     // + k * (transA ? lda : 1)
+    const long ak = transA ? lda : 1;
+    const long bn = transB ? (long)(nv ? n : 0) * ldb : (long)(nv ? n : 0);     // + k * (transB ? 1 : ldb)
+    const long bk = transB ? 1 : ldb;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int k0 = 2 * wave; k0 < K; k0 += 8) {
+        const int k = k0 + h;
+        const bool kv = k < K;
+        const float av = (mv && kv) ? (float)A[am + (long)k * ak] : 0.f;
+        const float bv = (nv && kv) ? B[bn + (long)k * bk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    // acc[r] = partial C[m0 + row(r,h)][n0 + l31]
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][mfma32_row(r, h) * 33 + l31] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && nv) {
+        const float bvv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma32_row(r, h), mm = m0 + row;
+            if (mm < M) {
+                float v = acc[r] + red[0][row * 33 + l31] + red[1][row * 33 + l31] + red[2][row * 33 + l31] + bvv;
+                float* p = C + (size_t)mm * ldc + n;
+                if (accumulate) v += *p;
+                if (act == 1) v = fmaxf(v, 0.f);
+                else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+                if (resid) v += resid[(size_t)mm * ldr + n];
+                *p = v;
+            }
+        }
+    }
+}
+
 // C = act(A W^T + bias) (+ resid) for the common layout (A [M,K] and W [N,K] both k-contiguous, 16-byte aligned rows,
 // K % 4 == 0, no split-K): the next K chunk travels global -> registers while the MFMAs of the current one run, so a
 // workgroup does not alternate between "everybody loads" and "everybody multiplies" (the generic kernel above: 59
@@ -381,6 +436,19 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     if (!a_is_f64 && !transA && transB && splits == 1 && a_al && b_al && K % 4 == 0) {
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(gx, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
                            bias, M, N, K, accumulate, act, resid, ldr);
+        SGA_CHECK_LAUNCH("sga_gemm");
+        return SGA_OK;
+    }
+    // shapes none of the fast kernels take, narrow and short: one workgroup per 32 x 32 tile.  The choice depends on (N, K) only, never on
+    // M: a batch walked in chunks of rows (pct inference) must get the same bits as the unchunked call
+    if (!use_atomic && N <= 256 && K <= 512) {
+        dim3 g2((M + 31) / 32, (N + 31) / 32);
+        if (a_is_f64)
+            hipLaunchKernelGGL(gemm_small_kernel<double>, g2, dim3(GM_THREADS), 0, s, static_cast<const double*>(A), lda, transA, B, ldb,
+                               transB, C, ldc, bias, M, N, K, accumulate, act, resid, ldr);
+        else
+            hipLaunchKernelGGL(gemm_small_kernel<float>, g2, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, transA, B, ldb,
+                               transB, C, ldc, bias, M, N, K, accumulate, act, resid, ldr);
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;
     }
