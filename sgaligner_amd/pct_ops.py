@@ -101,6 +101,43 @@ class PCTAttentionFn(torch.autograd.Function):
         return dq, dv, None, None
 
 
+class PCTAttentionQVFn(torch.autograd.Function):
+    """PCTAttentionFn on ONE [T*N, 160] tensor holding q (columns 0..31) and v (32..159) side by side -- the output of a single
+    N = 160 GEMM over x (q_conv and v_conv read the same rows): x is read once instead of twice, the two dX GEMMs and the add of
+    their results become one, and the gradient leaves as one [T*N, 160] tensor (no concatenation)."""
+
+    @staticmethod
+    def forward(ctx, qv, n_obj, n_pts):
+        dev = qv.device
+        qv = qv if qv.is_contiguous() else qv.contiguous()
+        q, v = qv[:, :32], qv[:, 32:]
+        stats = torch.empty((2 * n_obj * n_pts,), device=dev, dtype=torch.float32)
+        xs = torch.empty((n_obj * n_pts, 128), device=dev, dtype=torch.float32)
+        _chk(_lib.lib().sga_pct_attention(_p(q), q.stride(0), _p(v), v.stride(0), n_obj, n_pts, _p(stats), _p(xs), xs.stride(0), _stream()),
+             'sga_pct_attention')
+        ctx.save_for_backward(qv, stats)
+        ctx.dims = (n_obj, n_pts)
+        return xs
+
+    @staticmethod
+    def backward(ctx, dxs):
+        qv, stats = ctx.saved_tensors
+        n_obj, n_pts = ctx.dims
+        q, v = qv[:, :32], qv[:, 32:]
+        dxs = dxs.contiguous()
+        dev = qv.device
+        work = torch.empty((n_obj * n_pts,), device=dev, dtype=torch.float32)
+        dqv = torch.empty_like(qv)
+        dq, dv = dqv[:, :32], dqv[:, 32:]
+        _chk(_lib.lib().sga_pct_attention_bwd(_p(q), q.stride(0), _p(v), v.stride(0), _p(dxs), dxs.stride(0), n_obj, n_pts, _p(stats),
+                                             _p(work), _p(dq), dq.stride(0), _p(dv), dv.stride(0), _stream()), 'sga_pct_attention_bwd')
+        return dqv, None, None
+
+
+def pct_attention_qv(qv, n_obj, n_pts):
+    return PCTAttentionQVFn.apply(qv, n_obj, n_pts)
+
+
 def pct_attention(q, v, n_obj, n_pts):
     return PCTAttentionFn.apply(q, v, n_obj, n_pts)
 
