@@ -7,11 +7,13 @@ val-style subsample.
   python bench.py [--gpus N --steps K --warmup W --config auto|c2|c3]      (N > 1: launched by torch.distributed.run)
 
 Workloads (config.workload):
+  c3 = BASELINE.json configs[2] = the configuration north_star quotes its target on ("4096-pair / 128-object / 512-pt synthetic
+       batches at 1 GPU" + the 1/2/4/8-GPU series): 4096 pairs x 128 objects x 512 points IN TOTAL, sharded 4096/N pairs per
+       GPU, batch-global loss via the table all-gather (strong scaling; N = 1 runs the whole batch on one GPU, 26 GiB).
+       DEFAULT at every N: `roofline` is the kernel that carries this step (the loss-gradient sweep), `cpu_baseline` is taken
+       at this shape (128 objects per scene, the reference's b = 2).
   c2 = BASELINE.json configs[1]: 512 synthetic subscan pairs PER GPU x 64 objects x 512 points, P+S+R, batch-global
-       loss over all 512*N pairs (weak scaling).  Default at N = 1.
-  c3 = BASELINE.json configs[2] / the north-star target: 4096 pairs x 128 objects x 512 points IN TOTAL, sharded
-       4096/N pairs per GPU, batch-global loss via the table all-gather (strong scaling; N = 1 runs the whole batch on
-       one GPU).  Default at N > 1.
+       loss over all 512*N pairs (weak scaling).  `--config c2`; at N = 1 the default line carries it as `extra_c2`.
 Prints ONE JSON line (rank 0)."""
 import argparse
 import hashlib
@@ -37,6 +39,7 @@ CONFIGS = {
 }
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) dense peak
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC_FILE = 'r03_pmc_traffic.csv'   # written by tools/pmc_traffic.sh on the GPU box, committed under profiles/
 HITS_PAIRS = 8                   # fixed val-style subsample for the Hits@K half of the metric
 
 
@@ -107,12 +110,12 @@ def _sha16(path):
 
 
 def pmc_traffic_bytes(kernel_tag, workload_key, source):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.csv, written
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.csv, written
     by tools/pmc_traffic.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of THIS script; KiB per dispatch; gfx950
     correction: FETCH_SIZE counts wide coalesced reads at half their size -> x2, MI355X_MICROARCH.md, HBM).
     A row is used only if it was taken on the same workload (`workload_key`) AND the kernel's source file is unchanged
     since (sha256 recorded by the tool): a stale measurement is reported as null, never as a number."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.csv')
+    path = os.path.join(ROOT, 'profiles', PMC_TRAFFIC_FILE)
     sha = _sha16(os.path.join(ROOT, 'sgaligner_amd', 'csrc', source))
     try:
         f = w = None
@@ -136,6 +139,52 @@ def pmc_traffic_bytes(kernel_tag, workload_key, source):
         return None
 
 
+def roofline_objects(events, world):
+    """The kernels that carry the step, each timed with HIP events on its launch stream (ops.KERNEL_EVENTS), sorted by their time per
+    step: [0] is the line's `roofline`, the rest `roofline_other`.  All are bound by the exact-fp32 MFMA rate (157.3 TFLOP/s dense;
+    on gfx950 fp32 MFMA and fp32 VALU share the SIMD's FMA datapath -- tools/micro/mfma_valu_overlap.hip -- so epilogue VALU work adds
+    to, rather than hides under, the MFMA time).  `achieved` = ALGORITHMIC FLOPs per launch / mean launch time."""
+    from sgaligner_amd import ops
+    roofs = []
+    evs = events.get('pointnet_fwd_kernel', [])
+    if evs:
+        durs = [a.elapsed_time(b) for a, b, _ in evs]
+        T, P, C1, C2, C3 = evs[0][2]
+        alg = 2.0 * T * P * (3 * C1 + C1 * C2 + C2 * C3)           # three per-point layers
+        avg_ms = float(np.mean(durs))
+        ach = alg / (avg_ms * 1e-3) / 1e12
+        roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                      'frac': round(ach / PEAK_F32_TFLOPS, 4),
+                      'traffic': pmc_traffic_bytes('pointnet_fwd_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
+                      'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object)',
+                      'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
+                      'algorithmic_flops_per_launch': alg})
+    for key, grad in (('loss_multi_grad', True), ('loss_multi_sums', False)):
+        evs = events.get(key, [])
+        if not evs:
+            continue
+        durs = [a.elapsed_time(b) for a, b, _ in evs]
+        ns, A, J1, J2, M = evs[0][2]          # ns = anchors in this rank's shard (== A on one GPU)
+        # Algorithmic FLOPs (SURVEY.md 8d) of the four anchors x negatives products of all M+1 tables, sum_tab D_tab = 100 M + 100 M:
+        # forward = sum_tab 2 D_tab * 2 ns (J1+J2); backward = 2 x that (one GEMM per side).
+        d_sum = 100 * M + 100 * M
+        alg = (2.0 if grad else 1.0) * (2.0 * d_sum * 2.0 * ns * (J1 + J2))
+        avg_ms = float(np.mean(durs))
+        ach = alg / (avg_ms * 1e-3) / 1e12
+        info = ops.SWEEP_GRAD_INFO if grad else ops.SWEEP_SUMS_INFO
+        executed = info['executed_flops'](ns, J1 + J2, M)
+        tag = info['tag'] % M if M != 4 else ('sweep16x2_kernel<true>' if grad else 'sweep16x2_kernel<false>')
+        roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                      'frac': round(ach / PEAK_F32_TFLOPS, 4),
+                      'traffic': pmc_traffic_bytes(info['tag'] % M, f'ns={ns},A={A},J={J1 + J2}', 'contrastive.hip') if world == 1 else None,
+                      'kernel': f'{tag} ({info["what"]}, all {M}+1 tables)',
+                      'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
+                      'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed,
+                      'executed_tflops': round(executed / (avg_ms * 1e-3) / 1e12, 2)})
+    roofs.sort(key=lambda r: -r['step_ms'])
+    return roofs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -145,7 +194,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hits', action='store_true')
     ap.add_argument('--no-attr', action='store_true', help='skip the extra point+gat+rel+attr (M = 4) measurement (N = 1)')
-    ap.add_argument('--no-scale-ref', action='store_true', help='skip the extra configs[2]-on-one-GPU measurement (N = 1, --config auto)')
+    ap.add_argument('--no-scale-ref', action='store_true', help='skip the extra weak-scaling point (N > 1, --config auto)')
+    ap.add_argument('--no-c2', action='store_true', help='skip the extra BASELINE configs[1] measurement (N = 1)')
     ap.add_argument('--no-bf16x3', action='store_true', help='skip the extra (opt-in split-bf16 x3 MFMA mode) measurement')
     args = ap.parse_args()
 
@@ -160,7 +210,7 @@ def main():
     dev = torch.device('cuda', local)
     if world != args.gpus and rank == 0:
         print(f'[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
-    cname = args.config if args.config != 'auto' else ('c2' if world == 1 else 'c3')
+    cname = args.config if args.config != 'auto' else 'c3'
     cfg = CONFIGS[cname]
     n_obj, n_pts = cfg['n_obj'], cfg['n_pts']
     if cfg['scaling'] == 'weak':
@@ -171,36 +221,49 @@ def main():
 
     steps = AlignerSteps(MODULES, device=dev, seed=42)
     dd = make_batch_fast(my_pairs, n_obj, n_pts, seed=43 + rank, device=dev)
+    if world > 1 and cfg['scaling'] == 'strong' and cfg['global_pairs'] % world == 0:
+        # every rank's shard has the same shape (uniform synthetic scenes): the step needs no layout all-gather / host read-back
+        dd['_sga_layout'] = sdist.known_layout(dd['tot_obj_pts'].shape[0], len(dd['e1i']), len(dd['e1j']), len(dd['e2j']), world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(st, batch, warm, n):
+        """`warm` untimed steps, then exactly `n` steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(warm):
+            st.forward_backward(batch)
+        barrier()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(n):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _, ld = st.forward_backward(batch)
+            e1.record()
+            evs.append((e0, e1))
+        barrier()
+        el = time.perf_counter() - t0
+        med = float(np.median([x.elapsed_time(y) for x, y in evs]))
+        if world > 1:
+            t = torch.tensor([el, med], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el, med = float(t[0].item()), float(t[1].item())
+        return el, med, ld
+
     for _ in range(args.warmup):
         steps.forward_backward(dd)
     barrier()
     ops.KERNEL_EVENTS = {}
-    step_ev = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _, loss_dict = steps.forward_backward(dd)
-        e1.record()
-        step_ev.append((e0, e1))
-    barrier()
-    elapsed = time.perf_counter() - t0
+    sdist.COLLECTIVE_EVENTS = [] if world > 1 else None
+    elapsed, med_ms, loss_dict = timed(steps, dd, 0, args.steps)
     events = ops.KERNEL_EVENTS
     ops.KERNEL_EVENTS = None
-    step_ms = [a.elapsed_time(b) for a, b in step_ev]
-    med_ms = float(np.median(step_ms))
-    if world > 1:
-        t = torch.tensor([elapsed, med_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, med_ms = float(t[0].item()), float(t[1].item())
+    coll_events, sdist.COLLECTIVE_EVENTS = sdist.COLLECTIVE_EVENTS, None
     loss_val = float(loss_dict['loss'].item())
     peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
+    roofs = roofline_objects(events, world)
 
     # ---- extra, NOT the headline: the same steps in the opt-in split-bf16 x3 MFMA mode (ops.set_mfma_mode), with its error against
     # the exact-fp32 step on the same batch and weights.  `value` above is always exact fp32.
@@ -209,19 +272,8 @@ def main():
         ref_grads = {n: p.grad.detach().clone() for n, p in steps.model.named_parameters() if p.grad is not None}
         ops.set_mfma_mode('bf16x3')
         try:
-            for _ in range(min(2, args.warmup)):
-                steps.forward_backward(dd)
-            barrier()
-            n_x = max(2, min(args.steps, 10))
-            t1 = time.perf_counter()
-            for _ in range(n_x):
-                _, ld_x = steps.forward_backward(dd)
-            barrier()
-            el_x = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([el_x], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el_x = float(t.item())
+            n_x = 2 if cname == 'c3' else max(2, min(args.steps, 10))
+            el_x, _, ld_x = timed(steps, dd, 1 if cname == 'c3' else min(2, args.warmup), n_x)
             gmax = max(float(g.abs().max()) for g in ref_grads.values())
             worst, worst_name, worst_glob = 0.0, None, 0.0
             for n, p in steps.model.named_parameters():
@@ -232,7 +284,7 @@ def main():
                 worst_glob = max(worst_glob, err / max(1e-30, gmax))
                 if own > worst:
                     worst, worst_name = own, n
-            extra = {'mode': 'bf16x3 (opt-in): PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate',
+            extra = {'mode': 'bf16x3 (opt-in): ' + ops.BF16X3_COVERAGE,
                      'value': round(total_pairs * n_x / el_x, 2), 'unit': 'pairs/s', 'ms_per_step': round(el_x / n_x * 1e3, 3), 'steps': n_x,
                      'loss_rel_err_vs_f32': abs(float(ld_x['loss'].item()) - loss_val) / max(1e-30, abs(loss_val)),
                      # gradient error against the exact-fp32 step on the same batch: relative to the largest gradient entry of the
@@ -243,54 +295,50 @@ def main():
             extra = {'mode': 'bf16x3 (opt-in)', 'error': f'{type(e).__name__}: {e}'}
         finally:
             ops.set_mfma_mode('f32')
+        del ref_grads
 
-    # ---- extra at N = 1: the same batch with the reference's full module list (point+gat+rel+attr, M = 4: what every yaml the
-    # reference ships trains; SURVEY.md 8(d) "also report +'attr'").  Exact fp32, same step definition; never the headline.
-    extra_attr = None
-    if world == 1 and not args.no_attr and 'attr' not in MODULES:
+    # ---- extras at N = 1 under --config auto (the headline is configs[2]): BASELINE configs[1] (512 pairs x 64 objects x 512 pts) as
+    # its own full measurement with its own roofline object, and the same batch with the reference's full module list
+    # (point+gat+rel+attr, M = 4: what every yaml the reference ships trains; SURVEY.md 8(d) "also report +'attr'").  Exact fp32.
+    extra_c2 = extra_attr = None
+    if world == 1 and not args.no_c2 and (cname != 'c2'):
+        try:
+            del dd
+            torch.cuda.empty_cache()
+            c2 = CONFIGS['c2']
+            dd2 = make_batch_fast(c2['pairs_per_gpu'], c2['n_obj'], c2['n_pts'], seed=43, device=dev)
+            for _ in range(3):
+                steps.forward_backward(dd2)
+            torch.cuda.synchronize()
+            ops.KERNEL_EVENTS = {}
+            n2 = max(5, min(args.steps, 20))
+            el2, med2, _ = timed(steps, dd2, 0, n2)
+            ev2, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+            extra_c2 = {'workload': f'{c2["ref"]}: {c2["pairs_per_gpu"]} pairs x {c2["n_obj"]} objects x {c2["n_pts"]} pts, modules '
+                                    f'{"+".join(MODULES)}, batch-global loss', 'value': round(c2['pairs_per_gpu'] * n2 / el2, 2), 'unit': 'pairs/s',
+                        'ms_per_step': round(el2 / n2 * 1e3, 3), 'median_ms_per_step': round(med2, 3), 'steps': n2, 'warmup': 3,
+                        'dtype': 'f32', 'roofline': roofline_objects(ev2, world)}
+        except Exception as e:
+            extra_c2 = {'error': f'{type(e).__name__}: {e}'}
+            dd2 = None
+    elif world == 1 and cname == 'c2':
+        dd2 = dd
+    else:
+        dd2 = None
+    if world == 1 and not args.no_attr and 'attr' not in MODULES and dd2 is not None:
         try:
             mods4 = MODULES + ['attr']
             steps4 = AlignerSteps(mods4, device=dev, seed=42)
-            for _ in range(2):
-                steps4.forward_backward(dd)
-            torch.cuda.synchronize()
             n4 = max(3, min(args.steps, 10))
-            t4 = time.perf_counter()
-            for _ in range(n4):
-                steps4.forward_backward(dd)
-            torch.cuda.synchronize()
-            el4 = time.perf_counter() - t4
-            extra_attr = {'modules': mods4, 'value': round(total_pairs * n4 / el4, 2), 'unit': 'pairs/s',
+            el4, _, _ = timed(steps4, dd2, 2, n4)
+            extra_attr = {'modules': mods4, 'workload': 'BASELINE.json configs[1] shape (512 pairs x 64 objects x 512 pts)',
+                          'value': round(CONFIGS['c2']['pairs_per_gpu'] * n4 / el4, 2), 'unit': 'pairs/s',
                           'ms_per_step': round(el4 / n4 * 1e3, 3), 'steps': n4, 'warmup': 2, 'dtype': 'f32'}
             del steps4
         except Exception as e:
             extra_attr = {'error': f'{type(e).__name__}: {e}'}
-
-    # ---- extra at N = 1 under --config auto: configs[2] (the workload the N > 1 lines run, strong scaling at a fixed 4096-pair
-    # global batch) on THIS one GPU, so that a 1/2/4/8 series of lines carries its own same-workload single-GPU point.
-    scale_ref = None
-    if world == 1 and args.config == 'auto' and not args.no_scale_ref:
-        try:
-            c3 = CONFIGS['c3']
-            del dd
-            torch.cuda.empty_cache()
-            dd3 = make_batch_fast(c3['global_pairs'], c3['n_obj'], c3['n_pts'], seed=43, device=dev)
-            steps.forward_backward(dd3)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            n3 = 2
-            for _ in range(n3):
-                steps.forward_backward(dd3)
-            torch.cuda.synchronize()
-            el3 = time.perf_counter() - t2
-            scale_ref = {'workload': f'{c3["ref"]}: {c3["global_pairs"]} pairs x {c3["n_obj"]} objects x {c3["n_pts"]} pts on one GPU (what the '
-                                     f'n_gpus > 1 lines run, sharded)', 'value': round(c3['global_pairs'] * n3 / el3, 2), 'unit': 'pairs/s',
-                         'ms_per_step': round(el3 / n3 * 1e3, 1), 'steps': n3, 'warmup': 1, 'dtype': 'f32',
-                         'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
-            del dd3
-            torch.cuda.empty_cache()
-        except Exception as e:
-            scale_ref = {'error': f'{type(e).__name__}: {e}'}
+    dd2 = None
+    torch.cuda.empty_cache()
 
     # ---- extra at N > 1 under --config auto: the weak-scaling point (BASELINE configs[1] per GPU: 512 pairs x 64 objects on every
     # rank, batch-global loss over 512 N pairs) next to the strong-scaling headline of the same line.
@@ -299,17 +347,8 @@ def main():
         try:
             c2 = CONFIGS['c2']
             ddw = make_batch_fast(c2['pairs_per_gpu'], c2['n_obj'], c2['n_pts'], seed=143 + rank, device=dev)
-            steps.forward_backward(ddw)
-            barrier()
-            tw = time.perf_counter()
             nw = 3
-            for _ in range(nw):
-                steps.forward_backward(ddw)
-            barrier()
-            elw = time.perf_counter() - tw
-            t = torch.tensor([elw], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elw = float(t.item())
+            elw, _, _ = timed(steps, ddw, 1, nw)
             weak_ref = {'workload': f'{c2["ref"]} per GPU: {c2["pairs_per_gpu"]} pairs x {c2["n_obj"]} objects x {c2["n_pts"]} pts on each of {world} '
                                     f'GPUs, batch-global loss over {c2["pairs_per_gpu"] * world} pairs', 'scaling': 'weak',
                         'value': round(c2['pairs_per_gpu'] * world * nw / elw, 2), 'unit': 'pairs/s', 'ms_per_step': round(elw / nw * 1e3, 2),
@@ -318,47 +357,10 @@ def main():
         except Exception as e:
             weak_ref = {'error': f'{type(e).__name__}: {e}'}
 
+    collectives = sdist.collective_summary(coll_events, args.steps, dev) if world > 1 else None
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        # The two kernels that carry the step, each timed with HIP events on its launch stream; `roofline` is the
-        # one with the larger per-step time, the other is reported under `roofline_other`.  Both are bound by the
-        # exact-fp32 MFMA rate (157.3 TFLOP/s dense; on gfx950 fp32 MFMA and fp32 VALU share the SIMD's FMA datapath --
-        # tools/micro/mfma_valu_overlap.hip -- so epilogue VALU work adds to, rather than hides under, the MFMA time).
-        roofs = []
-        evs = events.get('pointnet_fwd_kernel', [])
-        if evs:
-            durs = [a.elapsed_time(b) for a, b, _ in evs]
-            T, P, C1, C2, C3 = evs[0][2]
-            # algorithmic FLOPs: 2 * T * P * (3*C1 + C1*C2 + C2*C3) for the three per-point layers
-            alg = 2.0 * T * P * (3 * C1 + C1 * C2 + C2 * C3)
-            avg_ms = float(np.mean(durs))
-            ach = alg / (avg_ms * 1e-3) / 1e12
-            roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                          'frac': round(ach / PEAK_F32_TFLOPS, 4),
-                          'traffic': pmc_traffic_bytes('pointnet_fwd_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
-                          'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object)',
-                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
-                          'algorithmic_flops_per_launch': alg})
-        evs = events.get('loss_multi_grad', [])
-        if evs:
-            durs = [a.elapsed_time(b) for a, b, _ in evs]
-            ns, A, J1, J2, M = evs[0][2]          # ns = anchors in this rank's shard (== A on one GPU)
-            # Algorithmic FLOPs: backward of the four anchors x negatives products of all M+1 tables
-            # = 2 x [ sum_tab 2*D_tab * 2A(J1+J2) ]  with sum_tab D_tab = 100*M + 100*M.
-            d_sum = 100 * M + 100 * M
-            alg = 2.0 * (2.0 * d_sum * 2.0 * ns * (J1 + J2))
-            avg_ms = float(np.mean(durs))
-            ach = alg / (avg_ms * 1e-3) / 1e12
-            info = ops.SWEEP_GRAD_INFO
-            executed = info['executed_flops'](ns, J1 + J2, M)
-            roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                          'frac': round(ach / PEAK_F32_TFLOPS, 4),
-                          'traffic': pmc_traffic_bytes(info['tag'] % M, f'ns={ns},A={A},J={J1 + J2}', 'contrastive.hip') if world == 1 else None,
-                          'kernel': f'{info["tag"] % M if M != 4 else "sweep16x2_kernel<true>"} ({info["what"]}, all {M}+1 tables)',
-                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
-                          'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed,
-                          'executed_tflops': round(executed / (avg_ms * 1e-3) / 1e12, 2)})
-        roofs.sort(key=lambda r: -r['step_ms'])
         roof = roofs[0] if roofs else None
         per = f'{my_pairs} pairs/GPU' if world > 1 else f'{my_pairs} pairs'
         line = {
@@ -375,12 +377,14 @@ def main():
             'roofline': roof,
             'roofline_other': roofs[1:],
         }
+        if collectives is not None:
+            line['collectives'] = collectives
         if extra is not None:
             line['extra_bf16x3'] = extra
+        if extra_c2 is not None:
+            line['extra_c2'] = extra_c2
         if extra_attr is not None:
             line['extra_full_module_list'] = extra_attr
-        if scale_ref is not None:
-            line['strong_scaling_one_gpu'] = scale_ref
         if weak_ref is not None:
             line['weak_scaling_point'] = weak_ref
         if not args.no_hits:

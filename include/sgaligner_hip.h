@@ -79,10 +79,12 @@ int sga_fusion_bwd(const float* const* embs, int M, const float* weight, const f
  * Limits the CALLER must respect (the Python wrapper checks the first two on the host once per batch): node ids are
  * graph-local in [0, nodes of that graph) -- an endpoint outside that range is DROPPED by the kernels, where PyG would raise;
  * duplicate edges count with their multiplicity (as PyG's scatter does) up to 255 copies of one (source, target) pair -- the
- * multiplicity matrix is 8-bit and saturates there. */
+ * multiplicity matrix is 8-bit and saturates there; when that happens bit 0 of *status (device int32, caller-zeroed, may be NULL)
+ * is set, and the Python wrapper turns it into an exception (deferred by at most one step, like the edge range check).
+ * A graph with more than 256 nodes is rejected with SGA_ERR_ARG. */
 int sga_gat_attn_fwd(const float* H, const float* att_src, const float* att_dst, const float* bias,
                      const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G, int nmax,
-                     float* out, void* stream);
+                     float* out, int32_t* status, void* stream);
 int sga_gat_attn_bwd(const float* H, const float* dO, const float* att_src, const float* att_dst, const int64_t* edges,
                      const int32_t* node_off, const int32_t* edge_off, int G, int nmax, float* dH, float* d_att_src,
                      float* d_att_dst, void* stream);

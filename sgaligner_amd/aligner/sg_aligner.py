@@ -78,21 +78,27 @@ class MultiModalEncoder(nn.Module):
             self.object_encoder = PointNetfeat(global_feat=True, batch_norm=True, point_size=3, input_transform=False,
                                                feature_transform=False, out_size=self.pt_out_dim)
         elif 'pct' in self.modules:
-            self.object_encoder = NaivePCT()                             # sg_aligner.py:59-60; inference path only
+            self.object_encoder = NaivePCT()                             # sg_aligner.py:59-60 (eval and training: pct_ops.py)
         else:
             raise NotImplementedError                                   # sg_aligner.py:61-62
         self.object_embedding = _Linear(self.pt_out_dim, self.emb_dim)
         self.structure_encoder = MultiGAT(n_units=self.hidden_units, n_heads=self.heads, dropout=self.dropout)
         self.structure_embedding = _Linear(256, self.emb_dim)
         self.fusion = MultiModalFusion(modal_num=self.inner_view_num, with_weight=1)
+        self._on_table = None          # optional callable(module, table), see forward
 
     def forward(self, data_dict):
         pts = data_dict['tot_obj_pts']
         if not pts.is_cuda:
             raise RuntimeError('sgaligner_amd.MultiModalEncoder: data_dict tensors must be on the HIP device '
                                '(utils/torch_util.to_cuda in the reference); there is no CPU path')
-        embs = {}
-        for module in self.modules:
+        # Order of evaluation: the reference's module order -- unless a table hook is installed (multi-GPU, dist.EarlyGather: every
+        # finished table starts its all-gather at once), then the cheap modalities go first so that their tables travel while the
+        # object encoder runs.  The tables do not depend on each other, so the values are the same either way.
+        hook = self._on_table
+        order = self.modules if hook is None else sorted(self.modules, key=lambda m: m in ('point', 'pct'))
+        done = {}
+        for module in order:
             if module == 'gat':
                 # all 2B graphs in one launch per layer (reference: 2B sequential GATConv calls, :86-110)
                 gb = ops.GraphBatch.of(data_dict)
@@ -107,7 +113,10 @@ class MultiModalEncoder(nn.Module):
                 emb = self.meta_embedding_attr(data_dict['tot_bow_vec_object_attr_feats'])
             else:
                 raise NotImplementedError                               # :124-125
-            embs[module] = emb
+            done[module] = emb
+            if hook is not None:
+                hook(module, emb)
+        embs = {m: done[m] for m in self.modules}
         if len(self.modules) > 1:
             embs['joint'] = self.fusion([embs[m] for m in self.modules])
         return embs

@@ -75,7 +75,7 @@ struct Rows { const float* p; int stride; };
 template <int NJ, bool LDSF>
 __device__ __forceinline__ Rows gat_prologue(const GatLds& l, const float* __restrict__ H, const float* __restrict__ att_s,
                                              const float* __restrict__ att_d, const long long* __restrict__ edges,
-                                             int n0, int N, int e0, int E, int hd, int npad) {
+                                             int n0, int N, int e0, int E, int hd, int npad, int* status = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Hg = H + (size_t)n0 * (GAT_H * GAT_C) + hd * GAT_C;
     if (LDSF)
@@ -93,14 +93,17 @@ __device__ __forceinline__ Rows gat_prologue(const GatLds& l, const float* __res
         const float vs = wave_sum(h0 * s0 + h1 * s1), vd = wave_sum(h0 * d0 + h1 * d1);
         if (lane == 0) { l.as[j] = vs; l.ad[j] = vd; }
     }
-    // edge list -> multiplicities (self loops dropped, out-of-range ids ignored, counts saturate at 255)
+    // edge list -> multiplicities (self loops dropped, out-of-range ids ignored, counts saturate at 255: reported through `status`)
     for (int e = tid; e < E; e += GAT_THREADS) {
         const long long sj = edges[(size_t)(e0 + e) * 2 + 0], di = edges[(size_t)(e0 + e) * 2 + 1];
         if (sj != di && sj >= 0 && sj < N && di >= 0 && di < N) {
             const int idx = (int)di * npad + (int)sj;
             const unsigned sh = 8u * (idx & 3);
             const unsigned old = atomicAdd(&l.cnt[idx >> 2], 1u << sh);
-            if (((old >> sh) & 255u) == 255u) atomicSub(&l.cnt[idx >> 2], 1u << sh);
+            if (((old >> sh) & 255u) == 255u) {
+                atomicSub(&l.cnt[idx >> 2], 1u << sh);
+                if (status) atomicOr(status, 1);           // a (source, target) pair listed > 255 times: PyG would count them all
+            }
         }
     }
     __syncthreads();
@@ -142,7 +145,7 @@ template <int NJ, bool LDSF>
 __global__ __launch_bounds__(GAT_THREADS) void gat_attn_fwd_kernel(
     const float* __restrict__ H, const float* __restrict__ att_s, const float* __restrict__ att_d,
     const float* __restrict__ bias, const long long* __restrict__ edges, const int* __restrict__ node_off,
-    const int* __restrict__ edge_off, float* __restrict__ out, int nmax) {
+    const int* __restrict__ edge_off, float* __restrict__ out, int nmax, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const GatLds l = carve<NJ, LDSF>(lds_raw, nmax, false);
     const int g = blockIdx.x, hd = blockIdx.y;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_fwd_kernel(
     const int npad = (nmax + 3) & ~3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (N <= 0) return;
-    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad);
+    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad, status);
     const float b0 = bias[hd * GAT_C + lane], b1 = bias[hd * GAT_C + 64 + lane];
     // GAT_TB targets per wave at a time: every h[j] row read feeds GAT_TB aggregates (the loop is LDS / L2 bound)
     for (int ib = wave * GAT_TB; ib < N; ib += (GAT_THREADS / 64) * GAT_TB) {
@@ -339,7 +342,7 @@ int check_common(int G, int nmax, const char* who) {
 
 extern "C" int sga_gat_attn_fwd(const float* H, const float* att_src, const float* att_dst, const float* bias,
                                 const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G,
-                                int nmax, float* out, void* stream) {
+                                int nmax, float* out, int32_t* status, void* stream) {
     int rc = check_common(G, nmax, "sga_gat_attn_fwd");
     if (rc) return rc;
     if (G == 0 || nmax == 0) return SGA_OK;
@@ -349,13 +352,13 @@ extern "C" int sga_gat_attn_fwd(const float* H, const float* att_src, const floa
         auto k = gat_attn_fwd_kernel<2, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, static_cast<hipStream_t>(stream), H, att_src,
-                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax);
+                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax, status);
     } else {                                              // 129..256 nodes: features from global memory
         const size_t lds = gat_lds_bytes(nmax, false, 4, false);
         auto k = gat_attn_fwd_kernel<4, false>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, static_cast<hipStream_t>(stream), H, att_src,
-                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax);
+                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax, status);
     }
     SGA_CHECK_LAUNCH("sga_gat_attn_fwd");
     return SGA_OK;

@@ -8,11 +8,16 @@
 // and gets the same vertex set.  Per object (one workgroup):
 //   1. support points of 26 directions (the +-axes, the 12 edge and the 8 corner diagonals of the cube);
 //   2. the facets of THEIR convex hull P (<= 26 vertices, P is inside the object's hull): every triple of support points whose
-//      plane has all 26 on one side is a supporting plane of P; duplicates (coplanar triples) are dropped;
+//      plane has all 26 on one side is a supporting plane of P;
 //   3. a point strictly inside every facet half-space, by a margin of 1e-5 of the object's extent, is interior to P, hence to the
 //      hull: discarded.  Everything else is kept.
-// Degenerate objects (flat, collinear, < 4 distinct support points, too many distinct planes) keep all their points.
-// fp32 throughout; the margin is three orders of magnitude above the rounding of the plane evaluations.
+// Soundness (a hull vertex is never discarded) needs EVERY facet of P in the list -- a missing facet enlarges the tested region
+// beyond P -- so nothing is ever dropped from it: coplanar triples all stay (no de-duplication), and an object with a triple of
+// three DISTINCT but nearly collinear support points (a facet whose plane fp32 cannot determine) keeps all its points, as do
+// flat / collinear objects, objects with < 4 planes and objects whose list overflows.
+// fp32 throughout, on coordinates translated to the object's first support point (the rounding of a plane evaluation then scales
+// with the object's extent, not with its distance from the origin); the margin adds 16 ulp of the largest raw coordinate for
+// the rounding of that translation itself.
 #include "sga_common.h"
 
 namespace {
@@ -20,7 +25,7 @@ namespace {
 constexpr int HU_THREADS = 256;
 constexpr int HU_NDIR = 13;                  // direction pairs: +d gives the max, -d the min support
 constexpr int HU_NSUP = 26;
-constexpr int HU_MAXPLANES = 192;
+constexpr int HU_MAXPLANES = 512;
 
 __constant__ float hu_dirs[HU_NDIR][3] = {
     {1, 0, 0}, {0, 1, 0}, {0, 0, 1},
@@ -34,6 +39,7 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
     __shared__ float s_sup[HU_NSUP][3];
     __shared__ float s_plane[HU_MAXPLANES][4];
     __shared__ int s_np, s_overflow;
+    __shared__ float s_cmax[HU_THREADS / 64];
     const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p0 = offsets[obj], n = offsets[obj + 1] - p0;
     const float* __restrict__ P = pts + (size_t)p0 * 3;
@@ -45,8 +51,10 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
     int bi[HU_NSUP];
 #pragma unroll
     for (int k = 0; k < HU_NSUP; ++k) { bv[k] = -INFINITY; bi[k] = 0; }
+    float cmax = 0.f;
     for (int i = tid; i < n; i += HU_THREADS) {
         const float x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
+        cmax = fmaxf(cmax, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
 #pragma unroll
         for (int d = 0; d < HU_NDIR; ++d) {
             const float v = hu_dirs[d][0] * x + hu_dirs[d][1] * y + hu_dirs[d][2] * z;
@@ -64,6 +72,8 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
         }
         if (lane == 0) { s_val[k][wave] = v; s_idx[k][wave] = ix; }
     }
+    cmax = wave_max(cmax);
+    if (lane == 0) s_cmax[wave] = cmax;
     if (tid == 0) { s_np = 0; s_overflow = 0; }
     __syncthreads();
     if (tid < HU_NSUP) {
@@ -75,7 +85,11 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
     __syncthreads();
     // object extent (from the axis supports) sets the tolerances
     const float ext = fmaxf(fmaxf(s_sup[0][0] - s_sup[1][0], s_sup[2][1] - s_sup[3][1]), s_sup[4][2] - s_sup[5][2]);
-    const float tol = 1e-6f * ext, margin = 1e-5f * ext;
+    float cm = s_cmax[0];
+#pragma unroll
+    for (int w = 1; w < HU_THREADS / 64; ++w) cm = fmaxf(cm, s_cmax[w]);
+    const float tol = 1e-6f * ext, margin = 1e-5f * ext + 16.f * 1.1920929e-7f * cm;
+    const float ox = s_sup[0][0], oy = s_sup[0][1], oz = s_sup[0][2];          // local origin: the +x support point
 
     // ---- 2. supporting planes of the 26-point polytope: triples (i < j < k) with every support point on one side
     for (int t = tid; t < HU_NSUP * HU_NSUP * HU_NSUP; t += HU_THREADS) {
@@ -86,7 +100,14 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
         const float vx = s_sup[k][0] - ax, vy = s_sup[k][1] - ay, vz = s_sup[k][2] - az;
         float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
         const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
-        if (!(nn > 1e-4f * ext * ext)) continue;                       // (nearly) collinear triple: no plane
+        if (!(nn > 1e-4f * ext * ext)) {                               // (nearly) collinear triple: no plane fp32 can determine
+            const float uu = ux * ux + uy * uy + uz * uz, vv = vx * vx + vy * vy + vz * vz;
+            const float wx = vx - ux, wy = vy - uy, wz = vz - uz, ww = wx * wx + wy * wy + wz * wz;
+            // three DISTINCT points: it may be a sliver facet of P that the list would miss -> keep every point of the object.
+            // (Triples with a repeated support point -- one point is the support of several directions -- are no facets at all.)
+            if (uu > tol * tol && vv > tol * tol && ww > tol * tol) s_overflow = 1;
+            continue;
+        }
         nx /= nn; ny /= nn; nz /= nn;
         float lo = 0.f, hi = 0.f;
         for (int q = 0; q < HU_NSUP; ++q) {
@@ -95,7 +116,7 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
         }
         if (hi > tol && lo < -tol) continue;                           // points on both sides: not a supporting plane
         if (hi > tol) { nx = -nx; ny = -ny; nz = -nz; }                // orient the normal outwards (all points at n.x <= d)
-        const float d = nx * ax + ny * ay + nz * az;
+        const float d = nx * (ax - ox) + ny * (ay - oy) + nz * (az - oz);     // plane offset in translated coordinates
         const int slot = atomicAdd(&s_np, 1);
         if (slot < HU_MAXPLANES) { s_plane[slot][0] = nx; s_plane[slot][1] = ny; s_plane[slot][2] = nz; s_plane[slot][3] = d; }
         else s_overflow = 1;
@@ -103,27 +124,6 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
     __syncthreads();
     int np = min(s_np, HU_MAXPLANES);
     __syncthreads();
-    // drop duplicate planes (coplanar triples): plane q survives unless an earlier plane is the same within tolerance
-    if (!s_overflow && np > 0) {
-        __shared__ unsigned char s_dup[HU_MAXPLANES];
-        for (int q = tid; q < np; q += HU_THREADS) {
-            bool dup = false;
-            for (int r = 0; r < q && !dup; ++r) {
-                const float c = s_plane[q][0] * s_plane[r][0] + s_plane[q][1] * s_plane[r][1] + s_plane[q][2] * s_plane[r][2];
-                dup = c > 1.f - 1e-6f && fabsf(s_plane[q][3] - s_plane[r][3]) < 4.f * tol;
-            }
-            s_dup[q] = dup ? 1 : 0;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int m = 0;
-            for (int q = 0; q < np; ++q)
-                if (!s_dup[q]) { if (m != q) { s_plane[m][0] = s_plane[q][0]; s_plane[m][1] = s_plane[q][1]; s_plane[m][2] = s_plane[q][2]; s_plane[m][3] = s_plane[q][3]; } ++m; }
-            s_np = m;
-        }
-        __syncthreads();
-        np = s_np;
-    }
     // a proper polytope has >= 4 facets; anything else (flat / degenerate object, plane list overflow) keeps every point
     const bool cull = !s_overflow && np >= 4;
     if (tid == 0 && n_planes_out) n_planes_out[obj] = cull ? np : 0;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(HU_THREADS) void hull_candidates_kernel(const float
     for (int i = tid; i < n; i += HU_THREADS) {
         bool inside = cull;
         if (cull) {
-            const float x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
+            const float x = P[3 * i] - ox, y = P[3 * i + 1] - oy, z = P[3 * i + 2] - oz;
             for (int q = 0; q < np && inside; ++q)
                 inside = s_plane[q][0] * x + s_plane[q][1] * y + s_plane[q][2] * z - s_plane[q][3] < -margin;
         }

@@ -19,8 +19,10 @@ training step does no per-iteration host->device index traffic.
 from __future__ import annotations
 
 import json
+import os
 import os.path as osp
 import pickle
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -39,13 +41,20 @@ def _load_pkl(path):
 
 
 class Scan3RDataset(data.Dataset):
-    def __init__(self, cfg, split, cache=True):
+    def __init__(self, cfg, split, cache=True, cache_bytes=None):
         """cache (beyond the reference, which re-reads both files of both scans for every item): keep each scan's centroid (all that
-        is used of data.npy) and its unpickled graph dict in memory after the first read -- same values, same np.random draws;
-        17 of the 43 ms per iteration of the end-to-end loop at 16 pairs were these reads.  Per DataLoader worker when workers are used."""
+        is used of data.npy, 24 bytes) and the fields of its graph dict that `__getitem__` reads -- the obj_points array of THIS
+        dataset's resolution only, not every preprocessed resolution -- after the first read: same values, same np.random draws;
+        17 of the 43 ms per iteration of the end-to-end loop at 16 pairs were these reads.
+        The graph cache is an LRU bounded by `cache_bytes` (default 1 GiB, env SGA_DATASET_CACHE_MB; 0 disables it): every
+        DataLoader worker process holds its own copy (and `persistent_workers` keeps it for the whole run), so the bound is per
+        worker -- budget num_workers x cache_bytes of host memory per loader."""
         self.split = split
         self.cache = bool(cache)
-        self._centroids, self._pkls = {}, {}
+        if cache_bytes is None:
+            cache_bytes = int(float(os.environ.get('SGA_DATASET_CACHE_MB', '1024')) * (1 << 20))
+        self.cache_bytes = int(cache_bytes) if self.cache else 0
+        self._centroids, self._pkls, self._pkl_bytes = {}, OrderedDict(), 0
         self.pc_resolution = cfg.val.pc_res if split == 'val' else cfg.train.pc_res
         self.anchor_type_name = cfg.preprocess.anchor_type_name
         self.model_name = cfg.model_name
@@ -134,12 +143,27 @@ class Scan3RDataset(data.Dataset):
                 self._centroids[scan_id] = c
         return c
 
+    _GRAPH_KEYS = ('objects_id', 'objects_cat', 'edges', 'object_id2idx', 'rel_trans', 'bow_vec_object_edge_feats',
+                   'bow_vec_object_attr_feats')
+
     def _graph(self, scan_id):
-        d = self._pkls.get(scan_id) if self.cache else None
-        if d is None:
-            d = _load_pkl(osp.join(self.scans_files_dir, '{}/data/{}.pkl'.format(self.mode, scan_id)))
-            if self.cache:
-                self._pkls[scan_id] = d
+        if self.cache_bytes <= 0:
+            return _load_pkl(osp.join(self.scans_files_dir, '{}/data/{}.pkl'.format(self.mode, scan_id)))
+        d = self._pkls.get(scan_id)
+        if d is not None:
+            self._pkls.move_to_end(scan_id)
+            return d[0]                                               # (fields, bytes)
+        full = _load_pkl(osp.join(self.scans_files_dir, '{}/data/{}.pkl'.format(self.mode, scan_id)))
+        d = {k: full[k] for k in self._GRAPH_KEYS if k in full}
+        d['obj_points'] = {self.pc_resolution: full['obj_points'][self.pc_resolution]}
+        nbytes = sum(v.nbytes for v in d.values() if isinstance(v, np.ndarray)) + d['obj_points'][self.pc_resolution].nbytes \
+            + 64 * len(d.get('object_id2idx', ()))
+        if nbytes <= self.cache_bytes:
+            self._pkls[scan_id] = (d, nbytes)
+            self._pkl_bytes += nbytes
+            while self._pkl_bytes > self.cache_bytes:                 # least recently used scans leave first
+                _, (_, nb) = self._pkls.popitem(last=False)
+                self._pkl_bytes -= nb
         return d
 
     @staticmethod

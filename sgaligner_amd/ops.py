@@ -240,8 +240,8 @@ def fusion(weight, embs):
 
 
 # ------------------------------------------------------------------------------------------ contrastive loss
+import hashlib as _hashlib
 import os as _os
-import zlib as _zlib
 from collections import OrderedDict as _OrderedDict
 
 import numpy as _np
@@ -250,13 +250,13 @@ import numpy as _np
 def _fingerprint(arrays, extra=()):
     """Content fingerprint of small host arrays: a cached device copy is reused only while the arrays a caller hands in
     still hold the same values (the reference's tester shifts e1i/e2i IN PLACE between uses, inference_align_reg.py:119-120)."""
-    h = 1
+    h = _hashlib.blake2b(digest_size=16)        # a cryptographic digest: a collision between two batches is not a practical event
     shapes = []
     for a in arrays:
         a = _np.ascontiguousarray(a)
         shapes.append((a.shape, a.dtype.str))
-        h = _zlib.adler32(a.reshape(-1).view(_np.uint8), h)
-    return (h, tuple(shapes), tuple(extra))
+        h.update(a.reshape(-1).view(_np.uint8))
+    return (h.digest(), tuple(shapes), tuple(extra))
 
 
 class _SmallCache:
@@ -323,29 +323,36 @@ class _DeferredChecks:
     latest one step after it was used; the kernels themselves never read out of bounds (they drop such endpoints)."""
 
     def __init__(self):
-        self.pending = []          # (event, pinned host tensor, upper bound, message)
+        self.pending = []          # (event, pinned host tensor, n values, verdict(values) -> error text or None)
         self.free = []
 
-    def submit(self, minmax_dev, upper, what):
+    def submit_fn(self, dev_tensor, verdict):
+        """Queue `verdict(list of ints)` on the (<= 2 element, int32/int64) device tensor's values, read back without blocking."""
+        n = int(dev_tensor.numel())
         host = self.free.pop() if self.free else torch.empty((2,), dtype=torch.int64).pin_memory()
-        host.copy_(minmax_dev, non_blocking=True)
+        view = host[:n] if dev_tensor.dtype == torch.int64 else host.view(torch.int32)[:n]
+        view.copy_(dev_tensor.reshape(-1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((ev, host, int(upper), what))
+        self.pending.append((ev, host, view, verdict))
+
+    def submit(self, minmax_dev, upper, what):
+        upper = int(upper)
+        self.submit_fn(minmax_dev, lambda v: (what % (v[0], v[1], upper)) if (v[0] < 0 or v[1] >= upper) else None)
 
     def poll(self, wait=False):
         keep = []
         err = None
-        for ev, host, upper, what in self.pending:
+        for ev, host, view, verdict in self.pending:
             if wait:
                 ev.synchronize()
             if wait or ev.query():
-                mn, mx = int(host[0]), int(host[1])
+                msg = verdict([int(x) for x in view])
                 self.free.append(host)
-                if (mn < 0 or mx >= upper) and err is None:
-                    err = what % (mn, mx, upper)
+                if msg is not None and err is None:
+                    err = msg
             else:
-                keep.append((ev, host, upper, what))
+                keep.append((ev, host, view, verdict))
         self.pending = keep
         if err is not None:
             raise RuntimeError(err)
@@ -426,6 +433,13 @@ SWEEP_GRAD_INFO = {
     'what': 'loss: negatives backward',
     'executed_flops': lambda ns, j, m: 2.0 * (2.0 * ns * j) * 2.0 * m * (100 + 112),
 }
+
+SWEEP_SUMS_INFO = {                             # sga_loss_multi_sums: one owner sweep, S only (K = 100), the joint table derived
+    'tag': 'sweep16_kernel<%d,false>',
+    'what': 'loss: global sums over anchors x negatives (forward)',
+    'executed_flops': lambda ns, j, m: (2.0 * ns * j) * 2.0 * m * 100,
+}
+BF16X3_COVERAGE = 'PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate'
 
 TAU_ICL = 0.1      # losses.py:39 (ctor argument ignored by the reference)
 TAU_IAL = 1.0      # losses.py:63
@@ -546,7 +560,9 @@ class LossHeadFn(torch.autograd.Function):
         sums = sums.contiguous()
         la, lc = _req(lv_ial.detach(), 'log_vars (ial)'), _req(lv_icl.detach(), 'log_vars (icl)')
         out = torch.empty((4,), device=sums.device, dtype=torch.float64)
-        ctx.consts = (M, 1.0 / float(n_anchors * n_anchors), float(z_ial), float(alpha_ial), float(zoom))
+        # a batch without anchors: the reference's .mean() over an empty A x A matrix is NaN, not an exception (losses.py:57)
+        inv_aa = 1.0 / float(n_anchors * n_anchors) if n_anchors else float('nan')
+        ctx.consts = (M, inv_aa, float(z_ial), float(alpha_ial), float(zoom))
         ctx.f64 = int(sums.dtype == torch.float64)
         _lib.check(_lib.lib().sga_loss_head_fwd(_p(sums), ctx.f64, _p(la), _p(lc), *ctx.consts, _p(out), _stream()), 'sga_loss_head_fwd')
         ctx.save_for_backward(sums, la, lc)
@@ -752,10 +768,31 @@ class GraphBatch:
         return gb
 
 
-def _attn_fwd(h, att_s, att_d, bias, gb):
+_GAT_STATUS = {}          # device -> int32[1], bit 0 set by the GAT kernel when an edge multiplicity saturates (never reset by the kernel)
+
+
+def _gat_status_verdict(dev):
+    def verdict(v):
+        if v[0] == 0:
+            return None
+        _GAT_STATUS[dev].zero_()
+        return ('sgaligner_amd: a (source, target) edge occurs more than 255 times in one graph; the GAT kernels count duplicate '
+                'edges in 8 bits (PyG would count them all) -- deduplicate the edge list')
+    return verdict
+
+
+def _attn_fwd(h, att_s, att_d, bias, gb, check_status=False):
     out = torch.empty_like(h)
+    st = None
+    if check_status and VALIDATE:
+        st = _GAT_STATUS.get(h.device)
+        if st is None:
+            st = _GAT_STATUS[h.device] = torch.zeros((1,), device=h.device, dtype=torch.int32)
     _lib.check(_lib.lib().sga_gat_attn_fwd(_p(h), _p(att_s), _p(att_d), _p(bias), _p(gb.edges), _p(gb.node_off),
-                                           _p(gb.edge_off), gb.G, gb.nmax, _p(out), _stream()), 'sga_gat_attn_fwd')
+                                           _p(gb.edge_off), gb.G, gb.nmax, _p(out), _p(st), _stream()), 'sga_gat_attn_fwd')
+    if st is not None:            # read back without blocking; raises at the next batch's poll (or DEFERRED_CHECKS.flush())
+        DEFERRED_CHECKS.poll()
+        DEFERRED_CHECKS.submit_fn(st, _gat_status_verdict(h.device))
     return out
 
 
@@ -796,7 +833,7 @@ class MultiGATFn(torch.autograd.Function):
         if w0.shape[0] != 256 or w1.shape != (256, 256):
             raise RuntimeError('sgaligner_amd: the HIP GAT path implements hidden_units=[F,128,128], heads=[2,2]')
         h0 = gemm(x32, w0, False, True, t, 256, x32.shape[1])
-        o0 = _attn_fwd(h0, as0f, ad0f, b0, gb)
+        o0 = _attn_fwd(h0, as0f, ad0f, b0, gb, check_status=True)      # both layers see the same edge list: one check per batch
         x1 = _elu(o0)
         h1 = gemm(x1, w1, False, True, t, 256, 256)
         o1 = _attn_fwd(h1, as1f, ad1f, b1, gb)
@@ -895,6 +932,26 @@ def simrank(emb, pair_counts, q_idx, q_tgt, k: int, f16=None):
     lay = PairLayout.of(pair_counts, dev)
     if lay.T != T:
         raise RuntimeError(f'sgaligner_amd: the pairs hold {lay.T} objects but the embedding table has {T} rows')
+    # The kernel keeps ONE query slot per object.  An object queried several times (never produced by the reference's collate,
+    # but legal for a caller of this function) is served in rounds of distinct objects and the rows are stitched back.
+    qi_h = _np.asarray(q_idx).reshape(-1)
+    if qi_h.size > 1:
+        order = _np.argsort(qi_h, kind='stable')
+        srt = qi_h[order]
+        if (srt[1:] == srt[:-1]).any():
+            occ = _np.zeros(qi_h.size, dtype=_np.int64)          # occurrence number of every query among those of its object
+            run_start = _np.concatenate([[0], _np.flatnonzero(srt[1:] != srt[:-1]) + 1])
+            occ[order] = _np.arange(qi_h.size) - _np.repeat(run_start, _np.diff(_np.concatenate([run_start, [qi_h.size]])))
+            qt_h = None if q_tgt is None else _np.asarray(q_tgt).reshape(-1)
+            rank = torch.empty((qi_h.size,), device=dev, dtype=torch.int32)
+            tk = torch.empty((qi_h.size, k), device=dev, dtype=torch.int32)
+            ts = torch.empty((qi_h.size, k), device=dev, dtype=torch.float32)
+            for r in range(int(occ.max()) + 1):
+                sel = _np.flatnonzero(occ == r)
+                rr, kk, ss, _ = simrank(emb, pair_counts, qi_h[sel], None if qt_h is None else qt_h[sel], k, f16)
+                sel_d = torch.from_numpy(sel).to(dev)
+                rank[sel_d], tk[sel_d], ts[sel_d] = rr, kk, ss
+            return rank, tk, ts, lay
     qb = QueryBlocks.of(lay, pair_counts, q_idx, q_tgt, dev)
     Q = qb.Q
     rank = torch.empty((max(Q, 1),), device=dev, dtype=torch.int32)
@@ -981,8 +1038,15 @@ class FusedContrastiveFn(torch.autograd.Function):
             _lib.check(L.sga_loss_multi_sums_bf16x3(_ptr_array(zbs), M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums),
                                                     a_lo, a_hi, st), 'sga_loss_multi_sums_bf16x3')
         else:
+            ev = None
+            if KERNEL_EVENTS is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _lib.check(L.sga_loss_multi_sums(zarr, M, dmax, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums), a_lo, a_hi, st),
                        'sga_loss_multi_sums')
+            if ev is not None:
+                ev[1].record()
+                KERNEL_EVENTS.setdefault('loss_multi_sums', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
         sums = _allreduce_sum(sums[0].contiguous(), reduce)
         zj = torch.empty((2 * s.A, M * dp), device=dev, dtype=torch.float32)
         _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')

@@ -36,11 +36,24 @@ class AlignerSteps:
             self.params += list(self.multi_loss_layer_ial.parameters()) + list(self.multi_loss_layer_icl.parameters())
 
     # -- reference hook names ---------------------------------------------------------------------
+    # Multi-GPU, batch-global loss: launch each modality table's all-gather the moment the encoder has produced it (dist.EarlyGather)
+    # instead of gathering all tables after the encoder.  Same numbers (tests/test_dist_gpu.py); False = the blocking path.
+    overlap_gather = True
+
     def train_step(self, epoch, iteration, data_dict):
-        output_dict = self.model(data_dict)
         if dist.is_initialized() and dist.get_world_size() > 1 and self.loss_group in (None, 'global'):
-            loss_dict = self._global_loss(output_dict, data_dict)
+            layout = sdist.layout_of(data_dict, self.device)                  # [world, 4]: rows, |e1i|, |e1j|, |e2j|
+            early = None
+            if len(self.modules) > 1 and self.overlap_gather:
+                early = sdist.EarlyGather([int(v) for v in layout[:, 0]])
+                self.model._on_table = early
+            try:
+                output_dict = self.model(data_dict)
+            finally:
+                self.model._on_table = None
+            loss_dict = self._global_loss(output_dict, data_dict, layout, early)
         else:
+            output_dict = self.model(data_dict)
             loss_dict = self.loss_func(output_dict, data_dict)
         return output_dict, loss_dict
 
@@ -79,14 +92,15 @@ class AlignerSteps:
         sdist.allreduce_grads(self.params)
 
     # -- batch-global loss across ranks -------------------------------------------------------------
-    def _global_loss(self, output_dict, data_dict):
+    def _global_loss(self, output_dict, data_dict, layout=None, early=None):
         """Batch-global loss over all ranks' pairs.  Tables and index sets are all-gathered (RCCL).
         M >= 2 (fused joint path): the anchors are SHARDED -- each rank evaluates the loss terms / global sums of its own
         anchors against all negatives (partial scalars all-reduced inside ops.FusedContrastiveFn, so every rank holds the
         global loss value) and its share of dL/dE for all rows, summed over ranks in AllGatherRows.backward.
         M == 1: every rank evaluates the (small) global loss as a replica and keeps only its own rows' gradient."""
         world, rank = dist.get_world_size(), dist.get_rank()
-        layout = sdist.gather_batch_layout(data_dict, self.device)          # [world, 4]: rows, |e1i|, |e1j|, |e2j|
+        if layout is None:
+            layout = sdist.layout_of(data_dict, self.device)                # [world, 4]: rows, |e1i|, |e1j|, |e2j|
         rows = [int(v) for v in layout[:, 0]]
         anchors = [int(v) for v in layout[:, 1]]
         sharded = len(self.modules) > 1
@@ -96,7 +110,10 @@ class AlignerSteps:
             # only the M modality tables travel: the fused loss derives every joint similarity from them (S_J = sum beta_m
             # S_m with the replicated fusion weight), so the 100*M-wide joint table is neither gathered nor reduced --
             # half of the bytes of both collectives.  The placeholder only carries the provenance tag OverallLoss checks.
-            gathered = sdist.gather_tables({m: output_dict[m] for m in self.modules}, rows, reduce_grad=True)
+            if early is not None:                                            # launched from inside the encoder, table by table
+                gathered = early.tables(self.modules)
+            else:
+                gathered = sdist.gather_tables({m: output_dict[m] for m in self.modules}, rows, reduce_grad=True)
             joint = torch.empty((0,), device=self.device)
             joint._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
             gathered['joint'] = joint

@@ -65,6 +65,36 @@ def test_dataloader_and_hot_path_contract(dataset_root):
     assert seen == len(ds)
 
 
+def test_scan_cache_is_bounded_and_value_neutral(dataset_root):
+    """The per-process scan cache is an LRU bounded in bytes (every DataLoader worker holds one): whatever the bound -- off, smaller
+    than one scan, two scans, unbounded -- the items are identical, and the bytes held never exceed the bound."""
+    from sgaligner_amd.datasets import Scan3RDataset, synthetic_scan3r as S
+    cfg = S.make_cfg(dataset_root, pc_res=64)
+    ref = Scan3RDataset(cfg, 'val', cache=False)
+    ref_items = [ref[i] for i in range(len(ref))]
+    assert ref.cache_bytes == 0 and len(ref._pkls) == 0
+    probe = Scan3RDataset(cfg, 'val')
+    probe[0]
+    one_scan = max(nb for _, nb in probe._pkls.values())
+    for bound in (1, int(2.5 * one_scan), 1 << 30):
+        ds = Scan3RDataset(cfg, 'val', cache_bytes=bound)
+        for rep in range(2):                                           # second sweep reads through the cache where it holds
+            for i in range(len(ds)):
+                it = ds[i]
+                for k, v in ref_items[i].items():
+                    if isinstance(v, torch.Tensor):
+                        assert torch.equal(v, it[k]), k
+                    elif isinstance(v, np.ndarray):
+                        assert np.array_equal(v, it[k]), k
+                    else:
+                        assert v == it[k], k
+                assert ds._pkl_bytes <= bound and ds._pkl_bytes == sum(nb for _, nb in ds._pkls.values())
+        assert (len(ds._pkls) == 0) == (bound < one_scan)
+        # only the fields __getitem__ reads are kept, and only this dataset's point resolution
+        for d, _ in ds._pkls.values():
+            assert list(d['obj_points']) == [64]
+
+
 def test_missing_files_fail_loudly(tmp_path):
     from sgaligner_amd.datasets import Scan3RDataset, synthetic_scan3r as S
     with pytest.raises(FileNotFoundError):

@@ -71,6 +71,39 @@ def _worker(rank, world, port, out):
         part.backward()
         expect = 2 * table[o0:o1] * sum(r + 1 for r in range(world))
         assert torch.allclose(mine2.grad, expect, atol=1e-12)
+        # (4) the overlapped path: equal shards, every table's gather launched asynchronously by dist.EarlyGather (as
+        # MultiModalEncoder does through its table hook), values and gradients identical to the blocking gather; the step's
+        # collectives logged and summarised (bench.py's `collectives` object); a known layout replaces the layout all-gather.
+        torch.manual_seed(1)
+        tabs = {m: torch.randn(world * 6, 8, dtype=torch.float64) for m in ('rel', 'gat', 'point')}
+        sdist.COLLECTIVE_EVENTS = []
+        eg = sdist.EarlyGather([6] * world)
+        loc = {m: t[rank * 6:(rank + 1) * 6].clone().requires_grad_(True) for m, t in tabs.items()}
+        for m in ('rel', 'gat', 'point'):
+            eg(m, loc[m] * 2.0)
+        got = eg.tables(['point', 'gat', 'rel'])
+        assert list(got) == ['point', 'gat', 'rel'] and not eg.works
+        sum((got[m] ** 2).sum() * (rank + 1) for m in got).backward()
+        for m in tabs:
+            assert torch.equal(got[m].detach(), tabs[m] * 2.0), m
+            assert torch.allclose(loc[m].grad, 8 * tabs[m][rank * 6:(rank + 1) * 6] * sum(r + 1 for r in range(world)), atol=1e-12), m
+        ev, sdist.COLLECTIVE_EVENTS = sdist.COLLECTIVE_EVENTS, None
+        summ = sdist.collective_summary(ev, 1, 'cpu', repeats=2)
+        assert summ['backend'] == 'gloo' and summ['world_size'] == world and [r['rank'] for r in summ['ranks_seen']] == list(range(world))
+        assert summ['per_step_this_rank']['all_gather']['calls_per_step'] == 3 and summ['all_gather_bytes'] == 3 * world * 6 * 8 * 8
+        assert summ['per_step_this_rank']['all_reduce']['calls_per_step'] == 3          # gloo: all-reduce + slice instead of reduce-scatter
+        assert all(t['ms_each'] >= 0 for t in summ['timed_alone']) and len(summ['timed_alone']) == 2
+        lay = sdist.known_layout(6, 2, 4, 4, world)
+        dd = {'tot_obj_pts': torch.zeros(6, 4, 3), 'e1i': np.zeros(2), 'e2i': np.zeros(2), 'e1j': np.zeros(4), 'e2j': np.zeros(4), '_sga_layout': lay}
+        assert np.array_equal(sdist.layout_of(dd, 'cpu'), lay)
+        del dd['_sga_layout']
+        assert np.array_equal(sdist.layout_of(dd, 'cpu'), lay)                            # the gathered one agrees
+        dd['_sga_layout'] = sdist.known_layout(7, 2, 4, 4, world)
+        try:
+            sdist.layout_of(dd, 'cpu')
+            raise AssertionError('a layout that does not describe the batch must be refused')
+        except RuntimeError:
+            pass
         out[rank] = 'ok'
     finally:
         dist.destroy_process_group()

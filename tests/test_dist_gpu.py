@@ -92,6 +92,76 @@ def test_two_ranks_equal_single_process(mods, n_pairs, cuts):
                 assert (r['lv:' + tag] - a).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), (rank, tag)
 
 
+def _overlap_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from sgaligner_amd import dist as sdist
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda', 0)
+        full = to_device(make_batch(6, 12, 48, seed=33), dev)             # uniform scenes: equal shards -> the asynchronous gathers
+        mine = sdist.shard_data_dict(full, 3 * rank, 3 * rank + 3)
+        res = {}
+        for tag, overlap, known in (('overlap', True, True), ('blocking', False, False)):
+            steps = AlignerSteps(['point', 'gat', 'rel'], device=dev, seed=42)
+            steps.overlap_gather = overlap
+            dd = dict(mine)
+            if known:                                                     # no layout all-gather, no host read-back
+                dd['_sga_layout'] = sdist.known_layout(mine['tot_obj_pts'].shape[0], len(mine['e1i']), len(mine['e1j']), len(mine['e2j']), world)
+            sdist.COLLECTIVE_EVENTS = []
+            _, loss = steps.forward_backward(dd)
+            torch.cuda.synchronize()
+            ev, sdist.COLLECTIVE_EVENTS = sdist.COLLECTIVE_EVENTS, None
+            r = {'loss': float(loss['loss'].item()), 'kinds': sorted(set(e[0] for e in ev)),
+                 'n_gather': sum(1 for e in ev if e[0] == 'all_gather')}
+            for n, p in steps.model.named_parameters():
+                if p.grad is not None:
+                    r['g:' + n] = p.grad.detach().cpu()
+            if overlap:
+                r['summary'] = sdist.collective_summary(ev, 1, dev, repeats=1)
+            res[tag] = r
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gathers_equal_blocking_and_single_process():
+    """The table all-gathers launched from inside the encoder (dist.EarlyGather: cheap modalities first, asynchronous) + a known
+    batch layout (no host sync) give the loss and gradients of the blocking path and of the single-process run; the step's
+    collectives are logged for bench.py's `collectives` object."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    ref = AlignerSteps(['point', 'gat', 'rel'], device='cuda', seed=42)
+    _, loss = ref.forward_backward(to_device(make_batch(6, 12, 48, seed=33), 'cuda'))
+    torch.cuda.synchronize()
+    for rank in range(world):
+        a, b = out[rank]['overlap'], out[rank]['blocking']
+        assert abs(a['loss'] - b['loss']) <= 1e-6 * max(1.0, abs(b['loss']))
+        assert abs(a['loss'] - loss['loss'].item()) <= 1e-5 * max(1.0, abs(loss['loss'].item()))
+        # 3 table gathers + the packed index sets (+ the layout gather on the blocking path only)
+        assert a['n_gather'] == 4 and b['n_gather'] == 5, (a['n_gather'], b['n_gather'])
+        for n, p in ref.model.named_parameters():
+            if p.grad is None:
+                continue
+            sc = max(1.0, p.grad.abs().max().item())
+            assert (a['g:' + n] - b['g:' + n]).abs().max().item() <= 1e-5 * sc, (rank, n)
+            assert (a['g:' + n] - p.grad.cpu()).abs().max().item() <= 1e-4 * sc, (rank, n)
+        summ = a['summary']
+        assert summ['world_size'] == 2 and len(summ['ranks_seen']) == 2 and summ['all_gather_bytes'] > 0
+        assert all(t['ms_each'] > 0 for t in summ['timed_alone'])
+
+
 def _acc_worker(rank, world, port, out):
     import sys
     sys.path.insert(0, ROOT)
@@ -158,12 +228,19 @@ def _rccl_worker(rank, world, port, mods, ragged_pad, out):
         dd = to_device(make_batch(5, 14, 48, seed=23, ragged=True), dev)
         steps = AlignerSteps(mods, device=dev, seed=42)
         steps.zero_grad()
+        sdist.COLLECTIVE_EVENTS = []
+        early = None
+        if len(mods) > 1:                                   # as AlignerSteps.train_step does for N > 1: asynchronous RCCL gathers
+            early = sdist.EarlyGather([int(dd['tot_obj_pts'].shape[0])])
+            steps.model._on_table = early
         output_dict = steps.model(dd)
-        loss = steps._global_loss(output_dict, dd)          # the N > 1 code path, over RCCL, with a world of one
+        steps.model._on_table = None
+        loss = steps._global_loss(output_dict, dd, None, early)   # the N > 1 code path, over RCCL, with a world of one
         loss['loss'].backward()
         steps.reduce_grads()
         torch.cuda.synchronize()
-        res = {'loss': float(loss['loss'].item())}
+        ev, sdist.COLLECTIVE_EVENTS = sdist.COLLECTIVE_EVENTS, None
+        res = {'loss': float(loss['loss'].item()), 'summary': sdist.collective_summary(ev, 1, dev, repeats=2)}
         for n, p in steps.model.named_parameters():
             if p.grad is not None:
                 res['g:' + n] = p.grad.detach().cpu()
@@ -208,3 +285,8 @@ def test_rccl_collectives_world_of_one(mods):
     assert seen >= (8 if len(mods) > 1 else 4)
     assert torch.equal(r['ag_grad'], torch.arange(35, dtype=torch.float32).view(7, 5))
     assert r['layout'][0][0] == int(dd['tot_obj_pts'].shape[0])
+    summ = r['summary']                                       # bench.py's `collectives` object, from real RCCL calls
+    assert summ['backend'] == 'nccl' and summ['ranks_seen'][0]['rank'] == 0
+    kinds = set(summ['per_step_this_rank'])
+    assert 'all_gather' in kinds and 'all_reduce' in kinds and (('reduce_scatter' in kinds) == (len(mods) > 1))
+    assert all(t['ms_each'] > 0 for t in summ['timed_alone'])

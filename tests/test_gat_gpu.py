@@ -69,3 +69,50 @@ def test_gat_too_many_nodes_fails_loudly():
     h = torch.randn(257, 256, device='cuda')
     with pytest.raises(RuntimeError, match='at most 256'):
         ops._attn_fwd(h, torch.randn(256, device='cuda'), torch.randn(256, device='cuda'), torch.zeros(256, device='cuda'), gb)
+
+
+def test_gat_kernel_vs_hand_derived_case():
+    """The HIP attention kernel against the hand-derived GATConv case of tests/gat_handcase.py (not through the oracle): duplicate
+    edge counted twice, the input's self loop replaced by exactly one, LeakyReLU(0.2) on both signs, both heads, bias."""
+    import gat_handcase as G
+    from sgaligner_amd import ops
+    h, a_s, a_d, b = G.inputs()
+    for sizes, off in (([3], 0), ([2, 3, 4], 2)):                  # alone, and as the middle graph of a batch
+        T = sum(sizes)
+        hh = np.zeros((T, G.H * G.C))
+        hh[off:off + 3] = h
+        ecnt = np.asarray([len(G.EDGES)] if len(sizes) == 1 else [0, len(G.EDGES), 0])
+        gb = ops.GraphBatch(np.asarray(sizes), ecnt, torch.from_numpy(G.EDGES).cuda())
+        f = lambda a: torch.from_numpy(a).float().cuda()
+        out = ops._attn_fwd(f(hh), f(a_s), f(a_d), f(b), gb, check_status=True)
+        torch.cuda.synchronize()
+        ops.DEFERRED_CHECKS.flush()
+        got = out.cpu().double().numpy()[off:off + 3]
+        assert np.allclose(got, G.expected(), rtol=0, atol=2e-5), np.abs(got - G.expected()).max()
+
+
+def test_gat_multiplicity_overflow_fails_loudly():
+    """More than 255 copies of one (source, target) edge saturate the kernels' 8-bit multiplicity matrix: the wrapper must raise
+    (deferred by at most one step), never return numbers PyG would not produce.  255 copies are fine and match the oracle."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    torch.manual_seed(0)
+    n = 5
+    h = torch.randn(n, 256)
+    a_s, a_d, b = torch.randn(256) * 0.1, torch.randn(256) * 0.1, torch.zeros(256)
+    base = np.array([[1, 0], [2, 0], [3, 4]], dtype=np.int64)
+    for copies, ok in ((255, True), (256, False), (700, False)):
+        e = np.concatenate([base, np.repeat(np.array([[4, 2]], dtype=np.int64), copies, axis=0)])
+        gb = ops.GraphBatch(np.asarray([n]), np.asarray([len(e)]), torch.from_numpy(e).cuda())
+        out = ops._attn_fwd(h.cuda(), a_s.cuda(), a_d.cuda(), b.cuda(), gb, check_status=True)
+        torch.cuda.synchronize()
+        if ok:
+            ops.DEFERRED_CHECKS.flush()
+            # x = identity, lin_w = h^T  ->  the oracle's projection reproduces h
+            ref = O.gat_conv(torch.eye(n, dtype=torch.float64), torch.from_numpy(e.T.copy()), h.double().t().contiguous(),
+                             a_s.double().view(1, 2, 128), a_d.double().view(1, 2, 128), b.double())
+            assert (out.cpu().double() - ref).abs().max() < 1e-4
+        else:
+            with pytest.raises(RuntimeError, match='more than 255 times'):
+                ops.DEFERRED_CHECKS.flush()
+    ops.DEFERRED_CHECKS.flush()                                    # the status word was reset: nothing pending raises again

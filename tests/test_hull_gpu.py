@@ -58,3 +58,31 @@ def test_random_objects_vs_oracle(seed):
     for k, o in enumerate(objs):
         bc, verts = hull_oracle.hull_barycenter(o)
         assert np.allclose(bcs[k], bc, rtol=0, atol=1e-9 * max(1.0, np.abs(o).max())), (k, bcs[k], bc)
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_small_objects_far_from_origin(seed):
+    """Objects a few centimetres across, tens to thousands of metres from the origin: the rounding of raw fp32 coordinates is then
+    of the order of (or above) a margin that scales with the object's extent alone.  The filter works in coordinates translated to
+    a support point and widens its margin by the ulp of the largest coordinate, so no hull vertex may ever be discarded -- and at
+    moderate distances it must still discard interior points."""
+    from sgaligner_amd.utils import point_cloud
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(100 + seed)
+    objs = []
+    for dist, size in ((5.0, 0.05), (40.0, 0.05), (300.0, 0.02), (3000.0, 0.3), (2.0e4, 1.0)):
+        centre = rng.standard_normal(3)
+        centre = centre / np.linalg.norm(centre) * dist
+        shape = rng.standard_normal((3000, 3)) * rng.uniform(0.3, 1.0, size=3) * size
+        objs.append((shape + centre).astype(np.float32))            # what a scan holds: fp32 coordinates
+    off = np.concatenate([[0], np.cumsum([len(o) for o in objs])])
+    keep, npl = point_cloud.hull_candidate_mask_batch(torch.from_numpy(np.concatenate(objs)).cuda(), off)
+    keep = keep.cpu().numpy()
+    bcs = point_cloud.convex_hull_barycenters_batch(objs)
+    for k, o in enumerate(objs):
+        hull = ConvexHull(o)
+        kk = keep[off[k]:off[k + 1]]
+        assert kk[hull.vertices].all(), (k, int((~kk[hull.vertices]).sum()))
+        v = hull.points[hull.vertices]
+        assert np.allclose(bcs[k], v.mean(0), rtol=0, atol=1e-9 * np.abs(o).max()), k
+    assert keep[off[0]:off[1]].mean() < 0.5 and keep[off[1]:off[2]].mean() < 0.6      # still a filter where fp32 resolves the object

@@ -177,6 +177,21 @@ def test_gat_edge_vs_dense():
     close(a, b, 1e-12)
 
 
+def test_gat_oracle_vs_hand_derived_case():
+    """Row G's oracle against numbers derived by hand from the published GATConv definition (tests/gat_handcase.py: 3 nodes,
+    2 heads, a duplicate edge, an explicit self loop in the input) -- an implementation-independent pin of the restatement."""
+    import gat_handcase as G
+    h, a_s, a_d, b = G.inputs()
+    # x = one-hot node features and lin_w[:, j] = h_j make  x @ lin_w^T == h  exactly
+    x = torch.eye(3, dtype=torch.float64)
+    lin_w = torch.from_numpy(h.T.copy())
+    ei = torch.from_numpy(G.EDGES.T.copy())
+    args = (lin_w, torch.from_numpy(a_s).view(1, G.H, G.C), torch.from_numpy(a_d).view(1, G.H, G.C), torch.from_numpy(b))
+    for conv in (O.gat_conv, O.gat_conv_dense):
+        out = conv(x, ei, *args)
+        assert np.allclose(out.numpy(), G.expected(), rtol=0, atol=1e-13), conv.__name__
+
+
 def test_gat_gradcheck_fp64():
     torch.manual_seed(1)
     n = 5

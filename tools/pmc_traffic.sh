@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the two dominant kernels: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over
 # `python bench.py --config <c2|c3> --steps 2 --warmup 1` (counters only, no trace domains).
-# usage: tools/pmc_traffic.sh <c2|c3> <out.csv>   (rows are APPENDED; bench.py reads profiles/r02_pmc_traffic.csv)
+# usage: tools/pmc_traffic.sh <c2|c3> <out.csv>   (rows are APPENDED; bench.py reads profiles/r03_pmc_traffic.csv)
 # row: kernel;workload_key;sha16(kernel source);counter;avg KiB per dispatch;launches  -- bench.py uses a row only when the
 # workload key matches what it runs and the source file is unchanged since the pass.
 set -u
