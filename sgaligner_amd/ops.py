@@ -758,6 +758,8 @@ class GraphBatch:
         """Offsets are cached by the CONTENT of the two host count arrays + the identity of the device edge list (nothing is
         stored in the caller's dict).  The cached object keeps only the small offset arrays, never the edge tensor."""
         edges = data_dict['edges']
+        if VALIDATE:
+            DEFERRED_CHECKS.poll()                                   # earlier batches' answers (no waiting): a bad batch raises here
         key = _fingerprint([_np.asarray(data_dict['graph_per_obj_count']), _np.asarray(data_dict['graph_per_edge_count'])],
                            (str(edges.device), edges.data_ptr(), tuple(edges.shape), str(edges.dtype)))
         proto = GraphBatch._cache.get(key, lambda: GraphBatch(data_dict['graph_per_obj_count'], data_dict['graph_per_edge_count'],
@@ -791,7 +793,6 @@ def _attn_fwd(h, att_s, att_d, bias, gb, check_status=False):
     _lib.check(_lib.lib().sga_gat_attn_fwd(_p(h), _p(att_s), _p(att_d), _p(bias), _p(gb.edges), _p(gb.node_off),
                                            _p(gb.edge_off), gb.G, gb.nmax, _p(out), _p(st), _stream()), 'sga_gat_attn_fwd')
     if st is not None:            # read back without blocking; raises at the next batch's poll (or DEFERRED_CHECKS.flush())
-        DEFERRED_CHECKS.poll()
         DEFERRED_CHECKS.submit_fn(st, _gat_status_verdict(h.device))
     return out
 

@@ -121,5 +121,8 @@ class AlignerSteps:
             gathered = sdist.gather_tables(output_dict, rows, reduce_grad=False)
         if sharded:
             gdd['_sga_shard'] = (sum(anchors[:rank]), sum(anchors[:rank + 1]))
-            gdd['_sga_reduce'] = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            def _reduce(t):                                                   # fp64 partial sums / loss terms / dL/d(sums)
+                sdist._log('all_reduce', t, t)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            gdd['_sga_reduce'] = _reduce
         return self.loss_func(gathered, gdd)

@@ -40,7 +40,7 @@ def _mosaicking_dict(root, src_id, ref_id, pc_res):
     }
 
 
-@pytest.mark.parametrize('modules', [['point', 'gat', 'rel', 'attr'], ['gat', 'rel'], ['point']])
+@pytest.mark.parametrize('modules', [['point', 'gat', 'rel', 'attr'], ['point', 'gat'], ['point']])
 def test_mosaicking_data_dict_through_test_step(tmp_path, modules):
     from oracle import sga_oracle as O
     from sgaligner_amd.datasets import synthetic_scan3r as S
