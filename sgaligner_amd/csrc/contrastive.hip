@@ -441,6 +441,10 @@ struct MultiArgs {
 #define SGA_S16_WAVES 4
 #endif
 constexpr int S16_WAVES = SGA_S16_WAVES;   // waves per workgroup; with 4, two workgroups share a CU (2 x 78 KiB of LDS)
+// The owner rows (the S product's register operand, used for nothing else) carry the factor log2(e)/tau1, so the MFMA result is
+// already the exp2 argument of the tau1 terms and the tau0 argument is one multiply away (k0/k1).  (Round 3; also tried there and
+// dropped: gradient columns 96..99 on VALU -- a broadcast ds_read_b128 + 4 FMAs per step instead of the 7th, 3/4-padded MFMA
+// tile: 24 MFMAs per tile less, same time; tools/experiments/r03_sweep16_vtail_prescale_nomask.diff.txt.)
 constexpr int S16_THREADS = S16_WAVES * 64;
 constexpr int S16_OWN = S16_WAVES * 16;     // owner rows per workgroup
 // SGA_DBG_NOEXP / NOBAR / NODMA / NOS / NOG: timing-only ablation switches (wrong results) for tools/build_variant.sh;
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const float* src = a.Z[m] + (size_t)(iv ? my_i : own0) * DP;
-        const float msk = iv ? 1.f : 0.f;
+        const float msk = iv ? a.k1 : 0.f;                      // pre-scaled: S arrives as the tau1 exp2 argument
 #pragma unroll
         for (int q = 0; q < 6; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 16 * q + 4 * g4) * msk;   // k = 16q + 4g4 + r
 #pragma unroll
@@ -493,6 +497,10 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
     float gam[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) gam[m] = 0.f;
+    // exp2 arguments from an S value `sv` as the MFMA delivers it (already times log2(e)/tau1):  tau1 term exp2(sv),  tau0 term exp2(sv * ka)
+    const float ka = a.k0 / a.k1;
+    auto e0 = [&](float sv) { return fexp2(sv * ka); };
+    auto e1 = [&](float sv) { return fexp2(sv); };
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
     auto issue = [&](int j0, float* buf) {
@@ -540,6 +548,17 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
 #ifndef SGA_DBG_NODMA
             if (jt + nsplit < ntile) issue(seg.row0 + (jt + nsplit) * OT, lds + ((it + 1) & 1) * BUF_F);
 #endif
+            if (GRAD && j0 + OT > j_end) {
+                // Last, partial tile of a segment (uniform, once per segment): the rows past the segment's end hold the next segment's
+                // data.  Zeroing them in LDS makes every one of their contributions vanish by itself -- S = 0, c * 0 added to the owner
+                // gradient, 0 added to Gamma -- so the gradient epilogue needs no per-element validity mask at all.
+                const int nval = j_end - j0;
+                for (int x = tid; x < M * (OT - nval) * (DP / 4); x += S16_THREADS) {
+                    const int m = x / ((OT - nval) * (DP / 4)), rem = x - m * ((OT - nval) * (DP / 4));
+                    *reinterpret_cast<f32x4*>(buf + m * TILE_F + nval * DP + rem * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __syncthreads();
+            }
 
             // ---- S^T tiles of the M tables: lane&15 = owner row, (g4, r) = other row.
             // Per 16-row half the M accumulation chains are interleaved (a dependent MFMA is M issues away) and the
@@ -610,25 +629,26 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
                         for (int m = 0; m < M; ++m) {
                             const float sv = sacc[m][jh][r];
                             sj = fmaf(beta[m], sv, sj);
-                            p0[m] = fmaf(okf, fexp2(sv * a.k0), p0[m]);
-                            p1[m] = fmaf(okf, fexp2(sv * a.k1), p1[m]);
+                            p0[m] = fmaf(okf, e0(sv), p0[m]);
+                            p1[m] = fmaf(okf, e1(sv), p1[m]);
                         }
-                        p0[M] = fmaf(okf, fexp2(sj * a.k0), p0[M]);
-                        p1[M] = fmaf(okf, fexp2(sj * a.k1), p1[M]);
+                        p0[M] = fmaf(okf, e0(sj), p0[M]);
+                        p1[M] = fmaf(okf, e1(sj), p1[M]);
                     }
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
-                float cj[2][4], okf[2][4];
+                // No validity masks here: rows past a segment's end were zeroed in LDS above, and owner rows past the group's end carry
+                // zero operands and are never written back.
+                float cj[2][4];
 #pragma unroll
                 for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        okf[jh][r] = (iv && (j0 + jh * 16 + jrow[r] < j_end)) ? 1.f : 0.f;
                         float sj = 0.f;
 #pragma unroll
                         for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][jh][r], sj);
-                        cj[jh][r] = okf[jh][r] * (c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1));
+                        cj[jh][r] = c0[M] * e0(sj) + c1[M] * e1(sj);
                     }
                 if (g < 2) {                                    // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
 #pragma unroll
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
                 auto coef = [&](int e) {
                     const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
                     const float sv = sacc[m][jh][r];
-                    return okf[jh][r] * fmaf(beta[m], cj[jh][r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1));
+                    return fmaf(beta[m], cj[jh][r], c0[m] * e0(sv) + c1[m] * e1(sv));
                 };
                 auto bload = [&](int e, float* dst) {
                     const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
         if (g < 2) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const float v = wave_sum(gam[m]);
+                const float v = wave_sum(gam[m]) / a.k1;       // Gamma was accumulated on pre-scaled S values
                 if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + m, (double)v);
             }
         }
@@ -753,7 +773,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const float* src = a.Z[2 * th + m] + (size_t)(iv ? my_i : own0) * DP;
-        const float msk = iv ? 1.f : 0.f;
+        const float msk = iv ? a.k1 : 0.f;                      // pre-scaled owner rows, as in sweep16_kernel
 #pragma unroll
         for (int q = 0; q < 6; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 16 * q + 4 * g4) * msk;
 #pragma unroll
@@ -767,6 +787,9 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) gacc[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float gam[MT] = {0.f, 0.f};
+    const float ka = a.k0 / a.k1;                                  // S arrives times log2(e)/tau1: tau1 term exp2(sv), tau0 term exp2(sv * ka)
+    auto e0 = [&](float sv) { return fexp2(sv * ka); };
+    auto e1 = [&](float sv) { return fexp2(sv); };
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int j0, float* buf) {
@@ -812,6 +835,14 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
             const int j0 = seg.row0 + jt * OT;
             __syncthreads();                               // tile `it` landed / other buffer free / exchange buffer free
             if (jt + nsplit < ntile) issue(seg.row0 + (jt + nsplit) * OT, lds + ((it + 1) & 1) * BUF_F);
+            if (GRAD && j0 + OT > j_end) {                 // partial last tile of a segment: zero the rows past its end (see sweep16_kernel)
+                const int nval = j_end - j0;
+                for (int x = tid; x < M * (OT - nval) * (DP / 4); x += S4_THREADS) {
+                    const int m = x / ((OT - nval) * (DP / 4)), rem = x - m * ((OT - nval) * (DP / 4));
+                    *reinterpret_cast<f32x4*>(buf + m * TILE_F + nval * DP + rem * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __syncthreads();
+            }
 
             // ---- S^T tiles of this wave's two tables
             f32x4 mine[MT][2], part[MT][2];
@@ -889,27 +920,26 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
                             const float sv = mine[m][jh][r];
-                            p0[m] = fmaf(okf, fexp2(sv * a.k0), p0[m]);
-                            p1[m] = fmaf(okf, fexp2(sv * a.k1), p1[m]);
+                            p0[m] = fmaf(okf, e0(sv), p0[m]);
+                            p1[m] = fmaf(okf, e1(sv), p1[m]);
                         }
                         if (jh == th) {                             // wave-uniform: the joint table's sums, one 16-row half per partner
-                            p0[MT] = fmaf(okf, fexp2(sj * a.k0), p0[MT]);
-                            p1[MT] = fmaf(okf, fexp2(sj * a.k1), p1[MT]);
+                            p0[MT] = fmaf(okf, e0(sj), p0[MT]);
+                            p1[MT] = fmaf(okf, e1(sj), p1[MT]);
                         }
                     }
 #pragma unroll
                 for (int m = 0; m <= MT; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
-                float cj[2][4], okf[2][4];
+                float cj[2][4];                             // no validity masks: see sweep16_kernel
 #pragma unroll
                 for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        okf[jh][r] = (iv && (j0 + jh * 16 + jrow[r] < j_end)) ? 1.f : 0.f;
                         float sj = 0.f;
 #pragma unroll
                         for (int m = 0; m < MT; ++m) sj = fmaf(bm[m], mine[m][jh][r], fmaf(bp[m], part[m][jh][r], sj));
-                        cj[jh][r] = okf[jh][r] * (c0[MT] * fexp2(sj * a.k0) + c1[MT] * fexp2(sj * a.k1));
+                        cj[jh][r] = c0[MT] * e0(sj) + c1[MT] * e1(sj);
                     }
                 if (g < 2) {
 #pragma unroll
@@ -923,7 +953,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
                 auto coef = [&](int e) {
                     const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
                     const float sv = mine[m][jh][r];
-                    return okf[jh][r] * fmaf(bm[m], cj[jh][r], c0[m] * fexp2(sv * a.k0) + c1[m] * fexp2(sv * a.k1));
+                    return fmaf(bm[m], cj[jh][r], c0[m] * e0(sv) + c1[m] * e1(sv));
                 };
                 auto bload = [&](int e, float* dst) {
                     const int m = e >> 3, jh = (e >> 2) & 1, r = e & 3;
@@ -981,7 +1011,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
         if (g < 2) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const float v = wave_sum(gam[m]);
+                const float v = wave_sum(gam[m]) / a.k1;       // accumulated on pre-scaled S values
                 if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + 2 * th + m, (double)v);
             }
         }

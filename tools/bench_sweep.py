@@ -22,7 +22,9 @@ ev = ops.KERNEL_EVENTS['loss_multi_grad'][2:]
 ms = [a.elapsed_time(b) for a, b, _ in ev]
 ns, A, J1, J2, M = ev[0][2]
 alg = 2.0 * (2.0 * 600 * 2.0 * ns * (J1 + J2))
-print(f'sweep grad: median {np.median(ms):.3f} ms (min {min(ms):.3f})  A={A} J={J1 + J2}  algorithmic {alg / np.median(ms) / 1e9:.1f} TFLOP/s = {alg / np.median(ms) / 1e9 / 157.3:.3f} of fp32 MFMA peak; grad checksum {float(tabs[0].grad.abs().sum()):.6e}')
+evf = ops.KERNEL_EVENTS.get('loss_multi_sums', [])[2:]
+msf = [a.elapsed_time(b) for a, b, _ in evf] or [float('nan')]
+print(f'sums {np.median(msf):.3f} ms | sweep grad: median {np.median(ms):.3f} ms (min {min(ms):.3f})  A={A} J={J1 + J2}  algorithmic {alg / np.median(ms) / 1e9:.1f} TFLOP/s = {alg / np.median(ms) / 1e9 / 157.3:.3f} of fp32 MFMA peak; grad checksum {float(tabs[0].grad.abs().sum()):.6e}')
 # accuracy of the opt-in mode against the exact-fp32 sweeps on the same inputs (run with SGA_BENCH_SWEEP_COMPARE=1)
 if os.environ.get('SGA_BENCH_SWEEP_COMPARE'):
     res = {}

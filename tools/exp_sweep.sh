@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage: tools/exp_sweep.sh <variant tags...>   -- time the loss-gradient sweep of each variants/libsga_<tag>.so (c2 and a c3-sized shard)
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+for t in "$@"; do
+  for rep in 1 2; do
+    echo "== $t c2: $(SGA_LIB_PATH=variants/libsga_$t.so python tools/bench_sweep.py 512 64 8 2>&1 | tail -1)"
+  done
+  echo "== $t c3/8: $(SGA_LIB_PATH=variants/libsga_$t.so python tools/bench_sweep.py 512 128 3 2>&1 | tail -1)"
+done
