@@ -15,7 +15,7 @@ if [ ! -f "$out" ]; then
   echo "kernel;workload_key;source_sha16;counter;avg_kib_per_launch;launches" >> $out
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, true>|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, (true|false)>|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
   python - $c $cfg >> $out <<'PY'
 import csv, glob, sys, collections, hashlib
 c, cfg = sys.argv[1], sys.argv[2]
@@ -31,8 +31,8 @@ for f in glob.glob(f'gpurun_out/pmc_t_{cfg}_{c}/**/*counter_collection.csv', rec
             k = ('pointnet_fwd_kernel', keys[0], sha('pointnet.hip'))
         else:
             import re
-            base = re.search(r'(\w+_kernel)<', name).group(1)
-            k = (base + '<3,true>', keys[1], sha('contrastive.hip'))
+            mm = re.search(r'(\w+_kernel)<3, (true|false)>', name)
+            k = (mm.group(1) + '<3,' + mm.group(2) + '>', keys[1], sha('contrastive.hip'))
         acc[k] += float(r['Counter_Value']); n[k] += 1
 for k in sorted(acc):
     print(f'{k[0]};{k[1]};{k[2]};{c};{acc[k] / n[k]:.4f};{n[k]}')
