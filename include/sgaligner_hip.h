@@ -259,6 +259,18 @@ size_t sga_loss_neg_grad_wide_floats(int A, int J1, int J2);
 int sga_loss_neg_grad_wide(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8, float* dZ,
                            float* stash, size_t stash_floats, void* stream);
 
+/* fp16-input / fp32-accumulate variant of the two functions above for WIDE tables (BASELINE.json configs[4]: 1024-d embeddings,
+ * "similarity GEMM at fp16"); opt-in from Python (ops.set_mfma_mode('f16')), tolerance 1e-2 on gradients (tests/test_c5_gpu.py).
+ * sga_wide16_prepare: packed normalised table Z fp32 [2A+J1+J2][Dp] -> Zh fp16 (same layout) and ZhT fp16 [Dp][sga_wide16_ldt()]
+ * (transposed; every segment X1|X2|N1|N2 starts at a multiple of 8 columns).  sums8 / gs8 as in sga_loss_neg_sums / _grad.
+ * stash: caller-owned workspace of stash_bytes (sga_loss_neg_grad_f16_bytes() = the whole batch in one pass; less -> anchor-row blocks). */
+long sga_wide16_ldt(int A, int J1, int J2);
+int sga_wide16_prepare(const float* Z, int Dp, int A, int J1, int J2, void* Zh, void* ZhT, void* stream);
+int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, void* stream);
+size_t sga_loss_neg_grad_f16_bytes(int A, int J1, int J2);
+int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
+                          float* dZ, void* stash, size_t stash_bytes, void* stream);
+
 /* ---- scalar head of OverallLoss -----------------------------------------------------------------------
  * replaces the one-element arithmetic of src/aligner/losses.py:114-152 + CustomMultiLossLayer.forward :28-34 on the raw terms
  * sums = [S_icl[M+1] | S_ial_a[M] | S_ial_b[M]] (doubles) returned by the loss kernels:

@@ -1,0 +1,324 @@
+// fp16-input / fp32-accumulate path of the batch-global loss on WIDE tables (BASELINE.json configs[4]: 1024-d embeddings, "MFMA
+// similarity GEMM at fp16").  Opt-in (ops.set_mfma_mode('f16')); exact fp32 stays the default everywhere.
+//
+// Replaces, for packed tables wider than 128 columns, the fp32 sweeps of contrastive.hip:
+//   sga_loss_neg_sums      -> sga_loss_neg_sums_f16       the 4x2 global sums  sum_ij exp(S_ij / tau)              (losses.py:6-11)
+//   sga_loss_neg_grad_wide -> sga_loss_neg_grad_f16       dL/dZ through the anchors x negatives similarities       (autograd of :6-11)
+// with S = Z Z^T and both gradient GEMMs on v_mfma_f32_32x32x16_f16.  One tiled NT-GEMM core (out[m][n] = sum_k A[m][k] B[n][k],
+// both operands fp16 with k contiguous, 128 x 128 tile per workgroup, K chunks of 64 through LDS, next chunk prefetched into registers
+// under the MFMAs) carries three epilogues:
+//   SUMS  exp2 of the S tile, masked, reduced to the fp64 per-wave slots;
+//   COEF  c_ij = (g0/tau0 exp(S/tau0) + g1/tau1 exp(S/tau1)) / alpha  written as fp16 (alpha = the coefficient's bound, so |c/alpha| <= 1:
+//         inside fp16's range whatever the loss scale; values below 6e-8 of the bound flush to zero);
+//   GEMM  out += alpha * acc  (fp32 atomics; split over K for occupancy).
+// Operand layouts (sga_wide16_prepare): Zh [R][Dp] = fp16 copy of the packed normalised table (S operand), ZhT [Dp][ldt] = its
+// transpose with every segment (X1 | X2 | N1 | N2) starting at a multiple of 8 columns (the gradient GEMMs' B operand: k = packed row).
+// The coefficient tile leaves the S kernel with lanes along its B operand, so it is produced twice, once per orientation
+// (anchor-major C for dZ[anchors] = C Z[neg], negative-major C^T for dZ[neg] = C^T Z[anchors]) -- S costs 1/16 of its fp32 time here,
+// recomputing it is cheaper than a transposing store.
+#include "loss_math.h"
+
+namespace {
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int W_THREADS = 256, W_T = 128, W_KC = 64, W_LS = W_KC + 8;     // LDS row stride in halfs (144 B: conflict-free ds_read_b128)
+constexpr int W_SUMS = 0, W_COEF = 1, W_GEMM = 2;
+
+struct W16Args {
+    const f16* A; long lda; int M;          // A operand rows [M][K]  (MFMA rows: r / lane>>5)
+    const f16* B; long ldb; int N;          // B operand rows [N][K]  (MFMA columns: lane & 31)
+    int K, kper;                            // contraction length, K range per blockIdx.z (multiple of W_KC)
+    float k0, k1, it0, it1;                 // log2(e)/tau, 1/tau
+    const double* gs; int fam;              // dL/d(sums) [8] (COEF / GEMM: the block's coefficient scale), sum family 0..3
+    double* sums;                           // SUMS out (slots)
+    f16* cout; long ldc;                    // COEF out [M][ldc]
+    float* out; long ldo;                   // GEMM out [M][ldo], atomically accumulated
+};
+
+// 8 halfs of row `row` starting at column k: zero past the matrix (row >= rows or k >= K), tail elements of a partial group zeroed
+__device__ __forceinline__ f16x8 load8(const f16* __restrict__ base, long ld, int row, int rows, int k, int K) {
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < rows && k < K) {
+        v = *reinterpret_cast<const f16x8*>(base + (size_t)row * ld + k);
+        if (k + 8 > K) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (k + e >= K) v[e] = (f16)0.f;
+        }
+    }
+    return v;
+}
+
+// the coefficient bound of a sum family: |g0|/tau0 * 2^k0 + |g1|/tau1 * 2^k1  (S <= 1 for normalised rows; +2 % for fp16 rounding of S)
+__device__ __forceinline__ float coef_bound(const double* gs, int fam, float k0, float k1, float it0, float it1) {
+    const float c0 = fabsf((float)(gs[fam * 2 + 0] * (double)it0)), c1 = fabsf((float)(gs[fam * 2 + 1] * (double)it1));
+    return fmaxf(1.02f * (c0 * fexp2(k0) + c1 * fexp2(k1)), 1e-30f);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(W_THREADS, 2) void wide16_kernel(W16Args a) {
+    __shared__ __attribute__((aligned(16))) f16 As[W_T * W_LS];
+    __shared__ __attribute__((aligned(16))) f16 Bs[W_T * W_LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * W_T, n0 = blockIdx.x * W_T;
+    const int kb = blockIdx.z * a.kper, ke = min(a.K, kb + a.kper);
+    if (kb >= ke) return;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging: 128 rows x 8 groups of 8 halfs per operand = 1024 groups = 4 per thread; thread -> (row = e >> 3, group = e & 7)
+    f16x8 pa[4], pb[4];
+    auto gload = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * W_THREADS, r = e >> 3, g = e & 7;
+            pa[q] = load8(a.A, a.lda, m0 + r, a.M, k + g * 8, ke);
+            pb[q] = load8(a.B, a.ldb, n0 + r, a.N, k + g * 8, ke);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * W_THREADS, r = e >> 3, g = e & 7;
+            *reinterpret_cast<f16x8*>(As + r * W_LS + g * 8) = pa[q];
+            *reinterpret_cast<f16x8*>(Bs + r * W_LS + g * 8) = pb[q];
+        }
+    };
+    gload(kb);
+    for (int k = kb; k < ke; k += W_KC) {
+        __syncthreads();                        // previous chunk's reads done
+        lstore();
+        __syncthreads();
+        if (k + W_KC < ke) gload(k + W_KC);     // next chunk in flight under the MFMAs
+        const f16* ap = As + (wave * 32 + l31) * W_LS + h * 8;
+        const f16* bp = Bs + l31 * W_LS + h * 8;
+#pragma unroll
+        for (int kk = 0; kk < W_KC / 16; ++kk) {
+            const f16x8 av = *reinterpret_cast<const f16x8*>(ap + kk * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(bp + t * 32 * W_LS + kk * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: element (r, t) of this lane <-> A row m = m0 + wave*32 + mfma32_row(r, h), B row n = n0 + t*32 + l31
+    if (MODE == W_SUMS) {
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + mfma32_row(r, h), n = n0 + t * 32 + l31;
+                const float ok = (m < a.M && n < a.N) ? 1.f : 0.f;
+                p0 = fmaf(ok, fexp2(acc[t][r] * a.k0), p0);
+                p1 = fmaf(ok, fexp2(acc[t][r] * a.k1), p1);
+            }
+        const double v0 = wave_sum_d((double)p0), v1 = wave_sum_d((double)p1);
+        if (lane == 0) {
+            const int slot = (int)(((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) % SGA_SLOTS);
+            atomicAdd(a.sums + 8 * (1 + slot) + a.fam * 2 + 0, v0);
+            atomicAdd(a.sums + 8 * (1 + slot) + a.fam * 2 + 1, v1);
+        }
+    } else if (MODE == W_COEF) {
+        const float inv = 1.f / coef_bound(a.gs, a.fam, a.k0, a.k1, a.it0, a.it1);
+        const float c0 = (float)(a.gs[a.fam * 2 + 0] * (double)a.it0) * inv, c1 = (float)(a.gs[a.fam * 2 + 1] * (double)a.it1) * inv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + t * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + mfma32_row(r, h);
+                if (m < a.M && n < a.N) a.cout[(size_t)m * a.ldc + n] = (f16)(c0 * fexp2(acc[t][r] * a.k0) + c1 * fexp2(acc[t][r] * a.k1));
+            }
+        }
+    } else {
+        const float alpha = coef_bound(a.gs, a.fam, a.k0, a.k1, a.it0, a.it1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + t * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + mfma32_row(r, h);
+                if (m < a.M && n < a.N) atomicAdd(a.out + (size_t)m * a.ldo + n, alpha * acc[t][r]);
+            }
+        }
+    }
+}
+
+// Z fp32 [R][Dp] -> Zh fp16 [R][Dp] and ZhT fp16 [Dp][ldt] (column of packed row r: r + shift of its segment)
+struct PrepArgs { const float* Z; int R, Dp; f16* Zh; f16* ZhT; long ldt; int seg_end[4]; int shift[4]; };
+__global__ __launch_bounds__(256) void wide16_prepare_kernel(PrepArgs a) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, d0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, d = d0 + tx;
+        float v = 0.f;
+        if (r < a.R && d < a.Dp) {
+            v = a.Z[(size_t)r * a.Dp + d];
+            a.Zh[(size_t)r * a.Dp + d] = (f16)v;
+        }
+        tile[ty * 16 + i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = d0 + ty * 16 + i, r = r0 + tx;
+        if (r < a.R && d < a.Dp) {
+            const int sg = (r >= a.seg_end[0]) + (r >= a.seg_end[1]) + (r >= a.seg_end[2]);
+            a.ZhT[(size_t)d * a.ldt + r + a.shift[sg]] = (f16)tile[tx][ty * 16 + i];
+        }
+    }
+}
+
+inline int pad8(int n) { return (n + 7) / 8 * 8; }
+// padded column of the first row of each segment of ZhT
+struct SegCols { int x1, x2, n1, n2, ldt; };
+inline SegCols seg_cols(int A, int J1, int J2) {
+    SegCols s;
+    s.x1 = 0; s.x2 = pad8(A); s.n1 = s.x2 + pad8(A); s.n2 = s.n1 + pad8(J1); s.ldt = s.n2 + pad8(J2);
+    if (s.ldt < 8) s.ldt = 8;
+    return s;
+}
+
+template <int MODE>
+void launch(const W16Args& a, int ksplit, hipStream_t s) {
+    hipLaunchKernelGGL(wide16_kernel<MODE>, dim3((a.N + W_T - 1) / W_T, (a.M + W_T - 1) / W_T, ksplit), dim3(W_THREADS), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" long sga_wide16_ldt(int A, int J1, int J2) { return seg_cols(A, J1, J2).ldt; }
+
+extern "C" int sga_wide16_prepare(const float* Z, int Dp, int A, int J1, int J2, void* Zh, void* ZhT, void* stream) {
+    SGA_CHECK_ARG(Dp > 0 && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0, "sga_wide16_prepare: bad sizes (Dp must be a multiple of 8)");
+    const int R = 2 * A + J1 + J2;
+    if (R == 0) return SGA_OK;
+    SGA_CHECK_ARG(Z && Zh && ZhT, "sga_wide16_prepare: null pointer");
+    const SegCols sc = seg_cols(A, J1, J2);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(ZhT, 0, (size_t)Dp * sc.ldt * sizeof(f16), s) != hipSuccess) { sga_set_error("sga_wide16_prepare: memset failed"); return SGA_ERR_HIP; }
+    PrepArgs p{};
+    p.Z = Z; p.R = R; p.Dp = Dp; p.Zh = static_cast<f16*>(Zh); p.ZhT = static_cast<f16*>(ZhT); p.ldt = sc.ldt;
+    p.seg_end[0] = A; p.seg_end[1] = 2 * A; p.seg_end[2] = 2 * A + J1; p.seg_end[3] = R;
+    p.shift[0] = sc.x1 - 0; p.shift[1] = sc.x2 - A; p.shift[2] = sc.n1 - 2 * A; p.shift[3] = sc.n2 - (2 * A + J1);
+    hipLaunchKernelGGL(wide16_prepare_kernel, dim3((R + 63) / 64, (Dp + 63) / 64), dim3(256), 0, s, p);
+    SGA_CHECK_LAUNCH("sga_wide16_prepare");
+    return SGA_OK;
+}
+
+namespace {
+struct Blk { int own_row, n_own, oth_row, n_oth, fam; int own_col, oth_col; };     // packed rows of Zh / padded columns of ZhT
+inline void four_blocks(Blk (&b)[4], int A, int J1, int J2) {
+    const SegCols sc = seg_cols(A, J1, J2);
+    const int x1 = 0, x2 = A, n1 = 2 * A, n2 = 2 * A + J1;
+    b[0] = Blk{x1, A, n1, J1, 0, sc.x1, sc.n1};       // s11   (losses.py:7 with e1i, e1j)
+    b[1] = Blk{x1, A, n2, J2, 1, sc.x1, sc.n2};       // s12   (:8   e1i, e2j)
+    b[2] = Blk{x2, A, n2, J2, 2, sc.x2, sc.n2};       // s22   (second call of calculate_prob_dist: e2i, e2j)
+    b[3] = Blk{x2, A, n1, J1, 3, sc.x2, sc.n1};       // s21
+}
+}  // namespace
+
+extern "C" int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, void* stream) {
+    SGA_CHECK_ARG(Zh && sums8 && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0 && tau0 > 0 && tau1 > 0, "sga_loss_neg_sums_f16: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = zero_slots(sums8, 8, s, "sga_loss_neg_sums_f16")) return rc;
+    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    Blk b[4];
+    four_blocks(b, A, J1, J2);
+    const f16* Z = static_cast<const f16*>(Zh);
+    for (int q = 0; q < 4; ++q) {
+        if (b[q].n_own == 0 || b[q].n_oth == 0) continue;
+        W16Args a{};
+        a.A = Z + (size_t)b[q].own_row * Dp; a.lda = Dp; a.M = b[q].n_own;
+        a.B = Z + (size_t)b[q].oth_row * Dp; a.ldb = Dp; a.N = b[q].n_oth;
+        a.K = Dp; a.kper = (Dp + W_KC - 1) / W_KC * W_KC;
+        a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.fam = b[q].fam; a.sums = sums8;
+        launch<W_SUMS>(a, 1, s);
+    }
+    fold_slots(sums8, 8, s);
+    SGA_CHECK_LAUNCH("sga_loss_neg_sums_f16");
+    return SGA_OK;
+}
+
+// bytes of stash for anchor-row blocks of `rows` anchors (one (X, N) block at a time: C [rows][pad8(J)] + C^T [J][pad8(rows)], fp16)
+extern "C" size_t sga_loss_neg_grad_f16_bytes(int A, int J1, int J2) {
+    const int J = J1 > J2 ? J1 : J2;
+    return sizeof(f16) * ((size_t)A * pad8(J) + (size_t)J * pad8(A)) + 256;
+}
+
+extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, int A, int J1, int J2, float tau0, float tau1,
+                                     const double* gs8, float* dZ, void* stash, size_t stash_bytes, void* stream) {
+    SGA_CHECK_ARG(Zh && ZhT && gs8 && dZ && stash && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_neg_grad_f16: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    const int Jmax = J1 > J2 ? J1 : J2;
+    // anchor rows per pass so that C + C^T of one block fit the workspace
+    auto need = [&](size_t r) { return sizeof(f16) * (r * pad8(Jmax) + (size_t)Jmax * pad8((int)r)) + 256; };
+    size_t rows = A;
+    while (rows > 128 && need(rows) > stash_bytes) rows = (rows / 2 + 127) / 128 * 128;
+    SGA_CHECK_ARG(need(rows) <= stash_bytes, "sga_loss_neg_grad_f16: workspace of %zu bytes holds fewer than %zu anchor rows for J = %d",
+                  stash_bytes, rows, Jmax);
+    const SegCols sc = seg_cols(A, J1, J2);
+    const f16* Z = static_cast<const f16*>(Zh);
+    const f16* ZT = static_cast<const f16*>(ZhT);
+    Blk b[4];
+    four_blocks(b, A, J1, J2);
+    const int ncu = sga_num_cus();
+    auto ksplit_for = [&](int M, int N, int K, int& kper) {
+        const int tiles = ((M + W_T - 1) / W_T) * ((N + W_T - 1) / W_T);
+        int ks = (2 * ncu + tiles - 1) / tiles;
+        const int kmax = (K + 511) / 512;                      // at least 512 of K per split
+        if (ks > kmax) ks = kmax;
+        if (ks < 1) ks = 1;
+        kper = ((K + ks - 1) / ks + W_KC - 1) / W_KC * W_KC;
+        return (K + kper - 1) / kper;
+    };
+    for (int lo = 0; lo < A; lo += (int)rows) {
+        const int ns = (lo + (int)rows < A ? (int)rows : A - lo);
+        for (int q = 0; q < 4; ++q) {
+            const int J = b[q].n_oth;
+            if (J == 0) continue;
+            f16* C = static_cast<f16*>(stash);                               // [ns][pad8(J)]   anchor-major
+            f16* CT = C + ((size_t)ns * pad8(J) + 7) / 8 * 8;                // [J][pad8(ns)]   negative-major
+            W16Args a{};
+            a.K = Dp; a.kper = (Dp + W_KC - 1) / W_KC * W_KC;
+            a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1; a.gs = gs8; a.fam = b[q].fam;
+            // C: rows = anchors of the block, lanes along the negatives
+            a.A = Z + (size_t)(b[q].own_row + lo) * Dp; a.lda = Dp; a.M = ns;
+            a.B = Z + (size_t)b[q].oth_row * Dp; a.ldb = Dp; a.N = J;
+            a.cout = C; a.ldc = pad8(J);
+            launch<W_COEF>(a, 1, s);
+            // C^T: rows = negatives, lanes along the anchors
+            a.A = Z + (size_t)b[q].oth_row * Dp; a.M = J;
+            a.B = Z + (size_t)(b[q].own_row + lo) * Dp; a.N = ns;
+            a.cout = CT; a.ldc = pad8(ns);
+            launch<W_COEF>(a, 1, s);
+            // dZ[anchors] += alpha C Z[negatives]          (B operand: ZhT rows = columns d, k = negative)
+            W16Args g{};
+            g.k0 = a.k0; g.k1 = a.k1; g.it0 = a.it0; g.it1 = a.it1; g.gs = gs8; g.fam = b[q].fam;
+            g.A = C; g.lda = pad8(J); g.M = ns;
+            g.B = ZT + b[q].oth_col; g.ldb = sc.ldt; g.N = Dp;
+            g.K = J;
+            g.out = dZ + (size_t)(b[q].own_row + lo) * Dp; g.ldo = Dp;
+            int ks = ksplit_for(g.M, g.N, g.K, g.kper);
+            launch<W_GEMM>(g, ks, s);
+            // dZ[negatives] += alpha C^T Z[anchors of the block]
+            g.A = CT; g.lda = pad8(ns); g.M = J;
+            g.B = ZT + b[q].own_col + lo; g.N = Dp;
+            g.K = ns;
+            g.out = dZ + (size_t)b[q].oth_row * Dp;
+            ks = ksplit_for(g.M, g.N, g.K, g.kper);
+            launch<W_GEMM>(g, ks, s);
+        }
+    }
+    SGA_CHECK_LAUNCH("sga_loss_neg_grad_f16");
+    return SGA_OK;
+}

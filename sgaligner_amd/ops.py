@@ -39,21 +39,24 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-MFMA_MODES = {'f32': 0, 'bf16x3': 1}
+MFMA_MODES = {'f32': 0, 'bf16x3': 1, 'f16': 2}
+_MFMA_NAMES = {v: k for k, v in MFMA_MODES.items()}
 
 
 def set_mfma_mode(mode: str) -> str:
-    """Arithmetic of the MFMA kernels that have a split-precision variant: 'f32' (exact fp32 MFMA: the default and every
-    headline number) or 'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate;
-    ~1e-5 relative error).  Returns the previous mode.  SGA_MFMA_MODE=bf16x3 in the environment sets the initial mode."""
+    """Arithmetic of the MFMA kernels that have a reduced-precision variant: 'f32' (exact fp32 MFMA: the default and every
+    headline number); 'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate; ~1e-5
+    relative error; PointNet forward + the fused 100-d loss sweeps); 'f16' (opt-in, BASELINE.json configs[4]: loss tables WIDER than
+    128 columns and the similarity ranking take fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; 100-d tables
+    and everything else stay exact fp32).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial mode."""
     if mode not in MFMA_MODES:
         raise ValueError(f"sgaligner_amd: mfma mode must be one of {sorted(MFMA_MODES)} (got {mode!r})")
     old = _lib.lib().sga_set_mfma_mode(MFMA_MODES[mode])
-    return 'bf16x3' if old == 1 else 'f32'
+    return _MFMA_NAMES.get(old, 'f32')
 
 
 def get_mfma_mode() -> str:
-    return 'bf16x3' if _lib.lib().sga_get_mfma_mode() == 1 else 'f32'
+    return _MFMA_NAMES.get(_lib.lib().sga_get_mfma_mode(), 'f32')
 
 
 # ------------------------------------------------------------------------------------------ PointNet
@@ -462,7 +465,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
         dev = tables[0].device
         s = index_sets
         T = tables[0].shape[0]
-        zs, nrms, dps = [], [], []
+        zs, nrms, dps, zhs, zts = [], [], [], [], []
+        f16 = get_mfma_mode() == 'f16'
         sums = torch.empty((nt, 8), device=dev, dtype=torch.float64)
         st = _stream()
         slots = 1 + L.sga_loss_slots()          # scalar accumulators are [result | per-wave slots] (contrastive.hip)
@@ -473,9 +477,25 @@ class ContrastiveTermsFn(torch.autograd.Function):
             nrm = torch.empty((s.R,), device=dev, dtype=torch.float32)
             _lib.check(L.sga_loss_gather(_p(e), T, d, _p(s.idx), s.R, _p(z), dp, _p(nrm), st), 'sga_loss_gather')
             sk = torch.empty((slots * 8,), device=dev, dtype=torch.float64)
-            _lib.check(L.sga_loss_neg_sums(_p(z), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), st), 'sga_loss_neg_sums')
+            zh = zt = None
+            if dp > 128 and f16:
+                # opt-in fp16-input MFMA for wide tables (configs[4]): fp16 copies of the normalised table, once per step
+                ldt = int(L.sga_wide16_ldt(s.A, s.J1, s.J2))
+                zh = torch.empty((max(s.R, 1), dp), device=dev, dtype=torch.float16)
+                zt = torch.empty((dp, ldt), device=dev, dtype=torch.float16)
+                _lib.check(L.sga_wide16_prepare(_p(z), dp, s.A, s.J1, s.J2, _p(zh), _p(zt), st), 'sga_wide16_prepare')
+                ev = None
+                if KERNEL_EVENTS is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                _lib.check(L.sga_loss_neg_sums_f16(_p(zh), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), st), 'sga_loss_neg_sums_f16')
+                if ev is not None:
+                    ev[1].record()
+                    KERNEL_EVENTS.setdefault('wide16_sums', []).append(ev + ((s.A, s.J1, s.J2, dp),))
+            else:
+                _lib.check(L.sga_loss_neg_sums(_p(z), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), st), 'sga_loss_neg_sums')
             sums[k].copy_(sk[:8])
-            zs.append(z); nrms.append(nrm); dps.append(dp)
+            zs.append(z); nrms.append(nrm); dps.append(dp); zhs.append(zh); zts.append(zt)
         out = torch.empty((slots * (nt + 2 * m),), device=dev, dtype=torch.float64)
         zarr = _ptr_array(zs)
         dparr = (_ct.c_int * nt)(*dps)
@@ -483,7 +503,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
                    'sga_loss_anchor_fwd')
         ctx.s, ctx.alpha, ctx.dps, ctx.nt = s, float(alpha), dps, nt
         ctx.shapes = [tuple(t.shape) for t in tables]
-        ctx.save_for_backward(sums, *zs, *nrms)
+        ctx.f16 = [zh is not None for zh in zhs]
+        ctx.save_for_backward(sums, *zs, *nrms, *[t for t in zhs if t is not None], *[t for t in zts if t is not None])
         return out[:nt + 2 * m].float()
 
     @staticmethod
@@ -491,7 +512,11 @@ class ContrastiveTermsFn(torch.autograd.Function):
         L = _lib.lib()
         s, nt, dps = ctx.s, ctx.nt, ctx.dps
         sums, *rest = ctx.saved_tensors
-        zs, nrms = rest[:nt], rest[nt:]
+        zs, nrms = rest[:nt], rest[nt:2 * nt]
+        n16 = sum(ctx.f16)
+        h_it, t_it = iter(rest[2 * nt:2 * nt + n16]), iter(rest[2 * nt + n16:])
+        zhs = [next(h_it) if f else None for f in ctx.f16]
+        zts = [next(t_it) if f else None for f in ctx.f16]
         dev = sums.device
         st = _stream()
         coef = gout.contiguous().float()
@@ -520,7 +545,22 @@ class ContrastiveTermsFn(torch.autograd.Function):
             if KERNEL_EVENTS is not None and dp <= 128:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            if dp > 128 and WIDE_STASH:
+            if zhs[k] is not None:
+                # opt-in fp16-input MFMA (configs[4]): S and both gradient GEMMs on v_mfma_f32_32x32x16_f16 (csrc/wide16.hip)
+                need = int(L.sga_loss_neg_grad_f16_bytes(A, s.J1, s.J2))
+                have = max(min(need, STASH_BYTES), int(L.sga_loss_neg_grad_f16_bytes(min(A, 128), s.J1, s.J2)))
+                stash = torch.empty((have,), device=dev, dtype=torch.uint8)
+                ev16 = None
+                if KERNEL_EVENTS is not None:
+                    ev16 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev16[0].record()
+                _lib.check(L.sga_loss_neg_grad_f16(_p(zhs[k]), _p(zts[k]), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz),
+                                                   _p(stash), have, st), 'sga_loss_neg_grad_f16')
+                if ev16 is not None:
+                    ev16[1].record()
+                    KERNEL_EVENTS.setdefault('wide16_grad', []).append(ev16 + ((A, s.J1, s.J2, dp),))
+                del stash
+            elif dp > 128 and WIDE_STASH:
                 # wide rows: S is the expensive part -> coefficient stash + GEMMs, S computed once (csrc/contrastive.hip, sweep_coef_kernel)
                 need = int(L.sga_loss_neg_grad_wide_floats(A, s.J1, s.J2))
                 have = max(min(need, STASH_BYTES // 4), 2 * (s.J1 + s.J2) * min(A, 32))
