@@ -36,14 +36,19 @@ CONFIGS = {
     'c2': {'ref': 'BASELINE.json configs[1]', 'n_obj': 64, 'n_pts': 512, 'pairs_per_gpu': 512, 'scaling': 'weak'},
     'c3': {'ref': 'BASELINE.json configs[2] (north-star target)', 'n_obj': 128, 'n_pts': 512, 'global_pairs': 4096,
            'scaling': 'strong'},
+    # configs[4] (stress shape; the config names no pair count: 32 pairs per GPU = 16 384 objects, 33.5 M points): 1024-d embeddings,
+    # loss + ranking GEMMs on fp16-input MFMA (ops.set_mfma_mode('f16'), csrc/wide16.hip); the encoder stays exact fp32
+    'c5': {'ref': 'BASELINE.json configs[4] (stress shape)', 'n_obj': 256, 'n_pts': 2048, 'pairs_per_gpu': 32, 'scaling': 'weak',
+           'emb_dim': 1024, 'mfma_mode': 'f16'},
 }
+PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) dense peak
 PEAK_HBM_GBS = 8000.0
 PMC_TRAFFIC_FILE = 'r03_pmc_traffic.csv'   # written by tools/pmc_traffic.sh on the GPU box, committed under profiles/
 HITS_PAIRS = 8                   # fixed val-style subsample for the Hits@K half of the metric
 
 
-def cpu_baseline(n_obj, n_pts, seconds_budget=20.0):
+def cpu_baseline(n_obj, n_pts, seconds_budget=20.0, emb_dim=100):
     """The oracle (CPU restatement pinned to the reference by tests/golden) on this box's host cores:
     fwd + loss + bwd at the reference's native batch size b=2 (configs/scan3r/scan3r_ground_truth.yaml:27)
     with the same (objects, points, modules) as the GPU workload.  Also returns the oracle's embeddings-based
@@ -56,7 +61,7 @@ def cpu_baseline(n_obj, n_pts, seconds_budget=20.0):
     torch.set_num_threads(cores)
     b = 2
     dd = make_batch(b, n_obj, n_pts, seed=43, device='cpu')
-    params = O.init_params(MODULES, seed=42)
+    params = O.init_params(MODULES, seed=42, emb_dim=emb_dim)
     O.train_step(params, dd, MODULES)                      # warm-up
     times = []
     t_end = time.time() + seconds_budget
@@ -72,7 +77,7 @@ def cpu_baseline(n_obj, n_pts, seconds_budget=20.0):
     except OSError:
         pass
     return {'value': b / med, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model,
-            'sample': f'oracle fwd+loss+bwd, b={b} pairs x {n_obj} obj x {n_pts} pts, {"+".join(MODULES)}, '
+            'sample': f'oracle fwd+loss+bwd, b={b} pairs x {n_obj} obj x {n_pts} pts, emb_dim {emb_dim}, {"+".join(MODULES)}, '
                       f'{len(times)} iterations, median {med*1e3:.1f} ms, torch {torch.__version__} CPU, {cores} threads '
                       f'(best of a thread-count sweep; host has {os.cpu_count()} hardware threads)'}
 
@@ -185,6 +190,25 @@ def roofline_objects(events, world):
                       'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                       'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed,
                       'executed_tflops': round(executed / (avg_ms * 1e-3) / 1e12, 2)})
+    for key, what, mult in (('wide16_grad', 'loss: negatives backward on fp16-input MFMA -- coefficient tiles in both orientations + both '
+                             'gradient GEMMs, every table', 2.0),
+                            ('wide16_sums', 'loss: global sums on fp16-input MFMA, every table', 1.0)):
+        evs = events.get(key, [])
+        if not evs:
+            continue
+        # one event pair per table per step; algorithmic FLOPs: forward = 2 Dp * 2A (J1 + J2) per table, backward = 2 x that
+        total_ms = sum(a_.elapsed_time(b_) for a_, b_, _ in evs)
+        widths = [shp[3] for _, _, shp in evs]
+        n_steps = max(1, events.get('_steps', 0)) or 1
+        alg = sum(mult * 2.0 * dp * 2.0 * A * (J1 + J2) for _, _, (A, J1, J2, dp) in evs) / n_steps
+        step_ms = total_ms / n_steps
+        ach = alg / (step_ms * 1e-3) / 1e12
+        roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4),
+                      'traffic': None, 'kernel': f'wide16_kernel ({what}; widths {sorted(set(widths))})', 'launch_groups_timed': len(evs),
+                      'avg_launch_ms': round(step_ms, 4), 'step_ms': round(step_ms, 4), 'algorithmic_flops_per_launch': alg,
+                      'executed_flops_per_launch': alg * (2.0 if mult == 2.0 else 1.0),
+                      'note': 'one entry = the launches of ONE step over all tables (4 x 2 coefficient + 4 x 2 GEMM launches per table '
+                              'backward; 4 launches per table forward), HIP events around each table\'s group'})
     roofs.sort(key=lambda r: -r['step_ms'])
     return roofs
 
@@ -194,7 +218,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', choices=['auto', 'c2', 'c3'], default=os.environ.get('SGA_BENCH_CONFIG', 'auto'))
+    ap.add_argument('--config', choices=['auto', 'c2', 'c3', 'c5'], default=os.environ.get('SGA_BENCH_CONFIG', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hits', action='store_true')
     ap.add_argument('--no-attr', action='store_true', help='skip the extra point+gat+rel+attr (M = 4) measurement (N = 1)')
@@ -223,7 +247,10 @@ def main():
         lo, hi = sdist.shard_range(cfg['global_pairs'], rank, world)
         my_pairs, total_pairs = hi - lo, cfg['global_pairs']
 
-    steps = AlignerSteps(MODULES, device=dev, seed=42)
+    if cfg.get('mfma_mode'):
+        ops.set_mfma_mode(cfg['mfma_mode'])
+        args.no_bf16x3 = args.no_c2 = args.no_attr = True              # the extras belong to the exact-fp32 configurations
+    steps = AlignerSteps(MODULES, device=dev, seed=42, emb_dim=cfg.get('emb_dim', 100))
     dd = make_batch_fast(my_pairs, n_obj, n_pts, seed=43 + rank, device=dev)
     if world > 1 and cfg['scaling'] == 'strong' and cfg['global_pairs'] % world == 0:
         # every rank's shard has the same shape (uniform synthetic scenes): the step needs no layout all-gather / host read-back
@@ -262,6 +289,7 @@ def main():
     ops.KERNEL_EVENTS = {}
     sdist.COLLECTIVE_EVENTS = [] if world > 1 else None
     elapsed, med_ms, loss_dict = timed(steps, dd, 0, args.steps)
+    ops.KERNEL_EVENTS['_steps'] = args.steps
     events = ops.KERNEL_EVENTS
     ops.KERNEL_EVENTS = None
     coll_events, sdist.COLLECTIVE_EVENTS = sdist.COLLECTIVE_EVENTS, None
@@ -317,6 +345,7 @@ def main():
             ops.KERNEL_EVENTS = {}
             n2 = max(5, min(args.steps, 20))
             el2, med2, _ = timed(steps, dd2, 0, n2)
+            ops.KERNEL_EVENTS['_steps'] = n2
             ev2, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
             extra_c2 = {'workload': f'{c2["ref"]}: {c2["pairs_per_gpu"]} pairs x {c2["n_obj"]} objects x {c2["n_pts"]} pts, modules '
                                     f'{"+".join(MODULES)}, batch-global loss', 'value': round(c2['pairs_per_gpu'] * n2 / el2, 2), 'unit': 'pairs/s',
@@ -365,6 +394,8 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        if cfg.get('mfma_mode') == 'f16':       # the configuration is ABOUT the fp16 GEMMs: they lead, whatever their share of the step
+            roofs.sort(key=lambda r: (0 if 'wide16_kernel (loss: negatives backward' in r['kernel'] else 1, -r['step_ms']))
         roof = roofs[0] if roofs else None
         per = f'{my_pairs} pairs/GPU' if world > 1 else f'{my_pairs} pairs'
         line = {
@@ -372,11 +403,13 @@ def main():
             'value': round(total_pairs * args.steps / elapsed, 2), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'median_ms_per_step': round(med_ms, 3), 'value_median': round(total_pairs / (med_ms * 1e-3), 2),
-            'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None,
+            'dtype': 'f16-in/f32-acc (loss + ranking GEMMs on wide tables); f32 encoder' if cfg.get('mfma_mode') == 'f16' else 'f32', 'data': 'synthetic',
             'config': {'workload': f'{cfg["ref"]}: {total_pairs} synthetic subscan pairs ({per}) x {n_obj} objects x '
                                    f'{n_pts} pts, modules {"+".join(MODULES)} (P+S+R), batch-global ICL/IAL loss over '
                                    f'{total_pairs} pairs', 'name': cname, 'global_pairs': total_pairs, 'pairs_per_gpu': my_pairs,
-                       'objects_per_scene': n_obj, 'points_per_object': n_pts, 'modules': MODULES, 'parallelism': f'dp{world}',
+                       'objects_per_scene': n_obj, 'points_per_object': n_pts, 'emb_dim': cfg.get('emb_dim', 100), 'modules': MODULES,
+                       'parallelism': f'dp{world}',
                        'loss': loss_val, 'peak_hbm_gib': round(peak_gib, 2)},
             'roofline': roof,
             'roofline_other': roofs[1:],
@@ -394,7 +427,7 @@ def main():
         if not args.no_hits:
             line['hits_at_1'] = hits_at_k(steps, n_obj, n_pts, dev)
         if not args.no_cpu_baseline and world == 1:         # the CPU leg runs on rank 0 of a one-GPU run only
-            line['cpu_baseline'] = cpu_baseline(n_obj, n_pts)
+            line['cpu_baseline'] = cpu_baseline(n_obj, n_pts, emb_dim=cfg.get('emb_dim', 100))
             line['speedup_vs_cpu_baseline'] = round(line['value'] / line['cpu_baseline']['value'], 1)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -179,6 +179,7 @@ int sga_group_loss_bwd(const float* const* Z, int M, const float* beta, int A, i
  * rank of q_tgt[q] among its pair's other objects (q_tgt NULL or out of the pair: -1); topk_*[q,:K] its K nearest
  * others (pair-local index, distance), ascending, ties by index.  K <= 8, <= 512 objects per pair. */
 size_t sga_simrank_workspace_bytes(int T);
+size_t sga_simrank_workspace_bytes_f16(int T, int D);   /* workspace for f16 != 0: + the normalised fp16 table when D > 416 */
 int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_pair, const int32_t* blk_row, int n_blocks, int B,
                 int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,
                 int32_t* topk_idx, float* topk_sim, int f16, void* workspace, size_t workspace_bytes, void* stream);

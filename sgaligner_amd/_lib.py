@@ -42,6 +42,7 @@ SIGNATURES = {
     'sga_elu_fwd': (I, [P, P, c_size_t, P]),
     'sga_elu_bwd': (I, [P, P, P, c_size_t, P]),
     'sga_simrank_workspace_bytes': (c_size_t, [I]),
+    'sga_simrank_workspace_bytes_f16': (c_size_t, [I, I]),
     'sga_simrank': (I, [P, I, I, P, P, P, I, I, I, P, P, I, I, P, P, P, I, P, c_size_t, P]),
     'sga_pair_metrics': (I, [P, P, P, I, P, P, P, I, P, P]),
     'sga_gemm_ex': (I, [I, I, I, I, I, P, c_long, P, c_long, P, c_long, P, I, P, c_long, P]),

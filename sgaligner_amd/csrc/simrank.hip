@@ -27,6 +27,18 @@ constexpr int SR_MAXPER = 8;          // objects per lane -> up to 512 objects p
 constexpr int SR_ROWS = 64;           // query rows per workgroup (4 waves x 16)
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// emb / ||emb|| as fp16, once per call: [T][Dp] with Dp = D padded to 32 (zero filled) -- the operand table of simrank_stream16_kernel
+__global__ void normalize_f16_kernel(const float* __restrict__ E, int T, int D, int Dp, _Float16* __restrict__ Eh) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int t = blockIdx.x * wpb + (threadIdx.x >> 6); t < T; t += gridDim.x * wpb) {
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) { const float v = E[(size_t)t * D + d]; ss += v * v; }
+        const float inv = 1.f / sqrtf(wave_sum(ss));      // no eps, as in the reference (:126)
+        for (int d = lane; d < Dp; d += 64) Eh[(size_t)t * Dp + d] = (_Float16)(d < D ? E[(size_t)t * D + d] * inv : 0.f);
+    }
+}
 
 __global__ void row_inv_norm_kernel(const float* __restrict__ E, int T, int D, float* __restrict__ inv) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
@@ -246,6 +258,46 @@ __global__ __launch_bounds__(256) void simrank_stream_kernel(SimArgs a) {
     rank_strip(a, S, NP, my_q, row0, o0, n, lane);
 }
 
+// fp16 form of the streaming kernel (BASELINE.json configs[4], "MFMA similarity GEMM at fp16"): both operands come from the
+// normalised fp16 table written ONCE per call by normalize_f16_kernel, as 16-byte groups of 8 halfs feeding v_mfma_f32_16x16x32_f16 --
+// half the bytes and an eighth of the MFMA instructions of the fp32 stream per K (the first version converted fp32 rows to half
+// inside this loop, twice per tile, and was slower than exact fp32: 2.84 vs 2.15 ms at 4096 queries on the 3072-d table).
+__global__ __launch_bounds__(256) void simrank_stream16_kernel(SimArgs a, const _Float16* __restrict__ Eh, int Dp) {
+    extern __shared__ float strip[];                       // [4 waves][16][npad_max]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int b = a.blk_pair[blockIdx.x];
+    const int o0 = a.pair_off[b], n = a.pair_off[b + 1] - o0;
+    const int row0 = a.blk_row[blockIdx.x] * SR_ROWS + wave * 16;
+    if (row0 >= n) return;
+    const int my_row = row0 + l15;
+    const int my_q = (my_row < n && g4 == 0) ? a.obj_query[o0 + my_row] : -1;
+    if (__ballot(my_q >= 0) == 0ull) return;
+    const int NP = a.npad_max;
+    float* S = strip + (size_t)wave * 16 * NP;
+    const _Float16* __restrict__ ap = Eh + (size_t)(o0 + min(my_row, n - 1)) * Dp + 8 * g4;
+    const int nk = Dp / 32;
+    for (int j0 = 0; j0 < n; j0 += 32) {                   // two 16-column tiles per pass: two independent accumulation chains
+        const _Float16* __restrict__ bp0 = Eh + (size_t)(o0 + min(j0 + l15, n - 1)) * Dp + 8 * g4;
+        const _Float16* __restrict__ bp1 = Eh + (size_t)(o0 + min(j0 + 16 + l15, n - 1)) * Dp + 8 * g4;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 4
+        for (int q = 0; q < nk; ++q) {
+            const f16x8 av = *reinterpret_cast<const f16x8*>(ap + 32 * q);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(bp0 + 32 * q);
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(bp1 + 32 * q);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b1, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            S[(4 * g4 + r) * NP + j0 + l15] = 1.f - acc0[r];
+            if (j0 + 16 < NP - 1) S[(4 * g4 + r) * NP + j0 + 16 + l15] = 1.f - acc1[r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    rank_strip(a, S, NP, my_q, row0, o0, n, lane);
+}
+
 // Per pair (one wave): Hits@1..5 counts, sum of reciprocal ranks, and SGAR for the modes '2', '50', '100'
 // (utils/alignment.py:13-25,27-57): the anchors' top-1 predictions are ordered by ascending distance (stable), and a mode is
 // satisfied when all of the first 2 / first half / all of them are correct.
@@ -291,6 +343,10 @@ __global__ void pair_metrics_kernel(const int* __restrict__ rank, const int* __r
     }
 }
 
+}  // namespace
+extern "C" size_t sga_simrank_workspace_bytes_f16(int T, int D);
+namespace {
+
 template <bool F16>
 int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_pair, const int32_t* blk_row, int n_blocks, int B,
                    int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank, int32_t* topk_idx,
@@ -322,7 +378,14 @@ int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const 
     else if (nkq <= 13) launch(simrank_staged_kernel<13, F16>, strip_b + tile_b(13));    // 200
     else if (nkq <= 20) launch(simrank_staged_kernel<20, F16>, strip_b + tile_b(20));    // 300 (P+S+R joint)
     else if (nkq <= 26) launch(simrank_staged_kernel<26, F16>, strip_b + tile_b(26));    // 400 (P+S+R+A joint)
-    else launch(simrank_stream_kernel<F16>, strip_b);                                    // wider: both operands streamed per wave
+    else if (F16) {                                                                       // wider, fp16: operands from the fp16 table
+        const int Dp = (D + 31) / 32 * 32;
+        SGA_CHECK_ARG(workspace_bytes >= sga_simrank_workspace_bytes_f16(T, D), "%s: workspace too small for the fp16 table (sga_simrank_workspace_bytes_f16)", who);
+        _Float16* Eh = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(workspace) + (sga_simrank_workspace_bytes(T) + 255) / 256 * 256);
+        hipLaunchKernelGGL(normalize_f16_kernel, dim3(g), dim3(256), 0, s, E, T, D, Dp, Eh);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(simrank_stream16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_b);
+        hipLaunchKernelGGL(simrank_stream16_kernel, dim3(n_blocks), dim3(256), strip_b, s, a, Eh, Dp);
+    } else launch(simrank_stream_kernel<F16>, strip_b);                                   // wider: both operands streamed per wave
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { sga_set_error("%s: launch failed: %s", who, hipGetErrorString(e_)); return SGA_ERR_HIP; }
     return SGA_OK;
@@ -331,6 +394,11 @@ int simrank_launch(const float* E, int T, int D, const int32_t* pair_off, const 
 }  // namespace
 
 extern "C" size_t sga_simrank_workspace_bytes(int T) { return (sizeof(float) + sizeof(int)) * (size_t)(T > 0 ? T : 1); }
+// f16 != 0 and D > 416: + the normalised fp16 copy of the table
+extern "C" size_t sga_simrank_workspace_bytes_f16(int T, int D) {
+    const size_t base = (sga_simrank_workspace_bytes(T) + 255) / 256 * 256;
+    return D > 416 ? base + sizeof(_Float16) * (size_t)(T > 0 ? T : 1) * (size_t)((D + 31) / 32 * 32) : base;
+}
 
 extern "C" int sga_simrank(const float* E, int T, int D, const int32_t* pair_off, const int32_t* blk_pair, const int32_t* blk_row, int n_blocks, int B,
                            int max_pair_objects, const int32_t* q_idx, const int32_t* q_tgt, int Q, int K, int32_t* rank,

@@ -998,9 +998,9 @@ def simrank(emb, pair_counts, q_idx, q_tgt, k: int, f16=None):
     rank = torch.empty((max(Q, 1),), device=dev, dtype=torch.int32)
     tk = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.int32)
     ts = torch.empty((max(Q, 1), max(k, 1)), device=dev, dtype=torch.float32)
-    nb = _lib.lib().sga_simrank_workspace_bytes(T)
+    use16 = (SIMRANK_F16 or get_mfma_mode() == 'f16') if f16 is None else bool(f16)
+    nb = _lib.lib().sga_simrank_workspace_bytes_f16(T, D) if use16 else _lib.lib().sga_simrank_workspace_bytes(T)
     ws = torch.empty((nb,), device=dev, dtype=torch.uint8)
-    use16 = SIMRANK_F16 if f16 is None else bool(f16)
     _lib.check(_lib.lib().sga_simrank(_p(emb), T, D, _p(lay.pair_off), _p(qb.blk_pair), _p(qb.blk_row), qb.n_blocks, lay.B, lay.nmax,
                                       _p(qb.q_idx), _p(qb.q_tgt), Q, k, _p(rank), _p(tk), _p(ts), int(use16), _p(ws), nb, _stream()),
                'sga_simrank')

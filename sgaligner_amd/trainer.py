@@ -17,13 +17,13 @@ from .utils import alignment
 
 
 class AlignerSteps:
-    def __init__(self, modules, rel_dim=41, attr_dim=164, zoom=0.1, device='cuda', seed=42, loss_group='global'):
+    def __init__(self, modules, rel_dim=41, attr_dim=164, zoom=0.1, device='cuda', seed=42, loss_group='global', emb_dim=100):
         if not torch.cuda.is_available() and str(device).startswith('cuda'):
             raise RuntimeError('sgaligner_amd.AlignerSteps: no HIP device; the product path has no CPU fallback')
         self.modules = list(modules)
         self.device = torch.device(device)
         torch.manual_seed(seed)                                   # identical replicas on every rank
-        self.model = MultiModalEncoder(modules=self.modules, rel_dim=rel_dim, attr_dim=attr_dim).to(self.device)
+        self.model = MultiModalEncoder(modules=self.modules, rel_dim=rel_dim, attr_dim=attr_dim, emb_dim=emb_dim).to(self.device)
         m = len(self.modules)
         self.multi_loss_layer_icl = CustomMultiLossLayer(loss_num=m, device=self.device).to(self.device)
         self.multi_loss_layer_ial = CustomMultiLossLayer(loss_num=m, device=self.device).to(self.device)

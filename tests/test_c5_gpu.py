@@ -130,3 +130,114 @@ def test_wide_table_stash_gradient_equals_multipass_sweep(D, stash_rows):
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert (a - b).abs().max() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+# ---- fp16-input / fp32-accumulate loss on wide tables (ops.set_mfma_mode('f16'), csrc/wide16.hip): BASELINE.json configs[4] -----------
+F16_TOL = 1e-2          # stated tolerance of the fp16-input path (11-bit operands): loss terms and gradients relative to their own maximum
+
+
+@pytest.mark.parametrize('D,stash_rows', [(264, None), (1024, None), (1024, 128), (136, None)])
+def test_f16_wide_loss_equals_fp32_wide_loss(D, stash_rows):
+    """The fp16-input kernels (S, coefficient stashes in both orientations, both gradient GEMMs on v_mfma_f32_32x32x16_f16) against
+    the exact-fp32 wide-table path on the same ragged batch: loss terms within 1e-2 (observed ~1e-3), gradients within 1e-2 of their
+    maximum; also with a workspace that forces several anchor-row blocks."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(9, 40, 4, seed=D, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    torch.manual_seed(D)
+    base = [torch.randn(T, D, device='cuda'), torch.randn(T, D, device='cuda') + 0.3]
+    cot = torch.rand(2 + 2, device='cuda') + 0.5
+    res = {}
+    keep = ops.STASH_BYTES
+    for mode in ('f32', 'f16'):
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        old = ops.set_mfma_mode(mode)
+        try:
+            if mode == 'f16' and stash_rows is not None:
+                s0 = ops.IndexSets.of(dd, 'cuda', T)
+                ops.STASH_BYTES = 2 * 2 * max(s0.J1, s0.J2) * (stash_rows + 8) + 4096
+            sums, s = ops.contrastive_terms(tabs, dict(dd))
+            (sums * cot).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_mfma_mode(old)
+            ops.STASH_BYTES = keep
+        res[mode] = (sums.detach().double(), [t.grad.double() for t in tabs])
+    assert ops.get_mfma_mode() == 'f32'
+    rel = ((res['f16'][0] - res['f32'][0]).abs() / res['f32'][0].abs().clamp_min(1e-12)).max().item()
+    assert rel < F16_TOL, rel
+    for a, b in zip(res['f16'][1], res['f32'][1]):
+        assert (a - b).abs().max().item() < F16_TOL * b.abs().max().item(), ((a - b).abs().max().item(), b.abs().max().item())
+        assert (a - b).abs().max().item() > 0          # the fp16 path really ran
+
+
+def test_c5_shape_two_pairs_f16_vs_fp64_oracle():
+    """B = 2 pairs of configs[4]'s scenes (256 objects each, 1024-d tables, P+S+R -> 3072-d joint): OverallLoss with the loss
+    GEMMs on fp16 inputs against the fp64 oracle -- loss terms and every table gradient within the fp16 tolerance."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    from sgaligner_amd.aligner import losses as L
+    from sgaligner_amd.aligner.sg_aligner import MultiModalFusion
+    from sgaligner_amd.synthetic import make_batch
+    mods = ['point', 'gat', 'rel']
+    D = 1024
+    dd = make_batch(2, 256, 1, seed=17)
+    T = int(dd['tot_obj_count'].sum())
+    assert T == 1024 and len(dd['e1i']) == 2 * 76
+    torch.manual_seed(5)
+    base = {k: torch.randn(T, D, dtype=torch.float64) for k in mods}
+    w0 = torch.tensor([[0.4], [1.3], [-0.2]], dtype=torch.float64)
+    lv1, lv2 = 0.2 * torch.randn(3, dtype=torch.float64), 0.2 * torch.randn(3, dtype=torch.float64)
+    eo = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    wo = w0.clone().requires_grad_(True)
+    out_o = dict(eo)
+    out_o['joint'] = O.fusion([eo[k] for k in mods], wo)
+    ref = O.overall_loss(out_o, dd, mods, lv1.clone().requires_grad_(True), lv2.clone().requires_grad_(True))
+    ref['loss'].backward()
+    e = {k: base[k].float().cuda().requires_grad_(True) for k in mods}
+    fus = MultiModalFusion(3).cuda()
+    ial, icl = L.CustomMultiLossLayer(3).cuda(), L.CustomMultiLossLayer(3).cuda()
+    with torch.no_grad():
+        fus.weight.copy_(w0.float()); ial.log_vars.copy_(lv1.float()); icl.log_vars.copy_(lv2.float())
+    out = dict(e)
+    out['joint'] = fus([e[k] for k in mods])
+    fn = L.OverallLoss(ial, icl, 'cuda', {'zoom': 0.1, 'wt_align_loss': 1.0, 'wt_contrastive_loss': 1.0, 'modules': mods})
+    old = ops.set_mfma_mode('f16')
+    try:
+        res = fn(out, dd)
+        res['loss'].backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_mfma_mode(old)
+    for key in ('loss', 'icl_loss_unimodal', 'icl_loss_multimodal', 'ial_loss'):
+        r = float(ref[key])
+        assert abs(float(res[key]) - r) < F16_TOL * max(1.0, abs(r)), (key, float(res[key]), r)
+    for k in mods:
+        gref = eo[k].grad
+        err = (e[k].grad.cpu().double() - gref).abs().max().item()
+        assert err < F16_TOL * gref.abs().max().item(), (k, err, gref.abs().max().item())
+    assert (fus.weight.grad.cpu().double() - wo.grad).abs().max().item() < F16_TOL * max(1e-3, wo.grad.abs().max().item())
+
+
+def test_simrank_f16_stream_table_converted_once():
+    """Ranking on a 3072-d table of 512-object pairs with fp16 inputs: the normalised rows are converted to half ONCE
+    (normalize_f16_kernel) and streamed as 16-byte groups into v_mfma_f32_16x16x32_f16.  Distances within 1e-2 of exact fp32; ranks and
+    nearest neighbours equal wherever the fp32 margin exceeds the fp16 error; also pairs whose size is not a multiple of 32 / 16."""
+    from sgaligner_amd import ops
+    torch.manual_seed(3)
+    counts = np.array([512, 37, 300, 16, 33])
+    T = int(counts.sum())
+    emb = torch.randn(T, 3072, device='cuda') + 0.5 * torch.randn(1, 3072, device='cuda')
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    q_idx = np.concatenate([np.arange(offs[b], offs[b] + min(counts[b], 40)) for b in range(len(counts))]).astype(np.int32)
+    q_tgt = np.concatenate([offs[b] + (np.arange(min(counts[b], 40)) * 7 + 3) % counts[b] for b in range(len(counts))]).astype(np.int32)
+    r32, k32, s32, _ = ops.simrank(emb, counts, q_idx, q_tgt, 3, f16=False)
+    r16, k16, s16, _ = ops.simrank(emb, counts, q_idx, q_tgt, 3, f16=True)
+    torch.cuda.synchronize()
+    assert (s32 - s16).abs().max().item() < 1e-2 and (s32 - s16).abs().max().item() > 0
+    # a rank can only move when another object's distance is within the fp16 error of the target's: compare where the top-1 margin is clear
+    gap = (s32[:, 1] - s32[:, 0]).cpu().numpy()
+    same = (k32[:, 0] == k16[:, 0]).cpu().numpy()
+    assert same[gap > 5e-3].all()
+    assert (r32 - r16).abs().float().mean().item() < 0.5

@@ -9,6 +9,8 @@ from sgaligner_amd.aligner.losses import CustomMultiLossLayer, OverallLoss
 from sgaligner_amd.aligner.sg_aligner import MultiModalEncoder
 from sgaligner_amd.synthetic import make_batch_fast
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+MODE = sys.argv[2] if len(sys.argv) > 2 else 'f32'          # f32 | f16 (fp16-input loss GEMMs, csrc/wide16.hip)
+ops.set_mfma_mode(MODE)
 mods = ['point', 'gat', 'rel']
 torch.manual_seed(2)
 model = MultiModalEncoder(modules=mods, rel_dim=41, attr_dim=164, emb_dim=1024).cuda()
@@ -35,7 +37,7 @@ for _ in range(n):
     res = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print(f'configs[4] shape, {B} pairs x 256 objects x 2048 pts, D = 1024, P+S+R: {dt * 1e3:.1f} ms/step = {B / dt:.1f} pairs/s, '
+print(f'[{MODE}] configs[4] shape, {B} pairs x 256 objects x 2048 pts, D = 1024, P+S+R: {dt * 1e3:.1f} ms/step = {B / dt:.1f} pairs/s, '
       f'peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB, loss {float(res["loss"].detach()):.4e}')
 ddv = make_batch_fast(B, 256, 8, seed=4, device='cuda', anchors='val')
 with torch.no_grad():
