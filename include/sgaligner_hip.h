@@ -249,6 +249,14 @@ int sga_fps(const float* pts, const int32_t* offsets, int n_obj, const int32_t* 
  * host's Qhull call sees a few per cent of the points and returns the same vertices.  pts [sum N,3] f32 packed per object,
  * offsets [n_obj+1]; n_planes [n_obj] (nullable): facets of the filter polytope, 0 = object kept whole (degenerate). */
 int sga_hull_candidates(const float* pts, const int32_t* offsets, int n_obj, unsigned char* keep, int32_t* n_planes, void* stream);
+/* The hull VERTICES of every object's candidates on the device: fp64 gift wrapping with a certificate (closed surface, Euler's
+ * relation, every other point behind every facet by > 1e-9 of the object's scale).  pts [sum n, 3] f64 packed per object (the survivors
+ * of sga_hull_candidates, in the object's own values), offsets [n_obj+1].  status[o] == 0: is_vertex[offsets[o] ..] flags exactly the
+ * vertices scipy.spatial.ConvexHull (Qhull) reports (one copy of bitwise-duplicate points); != 0 (fewer than 4 or more than
+ * sga_hull_max_candidates() points, coplanar / near-degenerate facets, any failed check): is_vertex is untouched and the caller
+ * must run Qhull on that object (utils/point_cloud.py does).  preprocessing/scan3r/preprocess.py:93-96. */
+int sga_hull_max_candidates(void);
+int sga_hull_vertices(const double* pts, const int32_t* offsets, int n_obj, unsigned char* is_vertex, int32_t* status, void* stream);
 
 /* loss_group kernels: 1 = the VALU forms of the similarity / gradient kernels (kept for cross-checks), 0 = MFMA (default); returns the old value. */
 int sga_set_group_valu(int on);

@@ -59,6 +59,8 @@ SIGNATURES = {
     'sga_fps_scratch_floats': (c_size_t, [I]),
     'sga_fps': (I, [P, P, I, P, I, P, I, P, I, P, I, P, P, P]),
     'sga_hull_candidates': (I, [P, P, I, P, P, P]),
+    'sga_hull_max_candidates': (I, []),
+    'sga_hull_vertices': (I, [P, P, I, P, P, P]),
     'sga_gemm': (I, [I, I, I, I, I, P, c_long, I, P, c_long, P, c_long, P, I, P]),
     'sga_colsum': (I, [P, c_long, I, I, P, I, P]),
     'sga_cast_f64_f32': (I, [P, P, c_size_t, P]),

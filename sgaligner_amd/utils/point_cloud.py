@@ -82,24 +82,71 @@ def hull_candidate_mask_batch(points, offsets):
     return keep[:pts.shape[0]].bool(), npl[:n_obj]
 
 
-def convex_hull_barycenters_batch(point_list):
+HULL_ON_DEVICE = True          # tests flip it to cross-check the device hull against Qhull on the same candidates
+
+
+def hull_vertices_batch(cand64, offsets):
+    """cand64 [sum n, 3] float64 numpy (objects packed back to back), offsets [n_obj+1].  Returns (is_vertex [sum n] bool numpy,
+    status [n_obj] int numpy): the device gift-wrapping hull with its certificate (csrc/hull.hip, sga_hull_vertices); status != 0
+    marks the objects the caller has to hand to Qhull."""
+    off = np.asarray(offsets, dtype=np.int64)
+    n_obj = len(off) - 1
+    if n_obj <= 0 or off[-1] == 0:
+        return np.zeros((int(off[-1]) if len(off) else 0,), dtype=bool), np.ones((max(n_obj, 0),), dtype=np.int32)
+    d_pts = torch.from_numpy(np.ascontiguousarray(cand64, dtype=np.float64)).cuda()
+    d_off = torch.from_numpy(off.astype(np.int32)).cuda()
+    isv = torch.zeros((int(off[-1]),), device='cuda', dtype=torch.uint8)
+    status = torch.full((n_obj,), -1, device='cuda', dtype=torch.int32)
+    _lib.check(_lib.lib().sga_hull_vertices(_p(d_pts), _p(d_off), n_obj, _p(isv), _p(status), _stream()), 'sga_hull_vertices')
+    return isv.cpu().numpy().astype(bool), status.cpu().numpy()
+
+
+def convex_hull_barycenters_batch(point_list, return_info=False):
     """Barycentre of the convex-hull vertices of every object (list of [N_i, 3] numpy arrays), as preprocess.py:93-96 computes
-    it per object: cx, cy, cz = mean of hull.points[hull.vertices, 0 / 1 / 2].  One kernel launch filters all objects down to
-    their hull candidates; Qhull (scipy, the reference's own dependency) then runs on those only and finds the same vertices."""
-    from scipy.spatial import ConvexHull
+    it per object: cx, cy, cz = mean of hull.points[hull.vertices, 0 / 1 / 2].  Three steps, no per-object host loop on the common path:
+    (1) one launch filters all objects down to their hull candidates (sga_hull_candidates); (2) one launch wraps every object's
+    candidates into its hull vertices in fp64, with a certificate (sga_hull_vertices); (3) the vertex means are segment sums.  Objects
+    the device declines (fewer than 4 or more than 512 candidates, coplanar / near-degenerate facets: lattices, flat objects) go to
+    Qhull -- scipy, the reference's own dependency -- on their candidates, so every answer is the reference's."""
     sizes = [int(p.shape[0]) for p in point_list]
-    off = np.concatenate([[0], np.cumsum(sizes)])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n_obj = len(point_list)
     if off[-1] == 0:
-        return np.zeros((len(point_list), 3))
-    flat = np.concatenate([np.asarray(p)[:, :3] for p in point_list]).astype(np.float32, copy=False)
+        return (np.zeros((n_obj, 3)), {'device': 0, 'qhull': 0}) if return_info else np.zeros((n_obj, 3))
+    src = np.concatenate([np.asarray(p)[:, :3] for p in point_list])          # the objects' own values (float32 scans stay float32)
+    flat = src if src.dtype == np.float32 else src.astype(np.float32)
     keep, _ = hull_candidate_mask_batch(torch.from_numpy(np.ascontiguousarray(flat)).cuda(), off)
     keep = keep.cpu().numpy()
-    out = np.zeros((len(point_list), 3))
-    for i, p in enumerate(point_list):
-        cand = np.asarray(p)[keep[off[i]:off[i + 1]]]          # candidates in the object's own dtype / values
-        hull = ConvexHull(cand)
-        v = hull.points[hull.vertices]
-        out[i] = (np.mean(v[:, 0]), np.mean(v[:, 1]), np.mean(v[:, 2]))
+    # fp32 can merge distinct fp64 points; the filter only ever DISCARDS points that are interior by a margin far above that rounding
+    idx = np.flatnonzero(keep)
+    counts = np.add.reduceat(keep.astype(np.int64), np.minimum(off[:-1], len(keep) - 1)) * (np.diff(off) > 0)
+    coff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    cand = src[idx].astype(np.float64, copy=False)                            # exact: float32 -> float64
+    out = np.zeros((n_obj, 3))
+    todo = np.ones((n_obj,), dtype=bool)
+    if HULL_ON_DEVICE:
+        isv, status = hull_vertices_batch(cand, coff)
+        ok = status == 0
+        if ok.any():
+            w = isv.astype(np.float64)
+            seg = np.minimum(coff[:-1], max(len(w) - 1, 0))
+            nz = counts > 0
+            nv = np.where(nz, np.add.reduceat(w, seg), 0.0)
+            for c in range(3):
+                sm = np.where(nz, np.add.reduceat(cand[:, c] * w, seg), 0.0)
+                out[ok, c] = sm[ok] / nv[ok]
+            todo = ~ok
+    n_q = 0
+    if todo.any():
+        from scipy.spatial import ConvexHull
+        for i in np.flatnonzero(todo):
+            p = np.asarray(point_list[i])
+            hull = ConvexHull(p[keep[off[i]:off[i + 1]]])          # candidates in the object's own dtype / values
+            v = hull.points[hull.vertices]
+            out[i] = (np.mean(v[:, 0]), np.mean(v[:, 1]), np.mean(v[:, 2]))
+            n_q += 1
+    if return_info:
+        return out, {'device': int(n_obj - n_q), 'qhull': int(n_q)}
     return out
 
 

@@ -86,3 +86,66 @@ def test_small_objects_far_from_origin(seed):
         v = hull.points[hull.vertices]
         assert np.allclose(bcs[k], v.mean(0), rtol=0, atol=1e-9 * np.abs(o).max()), k
     assert keep[off[0]:off[1]].mean() < 0.5 and keep[off[1]:off[2]].mean() < 0.6      # still a filter where fp32 resolves the object
+
+
+def _qhull_vertex_coords(pts):
+    from scipy.spatial import ConvexHull
+    h = ConvexHull(pts)
+    return np.unique(h.points[h.vertices], axis=0)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_device_hull_vertices_equal_qhull(seed):
+    """sga_hull_vertices (fp64 gift wrapping + certificate) on candidate sets: wherever it certifies (status 0) its vertex set is,
+    coordinate for coordinate, the one scipy/Qhull reports -- blobs, anisotropic clouds, objects far from the origin, objects with
+    bitwise-duplicate points, spheres (every point a vertex); and it must DECLINE (status != 0), not guess, on lattices, flat objects,
+    fewer than 4 and more than 512 points."""
+    from sgaligner_amd import _lib
+    from sgaligner_amd.utils import point_cloud
+    rng = np.random.default_rng(40 + seed)
+    sets = []
+    for n in (4, 5, 9, 30, 120, 400, 512):
+        sets.append(rng.standard_normal((n, 3)) * rng.uniform(0.2, 3.0, size=3) + rng.uniform(-5, 5, size=3))
+    s = rng.standard_normal((300, 3)); sets.append(s / np.linalg.norm(s, axis=1, keepdims=True))        # sphere: all vertices
+    sets.append((rng.standard_normal((200, 3)) * 0.02 + np.array([800.0, -300.0, 55.0])).astype(np.float32).astype(np.float64))
+    d = rng.standard_normal((150, 3)); sets.append(np.concatenate([d, d[:40]]))                          # exact duplicates
+    n_good = len(sets)
+    sets.append(np.round(rng.standard_normal((300, 3)) * 2) / 2)                                         # lattice: coplanar points on facets
+    sets.append(np.c_[rng.standard_normal((100, 2)), np.zeros(100)])                                     # flat
+    sets.append(rng.standard_normal((3, 3)))                                                             # < 4 points
+    sets.append(rng.standard_normal((600, 3)))                                                           # > 512 points
+    off = np.concatenate([[0], np.cumsum([len(x) for x in sets])])
+    isv, status = point_cloud.hull_vertices_batch(np.concatenate(sets), off)
+    assert _lib.lib().sga_hull_max_candidates() == 512
+    assert (status[:n_good] == 0).all(), status
+    assert (status[n_good:] != 0).all(), status
+    for k in range(n_good):
+        mine = np.unique(sets[k][isv[off[k]:off[k + 1]]], axis=0)
+        ref = _qhull_vertex_coords(sets[k])
+        assert mine.shape == ref.shape and np.array_equal(mine, ref), (k, mine.shape, ref.shape)
+    assert not isv[off[n_good]:].any()                                    # declined objects: flags untouched
+
+
+def test_barycentres_device_path_equals_qhull_path_and_golden():
+    """The whole batch function with the device hull (default) and with Qhull on the same candidates (HULL_ON_DEVICE = False): same
+    barycentres to 1e-12 of the coordinates' scale; the golden example-scan objects come out right on both; most random objects are
+    served by the device, the degenerate ones by Qhull."""
+    from sgaligner_amd.utils import point_cloud
+    g = load_golden('hull_cases')
+    n = int(g['n_cases'])
+    rng = np.random.default_rng(7)
+    objs = [g[f'pts{k}'] for k in range(n) if len(g[f'pts{k}']) >= 4]
+    gold = [g[f'bc{k}'] for k in range(n) if len(g[f'pts{k}']) >= 4]
+    for m in (50, 700, 5000, 20000):
+        objs.append((rng.standard_normal((m, 3)) * rng.uniform(0.3, 2.0, size=3)).astype(np.float32))
+    bc_dev, info = point_cloud.convex_hull_barycenters_batch(objs, return_info=True)
+    point_cloud.HULL_ON_DEVICE = False
+    try:
+        bc_q, info_q = point_cloud.convex_hull_barycenters_batch(objs, return_info=True)
+    finally:
+        point_cloud.HULL_ON_DEVICE = True
+    assert info_q['device'] == 0 and info['device'] >= 4, (info, info_q)
+    scale = np.array([max(1.0, np.abs(o).max()) for o in objs])[:, None]
+    assert (np.abs(bc_dev - bc_q) <= 1e-12 * scale).all(), np.abs(bc_dev - bc_q).max()
+    for k, ref in enumerate(gold):
+        assert np.allclose(bc_dev[k], ref, rtol=0, atol=1e-9), (k, bc_dev[k], ref)

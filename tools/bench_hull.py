@@ -10,10 +10,10 @@ npts = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 rng = np.random.default_rng(0)
 objs = [(rng.standard_normal((npts, 3)) * rng.uniform(0.2, 2.0, size=3)).astype(np.float32) for _ in range(n_obj)]
 point_cloud.convex_hull_barycenters_batch(objs[:4])
-t0 = time.time(); a = point_cloud.convex_hull_barycenters_batch(objs); t1 = time.time()
+t0 = time.time(); a, info = point_cloud.convex_hull_barycenters_batch(objs, return_info=True); t1 = time.time()
 b = np.stack([hull_oracle.hull_barycenter(o)[0] for o in objs]); t2 = time.time()
 import torch
 off = np.concatenate([[0], np.cumsum([len(o) for o in objs])])
 keep, _ = point_cloud.hull_candidate_mask_batch(torch.from_numpy(np.concatenate(objs)).cuda(), off)
-print(f'{n_obj} objects x {npts} points: filter + Qhull {1e3*(t1-t0):.0f} ms, Qhull on all points {1e3*(t2-t1):.0f} ms ({(t2-t1)/(t1-t0):.1f}x); '
+print(f'{n_obj} objects x {npts} points: filter + device hull ({info}) {1e3*(t1-t0):.0f} ms, Qhull on all points {1e3*(t2-t1):.0f} ms ({(t2-t1)/(t1-t0):.1f}x); '
       f'kept {100*float(keep.float().mean()):.1f} % of the points; max |barycentre diff| {np.abs(a-b).max():.2e}')
