@@ -223,6 +223,7 @@ def main():
     ap.add_argument('--no-hits', action='store_true')
     ap.add_argument('--no-attr', action='store_true', help='skip the extra point+gat+rel+attr (M = 4) measurement (N = 1)')
     ap.add_argument('--no-scale-ref', action='store_true', help='skip the extra weak-scaling point (N > 1, --config auto)')
+    ap.add_argument('--no-pct', action='store_true', help='skip the extra pct+gat+rel+attr small-batch measurement (N = 1)')
     ap.add_argument('--no-c2', action='store_true', help='skip the extra BASELINE configs[1] measurement (N = 1)')
     ap.add_argument('--no-bf16x3', action='store_true', help='skip the extra (opt-in split-bf16 x3 MFMA mode) measurement')
     args = ap.parse_args()
@@ -381,6 +382,39 @@ def main():
     dd2 = None
     torch.cuda.empty_cache()
 
+    # ---- extra at N = 1: the reference's OWN default configuration -- configs/scan3r/scan3r_ground_truth.yaml: modules pct+gat+rel+attr,
+    # 4 pairs per step, ~40 objects per scene, 512 points -- where the 'pct' object encoder is ~95 % of the step.  Exact fp32; the
+    # algorithmic rate counts the encoder's FLOPs only (forward x 3 for forward + backward; FLOPs per object stated).
+    extra_pct = None
+    if world == 1 and not args.no_pct and cname != 'c5':
+        try:
+            from sgaligner_amd.synthetic import make_batch, to_device
+            modsp = ['pct', 'gat', 'rel', 'attr']
+            stepsp = AlignerSteps(modsp, device=dev, seed=42)
+            ddp = [to_device(make_batch(4, 40, 512, seed=7 + i, ragged=True), dev) for i in range(4)]
+            for i in range(6):
+                stepsp.forward_backward(ddp[i % 4])
+            torch.cuda.synchronize()
+            npct = 40
+            tp = time.perf_counter()
+            for i in range(npct):
+                stepsp.forward_backward(ddp[i % 4])
+            torch.cuda.synchronize()
+            elp = (time.perf_counter() - tp) / npct
+            n_objs = float(np.mean([int(d['tot_obj_pts'].shape[0]) for d in ddp]))
+            Np = 512
+            conv = 2.0 * Np * (3 * 128 + 128 * 128 + 4 * (128 * 32 + 2 * 128 * 128) + 512 * 1024) + 2.0 * (1024 * 512 + 512 * 256)
+            attn = 4 * 2.0 * Np * Np * (32 + 128)
+            alg = 3.0 * (conv + attn) * n_objs
+            extra_pct = {'workload': "reference default (scan3r_ground_truth.yaml): modules pct+gat+rel+attr, 4 pairs x ~40 objects x 512 pts per step",
+                         'value': round(4 / elp, 1), 'unit': 'pairs/s', 'ms_per_step': round(elp * 1e3, 3), 'steps': npct, 'dtype': 'f32',
+                         'objects_per_step': n_objs, 'encoder_gflop_per_object_forward': round((conv + attn) / 1e9, 3),
+                         'encoder_algorithmic_tflops': round(alg / elp / 1e12, 1), 'frac_of_fp32_mfma_peak': round(alg / elp / 1e12 / PEAK_F32_TFLOPS, 3),
+                         'note': 'whole-step wall time; FLOPs = 3 x the NaivePCT forward (pct.py:275-317) of the step\'s objects'}
+            del stepsp, ddp
+        except Exception as e:
+            extra_pct = {'error': f'{type(e).__name__}: {e}'}
+
     # ---- extra at N > 1 under --config auto: the weak-scaling point (BASELINE configs[1] per GPU: 512 pairs x 64 objects on every
     # rank, batch-global loss over 512 N pairs) next to the strong-scaling headline of the same line.
     weak_ref = None
@@ -430,6 +464,8 @@ def main():
             line['extra_c2'] = extra_c2
         if extra_attr is not None:
             line['extra_full_module_list'] = extra_attr
+        if extra_pct is not None:
+            line['extra_pct'] = extra_pct
         if weak_ref is not None:
             line['weak_scaling_point'] = weak_ref
         if not args.no_hits:

@@ -207,6 +207,18 @@ int sga_pct_attention_bwd(const float* Q, long ldq, const float* V, long ldv, co
                           const float* stats, float* work, float* dQ, long ldo, float* dV, long ldw, void* stream);
 int sga_segment_max(const float* Y, long ldy, int T, int N, int C, float* G, int32_t* argmax, void* stream);
 int sga_segment_max_bwd(const float* dG, const int32_t* argmax, int T, int N, int C, float* dY, long ldd, void* stream);
+/* Backward of conv(512->1024, no bias) + BatchNorm + LeakyReLU(slope) + max over an object's points (pct.py:282-286,306-308) without the
+ * [T*N, 1024] gradient tensors: only arg-max rows carry dL/dz and the batch-statistic terms are affine in y = cat W^T, so
+ *   dW = a (x) colsum(cat) + diag(b) W (cat^T cat) + sparse,   dcat = 1 (x) a^T W + cat (W^T diag(b) W) + sparse    (pct_ops.LinearBNActMaxFn).
+ * head_prep: dG/G [T,C] (gradient / value of the pooled output), fin = [scale|shift|mean|rstd] of sga_bn_finalize, R = T*N rows ->
+ *   coef [T,C] = scale * dL/dz at the arg-max rows, ab [4C] = a | b | dgamma | dbeta.   head_dw: WG = W (cat^T cat) [C,K], cs = colsum(cat) [K]
+ *   -> dW [C,K], Wb = diag(b) W [C,K], a0 += a^T W [K] (caller-zeroed).   head_scatter: dcat[t N + amax[t,c], :] += coef[t,c] W[c,:]. */
+int sga_pct_head_prep(const float* dG, const float* G, const float* gamma, const float* beta, const float* fin, int T, int C, long R,
+                      int training, float slope, float* coef, float* ab, void* stream);
+int sga_pct_head_dw(const float* WG, const float* W, const float* ab, const float* cs, const float* coef, const int32_t* amax,
+                    const float* cat, long ldc, int T, int N, int C, int K, float* dW, float* Wb, float* a0, void* stream);
+int sga_pct_head_scatter(const float* coef, const int32_t* amax, const float* W, int T, int N, int C, int K, float* dcat, long ldd,
+                         void* stream);
 
 /* BatchNorm1d over point-major activations [R, C] fused with the following activation (0 none, 1 ReLU, 2 LeakyReLU 0.2)
  * and residual: the train-mode layers of pct.py:122-123, :226-229, :289-293, :311-315.  sums: 2*C doubles.

@@ -50,6 +50,9 @@ SIGNATURES = {
     'sga_pct_attention_bwd': (I, [P, c_long, P, c_long, P, c_long, I, I, P, P, P, c_long, P, c_long, P]),
     'sga_segment_max': (I, [P, c_long, I, I, I, P, P, P]),
     'sga_segment_max_bwd': (I, [P, P, I, I, I, P, c_long, P]),
+    'sga_pct_head_prep': (I, [P, P, P, P, P, I, I, c_long, I, c_float, P, P, P]),
+    'sga_pct_head_dw': (I, [P, P, P, P, P, P, P, c_long, I, I, I, I, P, P, P, P]),
+    'sga_pct_head_scatter': (I, [P, P, P, I, I, I, I, P, c_long, P]),
     'sga_bn_stats': (I, [P, c_long, I, I, P, P]),
     'sga_bn_finalize': (I, [P, I, I, P, P, P, P, P, c_float, c_float, I, P, P]),
     'sga_bn_bwd_finalize': (I, [P, I, I, P, P]),

@@ -110,6 +110,7 @@ class NaivePCT(nn.Module):
         self.bn2 = nn.BatchNorm1d(256)
         self.dp1 = nn.Dropout(p=0.5)
         self.dp2 = nn.Dropout(p=0.5)
+        self.fused_head = True               # tests flip it to cross-check the two backward formulations of the widest stage
         self.eval_chunk_rows = 1 << 19       # inference: points per chunk (x 1024 channels x 4 B = 2 GiB for the widest activation)
 
     def forward(self, x):
@@ -171,8 +172,11 @@ class NaivePCT(nn.Module):
             h = P.batch_norm_act(P.rows_linear(a, sa.trans_conv.weight, sa.trans_conv.bias), sa.after_norm, act=1, resid=h)
             xs.append(h)
         cat = torch.cat(xs, dim=1)
-        y = P.batch_norm_act(P.rows_linear(cat, self.linear[0].weight), self.linear[1], act=2)
-        g = P.segment_max(y, t, n)
+        if self.fused_head:      # conv + BatchNorm + LeakyReLU + point max as one node with the algebraic backward (pct_ops.LinearBNActMaxFn)
+            g = P.linear_bn_lrelu_max(cat, self.linear[0].weight, self.linear[1], t, n)
+        else:
+            y = P.batch_norm_act(P.rows_linear(cat, self.linear[0].weight), self.linear[1], act=2)
+            g = P.segment_max(y, t, n)
         f = P.batch_norm_act(P.rows_linear(g, self.linear1.weight), self.bn1, act=1)
         f = F.dropout(f, self.dp1.p, self.training)
         f = P.batch_norm_act(P.rows_linear(f, self.linear2.weight, self.linear2.bias), self.bn2, act=1)

@@ -342,6 +342,86 @@ __global__ void segment_max_bwd_kernel(const float* __restrict__ dG, const int* 
     dY[((size_t)t * N + amax[e]) * ldd + c] = dG[e];
 }
 
+
+// ---- backward of the encoder's widest stage, 512 -> 1024 conv + BatchNorm + LeakyReLU + max over points (pct.py:282-286,306-308),
+// WITHOUT the [T*N, 1024] gradient tensors.  Only the arg-max rows carry dL/dz, and the batch-statistic terms of the BatchNorm backward
+// are affine in y = cat W^T:   dL/dy[r,c] = a_c + b_c y[r,c] + (scale_c dz[t,c] at r = argmax(t,c)),  so
+//     dW   = a (x) colsum(cat) + diag(b) W (cat^T cat) + sum_t coef[t,c] cat[argrow(t,c), :]
+//     dcat = 1 (x) (a^T W) + cat (W^T diag(b) W) + scatter(coef[t,c] W[c, :] -> argrow(t,c))
+// : a 512 x 512 Gram matrix and one [T*N,512] x [512,512] product (half the FLOPs of dY W and dY^T cat) + two sparse passes.
+// head_prep: per channel (one workgroup per 64 channels, no atomics) dz at the arg-max rows from dL/dg and g (LeakyReLU' and z from the
+// sign of g), x_hat there from z, S1 = sum dz, S2 = sum dz x_hat  ->  coef = scale dz,  a, b, dgamma = S2, dbeta = S1.
+__global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict__ dG, const float* __restrict__ G, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ fin, int T, int C, double R,
+                                                        int training, float slope, float* __restrict__ coef, float* __restrict__ ab) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rw = threadIdx.x >> 6;
+    __shared__ double r1[4][64], r2[4][64];
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        const float ga = gamma[c], be = beta[c], sc = fin[c];
+        const float ig = ga != 0.f ? 1.f / ga : __int_as_float(0x7fc00000);       // gamma == 0: x_hat is not recoverable from z -> NaN (loud)
+        for (int t = rw; t < T; t += 4) {
+            const float g = G[(size_t)t * C + c], dg = dG[(size_t)t * C + c];
+            const float dz = g > 0.f ? dg : dg * slope;
+            const float z = g > 0.f ? g : g / slope;
+            coef[(size_t)t * C + c] = sc * dz;
+            s1 += (double)dz;
+            s2 += (double)dz * (double)((z - be) * ig);
+        }
+    }
+    r1[rw][threadIdx.x & 63] = s1; r2[rw][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (rw == 0 && c < C) {
+        const int k = threadIdx.x;
+        const double S1 = r1[0][k] + r1[1][k] + r1[2][k] + r1[3][k], S2 = r2[0][k] + r2[1][k] + r2[2][k] + r2[3][k];
+        const float sc = fin[c], mean = fin[2 * C + c], rstd = fin[3 * C + c];
+        float a = 0.f, b = 0.f;
+        if (training) {                       // dy = scale (dz - S1/R - x_hat S2/R),  x_hat = (y - mean) rstd
+            b = (float)(-(double)sc * (double)rstd * S2 / R);
+            a = (float)(-(double)sc * S1 / R) - b * mean;
+        }
+        ab[c] = a; ab[C + c] = b; ab[2 * C + c] = (float)S2; ab[3 * C + c] = (float)S1;
+    }
+}
+
+// dW[c,:] = b_c WG[c,:] + a_c cs + sum_t coef[t,c] cat[t N + amax[t,c], :];  Wb[c,:] = b_c W[c,:].   One workgroup per channel.
+__global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ WG, const float* __restrict__ W, const float* __restrict__ ab,
+                                                      const float* __restrict__ cs, const float* __restrict__ coef, const int* __restrict__ amax,
+                                                      const float* __restrict__ cat, long ldc, int T, int N, int C, int K,
+                                                      float* __restrict__ dW, float* __restrict__ Wb, float* __restrict__ a0) {
+    const int c = blockIdx.x;
+    const float a = ab[c], b = ab[C + c];
+    for (int k0 = threadIdx.x * 4; k0 < K; k0 += 256 * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            const float cf = coef[(size_t)t * C + c];
+            const f32x4 row = *reinterpret_cast<const f32x4*>(cat + ((size_t)t * N + amax[(size_t)t * C + c]) * ldc + k0);
+            acc += row * cf;
+        }
+        const f32x4 wg = *reinterpret_cast<const f32x4*>(WG + (size_t)c * K + k0);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)c * K + k0);
+        const f32x4 csv = *reinterpret_cast<const f32x4*>(cs + k0);
+        *reinterpret_cast<f32x4*>(dW + (size_t)c * K + k0) = wg * b + csv * a + acc;
+        *reinterpret_cast<f32x4*>(Wb + (size_t)c * K + k0) = w * b;
+        if (a != 0.f) {                                     // a0[k] = sum_c a_c W[c,k]  (caller-zeroed; C x K atomics in all)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(a0 + k0 + e, a * w[e]);
+        }
+    }
+}
+
+// dcat[t N + amax[t,c], :] += coef[t,c] W[c,:]   (one wave per (t, c); fp32 atomics: rows are shared by the channels whose maximum they hold)
+__global__ __launch_bounds__(256) void head_scatter_kernel(const float* __restrict__ coef, const int* __restrict__ amax, const float* __restrict__ W,
+                                                           int T, int N, int C, int K, float* __restrict__ dcat, long ldd) {
+    const size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= (size_t)T * C) return;
+    const int lane = threadIdx.x & 63, t = (int)(e / C), c = (int)(e % C);
+    const float cf = coef[e];
+    if (cf == 0.f) return;
+    float* row = dcat + ((size_t)t * N + amax[e]) * ldd;
+    for (int k = lane; k < K; k += 64) atomicAdd(row + k, cf * W[(size_t)c * K + k]);
+}
+
 }  // namespace
 
 extern "C" int sga_pct_attention(const float* Q, long ldq, const float* V, long ldv, int T, int N, float* stats,
@@ -404,5 +484,36 @@ extern "C" int sga_segment_max_bwd(const float* dG, const int32_t* argmax, int T
     const size_t n = (size_t)T * C;
     hipLaunchKernelGGL(segment_max_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dG, argmax, T, N, C, dY, ldd);
     SGA_CHECK_LAUNCH("sga_segment_max_bwd");
+    return SGA_OK;
+}
+
+// ---- algebraic backward of conv(512->1024) + BatchNorm + LeakyReLU + point max (head_*_kernel above; ops glue in pct_ops.py) -------
+extern "C" int sga_pct_head_prep(const float* dG, const float* G, const float* gamma, const float* beta, const float* fin, int T, int C,
+                                 long R, int training, float slope, float* coef, float* ab, void* stream) {
+    SGA_CHECK_ARG(dG && G && gamma && beta && fin && coef && ab && T >= 0 && C >= 1 && R >= 1 && slope > 0.f, "sga_pct_head_prep: bad argument");
+    hipLaunchKernelGGL(head_prep_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), dG, G, gamma, beta, fin, T, C,
+                       (double)R, training, slope, coef, ab);
+    SGA_CHECK_LAUNCH("sga_pct_head_prep");
+    return SGA_OK;
+}
+
+extern "C" int sga_pct_head_dw(const float* WG, const float* W, const float* ab, const float* cs, const float* coef, const int32_t* amax,
+                               const float* cat, long ldc, int T, int N, int C, int K, float* dW, float* Wb, float* a0, void* stream) {
+    SGA_CHECK_ARG(WG && W && ab && cs && coef && amax && cat && dW && Wb && a0 && T >= 0 && N >= 1 && C >= 1 && K >= 4 && K % 4 == 0 && ldc % 4 == 0,
+                  "sga_pct_head_dw: bad argument (K and the row stride of cat must be multiples of 4)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(head_dw_kernel, dim3(C), dim3(256), 0, s, WG, W, ab, cs, coef, amax, cat, ldc, T, N, C, K, dW, Wb, a0);
+    SGA_CHECK_LAUNCH("sga_pct_head_dw");
+    return SGA_OK;
+}
+
+extern "C" int sga_pct_head_scatter(const float* coef, const int32_t* amax, const float* W, int T, int N, int C, int K, float* dcat, long ldd,
+                                    void* stream) {
+    SGA_CHECK_ARG(coef && amax && W && dcat && T >= 0 && N >= 1 && C >= 1 && K >= 1 && ldd >= K, "sga_pct_head_scatter: bad argument");
+    const size_t n = (size_t)T * C;
+    if (n == 0) return SGA_OK;
+    hipLaunchKernelGGL(head_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), coef, amax, W, T, N, C, K,
+                       dcat, ldd);
+    SGA_CHECK_LAUNCH("sga_pct_head_scatter");
     return SGA_OK;
 }

@@ -204,3 +204,81 @@ class RowsLinearFn(torch.autograd.Function):
 
 def rows_linear(x, weight, bias=None):
     return RowsLinearFn.apply(x, weight, bias)
+
+
+class LinearBNActMaxFn(torch.autograd.Function):
+    """g[t, :] = max over object t's points of LeakyReLU_0.2(BatchNorm1d(cat W^T))  -- the encoder's widest stage (pct.py:282-286 + :308:
+    Conv1d(512 -> 1024, bias=False), BatchNorm1d(1024), LeakyReLU, torch.max over points) as ONE autograd node.
+    Forward: the same four launches as the separate nodes (GEMM, batch statistics, apply in place, arg-max pool); nothing of size
+    [T*N, 1024] is kept for the backward.  Backward: only the arg-max rows carry dL/dz, and the batch-statistic terms of the BatchNorm
+    backward are affine in y = cat W^T, so dW and dcat follow from a 512 x 512 Gram matrix and one [T*N, 512] x [512, 512] product plus
+    two sparse passes (csrc/pct.hip head_*_kernel): half the GEMM FLOPs of dY W / dY^T cat, none of the [T*N, 1024] gradient traffic."""
+
+    SLOPE = 0.2
+
+    @staticmethod
+    def forward(ctx, cat, weight, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, n_obj, n_pts):
+        from . import ops
+        L = _lib.lib()
+        st = _stream()
+        cat = cat if cat.is_contiguous() else cat.contiguous()
+        w = weight.reshape(weight.shape[0], -1).contiguous()
+        R, K = cat.shape
+        C = w.shape[0]
+        dev = cat.device
+        y = ops.gemm(cat, w, False, True, R, C, K)
+        sums = None
+        if training:
+            sums = torch.empty((2 * C,), device=dev, dtype=torch.float64)
+            _chk(L.sga_bn_stats(_p(y), y.stride(0), R, C, _p(sums), st), 'sga_bn_stats')
+        fin = torch.empty((4, C), device=dev, dtype=torch.float32)
+        nbt = num_batches_tracked if (num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64) else None
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        _chk(L.sga_bn_finalize(_p(sums), R, C, _p(g32), _p(b32), _p(running_mean), _p(running_var), _p(nbt), float(momentum), float(eps),
+                               int(bool(training)), _p(fin), st), 'sga_bn_finalize')
+        if training and num_batches_tracked is not None and nbt is None:
+            num_batches_tracked.add_(1)
+        _chk(L.sga_bn_apply(_p(y), y.stride(0), R, C, _p(fin[0]), _p(fin[1]), 2, None, 0, _p(y), y.stride(0), st), 'sga_bn_apply')   # in place
+        g = torch.empty((n_obj, C), device=dev, dtype=torch.float32)
+        am = torch.empty((n_obj, C), device=dev, dtype=torch.int32)
+        _chk(L.sga_segment_max(_p(y), y.stride(0), n_obj, n_pts, C, _p(g), _p(am), st), 'sga_segment_max')
+        del y
+        ctx.save_for_backward(cat, w, fin, g, am, g32, b32)
+        ctx.meta = (n_obj, n_pts, bool(training), tuple(weight.shape))
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        from . import ops
+        cat, w, fin, g, am, gamma, beta = ctx.saved_tensors
+        n_obj, n_pts, training, wshape = ctx.meta
+        L = _lib.lib()
+        st = _stream()
+        R, K = cat.shape
+        C = w.shape[0]
+        dev = cat.device
+        dg = dg.contiguous().float()
+        coef = torch.empty((n_obj, C), device=dev, dtype=torch.float32)
+        ab = torch.empty((4, C), device=dev, dtype=torch.float32)                  # a | b | dgamma | dbeta
+        _chk(L.sga_pct_head_prep(_p(dg), _p(g), _p(gamma), _p(beta), _p(fin), n_obj, C, R, int(training), LinearBNActMaxFn.SLOPE, _p(coef),
+                                 _p(ab), st), 'sga_pct_head_prep')
+        gram = ops.gemm(cat, cat, True, False, K, K, R)                            # cat^T cat  [K, K]  (split over the rows)
+        cs = ops.colsum(cat)                                                       # [K]
+        wg = ops.gemm(w, gram, False, True, C, K, K)                               # W (cat^T cat)  [C, K]  (the Gram matrix is symmetric: NT kernel)
+        dw = torch.empty((C, K), device=dev, dtype=torch.float32)
+        wb = torch.empty((C, K), device=dev, dtype=torch.float32)
+        a0 = torch.zeros((K,), device=dev, dtype=torch.float32)                    # accumulated atomically by head_dw_kernel
+        _chk(L.sga_pct_head_dw(_p(wg), _p(w), _p(ab), _p(cs), _p(coef), _p(am), _p(cat), cat.stride(0), n_obj, n_pts, C, K, _p(dw), _p(wb),
+                               _p(a0), st), 'sga_pct_head_dw')
+        dcat = None
+        if ctx.needs_input_grad[0]:
+            m = ops.gemm(w, wb, True, False, K, K, C)                              # W^T diag(b) W  [K, K]
+            dcat = ops.gemm(cat, m, False, True, R, K, K, bias=a0)                 # cat M + 1 (x) a^T W  (M is symmetric: NT kernel)
+            _chk(L.sga_pct_head_scatter(_p(coef), _p(am), _p(w), n_obj, n_pts, C, K, _p(dcat), dcat.stride(0), st), 'sga_pct_head_scatter')
+        return dcat, dw.reshape(wshape), ab[2].clone(), ab[3].clone(), None, None, None, None, None, None, None, None
+
+
+def linear_bn_lrelu_max(cat, weight, bn: torch.nn.BatchNorm1d, n_obj, n_pts):
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    return LinearBNActMaxFn.apply(cat, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training, mom,
+                                  bn.eps, n_obj, n_pts)

@@ -164,3 +164,44 @@ def test_pct_train_step_inside_the_aligner():
     with torch.no_grad():
         out = steps.model(dd)
     assert torch.isfinite(out['joint']).all()
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_fused_head_backward_equals_separate_nodes(training):
+    """conv(512 -> 1024) + BatchNorm + LeakyReLU + point max as ONE node with the algebraic backward (Gram matrix + [T*N,512] x [512,512]
+    product + sparse arg-max passes, pct_ops.LinearBNActMaxFn) against the chain of separate nodes (dense [T*N,1024] gradients): same
+    output, dcat, dW, dgamma, dbeta -- with batch statistics (train) and with running statistics (eval mode, gradients enabled);
+    gamma of both signs (a negative scale turns the max into a min of y), objects of 96 points."""
+    from sgaligner_amd import pct_ops as P
+    torch.manual_seed(11)
+    T, N, K, C = 24, 96, 512, 1024
+    cat0 = torch.randn(T * N, K, device='cuda') * 0.7
+    w0 = torch.randn(C, K, 1, device='cuda') * 0.05
+    cot = torch.randn(T, C, device='cuda')
+    res = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(C).cuda()
+        torch.manual_seed(5)                      # the same BatchNorm parameters / buffers on both sides
+        with torch.no_grad():
+            bn.weight.copy_(torch.randn(C, device='cuda').abs() + 0.2)
+            bn.weight[::7] *= -1.0
+            bn.bias.copy_(torch.randn(C, device='cuda') * 0.3)
+            bn.running_mean.copy_(torch.randn(C, device='cuda') * 0.1)
+            bn.running_var.copy_(torch.rand(C, device='cuda') + 0.5)
+        torch.manual_seed(3)
+        bn.train(training)
+        cat = cat0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        if fused:
+            g = P.linear_bn_lrelu_max(cat, w, bn, T, N)
+        else:
+            g = P.segment_max(P.batch_norm_act(P.rows_linear(cat, w), bn, act=2), T, N)
+        (g * cot).sum().backward()
+        torch.cuda.synchronize()
+        res.append((g.detach(), cat.grad, w.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    for k, name in ((1, 'dcat'), (2, 'dW'), (3, 'dgamma'), (4, 'dbeta')):
+        err = (a[k] - b[k]).abs().max().item()
+        assert err < 2e-4 * max(1e-6, b[k].abs().max().item()), (name, err, b[k].abs().max().item())
+    assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])

@@ -10,7 +10,7 @@ cfg=${SGA_PMC_CONFIG:-c2}
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $set --kernel-include-regex "$re" --output-format csv -d gpurun_out/pmc_${tag}_$i -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr < /dev/null > gpurun_out/pmc_${tag}_$i.log 2>&1
+  timeout 900 rocprofv3 --pmc $set --kernel-include-regex "$re" --output-format csv -d gpurun_out/pmc_${tag}_$i -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-pct < /dev/null > gpurun_out/pmc_${tag}_$i.log 2>&1
   python - "$tag" "$i" <<'PY'
 import csv, glob, sys, collections
 tag, i = sys.argv[1], sys.argv[2]

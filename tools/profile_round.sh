@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 for cfg in c2 c3; do
   st=10; wu=3; if [ $cfg = c3 ]; then st=3; wu=1; fi
-  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${cfg}_stats -- python bench.py --config $cfg --steps $st --warmup $wu --no-cpu-baseline --no-hits --no-attr --no-c2 < /dev/null > gpurun_out/${tag}_${cfg}_bench_under_rocprof.json 2> gpurun_out/${tag}_${cfg}_stats.err
+  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${cfg}_stats -- python bench.py --config $cfg --steps $st --warmup $wu --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct < /dev/null > gpurun_out/${tag}_${cfg}_bench_under_rocprof.json 2> gpurun_out/${tag}_${cfg}_stats.err
   python tools/prof_summary.py gpurun_out/${tag}_${cfg}_stats gpurun_out/${tag}_${cfg}_kernel_stats.csv > /dev/null
 done
 rm -f gpurun_out/${tag}_pmc_traffic.csv
