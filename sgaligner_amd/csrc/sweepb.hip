@@ -35,7 +35,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SB_WAVES = 8, SB_THREADS = SB_WAVES * 64, SB_OWN = SB_WAVES * 16;
+#ifndef SB_WAVES_N
+#define SB_WAVES_N 8
+#endif
+constexpr int SB_WAVES = SB_WAVES_N, SB_THREADS = SB_WAVES * 64, SB_OWN = SB_WAVES * 16;
 #ifndef SB_NBUF
 #define SB_NBUF 2
 #endif
@@ -111,7 +114,7 @@ struct BArgs {
 };
 
 template <int M, bool GRAD>
-__global__ __launch_bounds__(SB_THREADS, 1) void sweepb_kernel(BArgs a) {
+__global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kernel(BArgs a) {
     constexpr int NCT = 7;
     constexpr int TBYTES = SB_BLOCK;
     constexpr int BUF = M * TBYTES, NCH = TBYTES / 1024, NCHUNK = M * NCH;

@@ -1,0 +1,8 @@
+#!/bin/bash
+# usage: tools/exp_sweepb.sh <variant tags...>  -- time the bf16x3 loss sweeps of each variants/libsga_<tag>.so (c2 and a c3-sized shard)
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+for t in "$@"; do
+  echo "== $t c2: $(SGA_MFMA_MODE=bf16x3 SGA_LIB_PATH=variants/libsga_$t.so python tools/bench_sweep.py 512 64 8 2>&1 | tail -1)"
+  echo "== $t c3/8: $(SGA_MFMA_MODE=bf16x3 SGA_LIB_PATH=variants/libsga_$t.so python tools/bench_sweep.py 512 128 3 2>&1 | tail -1)"
+done
