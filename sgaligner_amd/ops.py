@@ -414,7 +414,22 @@ WIDE_STASH = True         # tables wider than 128 columns: coefficient stash + G
 FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
 KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel with HIP events on the launch stream
 
-STASH_BYTES = int(_os.environ.get('SGA_STASH_BYTES', str(4 << 30)))   # bound on the transposed dL/dS stashes of the A x A backward
+def _default_stash_bytes():
+    """Bound on the transposed dL/dS stashes of the A x A backward (and the wide-table coefficient stashes): 16 GiB on a device with
+    >= 128 GiB of memory (MI355X: 288 GB -- 18 anchor-row blocks instead of 69 at configs[2], +1.3 % step rate, 37.8 GiB peak),
+    4 GiB otherwise; env SGA_STASH_BYTES overrides."""
+    env = _os.environ.get('SGA_STASH_BYTES')
+    if env:
+        return int(env)
+    try:
+        if torch.cuda.is_available() and torch.cuda.get_device_properties(0).total_memory >= (128 << 30):
+            return 16 << 30
+    except Exception:
+        pass
+    return 4 << 30
+
+
+STASH_BYTES = _default_stash_bytes()
 
 
 def _anchor_chunks(a_lo, a_hi, A, n_tables):
