@@ -59,6 +59,11 @@ int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, cons
 int sga_gemm(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64, const float* B,
              long ldb, float* C, long ldc, const float* bias, int accumulate, void* stream);
 int sga_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream);   /* bias grads */
+/* C = A B^T (+ bias) for A [M,K], B [N,K] (Conv1d k=1 / Linear over point-major rows) with the BatchNorm batch statistics of C from the same
+ * launch: sums[0..N) = column sums, sums[N..2N) = column sums of squares (fp64) -- sga_bn_stats without its pass over C.  Shapes the NT
+ * kernel takes only (K % 4 == 0, 16-byte aligned rows); otherwise SGA_ERR_ARG and the caller uses sga_gemm + sga_bn_stats. */
+int sga_gemm_bnstats(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias,
+                     double* sums, void* stream);
 int sga_cast_f64_f32(const double* in, float* out, size_t n, void* stream);                        /* .float(), sg_aligner.py:73-75 */
 
 /* ---- modality fusion --------------------------------------------------------------------------------
@@ -219,6 +224,10 @@ int sga_pct_head_dw(const float* WG, const float* W, const float* ab, const floa
                     const float* cat, long ldc, int T, int N, int C, int K, float* dW, float* Wb, float* a0, void* stream);
 int sga_pct_head_scatter(const float* coef, const int32_t* amax, const float* W, int T, int N, int C, int K, float* dcat, long ldd,
                          void* stream);
+/* G[t,c] = max_n LeakyReLU_slope(scale[c] Y[t N + n, c] + shift[c]) with its first arg-max row: BatchNorm-apply + activation folded into
+ * the point max of that stage (Y read once, never rewritten); same numbers as sga_bn_apply + sga_segment_max. */
+int sga_segment_max_affine(const float* Y, long ldy, int T, int N, int C, const float* scale, const float* shift, float slope, float* G,
+                           int32_t* argmax, void* stream);
 
 /* BatchNorm1d over point-major activations [R, C] fused with the following activation (0 none, 1 ReLU, 2 LeakyReLU 0.2)
  * and residual: the train-mode layers of pct.py:122-123, :226-229, :289-293, :311-315.  sums: 2*C doubles.

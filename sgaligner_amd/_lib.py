@@ -53,6 +53,7 @@ SIGNATURES = {
     'sga_pct_head_prep': (I, [P, P, P, P, P, I, I, c_long, I, c_float, P, P, P]),
     'sga_pct_head_dw': (I, [P, P, P, P, P, P, P, c_long, I, I, I, I, P, P, P, P]),
     'sga_pct_head_scatter': (I, [P, P, P, I, I, I, I, P, c_long, P]),
+    'sga_segment_max_affine': (I, [P, c_long, I, I, I, P, P, c_float, P, P, P]),
     'sga_bn_stats': (I, [P, c_long, I, I, P, P]),
     'sga_bn_finalize': (I, [P, I, I, P, P, P, P, P, c_float, c_float, I, P, P]),
     'sga_bn_bwd_finalize': (I, [P, I, I, P, P]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     'sga_hull_vertices': (I, [P, P, I, P, P, P]),
     'sga_gemm': (I, [I, I, I, I, I, P, c_long, I, P, c_long, P, c_long, P, I, P]),
     'sga_colsum': (I, [P, c_long, I, I, P, I, P]),
+    'sga_gemm_bnstats': (I, [I, I, I, P, c_long, P, c_long, P, c_long, P, P, P]),
     'sga_cast_f64_f32': (I, [P, P, c_size_t, P]),
     'sga_loss_gather': (I, [P, I, I, P, I, P, I, P, P]),
     'sga_loss_scatter': (I, [P, P, P, P, I, I, I, P, P]),

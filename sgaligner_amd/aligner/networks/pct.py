@@ -158,8 +158,8 @@ class NaivePCT(nn.Module):
         import torch.nn.functional as F
         from ... import pct_ops as P
         e = self.embedding
-        h = P.batch_norm_act(P.rows_linear(rows, e.conv1.weight), e.bn1, act=1)
-        h = P.batch_norm_act(P.rows_linear(h, e.conv2.weight), e.bn2, act=1)
+        h = P.batch_norm_act(P.rows_linear(rows, e.conv1.weight, bn_stats=True), e.bn1, act=1)
+        h = P.batch_norm_act(P.rows_linear(h, e.conv2.weight, bn_stats=True), e.bn2, act=1)
         xs = []
         for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
             if sa.q_conv.weight is not sa.k_conv.weight and not torch.equal(sa.q_conv.weight, sa.k_conv.weight):
@@ -169,15 +169,15 @@ class NaivePCT(nn.Module):
             bqv = F.pad(sa.v_conv.bias, (wqv.shape[0] - 128, 0))
             a = P.pct_attention_qv(P.rows_linear(h, wqv, bqv), t, n) if wqv.shape[0] == 160 else \
                 P.pct_attention(P.rows_linear(h, sa.k_conv.weight), P.rows_linear(h, sa.v_conv.weight, sa.v_conv.bias), t, n)
-            h = P.batch_norm_act(P.rows_linear(a, sa.trans_conv.weight, sa.trans_conv.bias), sa.after_norm, act=1, resid=h)
+            h = P.batch_norm_act(P.rows_linear(a, sa.trans_conv.weight, sa.trans_conv.bias, bn_stats=True), sa.after_norm, act=1, resid=h)
             xs.append(h)
         cat = torch.cat(xs, dim=1)
         if self.fused_head:      # conv + BatchNorm + LeakyReLU + point max as one node with the algebraic backward (pct_ops.LinearBNActMaxFn)
             g = P.linear_bn_lrelu_max(cat, self.linear[0].weight, self.linear[1], t, n)
         else:
-            y = P.batch_norm_act(P.rows_linear(cat, self.linear[0].weight), self.linear[1], act=2)
+            y = P.batch_norm_act(P.rows_linear(cat, self.linear[0].weight, bn_stats=True), self.linear[1], act=2)
             g = P.segment_max(y, t, n)
-        f = P.batch_norm_act(P.rows_linear(g, self.linear1.weight), self.bn1, act=1)
+        f = P.batch_norm_act(P.rows_linear(g, self.linear1.weight, bn_stats=True), self.bn1, act=1)
         f = F.dropout(f, self.dp1.p, self.training)
-        f = P.batch_norm_act(P.rows_linear(f, self.linear2.weight, self.linear2.bias), self.bn2, act=1)
+        f = P.batch_norm_act(P.rows_linear(f, self.linear2.weight, self.linear2.bias, bn_stats=True), self.bn2, act=1)
         return F.dropout(f, self.dp2.p, self.training)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
                                                              float* __restrict__ C, long ldc,
                                                              const float* __restrict__ bias, int M, int N, int K,
                                                              int accumulate, int act, const float* __restrict__ resid,
-                                                             long ldr) {
+                                                             long ldr, double* __restrict__ colstats) {
     __shared__ __attribute__((aligned(16))) float As[128 * SGA_LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Bs[128 * SGA_LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,15 +202,17 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
         mfma_chunk<4>(acc, As, Bs + (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE, lane);
     }
     const int n = n0 + wave * 32 + (lane & 31);
-    if (n >= N) return;
-    const float bv = bias ? bias[n] : 0.f;
+    const bool nv = n < N;
+    if (!nv && !colstats) return;
+    const float bv = (bias && nv) ? bias[n] : 0.f;
     const int h = lane >> 5;
+    float cs = 0.f, cq = 0.f;                           // column sum / sum of squares of what is written (colstats != null)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + t * 32 + mfma32_row(r, h);
-            if (m < M) {
+            if (m < M && nv) {
                 float* p = C + (size_t)m * ldc + n;
                 float v = acc[t][r] + bv;
                 if (accumulate) v += *p;
@@ -218,8 +220,15 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
                 else if (act == 2) v = v > 0.f ? v : 0.2f * v;
                 if (resid) v += resid[(size_t)m * ldr + n];
                 *p = v;
+                cs += v; cq = fmaf(v, v, cq);
             }
         }
+    }
+    if (colstats) {
+        // BatchNorm batch statistics of the output in the epilogue that produces it (pct.py: every conv is followed by a BatchNorm):
+        // the two lane halves of a column fold, then one fp64 atomic pair per column and workgroup -- sums[0..N) = sum, [N..2N) = sum of squares
+        cs += __shfl_xor(cs, 32, 64); cq += __shfl_xor(cq, 32, 64);
+        if (h == 0 && nv) { atomicAdd(colstats + n, (double)cs); atomicAdd(colstats + N + n, (double)cq); }
     }
 }
 
@@ -386,7 +395,7 @@ extern "C" int sga_cast_f64_f32(const double* in, float* out, size_t n, void* st
 
 static int gemm_launch(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64,
                        const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
-                       int act, const float* resid, long ldr, void* stream) {
+                       int act, const float* resid, long ldr, void* stream, double* colstats = nullptr) {
     SGA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sga_gemm: negative size");
     
     SGA_CHECK_ARG(act >= 0 && act <= 2, "sga_gemm_ex: act=%d (0 none, 1 relu, 2 leaky-relu 0.2)", act);
@@ -397,7 +406,9 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     // split K when the output grid cannot fill the chip (weight-gradient shape)
     int splits = 1;
     const int ncu = sga_num_cus();
-    if (gx * gy < ncu && K >= 4096 && act == 0 && !resid) {          // split-K partial sums cannot carry an epilogue
+    if (colstats) {
+        // the statistics epilogue lives in the NT kernel only (one workgroup per output tile, no split)
+    } else if (gx * gy < ncu && K >= 4096 && act == 0 && !resid) {          // split-K partial sums cannot carry an epilogue
         // ~4 workgroups per CU, at least 256 K-rows each (64 splits of 1024 left 3/4 of the chip idle: 350-470 us per
         // weight gradient at K = 65536 objects)
         splits = min((4 * ncu) / (gx * gy), (K + 255) / 256);
@@ -435,10 +446,11 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     }
     if (!a_is_f64 && !transA && transB && splits == 1 && a_al && b_al && K % 4 == 0) {
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(gx, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
-                           bias, M, N, K, accumulate, act, resid, ldr);
+                           bias, M, N, K, accumulate, act, resid, ldr, colstats);
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;
     }
+    if (colstats) { sga_set_error("sga_gemm_bnstats: shape not taken by the NT kernel (needs K %% 4 == 0, 16-byte aligned operands)"); return SGA_ERR_ARG; }
     // shapes none of the fast kernels take, narrow and short: one workgroup per 32 x 32 tile.  The choice depends on (N, K) only, never on
     // M: a batch walked in chunks of rows (pct inference) must get the same bits as the unchunked call
     if (!use_atomic && N <= 256 && K <= 512) {
@@ -475,6 +487,16 @@ extern "C" int sga_gemm_ex(int transA, int transB, int M, int N, int K, const fl
                            long ldb, float* C, long ldc, const float* bias, int act, const float* resid, long ldr,
                            void* stream) {
     return gemm_launch(transA, transB, M, N, K, A, lda, 0, B, ldb, C, ldc, bias, 0, act, resid, ldr, stream);
+}
+
+// C = A B^T (+ bias) over point-major rows (A [M,K], B [N,K]) AND the BatchNorm batch statistics of C in the same launch:
+// sums[0..N) = column sums, sums[N..2N) = column sums of squares (fp64, zeroed here) -- what sga_bn_stats would compute in a second
+// pass over C (pct.py: every Conv1d / Linear of the encoder feeds a BatchNorm1d).  Needs the NT kernel's shape (K % 4 == 0, aligned).
+extern "C" int sga_gemm_bnstats(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                                const float* bias, double* sums, void* stream) {
+    SGA_CHECK_ARG(sums && N >= 1, "sga_gemm_bnstats: bad argument");
+    if (hipMemsetAsync(sums, 0, (size_t)2 * N * sizeof(double), static_cast<hipStream_t>(stream)) != hipSuccess) { sga_set_error("sga_gemm_bnstats: memset failed"); return SGA_ERR_HIP; }
+    return gemm_launch(0, 1, M, N, K, A, lda, 0, B, ldb, C, ldc, bias, 0, 0, nullptr, 0, stream, sums);
 }
 
 extern "C" int sga_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream) {

@@ -18,15 +18,18 @@ class BatchNormActFn(torch.autograd.Function):
     running variance); eval mode uses the running statistics.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, act, resid, out):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, act, resid, out, pre_sums=None):
         R, C = x.shape
         dev = x.device
         L = _lib.lib()
         st = _stream()
         sums = None
         if training:
-            sums = torch.empty((2 * C,), device=dev, dtype=torch.float64)
-            _chk(L.sga_bn_stats(_p(x), x.stride(0), R, C, _p(sums), st), 'sga_bn_stats')
+            if pre_sums is not None and pre_sums.numel() == 2 * C:       # from the producing GEMM's epilogue (rows_linear(bn_stats=True))
+                sums = pre_sums
+            else:
+                sums = torch.empty((2 * C,), device=dev, dtype=torch.float64)
+                _chk(L.sga_bn_stats(_p(x), x.stride(0), R, C, _p(sums), st), 'sga_bn_stats')
         # scale | shift | mean | rstd and the running-statistics update: one launch (csrc/bn.hip, bn_finalize_kernel)
         fin = torch.empty((4, C), device=dev, dtype=torch.float32)
         nbt = num_batches_tracked if (num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64) else None
@@ -62,14 +65,14 @@ class BatchNormActFn(torch.autograd.Function):
         dx = torch.empty((R, C), device=x.device, dtype=torch.float32)
         _chk(L.sga_bn_bwd_apply(_p(x), x.stride(0), _p(dyc), dyc.stride(0), R, C, _p(scale), _p(shift), _p(mean), _p(rstd), _p(mg), _p(mgx),
                                 ctx.act, _p(dx), dx.stride(0), st), 'sga_bn_bwd_apply')
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, (dy if ctx.has_resid else None), None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, (dy if ctx.has_resid else None), None, None
 
 
 def batch_norm_act(x, bn: torch.nn.BatchNorm1d, act=0, resid=None, out=None):
     """nn.BatchNorm1d `bn` applied to rows of x, then the activation, then `+ resid`."""
     mom = 0.1 if bn.momentum is None else bn.momentum
     return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training, mom,
-                                bn.eps, act, resid, out)
+                                bn.eps, act, resid, out, getattr(x, '_sga_bn_sums', None) if bn.training else None)
 
 
 class PCTAttentionFn(torch.autograd.Function):
@@ -174,12 +177,24 @@ class RowsLinearFn(torch.autograd.Function):
     Conv1d layout [out, in, 1]; the bias is optional (pct.py uses bias=False in front of every BatchNorm)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stats_holder=None):
         from . import ops
         x = x if x.is_contiguous() else x.contiguous()
         w = weight.reshape(weight.shape[0], -1)
         r, k = x.shape
-        y = ops.gemm(x, w, False, True, r, w.shape[0], k, bias=bias)
+        n = w.shape[0]
+        y = None
+        if stats_holder is not None and k % 4 == 0 and r > 0 and w.is_contiguous():
+            # the BatchNorm that follows needs sum / sum of squares of y: produced by the GEMM's own epilogue (no second pass over y)
+            y = torch.empty((r, n), device=x.device, dtype=torch.float32)
+            sums = torch.empty((2 * n,), device=x.device, dtype=torch.float64)
+            rc = _lib.lib().sga_gemm_bnstats(r, n, k, _p(x), x.stride(0), _p(w), w.stride(0), _p(y), y.stride(0), _p(bias), _p(sums), _stream())
+            if rc == 0:
+                stats_holder.append(sums)
+            else:
+                y = None
+        if y is None:
+            y = ops.gemm(x, w, False, True, r, n, k, bias=bias)
         ctx.save_for_backward(x, w)
         ctx.wshape = tuple(weight.shape)
         return y
@@ -199,18 +214,26 @@ class RowsLinearFn(torch.autograd.Function):
             gw = ops.gemm(gy, x, True, False, n, k, r).reshape(ctx.wshape)    # dW = dY^T X (split-K over the rows)
         if ctx.needs_input_grad[2]:
             gb = ops.colsum(gy)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def rows_linear(x, weight, bias=None):
-    return RowsLinearFn.apply(x, weight, bias)
+def rows_linear(x, weight, bias=None, bn_stats=False):
+    """bn_stats=True: the output carries the BatchNorm batch statistics of itself (`_sga_bn_sums`, from the GEMM's epilogue) for the
+    `batch_norm_act` call that consumes it."""
+    if not bn_stats:
+        return RowsLinearFn.apply(x, weight, bias, None)
+    holder = []
+    y = RowsLinearFn.apply(x, weight, bias, holder)
+    if holder:
+        y._sga_bn_sums = holder[0]
+    return y
 
 
 class LinearBNActMaxFn(torch.autograd.Function):
     """g[t, :] = max over object t's points of LeakyReLU_0.2(BatchNorm1d(cat W^T))  -- the encoder's widest stage (pct.py:282-286 + :308:
     Conv1d(512 -> 1024, bias=False), BatchNorm1d(1024), LeakyReLU, torch.max over points) as ONE autograd node.
-    Forward: the same four launches as the separate nodes (GEMM, batch statistics, apply in place, arg-max pool); nothing of size
-    [T*N, 1024] is kept for the backward.  Backward: only the arg-max rows carry dL/dz, and the batch-statistic terms of the BatchNorm
+    Forward: GEMM, batch statistics, then BatchNorm-apply + LeakyReLU folded into the arg-max pool (y is read twice and never rewritten);
+    nothing of size [T*N, 1024] is kept for the backward.  Backward: only the arg-max rows carry dL/dz, and the batch-statistic terms of the BatchNorm
     backward are affine in y = cat W^T, so dW and dcat follow from a 512 x 512 Gram matrix and one [T*N, 512] x [512, 512] product plus
     two sparse passes (csrc/pct.hip head_*_kernel): half the GEMM FLOPs of dY W / dY^T cat, none of the [T*N, 1024] gradient traffic."""
 
@@ -226,11 +249,17 @@ class LinearBNActMaxFn(torch.autograd.Function):
         R, K = cat.shape
         C = w.shape[0]
         dev = cat.device
-        y = ops.gemm(cat, w, False, True, R, C, K)
-        sums = None
-        if training:
+        y = sums = None
+        if training and K % 4 == 0 and R > 0:
+            y = torch.empty((R, C), device=dev, dtype=torch.float32)
             sums = torch.empty((2 * C,), device=dev, dtype=torch.float64)
-            _chk(L.sga_bn_stats(_p(y), y.stride(0), R, C, _p(sums), st), 'sga_bn_stats')
+            if L.sga_gemm_bnstats(R, C, K, _p(cat), cat.stride(0), _p(w), w.stride(0), _p(y), y.stride(0), None, _p(sums), st) != 0:
+                y = sums = None
+        if y is None:
+            y = ops.gemm(cat, w, False, True, R, C, K)
+            if training:
+                sums = torch.empty((2 * C,), device=dev, dtype=torch.float64)
+                _chk(L.sga_bn_stats(_p(y), y.stride(0), R, C, _p(sums), st), 'sga_bn_stats')
         fin = torch.empty((4, C), device=dev, dtype=torch.float32)
         nbt = num_batches_tracked if (num_batches_tracked is not None and num_batches_tracked.dtype == torch.int64) else None
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
@@ -238,10 +267,11 @@ class LinearBNActMaxFn(torch.autograd.Function):
                                int(bool(training)), _p(fin), st), 'sga_bn_finalize')
         if training and num_batches_tracked is not None and nbt is None:
             num_batches_tracked.add_(1)
-        _chk(L.sga_bn_apply(_p(y), y.stride(0), R, C, _p(fin[0]), _p(fin[1]), 2, None, 0, _p(y), y.stride(0), st), 'sga_bn_apply')   # in place
         g = torch.empty((n_obj, C), device=dev, dtype=torch.float32)
         am = torch.empty((n_obj, C), device=dev, dtype=torch.int32)
-        _chk(L.sga_segment_max(_p(y), y.stride(0), n_obj, n_pts, C, _p(g), _p(am), st), 'sga_segment_max')
+        # BatchNorm-apply + LeakyReLU folded into the point max: y is read once and never rewritten
+        _chk(L.sga_segment_max_affine(_p(y), y.stride(0), n_obj, n_pts, C, _p(fin[0]), _p(fin[1]), LinearBNActMaxFn.SLOPE, _p(g), _p(am), st),
+             'sga_segment_max_affine')
         del y
         ctx.save_for_backward(cat, w, fin, g, am, g32, b32)
         ctx.meta = (n_obj, n_pts, bool(training), tuple(weight.shape))

@@ -195,7 +195,7 @@ def test_fused_head_backward_equals_separate_nodes(training):
         if fused:
             g = P.linear_bn_lrelu_max(cat, w, bn, T, N)
         else:
-            g = P.segment_max(P.batch_norm_act(P.rows_linear(cat, w), bn, act=2), T, N)
+            g = P.segment_max(P.batch_norm_act(P.rows_linear(cat, w, bn_stats=True), bn, act=2), T, N)     # same statistics path on both sides
         (g * cot).sum().backward()
         torch.cuda.synchronize()
         res.append((g.detach(), cat.grad, w.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
@@ -205,3 +205,34 @@ def test_fused_head_backward_equals_separate_nodes(training):
         err = (a[k] - b[k]).abs().max().item()
         assert err < 2e-4 * max(1e-6, b[k].abs().max().item()), (name, err, b[k].abs().max().item())
     assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+
+
+def test_gemm_epilogue_bn_statistics_equal_separate_pass():
+    """sga_gemm_bnstats: the BatchNorm batch statistics from the producing GEMM's epilogue (column sums and sums of squares of the output,
+    fp64) against sga_bn_stats on the written output -- several shapes incl. row counts that are no multiple of the 128-row tile and
+    a bias; a shape the NT kernel does not take (K = 3) must be refused, and rows_linear then falls back to the separate pass."""
+    from sgaligner_amd import _lib, pct_ops as P
+    from sgaligner_amd.ops import _p, _stream
+    L = _lib.lib()
+    torch.manual_seed(2)
+    for R, K, N, with_bias in ((1000, 128, 128, False), (4097, 128, 160, True), (333, 512, 1024, False), (64, 1024, 512, False)):
+        x = torch.randn(R, K, device='cuda')
+        w = torch.randn(N, K, device='cuda') * 0.1
+        b = torch.randn(N, device='cuda') if with_bias else None
+        y = torch.empty(R, N, device='cuda')
+        sums = torch.empty(2 * N, device='cuda', dtype=torch.float64)
+        assert L.sga_gemm_bnstats(R, N, K, _p(x), K, _p(w), K, _p(y), N, _p(b), _p(sums), _stream()) == 0
+        ref = torch.empty(2 * N, device='cuda', dtype=torch.float64)
+        _lib.check(L.sga_bn_stats(_p(y), N, R, N, _p(ref), _stream()), 'sga_bn_stats')
+        torch.cuda.synchronize()
+        yd = y.double()
+        exact = torch.cat([yd.sum(0), (yd * yd).sum(0)])
+        assert (sums - exact).abs().max() <= 1e-6 * exact.abs().max()
+        assert (ref - exact).abs().max() <= 1e-5 * exact.abs().max()
+        yref = x @ w.t() + (b if b is not None else 0)
+        assert (y - yref).abs().max() < 1e-3
+    x3 = torch.randn(500, 3, device='cuda'); w3 = torch.randn(64, 3, device='cuda')
+    y3 = torch.empty(500, 64, device='cuda'); s3 = torch.empty(128, device='cuda', dtype=torch.float64)
+    assert L.sga_gemm_bnstats(500, 64, 3, _p(x3), 3, _p(w3), 3, _p(y3), 64, None, _p(s3), _stream()) != 0
+    out = P.rows_linear(x3, w3, None, bn_stats=True)
+    assert not hasattr(out, '_sga_bn_sums') and (out - x3 @ w3.t()).abs().max() < 1e-4

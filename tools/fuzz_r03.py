@@ -97,7 +97,7 @@ while time.time() < t_end:
         bn.train(training)
         cat = cat0.clone().requires_grad_(True)
         w = w0.clone().requires_grad_(True)
-        gg = P.linear_bn_lrelu_max(cat, w, bn, Tn, Np) if fused else P.segment_max(P.batch_norm_act(P.rows_linear(cat, w), bn, act=2), Tn, Np)
+        gg = P.linear_bn_lrelu_max(cat, w, bn, Tn, Np) if fused else P.segment_max(P.batch_norm_act(P.rows_linear(cat, w, bn_stats=True), bn, act=2), Tn, Np)
         (gg * cotp).sum().backward()
         torch.cuda.synchronize()
         out.append((gg.detach(), cat.grad, w.grad, bn.weight.grad, bn.bias.grad))
