@@ -131,13 +131,16 @@ int sga_loss_multi_sums(const float* const* Z, int M, int D, const float* beta, 
                         double* sums, int a_lo, int a_hi, void* stream);
 int sga_loss_multi_grad(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                         const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
-/* fused anchors x anchors terms (M in {2,3}): same outputs as sga_loss_anchor_fwd/bwd for tables (Z_1..Z_M, joint), with the
- * joint similarities derived in registers; bwd writes M1[m] = dL/dS_m + beta_m dL/dS_J (no joint stash) and gamma[m] += dL/dbeta_m */
+/* fused anchors x anchors terms (M in {2,3,4}): same outputs as sga_loss_anchor_fwd/bwd for tables (Z_1..Z_M, joint), with the
+ * joint similarities derived in registers; bwd writes M1[m] = dL/dS_m + beta_m dL/dS_J (no joint stash) and gamma[m] += dL/dbeta_m.
+ * bwd with out_terms != NULL ([(M+1) + 2M] doubles + slots, like `out` of the fwd call) ALSO returns the forward term values of the
+ * anchor rows [a_lo, a_hi) from the same launch: a training step whose dL/d(terms) (`coef`) is known before the terms are -- the
+ * standard loss head, losses.py:114-152 -- computes the A x A similarities once (ops.FusedContrastiveFn, one-pass mode). */
 int sga_loss_anchor_multi_fwd(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
                               float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream);
 int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
                               float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, double* gamma,
-                              int a_lo, int a_hi, void* stream);
+                              int a_lo, int a_hi, double* out_terms, void* stream);
 /* ZJ[r, m*104+d] = sqrt(beta_m) Z_m[r,d] for the anchor rows (operand of the anchors x anchors kernels), and its adjoint */
 int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream);
 int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows, float* const* dZ,

@@ -82,7 +82,7 @@ SIGNATURES = {
     'sga_loss_check_norms': (I, [P, I, P, P]),
     'sga_loss_slots': (I, []),
     'sga_loss_anchor_multi_fwd': (I, [P, I, P, I, P, F, F, F, P, I, I, P]),
-    'sga_loss_anchor_multi_bwd': (I, [P, I, P, I, P, F, F, F, P, P, P, P, I, I, P]),
+    'sga_loss_anchor_multi_bwd': (I, [P, I, P, I, P, F, F, F, P, P, P, P, I, I, P, P]),
     'sga_loss_stash_grad': (I, [P, P, I, I, P, I, I, P]),
     'sga_loss_split_bytes': (c_size_t, [I, I, I]),
     'sga_loss_split_tables': (I, [P, I, I, I, P, P]),

@@ -96,17 +96,24 @@ class OverallLoss(nn.Module):
             # one fused pass over all M+1 tables: every similarity tile is computed once and shared by
             # ICL_m, ICL_joint and IAL_m (the reference recomputes the joint table's q's M times)
             tabs, src = self._fusion_source(output_dict, mods)
+            al = self.align_loss
+            ml_a, ml_c = self.align_multi_loss_layer, self.contrastive_multi_loss_layer
+            head_fused = FUSED_HEAD and tabs[0].is_cuda and type(ml_a) is CustomMultiLossLayer and type(ml_c) is CustomMultiLossLayer
             if src is not None:      # the joint table IS the fusion of these tables: never multiply the 100*M-d table
+                hint = None
+                if head_fused and torch.is_grad_enabled() and ops.FUSED_AA_ONEPASS:
+                    # dL/d(terms) of the standard head depends on the log_vars and constants only: announce it, and the anchors x
+                    # anchors similarities are computed once (terms + gradients together) instead of once per direction
+                    n_anc = len(data_dict['e1i']) if data_dict.get('_sga_index_sets') is None else data_dict['_sga_index_sets'].A
+                    hint = ops.LossHeadFn.coef_hint(ml_a.log_vars, ml_c.log_vars, n_anc, al.zoom, al.alpha, self.zoom)
                 sums, s = ops.fused_contrastive_terms(tabs, src[0], data_dict, alpha=self.contrastive_loss.alpha,
-                                                      shard=data_dict.get('_sga_shard'), reduce=data_dict.get('_sga_reduce'))
+                                                      shard=data_dict.get('_sga_shard'), reduce=data_dict.get('_sga_reduce'), coef_hint=hint)
             else:          # arbitrary joint table: treat it as an independent (M+1)-th table
                 if data_dict.get('_sga_shard') is not None:
                     raise RuntimeError('sgaligner_amd: anchor sharding is implemented for the fused joint path only')
                 sums, s = ops.contrastive_terms(tabs + [output_dict['joint']], data_dict, alpha=self.contrastive_loss.alpha)
             nt = m + 1
-            al = self.align_loss
-            ml_a, ml_c = self.align_multi_loss_layer, self.contrastive_multi_loss_layer
-            if FUSED_HEAD and sums.is_cuda and type(ml_a) is CustomMultiLossLayer and type(ml_c) is CustomMultiLossLayer:
+            if head_fused and sums.is_cuda:
                 # losses.py:114-152 + the two multi-loss layers as one launch (ops.LossHeadFn)
                 loss, icl_uni, icl_multi, total_align_loss = ops.LossHeadFn.apply(
                     sums, ml_a.log_vars, ml_c.log_vars, s.A, al.zoom, al.alpha, self.zoom).unbind(0)

@@ -1350,14 +1350,18 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_kerne
 #pragma unroll
     for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
 
-    // per-lane partial sums over all this wave's tiles
-    float acc_out[NT + 2 * M];
+    // per-lane partial sums: fp32 within a tile (16 elements), fp64 across this wave's tiles.  (All-fp32 partials lost 1.7e-4 of the IAL
+    // terms at configs[2] -- 19 456 nearly equal addends per lane round with a bias, not a random walk; tools/dbg/aa_check64.py.)
+    double acc_d[NT + 2 * M];
 #pragma unroll
-    for (int e = 0; e < NT + 2 * M; ++e) acc_out[e] = 0.f;
+    for (int e = 0; e < NT + 2 * M; ++e) acc_d[e] = 0.0;
 
     const int ntile = (A + 31) / 32;
     for (int jt = split * 4 + wave; jt < ntile; jt += a.nsplit * 4) {
         const int j0 = jt * 32;
+        float acc_out[NT + 2 * M];
+#pragma unroll
+        for (int e = 0; e < NT + 2 * M; ++e) acc_out[e] = 0.f;
         const int jrow = min(j0 + l31, A - 1);                       // this lane's J row as an MFMA A-operand row
         // ---- S tiles: P[m][r] = S_m[i = lane, j = j0 + row(r,h)],  Q[m][r] = S_m[j, i]
         f32x16 P[M], Q[M];
@@ -1429,13 +1433,15 @@ __global__ __launch_bounds__(CT_THREADS, M <= 3 ? 2 : 1) void anchor_multi_kerne
             for (int e = 0; e < NT + 2 * M; ++e) asm volatile("" : "+v"(acc_out[e]));   // keep the updates out of the loop latch
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int e = 0; e < NT + 2 * M; ++e) acc_d[e] += (double)acc_out[e];
     }
     // ---- flush the wave's partial sums into its slot
     const int slot = my_slot();
 #pragma unroll
     for (int e = 0; e < NT + 2 * M; ++e) {
-        const float v = wave_sum(acc_out[e]);
-        if (lane == 0 && v != 0.f) atomicAdd(a.out + (NT + 2 * M) * (1 + slot) + e, (double)v);
+        const double v = wave_sum_d(acc_d[e]);
+        if (lane == 0 && v != 0.0) atomicAdd(a.out + (NT + 2 * M) * (1 + slot) + e, v);
     }
 }
 
@@ -1454,7 +1460,10 @@ __global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restri
 
 // RB = anchor rows staged per workgroup: 32 (two wave pairs, each walking its own J tiles) for M <= 3; 16 for M = 4, where 32 rows of
 // four tables are 106 KiB of LDS = one workgroup per CU (all four waves then share the 16 rows and split the J tiles four ways).
-template <int M, int RB = (M <= 3 ? 32 : 16)>
+// TERMS: the same launch also accumulates the forward TERM values (what anchor_multi_kernel<M,false> returns): the epilogue already holds
+// every q they are made of, so a training step whose dL/d(terms) is known at forward time (ops.FusedContrastiveFn one-pass mode) runs the
+// A x A similarities once instead of twice.
+template <int M, bool TERMS = false, int RB = (M <= 3 ? 32 : 16)>
 __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
     constexpr int DP = 104, NT = M + 1, NSUB = RB / 16, TW = 4 / NSUB;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][RB][DP] own rows
@@ -1486,6 +1495,39 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
         for (int e = 0; e < 8; ++e) acc_gs[k][e] = 0.f;
 #pragma unroll
     for (int m = 0; m < M; ++m) acc_gam[m] = 0.f;
+    float acc_out[TERMS ? NT + 2 * M : 1];                           // TERMS: [ICL_0..M | IAL_a 0..M-1 | IAL_b 0..M-1] partial sums
+#pragma unroll
+    for (int e = 0; e < (TERMS ? NT + 2 * M : 1); ++e) acc_out[e] = 0.f;
+    int tiles_done = 0;
+    // All running sums are fp32 per lane and leave for the fp64 slots every 32 tiles (<= 128 addends per partial): at configs[2] a lane
+    // sees thousands of nearly equal addends, whose fp32 rounding is a bias, not a random walk (1.7e-4 on the IAL terms with
+    // whole-sweep fp32 partials; tools/dbg/aa_check64.py).
+    const int slot = my_slot();
+    auto flush = [&]() {
+        if (TERMS) {
+#pragma unroll
+            for (int e = 0; e < NT + 2 * M; ++e) {
+                const float v = wave_sum(acc_out[TERMS ? e : 0]);
+                if (lane == 0 && v != 0.f) atomicAdd(a.out + (NT + 2 * M) * (1 + slot) + e, (double)v);
+                acc_out[TERMS ? e : 0] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float iv2 = inv_s[k * 8 + e];
+                const float v = -iv2 * iv2 * wave_sum(acc_gs[k][e]);          // dg/dsum = -d inv^2 (g/u)^2: the uniform factor, once
+                if (lane == 0 && v != 0.f) atomicAdd(a.gs + NT * 8 * (1 + slot) + k * 8 + e, (double)v);
+                acc_gs[k][e] = 0.f;
+            }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float v = wave_sum(acc_gam[m]);
+            if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + slot) + m, (double)v);
+            acc_gam[m] = 0.f;
+        }
+    };
     const float* js = inv_s + M * 8;
 
     const int ntile = (A + 15) / 16;
@@ -1546,8 +1588,10 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
                 const float dx = fexp2(xj * a.kc), dy = fexp2(yj * a.kc);
                 const GP Ax = g_parts(dx, js[0], js[2]), Bx = g_parts(dx, js[4], js[6]);
                 const float qAy = g_val(dy, js[0], js[2]), qBy = g_val(dy, js[4], js[6]);
-                const float wA = okf * (-cJ * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) * dx;      // weight * d
+                const float denA = a.alpha * Ax.q + (1.f - a.alpha) * qBy;
+                const float wA = okf * (-cJ * a.alpha) * frcp(denA) * dx;      // weight * d
                 const float wB = okf * (-cJ * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) * dx;
+                if (TERMS) acc_out[TERMS ? M : 0] = fmaf(okf, -flog(denA), acc_out[TERMS ? M : 0]);     // -log(a qA(x) + (1-a) qB(y)), losses.py:55-57
                 gJ = fmaf(wA, Ax.dd, wB * Bx.dd) * a.itc;
                 acc_gs[M][0] = fmaf(wA, Ax.p, acc_gs[M][0]); acc_gs[M][2] = fmaf(wA, Ax.r, acc_gs[M][2]);
                 acc_gs[M][4] = fmaf(wB, Bx.p, acc_gs[M][4]); acc_gs[M][6] = fmaf(wB, Bx.r, acc_gs[M][6]);
@@ -1566,14 +1610,21 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
                 const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
                 const GP Ax = g_parts(dx, is[0], is[2]), Bx = g_parts(dx, is[4], is[6]);
                 const float qAy = g_val(dy, is[0], is[2]), qBy = g_val(dy, is[4], is[6]);
-                const float wA = okf * (-c * a.alpha) * frcp(a.alpha * Ax.q + (1.f - a.alpha) * qBy) * dx;
+                const float denA = a.alpha * Ax.q + (1.f - a.alpha) * qBy;
+                const float wA = okf * (-c * a.alpha) * frcp(denA) * dx;
                 const float wB = okf * (-c * (1.f - a.alpha)) * frcp(a.alpha * qAy + (1.f - a.alpha) * Bx.q) * dx;
+                if (TERMS) acc_out[TERMS ? m : 0] = fmaf(okf, -flog(denA), acc_out[TERMS ? m : 0]);
                 float gxm = fmaf(wA, Ax.dd, wB * Bx.dd) * a.itc;
                 acc_gs[m][0] = fmaf(wA, Ax.p, acc_gs[m][0]); acc_gs[m][2] = fmaf(wA, Ax.r, acc_gs[m][2]);
                 acc_gs[m][4] = fmaf(wB, Bx.p, acc_gs[m][4]); acc_gs[m][6] = fmaf(wB, Bx.r, acc_gs[m][6]);
                 const float dm = fexp2(x * a.ki);
                 const GP OA = g_parts(dm, is[1], is[3]), OB = g_parts(dm, is[5], is[7]);
-                const float eA = okf * ca * __expf(OA.q), eB = okf * cb * __expf(OB.q);
+                const float xA = okf * __expf(OA.q), xB = okf * __expf(OB.q);
+                const float eA = ca * xA, eB = cb * xB;
+                if (TERMS) {                                                       // exp(qo) (qo - log qm): KLDiv with log_target, losses.py:90-94
+                    acc_out[TERMS ? NT + m : 0] = fmaf(xA, OA.q - lqma, acc_out[TERMS ? NT + m : 0]);
+                    acc_out[TERMS ? NT + M + m : 0] = fmaf(xB, OB.q - lqmb, acc_out[TERMS ? NT + M + m : 0]);
+                }
                 const float tA = eA * (OA.q - lqma + 1.f) * dm, tB = eB * (OB.q - lqmb + 1.f) * dm;
                 gxm = fmaf(fmaf(tA, OA.dd, tB * OB.dd), a.iti, gxm);
                 acc_gs[m][1] = fmaf(tA, OA.p, acc_gs[m][1]); acc_gs[m][3] = fmaf(tA, OA.r, acc_gs[m][3]);
@@ -1601,23 +1652,15 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
                 for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(acc_gs[k][e]));
 #pragma unroll
             for (int m = 0; m < M; ++m) asm volatile("" : "+v"(acc_gam[m]));
+            if (TERMS) {
+#pragma unroll
+                for (int e = 0; e < NT + 2 * M; ++e) asm volatile("" : "+v"(acc_out[TERMS ? e : 0]));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if ((++tiles_done & 31) == 0) flush();                       // uniform
     }
-    const int slot = my_slot();
-#pragma unroll
-    for (int k = 0; k < NT; ++k)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float iv2 = inv_s[k * 8 + e];
-            const float v = -iv2 * iv2 * wave_sum(acc_gs[k][e]);          // dg/dsum = -d inv^2 (g/u)^2: the uniform factor, once
-            if (lane == 0 && v != 0.f) atomicAdd(a.gs + NT * 8 * (1 + slot) + k * 8 + e, (double)v);
-        }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const float v = wave_sum(acc_gam[m]);
-        if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + slot) + m, (double)v);
-    }
+    flush();
 }
 
 int rows_grid(int R) {
@@ -2020,11 +2063,12 @@ extern "C" int sga_loss_anchor_multi_fwd(const float* const* Z, int M, const flo
 
 extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const float* beta, int A, const double* sums,
                                          float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
-                                         double* gs, double* gamma, int a_lo, int a_hi, void* stream) {
+                                         double* gs, double* gamma, int a_lo, int a_hi, double* out_terms, void* stream) {
     SGA_CHECK_ARG(Z && beta && sums && coef && M1 && gs && gamma && A >= 0, "sga_loss_anchor_multi_bwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(gs, (M + 1) * 8, s, "sga_loss_anchor_multi_bwd")) return rc0;
     if (int rc1 = zero_slots(gamma, M, s, "sga_loss_anchor_multi_bwd")) return rc1;
+    if (out_terms) { if (int rc2 = zero_slots(out_terms, (M + 1) + 2 * M, s, "sga_loss_anchor_multi_bwd")) return rc2; }
     if (A == 0 || a_hi <= a_lo) return SGA_OK;
     AnchorMultiArgs a{};
     int rc = fill_anchor_multi(a, Z, M, beta, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
@@ -2043,20 +2087,15 @@ extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const flo
         if (nsp > (ntile16 + TW - 1) / TW) nsp = (ntile16 + TW - 1) / TW;
         if (nsp < 1) nsp = 1;
         a.nsplit = nsp;
-        if (M == 2) {
-            auto k = anchor_multi_bwd16_kernel<2>;
+        a.out = out_terms;
+        auto go = [&](auto k) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
-        } else if (M == 3) {
-            auto k = anchor_multi_bwd16_kernel<3>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
-        } else {
-            auto k = anchor_multi_bwd16_kernel<4>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
-        }
+        };
+        if (out_terms) { if (M == 2) go(anchor_multi_bwd16_kernel<2, true>); else if (M == 3) go(anchor_multi_bwd16_kernel<3, true>); else go(anchor_multi_bwd16_kernel<4, true>); }
+        else { if (M == 2) go(anchor_multi_bwd16_kernel<2, false>); else if (M == 3) go(anchor_multi_bwd16_kernel<3, false>); else go(anchor_multi_bwd16_kernel<4, false>); }
     }
+    if (out_terms) fold_slots(out_terms, (M + 1) + 2 * M, s);
     fold_slots(gs, (M + 1) * 8, s);
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_multi_bwd");

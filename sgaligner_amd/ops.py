@@ -410,6 +410,8 @@ class IndexSets:
 
 
 FUSED_ANCHOR_BWD = True
+FUSED_AA_ONEPASS = True      # training: A x A terms + gradients from one pass in forward() when the loss head announces dL/d(terms)
+ONEPASS_MIN_ANCHORS = 256    # below this the A x A work is negligible and the saved gradients' bookkeeping is not worth its launches
 WIDE_STASH = True         # tables wider than 128 columns: coefficient stash + GEMMs instead of the multi-pass gradient sweep (tests flip it)
 FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
 KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel with HIP events on the launch stream
@@ -622,6 +624,28 @@ class LossHeadFn(torch.autograd.Function):
         _lib.check(_lib.lib().sga_loss_head_fwd(_p(sums), ctx.f64, _p(la), _p(lc), *ctx.consts, _p(out), _stream()), 'sga_loss_head_fwd')
         ctx.save_for_backward(sums, la, lc)
         return out
+
+    @staticmethod
+    def coef_hint(lv_ial, lv_icl, n_anchors, z_ial, alpha_ial, zoom):
+        """dL/d(terms) of the standard composition `loss_dict['loss']` with upstream gradient 1 -- it depends on the two log_vars vectors
+        and constants only, never on the term values, so it is known BEFORE the terms are (FusedContrastiveFn one-pass mode).  float32
+        [3M+1] on the device; no autograd."""
+        M = int(lv_ial.numel())
+        la, lc = _req(lv_ial.detach(), 'log_vars (ial)'), _req(lv_icl.detach(), 'log_vars (icl)')
+        dev = la.device
+        key = (str(dev), M)
+        cst = LossHeadFn._hint_const.get(key)
+        if cst is None:          # gout = (1, 0, 0, 0) and a dummy terms vector (the kernel reads it for the log_vars gradients only)
+            cst = LossHeadFn._hint_const[key] = (torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev, dtype=torch.float64),
+                                                 torch.zeros((3 * M + 1,), device=dev, dtype=torch.float32))
+        inv_aa = 1.0 / float(n_anchors * n_anchors) if n_anchors else float('nan')
+        d = torch.empty((3 * M + 1,), device=dev, dtype=torch.float32)
+        junk = torch.empty((2, M), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().sga_loss_head_bwd(_p(cst[0]), _p(cst[1]), 0, _p(la), _p(lc), M, inv_aa, float(z_ial), float(alpha_ial), float(zoom),
+                                                _p(d), _p(junk[0]), _p(junk[1]), _stream()), 'sga_loss_head_bwd')
+        return d
+
+    _hint_const = {}
 
     @staticmethod
     def backward(ctx, gout):
@@ -1055,7 +1079,7 @@ class FusedContrastiveFn(torch.autograd.Function):
     this rank's share as well (the parameter-gradient all-reduce completes it)."""
 
     @staticmethod
-    def forward(ctx, index_sets, alpha, shard, reduce, beta, *tables):
+    def forward(ctx, index_sets, alpha, shard, reduce, coef_hint, beta, *tables):
         L = _lib.lib()
         M = len(tables)
         nt = M + 1
@@ -1108,17 +1132,47 @@ class FusedContrastiveFn(torch.autograd.Function):
         _lib.check(L.sga_loss_build_joint(zarr, M, _p(beta), 2 * s.A, _p(zj), st), 'sga_loss_build_joint')
         out = torch.empty((slots * (nt + 2 * M),), device=dev, dtype=torch.float64)
         dps = [dp] * M + [M * dp]
-        if M <= 4 and FUSED_ANCHOR_FWD:      # joint similarities derived in registers, I block resident in LDS
-            _lib.check(L.sga_loss_anchor_multi_fwd(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out),
-                                                   a_lo, a_hi, st), 'sga_loss_anchor_multi_fwd')
+        onepass = coef_hint is not None and M <= 4 and FUSED_ANCHOR_BWD and FUSED_AA_ONEPASS and s.A >= ONEPASS_MIN_ANCHORS
+        extra = []
+        if onepass:
+            # ONE pass over the anchors x anchors similarities: dL/d(terms) is known (coef_hint), so the backward kernel runs now, block
+            # by block on the bounded stash, and returns the term values of its rows as well; backward() starts from the saved A x A
+            # gradients and only has the negatives' sweep left.
+            coef = _req(coef_hint.contiguous(), 'coef_hint')
+            n_terms = nt + 2 * M
+            dz_all = torch.zeros((M, s.R, dp), device=dev, dtype=torch.float32)
+            zz = torch.zeros((n_terms + nt * 8 + M,), device=dev, dtype=torch.float64)      # terms | gs | gamma: one fill
+            out_acc, gs_aa, gam_aa = zz[:n_terms], zz[n_terms:n_terms + nt * 8].view(nt, 8), zz[n_terms + nt * 8:]
+            chunks = _anchor_chunks(a_lo, a_hi, s.A, M)
+            if chunks:
+                cmax = max(hi - lo for lo, hi in chunks)
+                m1 = [torch.empty((s.A * cmax,), device=dev, dtype=torch.float32) for _ in range(M)]
+                gsc = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)
+                gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
+                for lo, hi in chunks:
+                    _lib.check(L.sga_loss_anchor_multi_bwd(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(coef),
+                                                           _ptr_array(m1), _p(gsc), _p(gam2), lo, hi, _p(out), st), 'sga_loss_anchor_multi_bwd')
+                    out_acc += out[:n_terms]
+                    gs_aa += gsc[0]
+                    gam_aa += gam2[0]
+                    for k in range(M):
+                        _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), s.A, dp, _p(dz_all[k]), lo, hi, st), 'sga_loss_stash_grad')
+                del m1
+            out = _allreduce_sum(out_acc.clone(), reduce)
+            extra = [dz_all, gs_aa.clone(), gam_aa.clone(), coef]
         else:
-            _lib.check(L.sga_loss_anchor_fwd(_ptr_array(zs + [zj]), (_ct.c_int * nt)(*dps), nt, s.A, _p(sums), float(alpha),
-                                             TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi, st), 'sga_loss_anchor_fwd')
-        out = _allreduce_sum(out[:nt + 2 * M].contiguous(), reduce)
+            if M <= 4 and FUSED_ANCHOR_FWD:      # joint similarities derived in registers, I block resident in LDS
+                _lib.check(L.sga_loss_anchor_multi_fwd(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out),
+                                                       a_lo, a_hi, st), 'sga_loss_anchor_multi_fwd')
+            else:
+                _lib.check(L.sga_loss_anchor_fwd(_ptr_array(zs + [zj]), (_ct.c_int * nt)(*dps), nt, s.A, _p(sums), float(alpha),
+                                                 TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi, st), 'sga_loss_anchor_fwd')
+            out = _allreduce_sum(out[:nt + 2 * M].contiguous(), reduce)
         ctx.s, ctx.alpha, ctx.M, ctx.shard, ctx.reduce = s, float(alpha), M, (a_lo, a_hi), reduce
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.n_zb = len(zbs)
-        ctx.save_for_backward(sums, beta, zj, *zs, *nrms, *zbs)
+        ctx.onepass = onepass
+        ctx.save_for_backward(sums, beta, zj, *zs, *nrms, *zbs, *extra)
         return out.float() + poison
 
     @staticmethod
@@ -1129,6 +1183,9 @@ class FusedContrastiveFn(torch.autograd.Function):
         ns = a_hi - a_lo
         nt = M + 1
         sums, beta, zj, *rest = ctx.saved_tensors
+        onepass_saved = None
+        if ctx.onepass:
+            rest, onepass_saved = rest[:-4], rest[-4:]
         zs, nrms, zbs = rest[:M], rest[M:2 * M], rest[2 * M:]
         dev = sums.device
         st = _stream()
@@ -1136,19 +1193,41 @@ class FusedContrastiveFn(torch.autograd.Function):
         A = s.A
         coef = gout.contiguous().float()
         slots = 1 + L.sga_loss_slots()
-        dz_all = torch.zeros((M, s.R, dp), device=dev, dtype=torch.float32)      # one fill for the M accumulation targets
-        dzs = [dz_all[k] for k in range(M)]
         gam_neg = torch.empty((slots, M), device=dev, dtype=torch.float64)   # dL/dbeta via the negatives (zeroed by the callee)
-        gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via the anchors x anchors terms
+        if onepass_saved is not None:
+            # The A x A part was done in forward() for coef_hint; everything it produced is linear in dL/d(terms), so an upstream factor
+            # (loss / k, loss * w) is applied here: u = <gout, hint> / <hint, hint>.  A gout that is NOT a multiple of the hint (a caller
+            # who backpropagates one of the returned components alone, or re-weights them) cannot be served from the saved gradients:
+            # that is detected on the device and raised at the next batch (deferred, no host sync) -- set ops.FUSED_AA_ONEPASS = False.
+            dz_aa, gs_aa, gam_aa, hint = onepass_saved
+            hh = torch.dot(hint, hint)
+            u = torch.dot(coef, hint) / hh
+            if VALIDATE:
+                bad = ((coef - u * hint).abs().max() > 1e-4 * hh.sqrt()).to(torch.int32).reshape(1)
+                DEFERRED_CHECKS.submit_fn(bad, lambda v: None if v[0] == 0 else (
+                    'sgaligner_amd: the gradient that reached the loss terms is not a multiple of the one OverallLoss announced at forward time '
+                    "(backward through something other than loss_dict['loss'] up to a factor); set sgaligner_amd.ops.FUSED_AA_ONEPASS = False"))
+            dz_all = dz_aa * u.float()                     # a fresh tensor: backward() may run twice on one graph (retain_graph)
+            dzs = [dz_all[k] for k in range(M)]
+            gs = _allreduce_sum(gs_aa * u, ctx.reduce)
+            gam_anc = gam_aa * u
+            chunks = []
+        else:
+            dz_all = torch.zeros((M, s.R, dp), device=dev, dtype=torch.float32)      # one fill for the M accumulation targets
+            dzs = [dz_all[k] for k in range(M)]
+            gam_anc = torch.zeros((M,), device=dev, dtype=torch.float64)         # ... via the anchors x anchors terms
         # The anchors x anchors backward runs one anchor-row block [lo, hi) at a time: the kernel writes the block's
         # transposed coefficient stash M1[m] [A, hi-lo], two GEMMs turn it into dX1 / dX2, the next block reuses the
         # buffers -- memory O(A*D + STASH_BYTES), never A x A (nothing of that size at configs[2]).
         fused = M <= 4 and FUSED_ANCHOR_BWD
         ntab = M if fused else nt
-        chunks = _anchor_chunks(a_lo, a_hi, A, ntab)
-        zz = torch.zeros((nt * 8 + M,), device=dev, dtype=torch.float64)              # gs and gam_acc: one fill
-        gs = zz[:nt * 8].view(nt, 8)
-        if fused:
+        if onepass_saved is None:
+            chunks = _anchor_chunks(a_lo, a_hi, A, ntab)
+            zz = torch.zeros((nt * 8 + M,), device=dev, dtype=torch.float64)              # gs and gam_acc: one fill
+            gs = zz[:nt * 8].view(nt, 8)
+        if onepass_saved is not None:
+            pass                                                                       # nothing of the A x A part is left to do
+        elif fused:
             gsc = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)     # + one block: float copy of 1/(sums+eps)
             gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
             gam_acc = zz[nt * 8:]
@@ -1163,7 +1242,7 @@ class FusedContrastiveFn(torch.autograd.Function):
             if fused:
                 # M1[m] already holds dL/dS_m + beta_m dL/dS_J, dL/dbeta comes out directly; no joint operand / stash
                 _lib.check(L.sga_loss_anchor_multi_bwd(_ptr_array(zs), M, _p(beta), A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
-                                                       _ptr_array(m1), _p(gsc), _p(gam2), lo, hi, st), 'sga_loss_anchor_multi_bwd')
+                                                       _ptr_array(m1), _p(gsc), _p(gam2), lo, hi, None, st), 'sga_loss_anchor_multi_bwd')
                 gam_acc += gam2[0]
             else:
                 _lib.check(L.sga_loss_anchor_bwd(_ptr_array(list(zs) + [zj]), (_ct.c_int * nt)(*dps), nt, A, _p(sums), ctx.alpha,
@@ -1182,7 +1261,8 @@ class FusedContrastiveFn(torch.autograd.Function):
                            'sga_loss_fold_joint')
                 gam_anc = gam_sq / (2.0 * torch.sqrt(beta.double()))     # through sqrt(beta_m) in the anchor rows of ZJ
                 del dzj
-        gs = _allreduce_sum(gs, ctx.reduce)                              # dL/d(global sums) needs every shard's tiles
+        if onepass_saved is None:
+            gs = _allreduce_sum(gs, ctx.reduce)                          # dL/d(global sums) needs every shard's tiles
         ev = None
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -1206,13 +1286,18 @@ class FusedContrastiveFn(torch.autograd.Function):
             grads.append(de)
         # d/dbeta_m: through the negatives (gamma) + through sqrt(beta_m) in the anchor rows of ZJ
         gbeta = (gam_neg[0] + gam_anc).float()
-        return (None, None, None, None, gbeta, *grads)
+        return (None, None, None, None, None, gbeta, *grads)
 
 
-def fused_contrastive_terms(tables, fusion_weight, data_dict, alpha=ALPHA, shard=None, reduce=None):
+def fused_contrastive_terms(tables, fusion_weight, data_dict, alpha=ALPHA, shard=None, reduce=None, coef_hint=None):
     """tables: the M modality tables the joint table was fused from; fusion_weight: the [M,1] parameter.
-    shard / reduce: see FusedContrastiveFn (anchor range owned by this rank, in-place SUM all-reduce)."""
+    shard / reduce: see FusedContrastiveFn (anchor range owned by this rank, in-place SUM all-reduce).
+    coef_hint (optional, float32 [3M+1], no grad): dL/d(terms) as the caller's loss head will deliver it (LossHeadFn.coef_hint).  With it,
+    and gradients enabled, the anchors x anchors similarities are computed ONCE -- terms and their gradients from the same launches in
+    forward(), backward() only scales them by the upstream factor -- instead of once per direction."""
     s = IndexSets.of(data_dict, tables[0].device, int(tables[0].shape[0]))
     w = torch.softmax(fusion_weight.reshape(-1), dim=0)                # sg_aligner.py:32
     beta = (w * w) / (w * w).sum()
-    return FusedContrastiveFn.apply(s, alpha, shard, reduce, beta, *tables), s
+    if coef_hint is not None and not (torch.is_grad_enabled() and (beta.requires_grad or any(t.requires_grad for t in tables))):
+        coef_hint = None
+    return FusedContrastiveFn.apply(s, alpha, shard, reduce, coef_hint, beta, *tables), s
