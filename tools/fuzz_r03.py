@@ -3,7 +3,8 @@
     random (pairs, objects, width, raggedness, workspace size -> anchor-row blocks);
   * device hull vertices vs scipy/Qhull on random point sets (blobs, spheres, boxes, duplicates, float32 origins): wherever the
     device certifies, the vertex coordinates are identical; it must decline, never differ;
-  * the PCT head's algebraic backward vs the chain of separate nodes, random (objects, points, gamma signs, train / eval).
+  * the PCT head's algebraic backward vs the chain of separate nodes, random (objects, points, gamma signs, train / eval);
+  * the one-pass anchors x anchors mode vs the two-pass path: terms and every gradient, random (batch, M, stash blocks, upstream factor).
   python tools/fuzz_r03.py [seconds=300] [seed=0]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,8 +17,8 @@ from sgaligner_amd.utils import point_cloud
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
-n_w = n_h = n_hd = n_p = 0
-worst_w = worst_p = 0.0
+n_w = n_h = n_hd = n_p = n_o = 0
+worst_w = worst_p = worst_o = 0.0
 keep_stash = ops.STASH_BYTES
 while time.time() < t_end:
     # ---- wide16 vs fp32 wide path
@@ -107,5 +108,38 @@ while time.time() < t_end:
         worst_p = max(worst_p, e)
         assert e < 1e-3, ('pct head', Tn, Np, training, k, e)
     n_p += 1
+
+    # ---- one-pass A x A (terms + gradients from one pass, ops.FusedContrastiveFn with coef_hint) vs the two-pass path:
+    # random batch, M, stash size (-> several anchor-row blocks), upstream factor
+    Mm = int(rng.integers(2, 5))
+    Bp, Nn = int(rng.integers(14, 60)), int(rng.integers(30, 70))
+    dd2 = make_batch(Bp, Nn, 1, seed=int(rng.integers(1 << 30)), ragged=bool(rng.integers(2)), anchors=('val', 'train')[int(rng.integers(2))])
+    if len(dd2['e1i']) >= ops.ONEPASS_MIN_ANCHORS:
+        T2 = int(dd2['tot_obj_count'].sum())
+        tb = [torch.randn(T2, 100, device='cuda', generator=g) for _ in range(Mm)]
+        wv = torch.randn(Mm, 1, device='cuda', generator=g) * 0.5
+        hint = (torch.rand(3 * Mm + 1, device='cuda', generator=g) + 0.2) * 1e-4
+        up = float(rng.uniform(0.2, 3.0))
+        rr = []
+        for h in (None, hint):
+            tabs2 = [t.clone().requires_grad_(True) for t in tb]
+            w2 = wv.clone().requires_grad_(True)
+            try:
+                if h is not None and rng.random() < 0.6:
+                    ops.STASH_BYTES = 4 * len(dd2['e1i']) * Mm * int(rng.choice([32, 64, 160]))
+                sm, _ = ops.fused_contrastive_terms(tabs2, w2, dd2, coef_hint=h)
+                (sm.double() * hint.double() * up).sum().backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.STASH_BYTES = keep_stash
+            rr.append((sm.detach().double(), [t.grad for t in tabs2] + [w2.grad]))
+        ops.DEFERRED_CHECKS.flush()
+        assert ((rr[0][0] - rr[1][0]).abs() / rr[0][0].abs().clamp_min(1e-12)).max().item() < 1e-6, 'one-pass terms'
+        for a_, b_ in zip(rr[1][1], rr[0][1]):
+            e = (a_ - b_).abs().max().item() / max(1e-30, b_.abs().max().item())
+            worst_o = max(worst_o, e)
+            assert e < 2e-4, ('one-pass grad', Bp, Nn, Mm, e)
+        n_o += 1
 print(f'fuzz_r03: {n_w} wide16 cases (worst gradient difference {worst_w:.2e} of the maximum), {n_h} hulls certified == Qhull '
-      f'({n_hd} declined), {n_p} PCT-head cases (worst difference {worst_p:.2e}); no mismatch')
+      f'({n_hd} declined), {n_p} PCT-head cases (worst difference {worst_p:.2e}), {n_o} one-pass A x A cases (worst gradient difference '
+      f'{worst_o:.2e}); no mismatch')
