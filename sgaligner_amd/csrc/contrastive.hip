@@ -23,6 +23,8 @@
 // the MFMA A-operand layout, so the gradient GEMM (coefficients x other rows) chains straight from the
 // accumulators with no LDS transpose and each owner row is accumulated by exactly one wave.
 #include "mfma_tiles.h"
+#include <type_traits>
+
 #include "loss_math.h"
 
 // gemm.hip (include/sgaligner_hip.h): the stash gradient of the anchors x anchors backward runs on the GEMM kernels
@@ -450,11 +452,15 @@ constexpr int S16_OWN = S16_WAVES * 16;     // owner rows per workgroup
 // SGA_DBG_NOEXP / NOBAR / NODMA / NOS / NOG: timing-only ablation switches (wrong results) for tools/build_variant.sh;
 // never defined in the product build (DESIGN.md 3b lists what they measured).
 __device__ __forceinline__ int s16_pi(int rho) { return (rho & 9) | ((rho & 2) << 1) | ((rho & 4) >> 1); }
+// A wave-uniform float that was produced by VALU arithmetic (so it sits in a VGPR) moved to an SGPR.
+__device__ __forceinline__ float to_sgpr(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
-template <int M, bool GRAD>
+// KT2: the table is wider than 100 columns (a second K step past k = 96 holds data).  emb_dim = 100 runs the KT2 = false build, whose
+// register file has no room for the 2 M operands of a step it would never execute.
+template <int M, bool GRAD, bool KT2 = false>
 __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) void sweep16_kernel(MultiArgs a) {
-    constexpr int DP = 104, OT = 32, NCT = 7;
-    constexpr int TILE_F = OT * DP, BUF_F = M * TILE_F, NCHUNK = M * 13;
+    constexpr int DP = 104, OT = 32, NCT = 7, NTL = KT2 ? 2 : 1;
+    constexpr int TILE_F = OT * DP, BUF_F = M * TILE_F;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][M][OT][DP] + slack for the 7th column tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
     const bool iv = my_i < own_end;
 
     f32x4 own[M][6];
-    float ownt[M][2], beta[M];
+    float ownt[M][NTL], beta[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const float* src = a.Z[m] + (size_t)(iv ? my_i : own0) * DP;
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
 #pragma unroll
         for (int q = 0; q < 6; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 16 * q + 4 * g4) * msk;   // k = 16q + 4g4 + r
 #pragma unroll
-        for (int t = 0; t < 2; ++t) ownt[m][t] = src[96 + 4 * t + g4] * msk;                                       // k = 96 + 4t + g4
+        for (int t = 0; t < NTL; ++t) ownt[m][t] = src[96 + 4 * t + g4] * msk;                                     // k = 96 + 4t + g4
         beta[m] = a.beta[m];
     }
     f32x4 gacc[GRAD ? M : 1][NCT];
@@ -498,20 +504,30 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
 #pragma unroll
     for (int m = 0; m < M; ++m) gam[m] = 0.f;
     // exp2 arguments from an S value `sv` as the MFMA delivers it (already times log2(e)/tau1):  tau1 term exp2(sv),  tau0 term exp2(sv * ka)
-    const float ka = a.k0 / a.k1;
+    const float ka = to_sgpr(a.k0 / a.k1);
     auto e0 = [&](float sv) { return fexp2(sv * ka); };
     auto e1 = [&](float sv) { return fexp2(sv); };
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
+    // A tile is M x 13 chunks of 1 KiB (64 lanes x 16 B).  Wave w fetches chunks (w + m) % WAVES + WAVES * k of table m: the table index is
+    // a compile-time constant of every DMA (its base pointer stays in two SGPRs) and the chunk offset is one uniform value plus a
+    // literal.  (Chunk c = c0 + wave over the flattened M x 13 list made the table a run-time index: an s_load of a.Z[m] from the
+    // kernel arguments + s_waitcnt before each of the 10 DMAs of every tile, and 80 loop-invariant SGPRs, half of them spilled.)
     auto issue = [&](int j0, float* buf) {
+        int l4 = threadIdx.x;
+        asm volatile("" : "+v"(l4));      // lane offset recomputed here (2 VALU): as a loop invariant it is folded into per-lane 64-bit bases that
+        l4 = (l4 & 63) * 4;               // get spilled, and a scratch reload's vmcnt(0) in front of the DMAs serialises them
 #pragma unroll
-        for (int c0 = 0; c0 < NCHUNK; c0 += S16_WAVES) {
-            const int c = c0 + wave_u;
-            if (c >= NCHUNK) break;
-            const int m = c / 13, cc = c - m * 13;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(a.Z[m] + (size_t)j0 * DP + cc * 256 + lane * 4),
-                (__attribute__((address_space(3))) void*)(buf + m * TILE_F + cc * 256), 16, 0, 0);
+        for (int m = 0; m < M; ++m) {
+            const int rot = (wave_u + m) & (S16_WAVES - 1);
+            const float* src = a.Z[m] + ((size_t)j0 * DP + rot * 256) + l4;    // uniform base (SGPR pair) + lane offset
+            float* dst = buf + m * TILE_F + rot * 256;
+#pragma unroll
+            for (int k = 0; k * S16_WAVES < 13; ++k) {
+                if ((k + 1) * S16_WAVES > 13 && rot + k * S16_WAVES >= 13) break;      // uniform; only the last k can fall off the table
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * S16_WAVES * 256),
+                                                 (__attribute__((address_space(3))) void*)(dst + k * S16_WAVES * 256), 16, 0, 0);
+            }
         }
     };
     // this lane's other rows inside a 32-row tile: element (jh, r) <-> row jh*16 + pi(4*g4 + r)
@@ -528,9 +544,9 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
         const int j_end = seg.row0 + seg.n;
         float c0[M + 1], c1[M + 1];
 #pragma unroll
-        for (int m = 0; m <= M; ++m) {
-            c0[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
-            c1[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
+        for (int m = 0; m <= M; ++m) {                      // uniform, but fp64 arithmetic leaves them in VGPRs: 2 (M + 1) registers of a full file
+            c0[m] = GRAD ? to_sgpr((float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0)) : 0.f;
+            c1[m] = GRAD ? to_sgpr((float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1)) : 0.f;
         }
         double dsum[M + 1][2];
 #pragma unroll
@@ -576,7 +592,7 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
                 const float* ap = buf + (jh * 16 + arow) * DP + 4 * g4;
                 const float* at = buf + (jh * 16 + arow) * DP + 96 + g4;
                 f32x4 avA[M], avB[M];
-                float tl[M][2];
+                float tl[M][NTL];
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     sacc[m][jh] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -594,7 +610,9 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
                         }
                     } else {
 #pragma unroll
-                        for (int m = 0; m < M; ++m) { tl[m][0] = at[m * TILE_F]; tl[m][1] = at[m * TILE_F + 4]; }
+                        for (int m = 0; m < M; ++m)
+#pragma unroll
+                            for (int t = 0; t < NTL; ++t) tl[m][t] = at[m * TILE_F + 4 * t];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -602,12 +620,12 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
                         for (int m = 0; m < M; ++m)
                             sacc[m][jh] = __builtin_amdgcn_mfma_f32_16x16x4f32((q & 1) ? avB[m][r] : avA[m][r], own[m][q][r], sacc[m][jh], 0, 0, 0);
                     if (q < 5) __builtin_amdgcn_sched_group_barrier(0x100, M, 0);          // next group's reads first ...
-                    else __builtin_amdgcn_sched_group_barrier(0x100, 2 * M, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, NTL * M, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * M, 0);                 // ... then this group's MFMAs
                 }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (t >= a.ktail) break;                       // uniform: the all-zero padding step is skipped (exact)
+                for (int t = 0; t < NTL; ++t) {
+                    if (t >= a.ktail) break;                       // uniform: an all-zero padding step is skipped (exact)
 #pragma unroll
                     for (int m = 0; m < M; ++m)
                         sacc[m][jh] = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[m][t], ownt[m][t], sacc[m][jh], 0, 0, 0);
@@ -748,7 +766,7 @@ constexpr int S4_THREADS = 512;
 template <bool GRAD>
 __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
     constexpr int M = 4, MT = 2, DP = 104, OT = 32, NCT = 7;
-    constexpr int TILE_F = OT * DP, BUF_F = M * TILE_F, NCHUNK = M * 13;
+    constexpr int TILE_F = OT * DP, BUF_F = M * TILE_F;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][M][OT][DP] + 32 slack + exchange [8 waves][16][64]
     float* xbuf = lds + 2 * BUF_F + 32;
 
@@ -792,15 +810,21 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
     auto e1 = [&](float sv) { return fexp2(sv); };
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto issue = [&](int j0, float* buf) {
+    auto issue = [&](int j0, float* buf) {      // chunk (wave + 2m) % 8 (+ 8) of table m: compile-time table index, see sweep16_kernel
+        int l4 = threadIdx.x;
+        asm volatile("" : "+v"(l4));
+        l4 = (l4 & 63) * 4;
 #pragma unroll
-        for (int c0 = 0; c0 < NCHUNK; c0 += 8) {
-            const int c = c0 + wave_u;
-            if (c >= NCHUNK) break;
-            const int m = c / 13, cc = c - m * 13;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(a.Z[m] + (size_t)j0 * DP + cc * 256 + lane * 4),
-                (__attribute__((address_space(3))) void*)(buf + m * TILE_F + cc * 256), 16, 0, 0);
+        for (int m = 0; m < M; ++m) {
+            const int rot = (wave_u + 2 * m) & 7;
+            const float* src = a.Z[m] + ((size_t)j0 * DP + rot * 256) + l4;
+            float* dst = buf + m * TILE_F + rot * 256;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && rot + 8 >= 13) break;            // uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 8 * 256),
+                                                 (__attribute__((address_space(3))) void*)(dst + k * 8 * 256), 16, 0, 0);
+            }
         }
     };
     int jrow[4];
@@ -1029,7 +1053,7 @@ static void launch_sweep16x2(const MultiArgs& a, int nwg, hipStream_t s) {
 template <int M, bool GRAD>
 static void launch_sweep16(const MultiArgs& a, int nwg, hipStream_t s) {
     const size_t lds = ((size_t)2 * M * 32 * 104 + 32) * sizeof(float);
-    auto k = sweep16_kernel<M, GRAD>;
+    auto k = a.ktail > 1 ? sweep16_kernel<M, GRAD, true> : sweep16_kernel<M, GRAD, false>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(nwg), dim3(S16_THREADS), lds, s, a);
 }
@@ -1562,7 +1586,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {                                    // tail k = 96 + 4t + g
+            for (int t = 0; t < 2; ++t) {                                    // tail k = 96 + 4t + g (emb_dim up to 104: no padding assumed)
                 const int kk = 96 + 4 * t + g;
                 P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[kk], bp[kk], P[m], 0, 0, 0);
                 Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[kk], bq[kk], Q[m], 0, 0, 0);
@@ -1573,12 +1597,16 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
         // scheduling barrier between elements: interleaving the four independent chains keeps ~4x the temporaries
         // live and pushes the loop into scratch.  Masks are multiplied in (rows/columns past the end are clamped
         // copies of valid rows, so every intermediate is finite) -- selects here become 28 exec-mask branches.
+        // Interior tiles (all 16 anchor rows and all 16 columns valid: everything but the last row block / column tile) run the
+        // mask-free instantiation -- the ~20 multiplications by okf and the predicated stores are 4 % of this VALU-bound loop.
         const float cJ = a.coef[M];
+        auto epilogue = [&](auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + 4 * g + r;
-            const bool ok = iv && (j < A);
-            const float okf = ok ? 1.f : 0.f;
+            const bool ok = !MASKED || (iv && (j < A));
+            const float okf = (!MASKED || ok) ? 1.f : 0.f;
             float xj = 0.f, yj = 0.f;
 #pragma unroll
             for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], P[m][r], xj); yj = fmaf(beta[m], Q[m][r], yj); }
@@ -1658,6 +1686,8 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        };
+        if (j0 + 16 <= A && i0 + RB <= a.i_hi) epilogue(std::false_type{}); else epilogue(std::true_type{});   // uniform
         if ((++tiles_done & 31) == 0) flush();                       // uniform
     }
     flush();

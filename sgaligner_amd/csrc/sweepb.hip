@@ -39,6 +39,17 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define SB_WAVES_N 8
 #endif
 constexpr int SB_WAVES = SB_WAVES_N, SB_THREADS = SB_WAVES * 64, SB_OWN = SB_WAVES * 16;
+constexpr int SB_ROT = SB_WAVES == 8 ? 3 : 1;    // per-table rotation of the DMA chunk -> wave assignment (spreads the waves that get one chunk more)
+constexpr int sb_min_chunks(int M, int nch) {    // fewest DMA chunks any wave issues per tile under that assignment
+    int best = 1 << 30;
+    for (int w = 0; w < SB_WAVES; ++w) {
+        int n = 0;
+        for (int m = 0; m < M; ++m)
+            for (int c = (w + SB_ROT * m) & (SB_WAVES - 1); c < nch; c += SB_WAVES) ++n;
+        best = n < best ? n : best;
+    }
+    return best;
+}
 #ifndef SB_NBUF
 #define SB_NBUF 2
 #endif
@@ -117,7 +128,7 @@ template <int M, bool GRAD>
 __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kernel(BArgs a) {
     constexpr int NCT = 7;
     constexpr int TBYTES = SB_BLOCK;
-    constexpr int BUF = M * TBYTES, NCH = TBYTES / 1024, NCHUNK = M * NCH;
+    constexpr int BUF = M * TBYTES, NCH = TBYTES / 1024;
     constexpr int NBUF = SB_NBUF;                                             // ring depth: tiles it+1 .. it+NBUF-1 are in flight
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];      // [NBUF][M][TBYTES]
 
@@ -175,15 +186,24 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
     const int tr_main = (tr_cs >> 1) * 256 + tr_io * 16 + (tr_cs & 1) * 8;        // + (ct >> 1) * 2048 + (ct & 1) * 512 + rd * 1024
     const int tr_tail = 6144 + (tr_cs & 1) * 128 + tr_io * 8;                    // + rd * 256  (columns 96..103; sub-pieces 2, 3 alias 0, 1)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
+    // Wave w fetches chunks (w + SB_ROT m) % WAVES + WAVES k of table m (as contrastive.hip's sweep16_kernel: the table index of every DMA
+    // is a compile-time constant, so no kernel-argument reload + s_waitcnt sits in front of it); sb_min_chunks() is what every wave
+    // issues at least per tile -- the counted vmcnt wait below relies on it.
     auto issue = [&](int blk, unsigned char* buf) {
+        int l16 = threadIdx.x;
+        asm volatile("" : "+v"(l16));         // lane offset recomputed here, not kept (and spilled) as part of per-lane 64-bit bases
+        l16 = (l16 & 63) * 16;
 #pragma unroll
-        for (int c0 = 0; c0 < NCHUNK; c0 += SB_WAVES) {
-            const int c = c0 + wave_u;
-            if (c >= NCHUNK) break;
-            const int m = c / NCH, cc = c - m * NCH;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(a.Zb[m] + (size_t)blk * SB_BLOCK + cc * 1024 + lane * 16),
-                (__attribute__((address_space(3))) void*)(buf + m * TBYTES + cc * 1024), 16, 0, 0);
+        for (int m = 0; m < M; ++m) {
+            const int rot = (wave_u + SB_ROT * m) & (SB_WAVES - 1);
+            const unsigned char* src = a.Zb[m] + ((size_t)blk * SB_BLOCK + rot * 1024) + l16;
+            unsigned char* dst = buf + m * TBYTES + rot * 1024;
+#pragma unroll
+            for (int k = 0; k * SB_WAVES < NCH; ++k) {
+                if ((k + 1) * SB_WAVES > NCH && rot + k * SB_WAVES >= NCH) break;       // uniform; only the last k can fall off the table
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * SB_WAVES * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + k * SB_WAVES * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
             if (NBUF == 2) {
                 __syncthreads();
             } else {
-                constexpr int keep = (NCHUNK / SB_WAVES) * (NBUF - 2);      // every wave issues >= NCHUNK / 8 chunks per tile
+                constexpr int keep = sb_min_chunks(M, NCH) * (NBUF - 2);    // every wave issues at least that many chunks per tile
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
