@@ -637,22 +637,27 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
                 float p0[M + 1], p1[M + 1];
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+                // interior tiles (every owner row of the block and every other row of the tile valid) add unmasked
+                auto sums_tile = [&](auto masked_c) {
+                    constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-                for (int jh = 0; jh < 2; ++jh)
+                    for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float okf = (iv && (j0 + jh * 16 + jrow[r] < j_end)) ? 1.f : 0.f;
-                        float sj = 0.f;
+                        for (int r = 0; r < 4; ++r) {
+                            const float okf = (!MASKED || (iv && (j0 + jh * 16 + jrow[r] < j_end))) ? 1.f : 0.f;
+                            float sj = 0.f;
 #pragma unroll
-                        for (int m = 0; m < M; ++m) {
-                            const float sv = sacc[m][jh][r];
-                            sj = fmaf(beta[m], sv, sj);
-                            p0[m] = fmaf(okf, e0(sv), p0[m]);
-                            p1[m] = fmaf(okf, e1(sv), p1[m]);
+                            for (int m = 0; m < M; ++m) {
+                                const float sv = sacc[m][jh][r];
+                                sj = fmaf(beta[m], sv, sj);
+                                p0[m] = MASKED ? fmaf(okf, e0(sv), p0[m]) : p0[m] + e0(sv);
+                                p1[m] = MASKED ? fmaf(okf, e1(sv), p1[m]) : p1[m] + e1(sv);
+                            }
+                            p0[M] = MASKED ? fmaf(okf, e0(sj), p0[M]) : p0[M] + e0(sj);
+                            p1[M] = MASKED ? fmaf(okf, e1(sj), p1[M]) : p1[M] + e1(sj);
                         }
-                        p0[M] = fmaf(okf, e0(sj), p0[M]);
-                        p1[M] = fmaf(okf, e1(sj), p1[M]);
-                    }
+                };
+                if (j0 + OT <= j_end && own0 + S16_OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
@@ -1491,9 +1496,14 @@ template <int M, bool TERMS = false, int RB = (M <= 3 ? 32 : 16)>
 __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
     constexpr int DP = 104, NT = M + 1, NSUB = RB / 16, TW = 4 / NSUB;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][RB][DP] own rows
-    // the (M+1)*8 sum coefficients are read from global memory at uniform addresses: s_load -> SGPRs.  As LDS reads
-    // each of the 32 values cost an address VGPR + a data VGPR and pushed the kernel into scratch.
+    // The (M+1)*8 sum coefficients and the 3M+1 upstream coefficients are read from global memory at uniform addresses, per element
+    // of the epilogue (the compiler re-issues them as vector loads after every stash store: it cannot rule out aliasing).  Measured
+    // alternatives, 2048 x 155 648 block: as is 9.50 ms; loaded once before the loop (the compiler turns them into s_loads, 82 SGPRs)
+    // 10.43 ms; pinned in SGPRs by readfirstlane 11.05 ms -- two-SGPR-operand VALU forms do not exist on gfx9, so the uniform values
+    // cost v_movs in the arithmetic, more than the L1-hit loads they replace (tools/bench_aa.py).  As LDS reads each value cost an
+    // address VGPR + a data VGPR and pushed the kernel into scratch.
     const float* __restrict__ inv_s = a.inv;
+    auto CF = [&](int e) { return a.coef[e]; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int A = a.A, ns = a.i_hi - a.i_lo;
     const int ib = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
@@ -1599,7 +1609,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
         // copies of valid rows, so every intermediate is finite) -- selects here become 28 exec-mask branches.
         // Interior tiles (all 16 anchor rows and all 16 columns valid: everything but the last row block / column tile) run the
         // mask-free instantiation -- the ~20 multiplications by okf and the predicated stores are 4 % of this VALU-bound loop.
-        const float cJ = a.coef[M];
+        const float cJ = CF(M);
         auto epilogue = [&](auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
@@ -1633,7 +1643,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const float* is = inv_s + m * 8;
-                const float c = a.coef[m], ca = a.coef[NT + m], cb = a.coef[NT + M + m];
+                const float c = CF(m), ca = CF(NT + m), cb = CF(NT + M + m);
                 const float x = P[m][r], y = Q[m][r];
                 const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
                 const GP Ax = g_parts(dx, is[0], is[2]), Bx = g_parts(dx, is[4], is[6]);
