@@ -141,6 +141,19 @@ int sga_loss_anchor_multi_fwd(const float* const* Z, int M, const float* beta, i
 int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
                               float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, double* gamma,
                               int a_lo, int a_hi, double* out_terms, void* stream);
+/* Symmetric walk of the anchors x anchors terms for an UNSHARDED anchor set (M in {2,3}; reference arithmetic losses.py:43-97, where
+ * term (i,j) and term (j,i) are made of the same two similarities S[i,j], S[j,i]): block [a_lo, a_hi) meets the columns j >= a_lo only
+ * and also evaluates the mirrored elements (j, i), j >= a_hi -- every unordered anchor pair once over the whole walk instead of twice.
+ * a_lo % 32 == 0; a_hi % 32 == 0 or a_hi == A.  M1[m]: [A - a_lo, a_hi - a_lo] floats, M1[m][(j-a_lo)*ns + (i-a_lo)] = dL/dS_m[i,j];
+ * M2[m]: [A - a_hi, ns], M2[m][(j-a_hi)*ns + (i-a_lo)] = dL/dS_m[j,i] (may be NULL when a_hi == A).  out_terms / gs / gamma: the block's
+ * share, both elements of every pair it visits; summed over the blocks of a walk they equal sga_loss_anchor_multi_bwd's over the same
+ * rows.  sga_loss_stash_grad_sym applies one table's two stashes: dX1[R] += M1^T X2[a_lo:A], dX2[a_lo:A] += M1 X1[R],
+ * dX1[a_hi:A] += M2 X2[R], dX2[R] += M2^T X1[a_hi:A]. */
+int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
+                                  float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2, double* gs,
+                                  double* gamma, int a_lo, int a_hi, double* out_terms, void* stream);
+int sga_loss_stash_grad_sym(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
+                            void* stream);
 /* ZJ[r, m*104+d] = sqrt(beta_m) Z_m[r,d] for the anchor rows (operand of the anchors x anchors kernels), and its adjoint */
 int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream);
 int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows, float* const* dZ,

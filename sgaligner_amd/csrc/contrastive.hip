@@ -1353,6 +1353,8 @@ struct AnchorMultiArgs {
     float* M1[4];                  // bwd: M1[m][j*ns + (i - i_lo)] = dL/dS_m[i,j] (+ beta_m dL/dS_J)
     double* gs;                    // bwd: [(M+1)][8] (+ slots)
     double* gamma;                 // bwd: [M] (+ slots)
+    int j_lo;                      // bwd: first column (a multiple of 16); stash rows are j - j_lo.  0 except in the symmetric mode
+    float* M2[4];                  // symmetric mode: M2[m][(j - i_hi)*ns + (i - i_lo)] = the MIRRORED coefficient dL/dS_m[j,i], j >= i_hi
 };
 
 template <int M, bool BWD>
@@ -1492,8 +1494,15 @@ __global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restri
 // TERMS: the same launch also accumulates the forward TERM values (what anchor_multi_kernel<M,false> returns): the epilogue already holds
 // every q they are made of, so a training step whose dL/d(terms) is known at forward time (ops.FusedContrastiveFn one-pass mode) runs the
 // A x A similarities once instead of twice.
-template <int M, bool TERMS = false, int RB = (M <= 3 ? 32 : 16)>
+// SYM (M <= 3, TERMS): every UNORDERED anchor pair is visited once.  The block's rows [i_lo, i_hi) meet the columns j >= i_lo only; in a
+// tile right of the block (j >= i_hi) a lane holds x = S[i,j] and y = S[j,i] anyway, so it also produces the mirrored element (j, i) --
+// its terms, its sum gradients and its coefficient dL/dS[j,i], which goes to a second stash M2 -- instead of leaving it to the block that
+// owns row j.  The ICL halves of the two elements share every exp2 / g() evaluation and both denominators; the IAL halves are
+// independent.  Half the MFMAs and J-operand loads, ~0.78 of the VALU work per pair.  Tiles inside the block's own
+// column range (the diagonal square) run the ordinary epilogue.
+template <int M, bool TERMS = false, int RB = (M <= 3 ? 32 : 16), bool SYM = false>
 __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
+    static_assert(!SYM || (TERMS && M <= 3), "symmetric mode: one-pass build, M <= 3");
     constexpr int DP = 104, NT = M + 1, NSUB = RB / 16, TW = 4 / NSUB;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][RB][DP] own rows
     // The (M+1)*8 sum coefficients and the 3M+1 upstream coefficients are read from global memory at uniform addresses, per element
@@ -1566,7 +1575,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
 
     const int ntile = (A + 15) / 16;
 #pragma unroll 1
-    for (int jt = split * TW + tw; jt < ntile; jt += a.nsplit * TW) {
+    for (int jt = (a.j_lo >> 4) + split * TW + tw; jt < ntile; jt += a.nsplit * TW) {
         const int j0 = jt * 16;
         const int jrow = min(j0 + l15, A - 1);
         // The anchor-row operands are loop invariant; left alone, LICM parks all M*2*26 of them in registers
@@ -1680,7 +1689,11 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 acc_gam[m] = fmaf(gJ, P[m][r], acc_gam[m]);
-                if (ok) a.M1[m][(size_t)j * ns + (my_i - a.i_lo)] = fmaf(beta[m], gJ, gx[m]);
+#ifdef SGA_DBG_AA_NOSTORE
+                acc_gam[m] += fmaf(beta[m], gJ, gx[m]);
+#else
+                if (ok) a.M1[m][(size_t)(j - a.j_lo) * ns + (my_i - a.i_lo)] = fmaf(beta[m], gJ, gx[m]);
+#endif
             }
             // pin the running sums here: otherwise their updates are sunk into the loop latch (they are only
             // consumed by the next iteration) and every factor of all four elements stays live until then
@@ -1697,8 +1710,102 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
             __builtin_amdgcn_sched_barrier(0);
         }
         };
-        if (j0 + 16 <= A && i0 + RB <= a.i_hi) epilogue(std::false_type{}); else epilogue(std::true_type{});   // uniform
-        if ((++tiles_done & 31) == 0) flush();                       // uniform
+        // Symmetric epilogue: elements (i, j) [x = P, "dir 0", stash M1] and (j, i) [y = Q, "dir 1", stash M2] together.
+        auto epilogue_sym = [&](auto) {      // generic: only instantiated where it is called
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 4 * g + r;
+            const bool ok = iv && (j < A);
+            const float okf = ok ? 1.f : 0.f;
+            float xj = 0.f, yj = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; ++m) { xj = fmaf(beta[m], P[m][r], xj); yj = fmaf(beta[m], Q[m][r], yj); }
+            float gci[NT][2];                                        // ICL part of dL/dx, dL/dy per table (joint = M)
+            // ---- ICL, every table and the joint: term(i,j) = -log(a qA(x) + (1-a) qB(y)), term(j,i) = -log(a qA(y) + (1-a) qB(x))
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const float* is = inv_s + k * 8;
+                const float x = k < M ? P[k < M ? k : 0][r] : xj, y = k < M ? Q[k < M ? k : 0][r] : yj;
+                const float c = CF(k);
+                const float dx = fexp2(x * a.kc), dy = fexp2(y * a.kc);
+                const GP Ax = g_parts(dx, is[0], is[2]), Bx = g_parts(dx, is[4], is[6]);
+                const GP Ay = g_parts(dy, is[0], is[2]), By = g_parts(dy, is[4], is[6]);
+                const float den1 = a.alpha * Ax.q + (1.f - a.alpha) * By.q;
+                const float den2 = a.alpha * Ay.q + (1.f - a.alpha) * Bx.q;
+                const float r1 = okf * -c * frcp(den1), r2 = okf * -c * frcp(den2);
+                const float wAx = a.alpha * r1 * dx, wBx = (1.f - a.alpha) * r2 * dx;
+                const float wAy = a.alpha * r2 * dy, wBy = (1.f - a.alpha) * r1 * dy;
+                acc_out[TERMS ? k : 0] = fmaf(okf, -(flog(den1) + flog(den2)), acc_out[TERMS ? k : 0]);
+                gci[k][0] = fmaf(wAx, Ax.dd, wBx * Bx.dd) * a.itc;
+                gci[k][1] = fmaf(wAy, Ay.dd, wBy * By.dd) * a.itc;
+                acc_gs[k][0] = fmaf(wAx, Ax.p, fmaf(wAy, Ay.p, acc_gs[k][0])); acc_gs[k][2] = fmaf(wAx, Ax.r, fmaf(wAy, Ay.r, acc_gs[k][2]));
+                acc_gs[k][4] = fmaf(wBx, Bx.p, fmaf(wBy, By.p, acc_gs[k][4])); acc_gs[k][6] = fmaf(wBx, Bx.r, fmaf(wBy, By.r, acc_gs[k][6]));
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) asm volatile("" : "+v"(acc_gs[k][e]));
+                asm volatile("" : "+v"(acc_out[TERMS ? k : 0]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- IAL, one direction at a time (nothing shared between x and y here)
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                const float vj = dir ? yj : xj;
+                const float dji = fexp2(vj * a.ki);
+                const GP MA = g_parts(dji, js[1], js[3]), MB = g_parts(dji, js[5], js[7]);
+                const float lqma = flog(MA.q), lqmb = flog(MB.q);
+                float gx[M], EA = 0.f, EB = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float* is = inv_s + m * 8;
+                    const float ca = CF(NT + m), cb = CF(NT + M + m);
+                    const float v = dir ? Q[m][r] : P[m][r];
+                    const float dm = fexp2(v * a.ki);
+                    const GP OA = g_parts(dm, is[1], is[3]), OB = g_parts(dm, is[5], is[7]);
+                    const float xA = okf * __expf(OA.q), xB = okf * __expf(OB.q);
+                    const float eA = ca * xA, eB = cb * xB;
+                    acc_out[TERMS ? NT + m : 0] = fmaf(xA, OA.q - lqma, acc_out[TERMS ? NT + m : 0]);
+                    acc_out[TERMS ? NT + M + m : 0] = fmaf(xB, OB.q - lqmb, acc_out[TERMS ? NT + M + m : 0]);
+                    const float tA = eA * (OA.q - lqma + 1.f) * dm, tB = eB * (OB.q - lqmb + 1.f) * dm;
+                    gx[m] = fmaf(fmaf(tA, OA.dd, tB * OB.dd), a.iti, gci[m][dir]);
+                    acc_gs[m][1] = fmaf(tA, OA.p, acc_gs[m][1]); acc_gs[m][3] = fmaf(tA, OA.r, acc_gs[m][3]);
+                    acc_gs[m][5] = fmaf(tB, OB.p, acc_gs[m][5]); acc_gs[m][7] = fmaf(tB, OB.r, acc_gs[m][7]);
+                    EA += eA; EB += eB;
+                }
+                const float uA = -EA * frcp(MA.q) * dji, uB = -EB * frcp(MB.q) * dji;
+                const float gJ = fmaf(fmaf(uA, MA.dd, uB * MB.dd), a.iti, gci[M][dir]);
+                acc_gs[M][1] = fmaf(uA, MA.p, acc_gs[M][1]); acc_gs[M][3] = fmaf(uA, MA.r, acc_gs[M][3]);
+                acc_gs[M][5] = fmaf(uB, MB.p, acc_gs[M][5]); acc_gs[M][7] = fmaf(uB, MB.r, acc_gs[M][7]);
+                float* const* dst = dir ? a.M2 : a.M1;
+                const size_t off = (size_t)(j - (dir ? a.i_hi : a.j_lo)) * ns + (my_i - a.i_lo);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    acc_gam[m] = fmaf(gJ, dir ? Q[m][r] : P[m][r], acc_gam[m]);
+                    if (ok) dst[m][off] = fmaf(beta[m], gJ, gx[m]);
+                }
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int e = 1; e < 8; e += 2) asm volatile("" : "+v"(acc_gs[k][e]));
+#pragma unroll
+                for (int m = 0; m < M; ++m) asm volatile("" : "+v"(acc_gam[m]));
+#pragma unroll
+                for (int e = NT; e < NT + 2 * M; ++e) asm volatile("" : "+v"(acc_out[TERMS ? e : 0]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        };
+#ifdef SGA_DBG_AA_NOEPI
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_gam[m] += P[m][r] * Q[m][r];
+#else
+        if constexpr (SYM) {
+            if (j0 >= a.i_hi) epilogue_sym(0); else epilogue(std::true_type{});                               // uniform
+        } else {
+            if (j0 + 16 <= A && i0 + RB <= a.i_hi) epilogue(std::false_type{}); else epilogue(std::true_type{});   // uniform
+        }
+#endif
+        if ((++tiles_done & (SYM ? 15 : 31)) == 0) flush();          // uniform
     }
     flush();
 }
@@ -2140,4 +2247,71 @@ extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const flo
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_multi_bwd");
     return SGA_OK;
+}
+
+/* Symmetric form of sga_loss_anchor_multi_bwd for an UNSHARDED anchor set walked in blocks (M = 2, 3; terms always returned): block
+ * [a_lo, a_hi) meets the columns j >= a_lo only and also produces the mirrored elements (j, i), j >= a_hi, i in the block, so every
+ * unordered pair is evaluated once over the whole walk.  a_lo must be a multiple of 32, a_hi a multiple of 32 or == A.
+ *   M1[m][(j - a_lo) * ns + (i - a_lo)] = dL/dS_m[i, j],  j in [a_lo, A)          ([A - a_lo, ns] floats)
+ *   M2[m][(j - a_hi) * ns + (i - a_lo)] = dL/dS_m[j, i],  j in [a_hi, A)          ([A - a_hi, ns] floats)
+ * out_terms / gs / gamma as in sga_loss_anchor_multi_bwd: this block's share (both elements of every pair it visits). */
+extern "C" int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
+                                             float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
+                                             double* gs, double* gamma, int a_lo, int a_hi, double* out_terms, void* stream) {
+    SGA_CHECK_ARG(Z && beta && sums && coef && M1 && M2 && gs && gamma && out_terms && A >= 0, "sga_loss_anchor_multi_bwd_sym: bad argument");
+    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_anchor_multi_bwd_sym: M=%d (2 or 3; M = 4 runs sga_loss_anchor_multi_bwd)", M);
+    SGA_CHECK_ARG(a_lo % 32 == 0 && (a_hi % 32 == 0 || a_hi == A), "sga_loss_anchor_multi_bwd_sym: block [%d,%d) not on 32-row boundaries", a_lo, a_hi);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc0 = zero_slots(gs, (M + 1) * 8, s, "sga_loss_anchor_multi_bwd_sym")) return rc0;
+    if (int rc1 = zero_slots(gamma, M, s, "sga_loss_anchor_multi_bwd_sym")) return rc1;
+    if (int rc2 = zero_slots(out_terms, (M + 1) + 2 * M, s, "sga_loss_anchor_multi_bwd_sym")) return rc2;
+    if (A == 0 || a_hi <= a_lo) return SGA_OK;
+    AnchorMultiArgs a{};
+    int rc = fill_anchor_multi(a, Z, M, beta, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
+    if (rc) return rc;
+    a.coef = coef; a.gs = gs; a.gamma = gamma; a.out = out_terms; a.j_lo = a_lo;
+    float* inv = reinterpret_cast<float*>(gs + (size_t)(1 + SGA_SLOTS) * (M + 1) * 8);
+    hipLaunchKernelGGL(inv_sums_kernel, dim3(1), dim3(64), 0, s, sums, inv, (M + 1) * 8);
+    a.inv = inv;
+    for (int m = 0; m < M; ++m) {
+        SGA_CHECK_ARG(M1[m] && (M2[m] || a_hi == A), "sga_loss_anchor_multi_bwd_sym: null stash");
+        a.M1[m] = M1[m]; a.M2[m] = M2[m];
+    }
+    const int RB = 32, TW = 2;
+    const size_t lds = (size_t)(M * 2 * RB * 104 + (M + 1) * 8) * sizeof(float);
+    const int nib = (a_hi - a_lo + RB - 1) / RB, ntile16 = (A - a_lo + 15) / 16;
+    int nsp = (6 * sga_num_cus() + nib - 1) / nib;
+    if (nsp > (ntile16 + TW - 1) / TW) nsp = (ntile16 + TW - 1) / TW;
+    if (nsp < 1) nsp = 1;
+    a.nsplit = nsp;
+    auto go = [&](auto k) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
+    };
+    if (M == 2) go(anchor_multi_bwd16_kernel<2, true, 32, true>); else go(anchor_multi_bwd16_kernel<3, true, 32, true>);
+    fold_slots(out_terms, (M + 1) + 2 * M, s);
+    fold_slots(gs, (M + 1) * 8, s);
+    fold_slots(gamma, M, s);
+    SGA_CHECK_LAUNCH("sga_loss_anchor_multi_bwd_sym");
+    return SGA_OK;
+}
+
+/* The four products of a symmetric block's two stashes for one table (Z = [X1 | X2 | ...] rows of width Dp; R = [a_lo, a_hi)):
+ *   dX1[R] += M1^T X2[a_lo:A]     dX2[a_lo:A] += M1 X1[R]     dX1[a_hi:A] += M2 X2[R]     dX2[R] += M2^T X1[a_hi:A] */
+extern "C" int sga_loss_stash_grad_sym(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
+                                       void* stream) {
+    SGA_CHECK_ARG(M1 && Z && dZ && A >= 0 && Dp >= 8 && Dp % 8 == 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi && (M2 || a_hi == A),
+                  "sga_loss_stash_grad_sym: bad argument");
+    const int ns = a_hi - a_lo, c1 = A - a_lo, c2 = A - a_hi;
+    if (A == 0 || ns == 0) return SGA_OK;
+    // (a last block whose row count is not a multiple of 4 takes sga_gemm's general kernel: correct, slower)
+    const float* X1 = Z;
+    const float* X2 = Z + (size_t)A * Dp;
+    float* d1 = dZ;
+    float* d2 = dZ + (size_t)A * Dp;
+    int rc = sga_gemm(1, 0, ns, Dp, c1, M1, ns, 0, X2 + (size_t)a_lo * Dp, Dp, d1 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
+    if (!rc) rc = sga_gemm(0, 0, c1, Dp, ns, M1, ns, 0, X1 + (size_t)a_lo * Dp, Dp, d2 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
+    if (!rc && c2 > 0) rc = sga_gemm(0, 0, c2, Dp, ns, M2, ns, 0, X2 + (size_t)a_lo * Dp, Dp, d1 + (size_t)a_hi * Dp, Dp, nullptr, 1, stream);
+    if (!rc && c2 > 0) rc = sga_gemm(1, 0, ns, Dp, c2, M2, ns, 0, X1 + (size_t)a_hi * Dp, Dp, d2 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
+    return rc;
 }

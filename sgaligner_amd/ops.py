@@ -411,6 +411,9 @@ class IndexSets:
 
 FUSED_ANCHOR_BWD = True
 FUSED_AA_ONEPASS = True      # training: A x A terms + gradients from one pass in forward() when the loss head announces dL/d(terms)
+# One-pass mode, unsharded anchors, M <= 3: walk the anchors x anchors pairs SYMMETRICALLY -- a block evaluates (i, j) and (j, i) from the
+# same two similarities, every unordered pair once (sga_loss_anchor_multi_bwd_sym: -34 % per ordered pair, tools/bench_aa.py).
+AA_SYMMETRIC = True
 ONEPASS_MIN_ANCHORS = 256    # below this the A x A work is negligible and the saved gradients' bookkeeping is not worth its launches
 WIDE_STASH = True         # tables wider than 128 columns: coefficient stash + GEMMs instead of the multi-pass gradient sweep (tests flip it)
 FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
@@ -444,6 +447,20 @@ def _anchor_chunks(a_lo, a_hi, A, n_tables):
         return []
     rows = max(32, (STASH_BYTES // (4 * A * max(1, n_tables))) // 32 * 32)
     return [(c, min(c + rows, a_hi)) for c in range(a_lo, a_hi, rows)]
+
+
+def _sym_chunks(A, n_tables):
+    """Blocks of the SYMMETRIC anchors x anchors walk (csrc/contrastive.hip, anchor_multi_bwd16_kernel<.., SYM>): block [lo, hi) meets
+    the columns >= lo and keeps two stashes, [A - lo, hi - lo] and [A - hi, hi - lo] floats per table, bounded together by STASH_BYTES --
+    so blocks get taller as the walk moves right.  32-row boundaries except the end."""
+    out, lo = [], 0
+    q = STASH_BYTES // (4 * max(1, n_tables))
+    while lo < A:
+        rows = max(32, (q // (2 * (A - lo))) // 32 * 32)
+        hi = min(lo + rows, A)
+        out.append((lo, hi))
+        lo = hi
+    return out
 
 
 # What sga_loss_multi_grad launches (bench.py's roofline line): two owner sweeps x M tables x (S with K = 100 + gradient
@@ -1143,12 +1160,32 @@ class FusedContrastiveFn(torch.autograd.Function):
             dz_all = torch.zeros((M, s.R, dp), device=dev, dtype=torch.float32)
             zz = torch.zeros((n_terms + nt * 8 + M,), device=dev, dtype=torch.float64)      # terms | gs | gamma: one fill
             out_acc, gs_aa, gam_aa = zz[:n_terms], zz[n_terms:n_terms + nt * 8].view(nt, 8), zz[n_terms + nt * 8:]
-            chunks = _anchor_chunks(a_lo, a_hi, s.A, M)
+            sym = AA_SYMMETRIC and M <= 3 and a_lo == 0 and a_hi == s.A
+            chunks = _sym_chunks(s.A, M) if sym else _anchor_chunks(a_lo, a_hi, s.A, M)
             if chunks:
-                cmax = max(hi - lo for lo, hi in chunks)
-                m1 = [torch.empty((s.A * cmax,), device=dev, dtype=torch.float32) for _ in range(M)]
                 gsc = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)
                 gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
+            if chunks and sym:
+                # every unordered anchor pair once: a block also evaluates the mirrored elements right of it (second stash)
+                fl = max((2 * s.A - lo - hi) * (hi - lo) for lo, hi in chunks)
+                buf = [torch.empty((fl,), device=dev, dtype=torch.float32) for _ in range(M)]
+                for lo, hi in chunks:
+                    n1 = (s.A - lo) * (hi - lo)
+                    m1 = [b[:n1] for b in buf]
+                    m2 = [b[n1:] for b in buf]
+                    _lib.check(L.sga_loss_anchor_multi_bwd_sym(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(coef),
+                                                               _ptr_array(m1), _ptr_array(m2) if hi < s.A else (_ct.c_void_p * M)(), _p(gsc), _p(gam2),
+                                                               lo, hi, _p(out), st), 'sga_loss_anchor_multi_bwd_sym')
+                    out_acc += out[:n_terms]
+                    gs_aa += gsc[0]
+                    gam_aa += gam2[0]
+                    for k in range(M):
+                        _lib.check(L.sga_loss_stash_grad_sym(_p(m1[k]), _p(m2[k]) if hi < s.A else None, _p(zs[k]), s.A, dp, _p(dz_all[k]),
+                                                             lo, hi, st), 'sga_loss_stash_grad_sym')
+                del buf, m1, m2
+            elif chunks:
+                cmax = max(hi - lo for lo, hi in chunks)
+                m1 = [torch.empty((s.A * cmax,), device=dev, dtype=torch.float32) for _ in range(M)]
                 for lo, hi in chunks:
                     _lib.check(L.sga_loss_anchor_multi_bwd(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(coef),
                                                            _ptr_array(m1), _p(gsc), _p(gam2), lo, hi, _p(out), st), 'sga_loss_anchor_multi_bwd')

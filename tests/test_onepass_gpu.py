@@ -101,3 +101,90 @@ def test_onepass_not_used_without_gradients():
         _, l_eval = steps.train_step(0, 0, dd)
     assert l_train['loss'].requires_grad and not l_eval['loss'].requires_grad
     assert abs(float(l_train['loss']) - float(l_eval['loss'])) <= 1e-6 * abs(float(l_eval['loss']))
+
+
+@pytest.mark.parametrize('mods,stash_rows', [(('point', 'gat', 'rel'), None), (('point', 'rel'), 64), (('point', 'gat', 'rel'), 32)])
+def test_symmetric_walk_equals_ordered_walk(mods, stash_rows):
+    """ops.AA_SYMMETRIC: every unordered anchor pair evaluated once (a block also produces the mirrored elements right of it) --
+    same terms and gradients as the walk that visits both orders; several blocks of growing height with a small stash."""
+    from sgaligner_amd import ops
+    dd, run = _setup(seed=11 + len(mods), pairs=30, mods=mods)
+    A = len(dd['e1i'])
+    keep_s, keep_b = ops.AA_SYMMETRIC, ops.STASH_BYTES
+    try:
+        if stash_rows:
+            ops.STASH_BYTES = 4 * len(mods) * 2 * A * stash_rows
+            assert len(ops._sym_chunks(A, len(mods))) >= 3
+        ops.AA_SYMMETRIC = False
+        r0, g0 = run(True)
+        ops.AA_SYMMETRIC = True
+        r1, g1 = run(True)
+        ops.DEFERRED_CHECKS.flush()
+    finally:
+        ops.AA_SYMMETRIC, ops.STASH_BYTES = keep_s, keep_b
+    for k in r0:
+        assert abs(r1[k] - r0[k]) <= 1e-6 * max(1.0, abs(r0[k])), (k, r1[k], r0[k])
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1e-12, b.abs().max().item()), ((a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize('A,rows,M', [(2100, 512, 3), (1000, 96, 2), (333, 160, 3)])
+def test_symmetric_kernel_walk_at_the_c_abi(A, rows, M):
+    """sga_loss_anchor_multi_bwd_sym + sga_loss_stash_grad_sym over a whole walk == sga_loss_anchor_multi_bwd + sga_loss_stash_grad:
+    terms, dL/d(sums), dL/dbeta and dZ; ragged last block, A not a multiple of 16, stashes poisoned with NaN beforehand."""
+    from sgaligner_amd import _lib
+    from sgaligner_amd.ops import _p, _ptr_array, _stream
+    L = _lib.lib(); st = _stream(); dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(A)
+    zs = []
+    for m in range(M):
+        z = torch.zeros(2 * A + 32, 104, device=dev)
+        z[:2 * A, :100] = torch.nn.functional.normalize(torch.randn(2 * A, 100, device=dev, generator=g), dim=1)
+        zs.append(z)
+    nt, n_terms, slots = M + 1, M + 1 + 2 * M, 1 + L.sga_loss_slots()
+    sums = torch.rand(nt, 8, device=dev, dtype=torch.float64, generator=g) * 1e3 + 1e3
+    beta = torch.softmax(torch.randn(M, device=dev, generator=g), 0)
+    coef = (torch.rand(3 * M + 1, device=dev, generator=g) + 0.5) * 1e-2
+    zarr = _ptr_array(zs)
+
+    def walk(sym):
+        dz = [torch.zeros(2 * A + 32, 104, device=dev) for _ in range(M)]
+        acc = [torch.zeros(n_terms, device=dev, dtype=torch.float64), torch.zeros(nt, 8, device=dev, dtype=torch.float64),
+               torch.zeros(M, device=dev, dtype=torch.float64)]
+        gsc = torch.empty(slots + 1, nt, 8, device=dev, dtype=torch.float64)
+        gam2 = torch.empty(slots, M, device=dev, dtype=torch.float64)
+        out = torch.empty(slots * n_terms, device=dev, dtype=torch.float64)
+        for lo in range(0, A, rows):
+            hi = min(lo + rows, A); ns = hi - lo
+            m1 = [torch.full(((A - lo if sym else A) * ns,), float('nan'), device=dev) for _ in range(M)]
+            if sym:
+                m2 = [torch.full((max(1, (A - hi) * ns),), float('nan'), device=dev) for _ in range(M)]
+                _lib.check(L.sga_loss_anchor_multi_bwd_sym(zarr, M, _p(beta), A, _p(sums), 0.5, 0.1, 1.0, _p(coef), _ptr_array(m1), _ptr_array(m2),
+                                                           _p(gsc), _p(gam2), lo, hi, _p(out), st), 'sym')
+                for k in range(M):
+                    _lib.check(L.sga_loss_stash_grad_sym(_p(m1[k]), _p(m2[k]), _p(zs[k]), A, 104, _p(dz[k]), lo, hi, st), 'stash sym')
+            else:
+                _lib.check(L.sga_loss_anchor_multi_bwd(zarr, M, _p(beta), A, _p(sums), 0.5, 0.1, 1.0, _p(coef), _ptr_array(m1), _p(gsc), _p(gam2),
+                                                       lo, hi, _p(out), st), 'ordered')
+                for k in range(M):
+                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, 104, _p(dz[k]), lo, hi, st), 'stash')
+            acc[0] += out[:n_terms]; acc[1] += gsc[0]; acc[2] += gam2[0]
+        torch.cuda.synchronize()
+        return acc + dz
+
+    a, b = walk(False), walk(True)
+    for x, y in zip(b, a):
+        assert torch.isfinite(x).all()
+        assert (x - y).abs().max().item() <= 5e-6 * y.abs().max().item(), ((x - y).abs().max().item(), y.abs().max().item())
+
+
+def test_symmetric_entry_refuses_blocks_off_the_32_row_grid():
+    from sgaligner_amd import _lib
+    from sgaligner_amd.ops import _p, _ptr_array, _stream
+    L = _lib.lib()
+    z = [torch.zeros(2 * 64 + 32, 104, device='cuda') for _ in range(2)]
+    d = torch.zeros(4096, device='cuda', dtype=torch.float64)
+    f = torch.zeros(64 * 64, device='cuda')
+    rc = L.sga_loss_anchor_multi_bwd_sym(_ptr_array(z), 2, _p(f), 64, _p(d), 0.5, 0.1, 1.0, _p(f), _ptr_array([f, f]), _ptr_array([f, f]),
+                                         _p(d), _p(d), 8, 40, _p(d), _stream())
+    assert rc != 0 and b'32-row' in L.sga_last_error()

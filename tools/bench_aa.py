@@ -43,3 +43,21 @@ for r in range(reps + 1):
 el = float(NS) * A
 print(f'A x A kernel (M={M}, {NS} rows x {A} anchors): {np.median(tk):.3f} ms = {np.median(tk) * 1e6 / el:.4f} ns per (i, j) pair; stash GEMMs {np.median(tg):.3f} ms '
       f'({2.0 * 2 * M * el * 104 / np.median(tg) / 1e9:.1f} TFLOP/s); checksum {float(out[:nt + 2 * M].sum()):.6e} {float(m1[0].abs().sum()):.6e}')
+# symmetric block: rows [0, NS) x columns [0, A), both elements of every pair -> compare HALF its time with the ordinary block above
+if M <= 3 and NS % 32 == 0:
+    m1s = [torch.empty(A * NS, device=dev) for _ in range(M)]
+    m2s = [torch.empty((A - NS) * NS, device=dev) for _ in range(M)]
+    ts, tgs = [], []
+    for r in range(reps + 1):
+        e[0].record()
+        _lib.check(L.sga_loss_anchor_multi_bwd_sym(zarr, M, _p(beta), A, _p(sums), 0.5, 0.1, 1.0, _p(coef), _ptr_array(m1s), _ptr_array(m2s), _p(gsc), _p(gam2),
+                                                   0, NS, _p(out), st), 'sym')
+        e[1].record()
+        for k in range(M):
+            _lib.check(L.sga_loss_stash_grad_sym(_p(m1s[k]), _p(m2s[k]), _p(zs[k]), A, 104, _p(dz[k]), 0, NS, st), 'sgs')
+        e[2].record()
+        torch.cuda.synchronize()
+        if r:
+            ts.append(e[0].elapsed_time(e[1])); tgs.append(e[1].elapsed_time(e[2]))
+    pairs = float(NS) * A * 2 - float(NS) * NS
+    print(f'symmetric block: kernel {np.median(ts):.3f} ms = {np.median(ts) * 1e6 / pairs:.4f} ns per ordered pair; stash GEMMs {np.median(tgs):.3f} ms')
