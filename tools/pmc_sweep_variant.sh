@@ -6,7 +6,7 @@ tag=$1; B=$2; N=$3
 lib=""; if [ -n "$tag" ]; then lib="variants/libsga_$tag.so"; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcv_${tag}_$c
-  SGA_LIB_PATH=$lib timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep16_kernel<3, (true|false)>' --output-format csv -d gpurun_out/pmcv_${tag}_$c -- python tools/bench_sweep.py $B $N 2 > /dev/null 2>&1
+  SGA_LIB_PATH=$lib timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep16_kernel<3, (true|false)' --output-format csv -d gpurun_out/pmcv_${tag}_$c -- python tools/bench_sweep.py $B $N 2 > /dev/null 2>&1
   python - "$tag" "$c" <<'PY'
 import csv, glob, sys, collections
 tag, c = sys.argv[1], sys.argv[2]

@@ -10,12 +10,12 @@ cd "$GRAFT_REPO_ROOT"
 cfg=$1
 out=$2
 if [ ! -f "$out" ]; then
-  echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex 'sweep.*_kernel<3, true>|pointnet_fwd_kernel'), bench.py --config <cfg> --steps 2 --warmup 1" > $out
+  echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex 'sweep.*_kernel<3, (true|false)|pointnet_fwd_kernel'), bench.py --config <cfg> --steps 2 --warmup 1" > $out
   echo "# unit: KiB per dispatch (average over the profiled launches); gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -> bytes = (2*FETCH + WRITE) * 1024" >> $out
   echo "kernel;workload_key;source_sha16;counter;avg_kib_per_launch;launches" >> $out
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, (true|false)>|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, (true|false)|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
   python - $c $cfg >> $out <<'PY'
 import csv, glob, sys, collections, hashlib
 c, cfg = sys.argv[1], sys.argv[2]
@@ -31,7 +31,7 @@ for f in glob.glob(f'gpurun_out/pmc_t_{cfg}_{c}/**/*counter_collection.csv', rec
             k = ('pointnet_fwd_kernel', keys[0], sha('pointnet.hip'))
         else:
             import re
-            mm = re.search(r'(\w+_kernel)<3, (true|false)>', name)
+            mm = re.search(r'(\w+_kernel)<3, (true|false)', name)
             k = (mm.group(1) + '<3,' + mm.group(2) + '>', keys[1], sha('contrastive.hip'))
         acc[k] += float(r['Counter_Value']); n[k] += 1
 for k in sorted(acc):

@@ -14,6 +14,6 @@ python tools/prof_summary.py gpurun_out/${tag}_c2_stats gpurun_out/${tag}_c2_ker
 rm -f gpurun_out/${tag}_pmc_traffic.csv
 tools/pmc_traffic.sh c2 gpurun_out/${tag}_pmc_traffic.csv > /dev/null
 tools/pmc_traffic.sh c3 gpurun_out/${tag}_pmc_traffic.csv > /dev/null
-re='sweep.*_kernel<3, true>|pointnet_fwd_kernel|pointnet_bwd_fused_kernel|sweep.*_kernel<3, false>|anchor_multi'
+re='sweep.*_kernel<3, true|pointnet_fwd_kernel|pointnet_bwd_fused_kernel|sweep.*_kernel<3, false|anchor_multi'
 tools/pmc_kernel.sh "$re" ${tag}_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" > gpurun_out/${tag}_sq_counters.txt 2>&1
 head -c 3000 gpurun_out/${tag}_bench_default.json; echo; cat gpurun_out/${tag}_pmc_traffic.csv; head -40 gpurun_out/${tag}_sq_counters.txt
