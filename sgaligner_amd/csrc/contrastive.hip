@@ -1584,33 +1584,48 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
         int lofs = 0;
         asm volatile("" : "+v"(lofs));
         f32x4 P[M], Q[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            P[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Q[m] = P[m];
+        // J-side operands of table m + 1 are requested (all 12 quads + tails) before table m's MFMAs start: a whole table of flight time
+        // for loads that come straight from L2 (compiler-scheduled two loads ahead: 12.80 ms per symmetric 2048 x 155 648 block; this: 12.39)
+        struct JOps { f32x4 p[6], q[6]; float pt[2], qt[2]; };
+        auto jload = [&](int m, JOps& o) {
             const float* gp = a.Z[m] + (size_t)(A + jrow) * DP;              // X2[j] for P
             const float* gq = a.Z[m] + (size_t)jrow * DP;                    // X1[j] for Q
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                o.p[q] = *reinterpret_cast<const f32x4*>(gp + 16 * q + 4 * g);
+                o.q[q] = *reinterpret_cast<const f32x4*>(gq + 16 * q + 4 * g);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { o.pt[t] = gp[96 + 4 * t + g]; o.qt[t] = gq[96 + 4 * t + g]; }
+        };
+        JOps jb[2];
+        jload(0, jb[0]);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            if (m + 1 < M) jload(m + 1, jb[(m + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            P[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Q[m] = P[m];
+            const JOps& o = jb[m & 1];
             const float* bp = lds + lofs + ((m * 2 + 0) * RB + ih * 16 + l15) * DP;   // X1[i]
             const float* bq = lds + lofs + ((m * 2 + 1) * RB + ih * 16 + l15) * DP;   // X2[i]
 #pragma unroll
             for (int q = 0; q < 6; ++q) {                                    // k = 16q + 4g + r
-                const f32x4 ap = *reinterpret_cast<const f32x4*>(gp + 16 * q + 4 * g);
-                const f32x4 aq = *reinterpret_cast<const f32x4*>(gq + 16 * q + 4 * g);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 16 * q + 4 * g);
                 const f32x4 b2 = *reinterpret_cast<const f32x4*>(bq + 16 * q + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r], b1[r], P[m], 0, 0, 0);
-                    Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[r], b2[r], Q[m], 0, 0, 0);
+                    P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.p[q][r], b1[r], P[m], 0, 0, 0);
+                    Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.q[q][r], b2[r], Q[m], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {                                    // tail k = 96 + 4t + g (emb_dim up to 104: no padding assumed)
+            for (int t = 0; t < 2; ++t) {
                 const int kk = 96 + 4 * t + g;
-                P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[kk], bp[kk], P[m], 0, 0, 0);
-                Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[kk], bq[kk], Q[m], 0, 0, 0);
+                P[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.pt[t], bp[kk], P[m], 0, 0, 0);
+                Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qt[t], bq[kk], Q[m], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);       // one table's operands in flight at a time (104 registers)
+            __builtin_amdgcn_sched_barrier(0);
         }
         // P[m][r] = S_m[i = lane&15, j = j0 + 4g + r], Q[m][r] = S_m[j, i].  One element (r) at a time, with a
         // scheduling barrier between elements: interleaving the four independent chains keeps ~4x the temporaries
