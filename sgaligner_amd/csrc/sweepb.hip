@@ -24,6 +24,8 @@
 //   8 (i>>2) + 4 jh + (i&3), so that a lane's 8 accumulator values (2 halves x 4) are the 8 CONSECUTIVE other rows 8 g4 .. 8 g4+7:
 //   exactly the k slots of the gradient MFMA  dZ[own] += C[own, other] Z[other, cols]  whose A operand is therefore the
 //   coefficient registers (split into bf16 hi/lo, 6 VALU per pair) and whose B operand comes from the transpose reads above.
+#include <type_traits>
+
 #include "loss_math.h"
 
 namespace {
@@ -150,9 +152,15 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
     const bool iv = my_i < own_end;
 
     // ---- owner rows as the S product's B operand: 3 K = 32 steps (8 columns per lane) + the K = 16 tail (columns 96 + 4 g4 .. +3)
-    u32x4 ohi[M][3], olo[M][3];
+    // OLDS: the gradient build for three tables needs 84 (owner hi/lo operands) + 84 (accumulators) + 24 (S tiles) registers before any
+    // temporary -- 39 spilled, with scratch reloads (and their vmcnt waits) inside the tile loop.  There the owner rows' LO planes live in
+    // the 80 KiB of LDS the two-deep ring leaves free instead: [table][K step][thread] 16-byte slots, written and read by the same
+    // lane only (lane-linear ds_read_b128: conflict free, no barrier), 9 more LDS reads per half tile.
+    constexpr bool OLDS = GRAD && M == 3;
+    u32x4 ohi[M][3], olo[OLDS ? 1 : M][3];
     u32x2 othi[M], otlo[M];
     float beta[M];
+    u32x4* const olds = reinterpret_cast<u32x4*>(ldsb + NBUF * BUF) + tid;       // + (m * 3 + q) * SB_THREADS
     {
         const int rel = (iv ? my_i : own0) - grp.own_old0;
         const int o = rel & 31, oi = 4 * (o >> 3) + (o & 3), ojh = (o >> 2) & 1;       // row o sits at (half ojh, operand row oi) of its block
@@ -163,8 +171,9 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 ohi[m][q] = *reinterpret_cast<const u32x4*>(base + ((q * 2 + ojh) * 64 + g4 * 16 + oi) * 16);
-                olo[m][q] = *reinterpret_cast<const u32x4*>(base + SB_PLANE + ((q * 2 + ojh) * 64 + g4 * 16 + oi) * 16);
-                if (!iv) { ohi[m][q] = u32x4{0, 0, 0, 0}; olo[m][q] = u32x4{0, 0, 0, 0}; }
+                u32x4 lo4 = *reinterpret_cast<const u32x4*>(base + SB_PLANE + ((q * 2 + ojh) * 64 + g4 * 16 + oi) * 16);
+                if (!iv) { ohi[m][q] = u32x4{0, 0, 0, 0}; lo4 = u32x4{0, 0, 0, 0}; }
+                if (OLDS) olds[(m * 3 + q) * SB_THREADS] = lo4; else olo[OLDS ? 0 : m][q] = lo4;
             }
             const bool tv = iv && g4 < 2;                      // columns 96..103 only: the k slots of lanes 32..63 multiply zeros
             othi[m] = tv ? *reinterpret_cast<const u32x2*>(base + 6144 + ((ojh * 2 + (g4 & 1)) * 16 + oi) * 8) : u32x2{0, 0};
@@ -182,9 +191,8 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
     for (int m = 0; m < M; ++m) gam[m] = 0.f;
 
     // transposed-read piece of this lane (see the header): operand row i_o = 4 g4 + (l15 >> 2), column sub-piece l15 & 3
-    const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
-    const int tr_main = (tr_cs >> 1) * 256 + tr_io * 16 + (tr_cs & 1) * 8;        // + (ct >> 1) * 2048 + (ct & 1) * 512 + rd * 1024
-    const int tr_tail = 6144 + (tr_cs & 1) * 128 + tr_io * 8;                    // + rd * 256  (columns 96..103; sub-pieces 2, 3 alias 0, 1)
+    // (per tile below: tr_main = (cs >> 1) * 256 + io * 16 + (cs & 1) * 8  [+ (ct >> 1) * 2048 + (ct & 1) * 512 + rd * 1024] and
+    //  tr_tail = 6144 + (cs & 1) * 128 + io * 8  [+ rd * 256; columns 96..103, sub-pieces 2, 3 alias 0, 1], io = 4 g4 + (l15 >> 2), cs = l15 & 3)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
     // Wave w fetches chunks (w + SB_ROT m) % WAVES + WAVES k of table m (as contrastive.hip's sweep16_kernel: the table index of every DMA
     // is a compile-time constant, so no kernel-argument reload + s_waitcnt sits in front of it); sb_min_chunks() is what every wave
@@ -230,6 +238,16 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
         for (int jt = seg.jt_lo + split; jt < seg.jt_hi; jt += nsplit, ++it) {
             unsigned char* buf = ldsb + (it % NBUF) * BUF;
             const int j0 = seg.old0 + 32 * jt;                 // old row of the tile's first row
+            // Three-table gradient build: the lane-derived LDS offsets are recomputed per tile from an opaque copy of the thread id (~10
+            // VALU).  As loop invariants they are the first thing the allocator spills at 256 registers, and every scratch reload in
+            // this loop brings a vmcnt wait that also stalls on the DMA ring.
+            int tid_t = tid;
+            if (OLDS) asm volatile("" : "+v"(tid_t));
+            const int lane_t = tid_t & 63, g4_t = lane_t >> 4, l15_t = lane_t & 15;
+            const int tr_io_t = 4 * g4_t + (l15_t >> 2), tr_cs_t = l15_t & 3;
+            const int tr_main_t = (tr_cs_t >> 1) * 256 + tr_io_t * 16 + (tr_cs_t & 1) * 8;
+            const int tr_tail_t = 6144 + (tr_cs_t & 1) * 128 + tr_io_t * 8;
+            u32x4* const olds_t = reinterpret_cast<u32x4*>(ldsb + NBUF * BUF) + tid_t;
             // tile `it` must have landed: all but the NBUF-2 most recently issued tiles of this wave are complete (a wave's DMA
             // chunks return in order), then the barrier publishes every wave's chunks; it also frees buffer (it-1) % NBUF
             if (NBUF == 2) {
@@ -241,20 +259,37 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
                 asm volatile("" ::: "memory");
             }
             if (jt + (NBUF - 1) * nsplit < seg.jt_hi) issue(seg.blk0 + jt + (NBUF - 1) * nsplit, ldsb + ((it + NBUF - 1) % NBUF) * BUF);
+            if (GRAD) {
+                // A segment's first / last tile may hold rows outside [lo, hi) (uniform test).  Zeroing those rows' pieces in the operand-order
+                // image (both planes, all tables; layout as in split_tables_kernel) makes their contributions vanish by themselves -- S = 0,
+                // c * 0 into the owner gradient, 0 into Gamma -- so the gradient epilogue carries no validity mask (8 registers, 32 multiplies).
+                const int vlo = max(seg.lo - j0, 0), vhi = min(seg.hi - j0, 32);
+                if (vlo > 0 || vhi < 32) {
+                    for (int x = tid; x < M * 2 * 32 * 14; x += SB_THREADS) {
+                        const int pc = x % 14, w = (x / 14) % 32, pl = (x / (14 * 32)) % 2, m = x / (14 * 32 * 2);
+                        if (w >= vlo && w < vhi) continue;
+                        const int wjh = (w >> 2) & 1, wi = 4 * (w >> 3) + (w & 3);
+                        unsigned char* base = buf + m * TBYTES + pl * SB_PLANE;
+                        if (pc < 12) *reinterpret_cast<u32x4*>(base + (((pc >> 2) * 2 + wjh) * 64 + (pc & 3) * 16 + wi) * 16) = u32x4{0, 0, 0, 0};
+                        else *reinterpret_cast<u32x2*>(base + 6144 + ((wjh * 2 + (pc - 12)) * 16 + wi) * 8) = u32x2{0, 0};
+                    }
+                    __syncthreads();
+                }
+            }
 
             // ---- S^T tiles: sacc[m][jh][r] = S_m[own = lane&15, other = 8 g4 + 4 jh + r].  Per half, the M main chains and the M
             // tail chains are interleaved (a dependent MFMA is M issues away) and a K step's operands are read for all tables first.
             f32x4 sacc[M][2];
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
-                const unsigned char* ar = buf + (jh * 64 + lane) * 16;          // lane-linear: [q][jh][lane][16 B]
+                const unsigned char* ar = buf + (jh * 64 + lane_t) * 16;        // lane-linear: [q][jh][lane][16 B]
                 f32x4 acc[M], tacc[M];
 #pragma unroll
                 for (int m = 0; m < M; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; tacc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 // tail K = 16: only lanes g4 < 2 carry columns 96..103; lanes 32..63 multiply the owner's zeros and re-read the same
                 // (finite) data.  It runs in its OWN accumulator chain: chaining v_mfma_*_16x16x16 onto an accumulator that a
                 // v_mfma_*_16x16x32 has just written gave schedule-dependent wrong sums on gfx950 (mixed-type SrcC forwarding).
-                const unsigned char* at = buf + 6144 + ((jh * 2 + (g4 & 1)) * 16 + l15) * 8;
+                const unsigned char* at = buf + 6144 + ((jh * 2 + (g4_t & 1)) * 16 + l15_t) * 8;
                 u32x2 th[M], tl[M];
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
@@ -274,7 +309,7 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
 #pragma unroll
                     for (int m = 0; m < M; ++m) tacc[m] = q == 0 ? mfma16(th[m], othi[m], tacc[m]) : (q == 1 ? mfma16(th[m], otlo[m], tacc[m]) : mfma16(tl[m], othi[m], tacc[m]));
 #pragma unroll
-                    for (int m = 0; m < M; ++m) acc[m] = mfma32(ah[m], olo[m][q], acc[m]);
+                    for (int m = 0; m < M; ++m) acc[m] = mfma32(ah[m], OLDS ? olds_t[(m * 3 + q) * SB_THREADS] : olo[OLDS ? 0 : m][q], acc[m]);
 #pragma unroll
                     for (int m = 0; m < M; ++m) acc[m] = mfma32(al[m], ohi[m][q], acc[m]);
                 }
@@ -282,33 +317,33 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
                 for (int m = 0; m < M; ++m) sacc[m][jh] = acc[m] + tacc[m];
             }
 
-            float okf[2][4];
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = j0 + 8 * g4 + 4 * jh + r;
-                    okf[jh][r] = (iv && row >= seg.lo && row < seg.hi) ? 1.f : 0.f;
-                }
             if (!GRAD) {
                 float p0[M + 1], p1[M + 1];
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+                // forward sums: exp2(0) = 1 of a padded / foreign row would count, so edge tiles are masked; interior tiles (every owner row of
+                // the block valid, all 32 other rows inside [lo, hi)) add unmasked
+                auto sums_tile = [&](auto masked_c) {
+                    constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-                for (int jh = 0; jh < 2; ++jh)
+                    for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sj = 0.f;
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = j0 + 8 * g4_t + 4 * jh + r;
+                            const float okf = (!MASKED || (iv && row >= seg.lo && row < seg.hi)) ? 1.f : 0.f;
+                            float sj = 0.f;
 #pragma unroll
-                        for (int m = 0; m < M; ++m) {
-                            const float sv = sacc[m][jh][r];
-                            sj = fmaf(beta[m], sv, sj);
-                            p0[m] = fmaf(okf[jh][r], fexp2(sv * a.k0), p0[m]);
-                            p1[m] = fmaf(okf[jh][r], fexp2(sv * a.k1), p1[m]);
+                            for (int m = 0; m < M; ++m) {
+                                const float sv = sacc[m][jh][r];
+                                sj = fmaf(beta[m], sv, sj);
+                                p0[m] = MASKED ? fmaf(okf, fexp2(sv * a.k0), p0[m]) : p0[m] + fexp2(sv * a.k0);
+                                p1[m] = MASKED ? fmaf(okf, fexp2(sv * a.k1), p1[m]) : p1[m] + fexp2(sv * a.k1);
+                            }
+                            p0[M] = MASKED ? fmaf(okf, fexp2(sj * a.k0), p0[M]) : p0[M] + fexp2(sj * a.k0);
+                            p1[M] = MASKED ? fmaf(okf, fexp2(sj * a.k1), p1[M]) : p1[M] + fexp2(sj * a.k1);
                         }
-                        p0[M] = fmaf(okf[jh][r], fexp2(sj * a.k0), p0[M]);
-                        p1[M] = fmaf(okf[jh][r], fexp2(sj * a.k1), p1[M]);
-                    }
+                };
+                if (j0 >= seg.lo && j0 + 32 <= seg.hi && own0 + SB_OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
@@ -320,7 +355,7 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
                         float sj = 0.f;
 #pragma unroll
                         for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][jh][r], sj);
-                        cj[jh][r] = okf[jh][r] * (c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1));
+                        cj[jh][r] = c0[M] * fexp2(sj * a.k0) + c1[M] * fexp2(sj * a.k1);
                     }
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
@@ -330,21 +365,22 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
                     for (int p = 0; p < 4; ++p) {
                         const int jh = p >> 1, r = (p & 1) * 2;
                         const float sv0 = sacc[m][jh][r], sv1 = sacc[m][jh][r + 1];
-                        const float v0 = okf[jh][r] * fmaf(beta[m], cj[jh][r], c0[m] * fexp2(sv0 * a.k0) + c1[m] * fexp2(sv0 * a.k1));
-                        const float v1 = okf[jh][r + 1] * fmaf(beta[m], cj[jh][r + 1], c0[m] * fexp2(sv1 * a.k0) + c1[m] * fexp2(sv1 * a.k1));
+                        const float v0 = fmaf(beta[m], cj[jh][r], c0[m] * fexp2(sv0 * a.k0) + c1[m] * fexp2(sv0 * a.k1));
+                        const float v1 = fmaf(beta[m], cj[jh][r + 1], c0[m] * fexp2(sv1 * a.k0) + c1[m] * fexp2(sv1 * a.k1));
                         unsigned hi, lo;
                         split_pair(v0, v1, hi, lo);
                         chi[p] = hi; clo[p] = lo;
                     }
                     // B operand (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes: lane i
                     // of a 16-lane group addresses the 8-byte piece (row 8 g4 + 4 rd + (i >> 2), columns 16 ct + 4 (i & 3) ..)
-                    const unsigned char* tb = buf + m * TBYTES + tr_main;
-                    const unsigned char* tb6 = buf + m * TBYTES + tr_tail;
+                    const unsigned char* tb = buf + m * TBYTES + tr_main_t;
+                    const unsigned char* tb6 = buf + m * TBYTES + tr_tail_t;
+                    constexpr int CU = OLDS ? 2 : 4;             // column tiles in flight (their hi/lo B operands are 8 registers each)
 #pragma unroll
-                    for (int c0t = 0; c0t < NCT; c0t += 4) {
-                        u32x4 bh[4], bl[4];
+                    for (int c0t = 0; c0t < NCT; c0t += CU) {
+                        u32x4 bh[CU], bl[CU];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < CU; ++u) {
                             const int ct = c0t + u;
                             if (ct < NCT) {
                                 const unsigned char* p0 = ct < 6 ? tb + (ct >> 1) * 2048 + (ct & 1) * 512 : tb6;
@@ -356,11 +392,11 @@ __global__ __launch_bounds__(SB_THREADS, SB_WAVES == 4 ? 2 : 1) void sweepb_kern
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(chi, bh[u], gacc[GRAD ? m : 0][c0t + u]);
+                        for (int u = 0; u < CU; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(chi, bh[u], gacc[GRAD ? m : 0][c0t + u]);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(chi, bl[u], gacc[GRAD ? m : 0][c0t + u]);
+                        for (int u = 0; u < CU; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(chi, bl[u], gacc[GRAD ? m : 0][c0t + u]);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(clo, bh[u], gacc[GRAD ? m : 0][c0t + u]);
+                        for (int u = 0; u < CU; ++u) if (c0t + u < NCT) gacc[GRAD ? m : 0][c0t + u] = mfma32(clo, bh[u], gacc[GRAD ? m : 0][c0t + u]);
                     }
                 }
                 if (g < 2) {                                   // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep)
@@ -461,7 +497,7 @@ int fill_b(BArgs& a, const void* const* Zb, int M, const float* beta, int A, int
 
 template <int M, bool GRAD>
 void launch_b(const BArgs& a, int nwg, hipStream_t s) {
-    const size_t lds = (size_t)SB_NBUF * M * SB_BLOCK;
+    const size_t lds = (size_t)SB_NBUF * M * SB_BLOCK + ((GRAD && M == 3) ? (size_t)M * 3 * SB_THREADS * 16 : 0);   // + the owner rows' lo planes
     auto k = sweepb_kernel<M, GRAD>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(nwg), dim3(SB_THREADS), lds, s, a);

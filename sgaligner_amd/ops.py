@@ -1132,8 +1132,15 @@ class FusedContrastiveFn(torch.autograd.Function):
                 zb = torch.empty((nb,), device=dev, dtype=torch.uint8)
                 _lib.check(L.sga_loss_split_tables(_p(z), s.A, s.J1, s.J2, _p(zb), st), 'sga_loss_split_tables')
                 zbs.append(zb)
+            ev = None
+            if KERNEL_EVENTS is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _lib.check(L.sga_loss_multi_sums_bf16x3(_ptr_array(zbs), M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums),
                                                     a_lo, a_hi, st), 'sga_loss_multi_sums_bf16x3')
+            if ev is not None:
+                ev[1].record()
+                KERNEL_EVENTS.setdefault('loss_multi_sums', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
         else:
             ev = None
             if KERNEL_EVENTS is not None:
