@@ -1169,6 +1169,8 @@ class FusedContrastiveFn(torch.autograd.Function):
             out_acc, gs_aa, gam_aa = zz[:n_terms], zz[n_terms:n_terms + nt * 8].view(nt, 8), zz[n_terms + nt * 8:]
             sym = AA_SYMMETRIC and M <= 3 and a_lo == 0 and a_hi == s.A
             chunks = _sym_chunks(s.A, M) if sym else _anchor_chunks(a_lo, a_hi, s.A, M)
+            if sym and len(chunks) < 2:             # one block = one diagonal square: nothing to mirror, the ordered kernel (unmasked interior) does it
+                sym, chunks = False, _anchor_chunks(a_lo, a_hi, s.A, M)
             if chunks:
                 gsc = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)
                 gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
