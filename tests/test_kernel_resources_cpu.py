@@ -30,3 +30,23 @@ def test_headline_kernels_do_not_spill():
                 v = res[k]
                 assert v['scratch'] == 0 and v['vspill'] == 0 and v['sspill'] == 0, (k, v)
                 assert not v.get('loop_scratch') and not v.get('loop_readlane'), (k, v)
+
+
+def test_symmetric_walk_blocks_cover_the_anchors_within_the_stash_bound():
+    """ops._sym_chunks: contiguous blocks on 32-row boundaries (except the end) whose two stashes -- [A - lo, ns] + [A - hi, ns] floats per
+    table -- stay inside STASH_BYTES, growing as the walk moves right."""
+    from sgaligner_amd import ops
+    keep = ops.STASH_BYTES
+    try:
+        for A, M, stash in ((155648, 3, 16 << 30), (19456, 3, 1 << 28), (1000, 2, 1 << 20), (31, 3, 1 << 30), (4099, 4, 1 << 24)):
+            ops.STASH_BYTES = stash
+            ch = ops._sym_chunks(A, M)
+            assert ch[0][0] == 0 and ch[-1][1] == A and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+            assert all(lo % 32 == 0 and (hi % 32 == 0 or hi == A) and hi > lo for lo, hi in ch)
+            for lo, hi in ch:
+                floats = (2 * A - lo - hi) * (hi - lo)
+                assert 4 * M * floats <= stash or hi - lo == 32 or hi == A and hi - lo < 32, (A, M, lo, hi)
+            heights = [hi - lo for lo, hi in ch[:-1]]
+            assert heights == sorted(heights)
+    finally:
+        ops.STASH_BYTES = keep
