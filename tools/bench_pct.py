@@ -11,31 +11,33 @@ N = 512
 torch.manual_seed(0)
 m = NaivePCT().cuda().eval()
 x = torch.randn(T, 3, N, device='cuda')
-for _ in range(2):
-    y = m(x)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(5):
-    y = m(x)
-torch.cuda.synchronize()
+with torch.no_grad():                    # inference: the chunked eval path (with gradients enabled the module keeps activations for backward)
+    for _ in range(2):
+        y = m(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        y = m(x)
+    torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
 # per object: convs 2*N*(3*128 + 128*128 + 4*(128*32 + 2*128*128) + 512*1024) + attention 4 * 2*N*N*(32 + 128) + head
 conv = 2.0 * N * (3 * 128 + 128 * 128 + 4 * (128 * 32 + 2 * 128 * 128) + 512 * 1024) + 2.0 * (1024 * 512 + 512 * 256)
 attn = 4 * 2.0 * N * N * (32 + 128)
 print(f'NaivePCT eval forward: T={T} objects x {N} pts: {dt*1e3:.2f} ms = {T/dt:.0f} objects/s, '
       f'{(conv + attn) * T / dt / 1e12:.1f} TFLOP/s algorithmic ({(conv + attn) / 1e9:.2f} GFLOP/object, attention {attn / 1e9:.2f})')
-q = torch.randn(T * N, 32, device='cuda'); v = torch.randn(T * N, 128, device='cuda')
-st = torch.empty(2 * T * N, device='cuda'); xs = torch.empty(T * N, 128, device='cuda')
+Ta = min(T, 4096)                          # the attention kernel alone: at most 4096 objects (2 x 17 GB of operands at 65 536)
+q = torch.randn(Ta * N, 32, device='cuda'); v = torch.randn(Ta * N, 128, device='cuda')
+st = torch.empty(2 * Ta * N, device='cuda'); xs = torch.empty(Ta * N, 128, device='cuda')
 L = _lib.lib()
-L.sga_pct_attention(_p(q), 32, _p(v), 128, T, N, _p(st), _p(xs), 128, _stream())
+L.sga_pct_attention(_p(q), 32, _p(v), 128, Ta, N, _p(st), _p(xs), 128, _stream())
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5):
-    L.sga_pct_attention(_p(q), 32, _p(v), 128, T, N, _p(st), _p(xs), 128, _stream())
+    L.sga_pct_attention(_p(q), 32, _p(v), 128, Ta, N, _p(st), _p(xs), 128, _stream())
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-alg = 2.0 * N * N * (32 + 128) * T
+alg = 2.0 * N * N * (32 + 128) * Ta
 print(f'sga_pct_attention: {ms:.3f} ms per SA layer, {alg / ms / 1e9:.1f} TFLOP/s algorithmic '
       f'({alg * (32 * 2 + 128) / (32 + 128) / ms / 1e9:.1f} executed: the energy tiles are computed in both passes) of 157.3 peak')
 # CPU baseline: the torch oracle (pinned to the reference module) on a bounded sample, 32 threads
