@@ -226,7 +226,24 @@ def main():
     ap.add_argument('--no-pct', action='store_true', help='skip the extra pct+gat+rel+attr small-batch measurement (N = 1)')
     ap.add_argument('--no-c2', action='store_true', help='skip the extra BASELINE configs[1] measurement (N = 1)')
     ap.add_argument('--no-bf16x3', action='store_true', help='skip the extra (opt-in split-bf16 x3 MFMA mode) measurement')
+    ap.add_argument('--no-split', action='store_true', help='skip the extra (opt-in fp32-faithful split-fp16 MFMA mode) measurement')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Launched bare (`python bench.py --gpus N`): create the N ranks ourselves -- one process per GPU under torch.distributed.run,
+        # the same command line the driver uses -- instead of silently measuring one GPU.  With fewer GPUs than ranks (the 2-rank test on
+        # a one-GPU box) the ranks share devices and talk over gloo: RCCL refuses two ranks on one device.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ)
+        if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+            env.setdefault('SGA_DIST_BACKEND', 'gloo')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     from sgaligner_amd import dist as sdist
     from sgaligner_amd import ops
@@ -237,8 +254,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the product path has no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world != args.gpus and rank == 0:
-        print(f'[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the line would be labelled with a rank count it did not run on')
     cname = args.config if args.config != 'auto' else 'c3'
     cfg = CONFIGS[cname]
     n_obj, n_pts = cfg['n_obj'], cfg['n_pts']

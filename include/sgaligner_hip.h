@@ -25,8 +25,10 @@ const char* sga_last_error(void);
 int sga_device_cus(void);
 /* Arithmetic of the MFMA kernels that have a split-precision variant (sga_pointnet_fwd): 0 = exact fp32 (default; every
  * headline number), 1 = split-bf16 x3 (each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product into an fp32
- * accumulator; relative error ~1e-5).  Returns the previous mode (-1 on a bad argument).  SGA_MFMA_MODE=bf16x3 in the
- * environment selects mode 1 at first use. */
+ * accumulator; relative error ~1e-5), 2 = fp16 inputs for loss tables wider than 128 columns (configs[4]), 3 = split-fp16
+ * (each fp32 operand as fp16 hi + lo of 4096 x, three fp16 MFMAs per product into an fp32 accumulator: the loss sweeps carry
+ * fp32's own rounding error -- the mode ops.set_mfma_mode('f16x2') selects; everything else stays exact fp32).  Returns the
+ * previous mode (-1 on a bad argument).  SGA_MFMA_MODE=bf16x3 | f16 | f16x2 in the environment selects the mode at first use. */
 int sga_set_mfma_mode(int mode);
 int sga_get_mfma_mode(void);
 
@@ -172,6 +174,21 @@ int sga_loss_multi_sums_bf16x3(const void* const* Zb, int M, const float* beta, 
                                double* sums, int a_lo, int a_hi, void* stream);
 int sga_loss_multi_grad_bf16x3(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
+
+/* ---- opt-in, fp32-faithful split-fp16 form of the two fused sweeps (sga_set_mfma_mode(3); sweeph.hip) -------------------------
+ * replaces the autograd of losses.py:5-15 on the anchors x negatives products, like sga_loss_multi_sums / sga_loss_multi_grad.
+ * sga_loss_split16_tables: packed fp32 table Z [R(+32), 104] -> Zb, 32-row blocks of fp16 hi / lo planes of 4096 z in MFMA operand
+ * order + the packed K tail (sga_loss_split16_bytes bytes; segments X1 | X2 | N1 | N2 each padded to whole blocks).
+ * sga_loss_multi_sums_f16x2 / _grad_f16x2: same arguments and outputs as sga_loss_multi_sums / sga_loss_multi_grad with the M tables
+ * given as Zb; every product is hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16 into fp32 (22 significand bits per operand).
+ * coef_lo != 0: the coefficients enter the gradient GEMM as hi + lo as well; 0: rounded to fp16 (11 bits, independent per pair).
+ * M in {2,3}. */
+size_t sga_loss_split16_bytes(int A, int J1, int J2);
+int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
+int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                              double* sums, int a_lo, int a_hi, void* stream);
+int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                              const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, int coef_lo, void* stream);
 
 /* ---- loss_group = b: the same loss on G independent groups of b consecutive pairs ------------------------
  * replaces the reference trainer feeding b pairs per iteration (configs/scan3r/scan3r_ground_truth.yaml:27,

@@ -1,0 +1,652 @@
+// Opt-in, fp32-FAITHFUL split-fp16 form of the anchors x negatives loss sweeps (sga_set_mfma_mode(3), ops.set_mfma_mode('f16x2'); the default
+// stays the exact-fp32 sweep16_kernel in contrastive.hip).  Same mathematics and the same two-owner-sweep structure as sweepb.hip:
+//     pass 1 (sums)   s_fam,temp[table] = sum exp(S / tau)                 S = X_own . X_other^T per modality table,
+//     backward (grad) dZ[own] += C . Z[other],  C = dL/dS_m + beta_m dL/dS_J    S_J = sum_m beta_m S_m (joint table derived)
+// (reference src/aligner/losses.py:5-15 and its autograd).
+//
+// Arithmetic.  Every fp32 operand z (|z| <= 1: the rows are L2-normalised) enters the matrix cores as TWO fp16 terms of 4096 z:
+// hi = fp16(4096 z), lo = fp16(4096 z - hi) -- 22 significand bits, and with the 2^12 pre-scale lo stays a NORMAL fp16 number for every
+// |z| >= 6e-5 (absolute error <= 2^-37 below that), so no second accumulator and no dependence on subnormal handling.  A product is
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16 into one fp32 accumulator (fp16 x fp16 is exact in fp32; the dropped lo.lo term is
+// 2^-24 relative).  Measured on the MI355X against an fp64 sum (tools/micro/f16x2_probe.hip, 2 M similarities of unit rows, D = 100):
+// max |dS| 1.7e-7 / rms 1.5e-8 (exact-fp32 MFMA chain: 2.1e-7 / 1.8e-8) for uncorrelated rows, 4.4e-7 / 9.2e-8 (6.6e-7 / 1.3e-7) for
+// rows with S ~ 0.99 -- the fp32 ACCUMULATION rounding dominates both, i.e. the similarities carry fp32's own error (the bf16 hi+lo
+// split of sweepb.hip: 16 bits, 20x worse, amplified by 1/tau = 10 in the coefficients).
+// The coefficient C (gradient GEMM A operand) is scaled per table by a power of two so that |C| <= 2^14 fits fp16 whatever the loss
+// scale (bound from dL/d(sums), |S| <= 1) and split the same way; the accumulators are unscaled by the exact inverse at the end.
+//
+// On gfx950 an MFMA occupies the SIMD's vector issue port for all of its passes: VALU, LDS and LDS-DMA instructions of the same AND of the
+// other resident waves add to the matrix time, they never hide under it (tools/micro/f16_valu_overlap.hip: an MFMA-only wave and an
+// FMA-only wave sharing a SIMD take the SUM of their solo times, 64.9 + 37.7 -> 102.5 cycles per iteration; in one stream every v_fma
+// costs 2.2-2.7 and every v_exp 4.5 cycles on top of the MFMAs).  So the kernel is built to minimise the instruction count per pair:
+//   * one wave owns 32 owner rows x ALL M tables (one wave per SIMD, up to 512 registers): every LDS read of the "other" tile feeds two
+//     owner halves (sweepb: 16 rows per wave, twice the reads per MFMA, owner lo planes re-read from LDS every tile);
+//   * the 8-column K tail (columns 96..103) packs its three products into the 32 k slots of ONE MFMA (k group 0: hi.hi, 1: hi.lo, 2: lo.hi,
+//     3: lo.lo): 10 instead of 12 MFMAs per 16 x 16 similarity tile, same accumulator chain;
+//   * the 16-byte slots of a K step are stored XOR-swizzled (slot i ^ 12 for odd k groups) so that BOTH the lane-linear ds_read_b128 of
+//     the S product and the ds_read_b64_tr_b16 transpose reads of the gradient GEMM are bank-conflict free (sweepb: 2-way conflicts on
+//     every transpose read).
+//
+// Data layout.  sga_loss_split16_tables turns a packed fp32 table Z [X1 | X2 | N1 | N2] into 32-row BLOCKS (each segment padded to whole
+// blocks) of 14 336 B: [hi plane 6 144 | lo plane 6 144 | packed tail 2 048], a plane = [K step q (3)][half jh (2)][64 slots][8 fp16],
+// slot(g, i) = 16 g + (i ^ 12 (g & 1)) holds columns 32 q + 8 g .. + 7 of row 8 (i >> 2) + 4 jh + (i & 3); the tail = [jh][64 slots][8 fp16]
+// with k groups 0, 1 = hi and 2, 3 = lo of columns 96 .. 103.  A tile of "other" rows is ONE contiguous 14 KiB copy per table (14
+// global_load_lds DMA chunks), double-buffered in LDS (3 tables: 84 KiB).
+// MFMA bookkeeping (v_mfma_f32_16x16x32_f16; A: lane&15 = row, B: lane&15 = column, lane>>4 = k group of 8 slots):
+//   S^T tile: A = other rows from LDS, B = owner rows (registers).  Half jh of a 32-row tile uses A row i <-> other row
+//   8 (i>>2) + 4 jh + (i&3), so that a lane's 8 accumulator values (2 halves x 4) are the 8 CONSECUTIVE other rows 8 g4 .. 8 g4+7:
+//   exactly the k slots of the gradient MFMA  dZ[own] += C[own, other] Z[other, cols]  whose A operand is therefore the coefficient
+//   registers (split into fp16 hi/lo) and whose B operand comes from transpose reads of the same planes.
+#include <type_traits>
+
+#include "loss_math.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SH_WAVES = 4, SH_THREADS = SH_WAVES * 64, SH_OWN = SH_WAVES * 32;
+constexpr int SH_DP = 104;
+constexpr int SH_PLANE = 3 * 2 * 1024;           // 6144 B
+constexpr int SH_TAIL = 2 * SH_PLANE;            // byte offset of the packed tail in a block
+constexpr int SH_BLOCK = SH_TAIL + 2 * 1024;     // 14336 B
+constexpr int SH_NCH = SH_BLOCK / 1024;          // 14 DMA chunks
+constexpr float SH_PRE = 4096.f;                 // operand pre-scale 2^12: S accumulates 2^24 S
+constexpr float SH_UNPRE = 1.f / (4096.f * 4096.f);
+#ifndef SH_NBUF
+#define SH_NBUF 2
+#endif
+constexpr int sh_min_chunks(int M) {             // fewest DMA chunks any wave issues per tile (wave w: chunks (w + m) % 4 + 4 k of table m)
+    int best = 1 << 30;
+    for (int w = 0; w < SH_WAVES; ++w) {
+        int n = 0;
+        for (int m = 0; m < M; ++m)
+            for (int c = (w + m) & (SH_WAVES - 1); c < SH_NCH; c += SH_WAVES) ++n;
+        best = n < best ? n : best;
+    }
+    return best;
+}
+
+// v0, v1 -> packed fp16 hi pair and lo pair (v = hi + lo to 22 bits)
+__device__ __forceinline__ void split_pair16(float v0, float v1, unsigned& hi, unsigned& lo) {
+    const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f16x2 l = __builtin_convertvector(f32x2{v0 - (float)h[0], v1 - (float)h[1]}, f16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x2 tr_read16(const unsigned char* p) {     // ds_read_b64_tr_b16
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p)));
+}
+__host__ __device__ constexpr int sh_slot(int g, int i) { return 16 * g + (i ^ (12 * (g & 1))); }
+
+struct HLayout { int nbA, nb1, nb2; };
+__host__ __device__ inline HLayout make_hlayout(int A, int J1, int J2) { return HLayout{(A + 31) / 32, (J1 + 31) / 32, (J2 + 31) / 32}; }
+
+// fp32 packed table -> blocked fp16 hi/lo planes + packed tail (one workgroup per 32-row block)
+__global__ __launch_bounds__(256) void split16_tables_kernel(const float* __restrict__ Z, int A, int J1, int J2, unsigned char* __restrict__ Zb) {
+    __shared__ float tile[32 * SH_DP];
+    const HLayout L = make_hlayout(A, J1, J2);
+    int b = blockIdx.x, old0, len;
+    if (b < L.nbA) { old0 = 0; len = A; }
+    else if (b < 2 * L.nbA) { b -= L.nbA; old0 = A; len = A; }
+    else if (b < 2 * L.nbA + L.nb1) { b -= 2 * L.nbA; old0 = 2 * A; len = J1; }
+    else { b -= 2 * L.nbA + L.nb1; old0 = 2 * A + J1; len = J2; }
+    const int nvalid = min(32, len - 32 * b);
+    const float* src = Z + (size_t)(old0 + 32 * b) * SH_DP;
+    for (int e = threadIdx.x; e < 32 * SH_DP; e += 256) tile[e] = (e / SH_DP) < nvalid ? src[e] * SH_PRE : 0.f;
+    __syncthreads();
+    unsigned* out = reinterpret_cast<unsigned*>(Zb + (size_t)blockIdx.x * SH_BLOCK);
+    // planes: dword e = (slot s of [q][jh][64], pair p of 4): stored slot (g, i ^ swz) <- logical (g, i)
+    for (int e = threadIdx.x; e < 3 * 2 * 64 * 4; e += 256) {
+        const int p = e & 3, st = (e >> 2) & 63, jh = (e >> 8) & 1, q = e >> 9;
+        const int g = st >> 4, i = (st & 15) ^ (12 * (g & 1));
+        const int row = 8 * (i >> 2) + 4 * jh + (i & 3), col = 32 * q + 8 * g + 2 * p;
+        unsigned hi, lo;
+        split_pair16(tile[row * SH_DP + col], tile[row * SH_DP + col + 1], hi, lo);
+        out[e] = hi; out[SH_PLANE / 4 + e] = lo;
+    }
+    // packed tail: dword e = (slot of [jh][64], pair p of 4): k groups 0, 1 = hi, 2, 3 = lo of columns 96 + 2 p, + 1
+    for (int e = threadIdx.x; e < 2 * 64 * 4; e += 256) {
+        const int p = e & 3, st = (e >> 2) & 63, jh = e >> 8;
+        const int g = st >> 4, i = (st & 15) ^ (12 * (g & 1));
+        const int row = 8 * (i >> 2) + 4 * jh + (i & 3), col = 96 + 2 * p;
+        unsigned hi, lo;
+        split_pair16(tile[row * SH_DP + col], tile[row * SH_DP + col + 1], hi, lo);
+        out[SH_TAIL / 4 + e] = g < 2 ? hi : lo;
+    }
+}
+
+struct HSeg { int blk0, jt_lo, jt_hi, old0, lo, hi, fam; };   // others: block blk0 + jt holds old rows old0 + 32 jt + w; valid rows in [lo, hi)
+struct HGroup { int own0, nown, own_old0, own_blk0, blk0, nsplit, nseg; HSeg seg[2]; };
+struct HArgs {
+    int M; const unsigned char* Zb[4]; int ngroups; HGroup grp[4];
+    float k0, k1, it0, it1;
+    const float* beta;
+    double* sums;                    // SUM out  [(M+1)][8] (+ slots)
+    const double* gs;                // GRAD in  [(M+1)][8]
+    float* dZ[4];                    // GRAD out (fp32, old row order), atomic accumulate
+    double* gamma;                   // GRAD out [M] (+ slots)
+};
+
+// CLO: the coefficients' lo terms (C = hi + lo, third gradient MFMA).  Without them C is rounded to fp16's 11 bits: an independent,
+// unbiased rounding error of <= 2^-12 per (owner, other) pair.
+template <int M, bool GRAD, bool CLO>
+__global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
+    constexpr int NCT = 7;
+    constexpr int BUF = M * SH_BLOCK;
+    constexpr int NBUF = SH_NBUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsh[];      // [NBUF][M][SH_BLOCK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
+    const HGroup& grp = a.grp[g];
+    // XCD-aware work order (as sweepb / sweep16): the group's (split major, owner block minor) work list in 8 contiguous per-XCD chunks
+    const int wg_in_grp = (int)blockIdx.x - grp.blk0;
+    const int nsplit = grp.nsplit, n_ob = (grp.nown + SH_OWN - 1) / SH_OWN, n_units = n_ob * nsplit;
+    const int unit = (wg_in_grp & 7) * ((n_units + 7) >> 3) + (wg_in_grp >> 3);
+    if ((wg_in_grp >> 3) >= ((n_units + 7) >> 3) || unit >= n_units) return;
+    const int split = unit / n_ob;
+    const int own0 = grp.own0 + (unit - split * n_ob) * SH_OWN;
+    const int own_end = grp.own0 + grp.nown;
+
+    // ---- owner rows (two halves of 16) as the S product's B operand: 3 K = 32 steps hi / lo + the packed tail (k group 0, 2: hi; 1, 3: lo)
+    u32x4 ohi[M][2][3], olo[M][2][3], otl[M][2];
+    float beta[M];
+#pragma unroll
+    for (int oh = 0; oh < 2; ++oh) {
+        const int my_i = own0 + wave * 32 + oh * 16 + l15;
+        const bool iv = my_i < own_end;
+        const int rel = (iv ? my_i : own0) - grp.own_old0;
+        const int o = rel & 31, oi = 4 * (o >> 3) + (o & 3), ojh = (o >> 2) & 1;       // row o sits at (half ojh, operand row oi) of its block
+        const size_t off = (size_t)(grp.own_blk0 + (rel >> 5)) * SH_BLOCK;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const unsigned char* base = a.Zb[m] + off;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int so = ((q * 2 + ojh) * 64 + sh_slot(g4, oi)) * 16;
+                ohi[m][oh][q] = iv ? *reinterpret_cast<const u32x4*>(base + so) : u32x4{0, 0, 0, 0};
+                olo[m][oh][q] = iv ? *reinterpret_cast<const u32x4*>(base + SH_PLANE + so) : u32x4{0, 0, 0, 0};
+            }
+            // tail B operand: k group 0 -> own hi, 1 -> own lo, 2 -> own hi, 3 -> own lo (against A = other hi, hi, lo, lo)
+            otl[m][oh] = iv ? *reinterpret_cast<const u32x4*>(base + SH_TAIL + (ojh * 64 + sh_slot((g4 & 1) * 2, oi)) * 16) : u32x4{0, 0, 0, 0};
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
+
+    f32x4 gacc[GRAD ? M : 1][2][NCT];
+#pragma unroll
+    for (int m = 0; m < (GRAD ? M : 1); ++m)
+#pragma unroll
+        for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) gacc[m][oh][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gam[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) gam[m] = 0.f;
+
+    // per-table power-of-two scale of the coefficients: |c_m| <= cmax_m (|S| <= 1, any family) -> |c_m sig_m| <= 2^14
+    float sig[M], isig[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { sig[m] = 1.f; isig[m] = 1.f; }
+    if (GRAD) {
+        const float e0 = __builtin_amdgcn_exp2f(a.k0 * 1.0000005f), e1 = __builtin_amdgcn_exp2f(a.k1 * 1.0000005f);   // e^{1/tau}, a hair above
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float cmax = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float t0 = (fabsf((float)a.gs[m * 8 + f * 2]) + beta[m] * fabsf((float)a.gs[M * 8 + f * 2])) * a.it0 * e0;
+                const float t1 = (fabsf((float)a.gs[m * 8 + f * 2 + 1]) + beta[m] * fabsf((float)a.gs[M * 8 + f * 2 + 1])) * a.it1 * e1;
+                cmax = fmaxf(cmax, t0 + t1);
+            }
+            if (cmax > 0.f && cmax < 3.0e38f) {
+                int ex;
+                (void)frexpf(cmax, &ex);                      // cmax = f 2^ex, f in [0.5, 1)
+                ex = min(max(ex, -100), 100);
+                sig[m] = ldexpf(1.f, 14 - ex);
+                isig[m] = ldexpf(1.f, ex - 14 - 12);          // ... and the 2^12 of the B operand
+            } else {
+                isig[m] = 1.f / SH_PRE;
+            }
+        }
+    }
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
+    auto issue = [&](int blk, unsigned char* buf) {
+#ifdef SH_DBG_NODMA
+        return;
+#endif
+        int l16 = threadIdx.x;
+        asm volatile("" : "+v"(l16));
+        l16 = (l16 & 63) * 16;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int rot = (wave_u + m) & (SH_WAVES - 1);
+            const unsigned char* src = a.Zb[m] + ((size_t)blk * SH_BLOCK + rot * 1024) + l16;
+            unsigned char* dst = buf + m * SH_BLOCK + rot * 1024;
+#pragma unroll
+            for (int k = 0; k * SH_WAVES < SH_NCH; ++k) {
+                if ((k + 1) * SH_WAVES > SH_NCH && rot + k * SH_WAVES >= SH_NCH) break;       // uniform; only the last k can fall off the block
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * SH_WAVES * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + k * SH_WAVES * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // lane-derived LDS offsets: S product (lane-linear up to the swizzle) and the transpose reads of the gradient GEMM's B operand:
+    // lane i of a 16-lane group addresses the 8-byte piece (row 8 g4 + 4 rd + (i >> 2), columns 16 ct + 4 (i & 3) ..)
+    const int aoff = sh_slot(g4, l15) * 16;
+    const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
+    const int tr_main = sh_slot(tr_cs >> 1, tr_io) * 16 + (tr_cs & 1) * 8;       // + (ct >> 1) * 2048 + rd * 1024 + (ct & 1) * 512
+    const int tr_tail = SH_TAIL + tr_io * 16 + (tr_cs & 1) * 8;                   // hi: k group 0; lo: + 512 (k group 2); + rd * 1024
+
+#pragma unroll 1
+    for (int sg = 0; sg < 2; ++sg) {
+        if (sg >= grp.nseg) break;
+        const HSeg seg = grp.seg[sg];
+        // coefficient constants of this segment's family, pre-multiplied by the table's scale; the joint coefficient stays unscaled (Gamma)
+        float c0[M + 1], c1[M + 1], bsig[M];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) {
+            const float s_ = m < M ? sig[m < M ? m : 0] : 1.f;
+            c0[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0) * s_ : 0.f;
+            c1[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1) * s_ : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) bsig[m] = beta[m] * sig[m];
+        const float k0s = a.k0 * SH_UNPRE, k1s = a.k1 * SH_UNPRE;         // exp2 arguments straight from the 2^24-scaled accumulators
+        double dsum[M + 1][2];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
+
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < NBUF - 1; ++d)
+            if (seg.jt_lo + split + d * nsplit < seg.jt_hi) issue(seg.blk0 + seg.jt_lo + split + d * nsplit, ldsh + d * BUF);
+        int it = 0;
+#pragma unroll 1
+        for (int jt = seg.jt_lo + split; jt < seg.jt_hi; jt += nsplit, ++it) {
+            unsigned char* buf = ldsh + (it % NBUF) * BUF;
+            const int j0 = seg.old0 + 32 * jt;                 // old row of the tile's first row
+            if (NBUF == 2) {
+                __syncthreads();
+            } else {
+                constexpr int keep = sh_min_chunks(M) * (NBUF - 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (jt + (NBUF - 1) * nsplit < seg.jt_hi) issue(seg.blk0 + jt + (NBUF - 1) * nsplit, ldsh + ((it + NBUF - 1) % NBUF) * BUF);
+            if (GRAD) {
+                // A segment's first / last tile may hold rows outside [lo, hi) (uniform test).  Zeroing those rows' 16-byte slots in the
+                // operand-order image (both planes + tail, all tables) makes their contributions vanish by themselves -- S = 0, c * 0 into the
+                // owner gradient, 0 into Gamma -- so the gradient epilogue carries no validity mask.
+                const int vlo = max(seg.lo - j0, 0), vhi = min(seg.hi - j0, 32);
+                if (vlo > 0 || vhi < 32) {
+                    for (int x = tid; x < M * 32 * 28; x += SH_THREADS) {
+                        const int pc = x % 28, w = (x / 28) % 32, m = x / (28 * 32);
+                        if (w >= vlo && w < vhi) continue;
+                        const int wjh = (w >> 2) & 1, wi = 4 * (w >> 3) + (w & 3);
+                        unsigned char* base = buf + m * SH_BLOCK;
+                        if (pc < 24) {
+                            const int pl = pc / 12, q = (pc % 12) >> 2, gq = pc & 3;
+                            *reinterpret_cast<u32x4*>(base + pl * SH_PLANE + ((q * 2 + wjh) * 64 + sh_slot(gq, wi)) * 16) = u32x4{0, 0, 0, 0};
+                        } else {
+                            *reinterpret_cast<u32x4*>(base + SH_TAIL + (wjh * 64 + sh_slot(pc - 24, wi)) * 16) = u32x4{0, 0, 0, 0};
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+
+            // ---- S^T tiles: sacc[m][oh][jh][r] = 2^24 S_m[own = 16 oh + lane&15, other = 8 g4 + 4 jh + r]
+            f32x4 sacc[M][2][2];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                // four independent accumulator chains (owner half x other half): a dependent MFMA is four issues away
+                const unsigned char* ar = buf + m * SH_BLOCK + aoff;
+                u32x4 ah[2][3], al[2][3], at[2];
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+#ifdef SH_DBG_NOSREAD
+                    at[jh] = u32x4{(unsigned)it, (unsigned)jh, 0x3c003c00u, 0x3c003c00u};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { al[jh][q] = at[jh]; ah[jh][q] = at[jh]; }
+#else
+                    at[jh] = *reinterpret_cast<const u32x4*>(ar + SH_TAIL + jh * 1024);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        al[jh][q] = *reinterpret_cast<const u32x4*>(ar + SH_PLANE + q * 2048 + jh * 1024);
+                        ah[jh][q] = *reinterpret_cast<const u32x4*>(ar + q * 2048 + jh * 1024);
+                    }
+#endif
+                }
+                f32x4 acc[2][2];
+#ifdef SH_DBG_NOSMFMA
+#pragma unroll
+                for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh) { acc[oh][jh] = __builtin_bit_cast(f32x4, at[jh] ^ ah[jh][0] ^ al[jh][1] ^ ah[jh][2] ^ al[jh][0] ^ ah[jh][1] ^ al[jh][2] ^ otl[m][oh]); sacc[m][oh][jh] = acc[oh][jh]; }
+                continue;
+#endif
+#pragma unroll
+                for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(at[jh], otl[m][oh], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(al[jh][q], ohi[m][oh][q], acc[oh][jh]);
+#pragma unroll
+                    for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(ah[jh][q], olo[m][oh][q], acc[oh][jh]);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)                    // the large hi.hi terms last
+#pragma unroll
+                    for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(ah[jh][q], ohi[m][oh][q], acc[oh][jh]);
+#pragma unroll
+                for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh) sacc[m][oh][jh] = acc[oh][jh];
+            }
+
+            if (!GRAD) {
+                float p0[M + 1], p1[M + 1];
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+                // forward sums: exp2(0) = 1 of a padded / foreign row would count, so edge tiles are masked; interior tiles add unmasked
+                auto sums_tile = [&](auto masked_c) {
+                    constexpr bool MASKED = decltype(masked_c)::value;
+#pragma unroll
+                    for (int oh = 0; oh < 2; ++oh) {
+                        const bool iv = own0 + wave * 32 + oh * 16 + l15 < own_end;
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = j0 + 8 * g4 + 4 * jh + r;
+                                const float okf = (!MASKED || (iv && row >= seg.lo && row < seg.hi)) ? 1.f : 0.f;
+                                float sj = 0.f;
+#pragma unroll
+                                for (int m = 0; m < M; ++m) {
+                                    const float sv = sacc[m][oh][jh][r];
+                                    sj = fmaf(beta[m], sv, sj);
+                                    p0[m] = MASKED ? fmaf(okf, fexp2(sv * k0s), p0[m]) : p0[m] + fexp2(sv * k0s);
+                                    p1[m] = MASKED ? fmaf(okf, fexp2(sv * k1s), p1[m]) : p1[m] + fexp2(sv * k1s);
+                                }
+                                p0[M] = MASKED ? fmaf(okf, fexp2(sj * k0s), p0[M]) : p0[M] + fexp2(sj * k0s);
+                                p1[M] = MASKED ? fmaf(okf, fexp2(sj * k1s), p1[M]) : p1[M] + fexp2(sj * k1s);
+                            }
+                    }
+                };
+                if (j0 >= seg.lo && j0 + 32 <= seg.hi && own0 + SH_OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
+            } else {
+                // joint coefficient dL/dS_J (unscaled) for this lane's 2 x 8 pairs
+                float cj[2][2][4];
+#pragma unroll
+                for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float sj = 0.f;
+#pragma unroll
+                            for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][oh][jh][r], sj);
+#ifdef SH_DBG_NOEPI
+                            cj[oh][jh][r] = sj;
+#else
+                            cj[oh][jh][r] = c0[M] * fexp2(sj * k0s) + c1[M] * fexp2(sj * k1s);
+#endif
+                        }
+                if (g < 2) {                                   // Gamma_m = sum dL/dS_J * S_m, each pair once (anchor-owner sweep); 2^24 folded out at the end
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+#pragma unroll
+                        for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                            for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[oh][jh][r], sacc[m][oh][jh][r], gam[m]);
+                        asm volatile("" : "+v"(gam[m]));
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    // sig_m c_m for this lane's 8 consecutive other rows (k slot j = 4 jh + r), split into fp16 hi / lo: the A operand
+                    u32x4 chi[2], clo[2];
+#pragma unroll
+                    for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const int jh = p >> 1, r = (p & 1) * 2;
+                            const float sv0 = sacc[m][oh][jh][r], sv1 = sacc[m][oh][jh][r + 1];
+#ifdef SH_DBG_NOEPI
+                            const float v0 = sv0 + cj[oh][jh][r], v1 = sv1 + cj[oh][jh][r + 1];
+#else
+                            const float v0 = fmaf(bsig[m], cj[oh][jh][r], fmaf(c0[m], fexp2(sv0 * k0s), c1[m] * fexp2(sv0 * k1s)));
+                            const float v1 = fmaf(bsig[m], cj[oh][jh][r + 1], fmaf(c0[m], fexp2(sv1 * k0s), c1[m] * fexp2(sv1 * k1s)));
+#endif
+                            if (CLO) {
+                                unsigned hi, lo;
+                                split_pair16(v0, v1, hi, lo);
+                                chi[oh][p] = hi; clo[oh][p] = lo;
+                            } else {
+                                chi[oh][p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, f16x2));
+                            }
+                        }
+                    // B operand (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes
+                    const unsigned char* tb = buf + m * SH_BLOCK + tr_main;
+                    const unsigned char* tt = buf + m * SH_BLOCK + tr_tail;
+#pragma unroll
+                    for (int c0t = 0; c0t < NCT; c0t += 2) {       // two column tiles at a time: four independent accumulator chains
+                        u32x4 bh[2], bl[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int ct = c0t + u;
+#ifdef SH_DBG_NOTR
+                            if (ct < NCT) { bh[u] = u32x4{chi[0][0], (unsigned)ct, 0x3c003c00u, 0x3c003c00u}; bl[u] = bh[u]; }
+                            if (false) {
+#else
+                            if (ct < NCT) {
+#endif
+                                const unsigned char* ph = ct < 6 ? tb + (ct >> 1) * 2048 + (ct & 1) * 512 : tt;
+                                const unsigned char* pl = ct < 6 ? ph + SH_PLANE : tt + 512;
+                                const u32x2 h0 = tr_read16(ph), h1 = tr_read16(ph + 1024);
+                                const u32x2 l0 = tr_read16(pl), l1 = tr_read16(pl + 1024);
+                                bh[u] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                                bl[u] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                            }
+                        }
+#ifdef SH_DBG_NOGMFMA
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int oh = 0; oh < 2; ++oh)
+                                if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] += __builtin_bit_cast(f32x4, chi[oh] ^ bh[u] ^ bl[u] ^ (CLO ? clo[oh] : chi[oh]));
+                        continue;
+#endif
+                        if (CLO) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                for (int oh = 0; oh < 2; ++oh)
+                                    if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] = mfma_h(clo[oh], bh[u], gacc[GRAD ? m : 0][oh][c0t + u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int oh = 0; oh < 2; ++oh)
+                                if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] = mfma_h(chi[oh], bl[u], gacc[GRAD ? m : 0][oh][c0t + u]);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int oh = 0; oh < 2; ++oh)
+                                if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] = mfma_h(chi[oh], bh[u], gacc[GRAD ? m : 0][oh][c0t + u]);
+                    }
+                }
+            }
+        }
+        if (!GRAD) {
+#pragma unroll
+            for (int m = 0; m <= M; ++m)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const double v = wave_sum_d(dsum[m][tt]);
+                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + (M + 1) * 8 * (1 + my_slot()) + m * 8 + seg.fam * 2 + tt, v);
+                }
+        }
+    }
+    if (GRAD) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float* dz = a.dZ[m];
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int d = ct * 16 + l15;
+                    if (d < SH_DP) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = own0 + wave * 32 + oh * 16 + 4 * g4 + r;
+                            if (i < own_end) atomicAdd(dz + (size_t)i * SH_DP + d, gacc[GRAD ? m : 0][oh][ct][r] * isig[m]);
+                        }
+                    }
+                }
+        }
+        if (g < 2) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float v = wave_sum(gam[m]) * SH_UNPRE;
+                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + m, (double)v);
+            }
+        }
+    }
+}
+
+int fill_h(HArgs& a, const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1, bool grad,
+           int a_lo, int a_hi, const char* who) {
+    if (M < 2 || M > 3) { sga_set_error("%s: M=%d (the split-fp16 sweeps are built for 2 or 3 modality tables)", who, M); return SGA_ERR_ARG; }
+    if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("%s: anchor shard [%d,%d) outside [0,%d]", who, a_lo, a_hi, A); return SGA_ERR_ARG; }
+    a.M = M;
+    for (int m = 0; m < M; ++m) { if (!Zb[m]) { sga_set_error("%s: null table", who); return SGA_ERR_ARG; } a.Zb[m] = static_cast<const unsigned char*>(Zb[m]); }
+    a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
+    const HLayout L = make_hlayout(A, J1, J2);
+    const int ns = a_hi - a_lo;
+    const int bx1 = 0, bx2 = L.nbA, bn1 = 2 * L.nbA, bn2 = 2 * L.nbA + L.nb1;
+    const int ox1 = 0, ox2 = A, on1 = 2 * A, on2 = 2 * A + J1;
+    const HSeg N1a{bn1, 0, L.nb1, on1, on1, on1 + J1, 0}, N2a{bn2, 0, L.nb2, on2, on2, on2 + J2, 1};
+    const HSeg N2b{bn2, 0, L.nb2, on2, on2, on2 + J2, 2}, N1b{bn1, 0, L.nb1, on1, on1, on1 + J1, 3};
+    int g = 0;
+    auto add = [&](int own0, int nown, int own_old0, int own_blk0, HSeg s0, HSeg s1) {
+        if (nown <= 0) return;
+        HGroup& G = a.grp[g++];
+        G.own0 = own0; G.nown = nown; G.own_old0 = own_old0; G.own_blk0 = own_blk0; G.nseg = 2; G.seg[0] = s0; G.seg[1] = s1; G.nsplit = 1; G.blk0 = 0;
+    };
+    add(ox1 + a_lo, ns, ox1, bx1, N1a, N2a);                       // s11, s12
+    add(ox2 + a_lo, ns, ox2, bx2, N2b, N1b);                       // s22, s21
+    if (grad) {
+        const int jl = a_lo / 32, jh = (a_hi + 31) / 32;
+        const HSeg X1f0{bx1, jl, jh, ox1, ox1 + a_lo, ox1 + a_hi, 0}, X2f3{bx2, jl, jh, ox2, ox2 + a_lo, ox2 + a_hi, 3};
+        const HSeg X1f1{bx1, jl, jh, ox1, ox1 + a_lo, ox1 + a_hi, 1}, X2f2{bx2, jl, jh, ox2, ox2 + a_lo, ox2 + a_hi, 2};
+        add(on1, J1, on1, bn1, X1f0, X2f3);
+        add(on2, J2, on2, bn2, X1f1, X2f2);
+    }
+    a.ngroups = g;
+    // uniform ~target-step work units (one 4-wave workgroup per CU at a time); see sweepb.hip for the XCD argument
+    int nwg = 0;
+    for (int i = 0; i < g; ++i) {
+        HGroup& G = a.grp[i];
+        int steps = 0;
+        for (int sg = 0; sg < G.nseg; ++sg) steps += G.seg[sg].jt_hi - G.seg[sg].jt_lo;
+        int nsp = (steps + 159) / 160;
+        if (nsp > steps) nsp = steps;
+        if (nsp < 1) nsp = 1;
+        G.nsplit = nsp;
+        G.blk0 = nwg;
+        nwg += (((G.nown + SH_OWN - 1) / SH_OWN) * nsp + 7) / 8 * 8;
+    }
+    return -nwg;                                                    // negative: number of workgroups (0 is a valid "nothing to do")
+}
+
+template <int M, bool GRAD, bool CLO>
+void launch_h(const HArgs& a, int nwg, hipStream_t s) {
+    const size_t lds = (size_t)SH_NBUF * M * SH_BLOCK;
+    auto k = sweeph_kernel<M, GRAD, CLO>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(SH_THREADS), lds, s, a);
+}
+
+}  // namespace
+
+extern "C" size_t sga_loss_split16_bytes(int A, int J1, int J2) {
+    const HLayout L = make_hlayout(A, J1, J2);
+    return (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * SH_BLOCK;      // + one block of slack
+}
+
+extern "C" int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream) {
+    SGA_CHECK_ARG(A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_split16_tables: bad sizes");
+    const HLayout L = make_hlayout(A, J1, J2);
+    const int nb = 2 * L.nbA + L.nb1 + L.nb2;
+    if (nb == 0) return SGA_OK;
+    SGA_CHECK_ARG(Z && Zb, "sga_loss_split16_tables: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(static_cast<unsigned char*>(Zb) + (size_t)nb * SH_BLOCK, 0, SH_BLOCK, s) != hipSuccess) { sga_set_error("sga_loss_split16_tables: memset failed"); return SGA_ERR_HIP; }
+    hipLaunchKernelGGL(split16_tables_kernel, dim3(nb), dim3(256), 0, s, Z, A, J1, J2, static_cast<unsigned char*>(Zb));
+    SGA_CHECK_LAUNCH("sga_loss_split16_tables");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                                         double* sums, int a_lo, int a_hi, void* stream) {
+    SGA_CHECK_ARG(Zb && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums_f16x2: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums_f16x2")) return rc0;
+    if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
+    HArgs a{};
+    const int r = fill_h(a, Zb, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi, "sga_loss_multi_sums_f16x2");
+    if (r > 0) return r;
+    a.sums = sums;
+    if (M == 2) launch_h<2, false, true>(a, -r, s); else launch_h<3, false, true>(a, -r, s);
+    fold_slots(sums, (M + 1) * 8, s);
+    SGA_CHECK_LAUNCH("sga_loss_multi_sums_f16x2");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                                         const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, int coef_lo, void* stream) {
+    SGA_CHECK_ARG(Zb && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad_f16x2: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rcz = zero_slots(gamma, M > 0 ? M : 1, s, "sga_loss_multi_grad_f16x2")) return rcz;
+    if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
+    HArgs a{};
+    const int r = fill_h(a, Zb, M, beta, A, J1, J2, tau0, tau1, true, a_lo, a_hi, "sga_loss_multi_grad_f16x2");
+    if (r > 0) return r;
+    a.gs = gs; a.gamma = gamma;
+    for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad_f16x2: null dZ"); a.dZ[m] = dZ[m]; }
+    if (M == 2) { if (coef_lo) launch_h<2, true, true>(a, -r, s); else launch_h<2, true, false>(a, -r, s); }
+    else { if (coef_lo) launch_h<3, true, true>(a, -r, s); else launch_h<3, true, false>(a, -r, s); }
+    fold_slots(gamma, M, s);
+    SGA_CHECK_LAUNCH("sga_loss_multi_grad_f16x2");
+    return SGA_OK;
+}

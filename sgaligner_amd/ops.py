@@ -39,7 +39,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-MFMA_MODES = {'f32': 0, 'bf16x3': 1, 'f16': 2}
+MFMA_MODES = {'f32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3}
 _MFMA_NAMES = {v: k for k, v in MFMA_MODES.items()}
 
 
@@ -48,7 +48,10 @@ def set_mfma_mode(mode: str) -> str:
     headline number); 'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate; ~1e-5
     relative error; PointNet forward + the fused 100-d loss sweeps); 'f16' (opt-in, BASELINE.json configs[4]: loss tables WIDER than
     128 columns and the similarity ranking take fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; 100-d tables
-    and everything else stay exact fp32).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial mode."""
+    and everything else stay exact fp32); 'f16x2' (opt-in, fp32-FAITHFUL: the fused 100-d loss sweeps with each fp32 operand as fp16
+    hi + lo of 4096 x -- 22 significand bits, three fp16 MFMAs per product, fp32 accumulate: the similarities carry fp32's own rounding
+    error, csrc/sweeph.hip; everything else exact fp32).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial
+    mode."""
     if mode not in MFMA_MODES:
         raise ValueError(f"sgaligner_amd: mfma mode must be one of {sorted(MFMA_MODES)} (got {mode!r})")
     old = _lib.lib().sga_set_mfma_mode(MFMA_MODES[mode])
@@ -477,6 +480,12 @@ SWEEP_SUMS_INFO = {                             # sga_loss_multi_sums: one owner
     'executed_flops': lambda ns, j, m: (2.0 * ns * j) * 2.0 * m * 100,
 }
 BF16X3_COVERAGE = 'PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate'
+F16X2_COVERAGE = ('anchors x negatives loss sweeps (forward sums + gradient) on fp16 MFMA with operands split into fp16 hi + lo of 4096 x '
+                  '(22 significand bits), fp32 accumulate; everything else exact fp32')
+# 'f16x2' gradient sweep: the coefficients dL/dS as fp16 hi + lo (True) or rounded to fp16 (False: an independent, unbiased 2^-12 rounding
+# per (anchor, negative) pair; 7 of 31 MFMAs and 1.5 VALU per pair less).  None = hi + lo unless every gradient row sums at least
+# F16X2_COEF_LO_MIN_TERMS pairs, where the rounding noise averages below fp32's own accumulation error.
+F16X2_COEF_LO = True
 
 TAU_ICL = 0.1      # losses.py:39 (ctor argument ignored by the reference)
 TAU_IAL = 1.0      # losses.py:63
@@ -1126,7 +1135,23 @@ class FusedContrastiveFn(torch.autograd.Function):
         dmax = max(e.shape[1] for e in tables)          # real width: the K step that only covers zero padding is skipped
         # opt-in split-bf16 x3 sweeps: the tables additionally as blocked bf16 hi/lo planes (sweepb.hip)
         zbs = []
-        if M <= 3 and get_mfma_mode() == 'bf16x3':
+        split16 = M in (2, 3) and get_mfma_mode() == 'f16x2'
+        if split16:
+            nb = L.sga_loss_split16_bytes(s.A, s.J1, s.J2)
+            for z in zs:
+                zb = torch.empty((nb,), device=dev, dtype=torch.uint8)
+                _lib.check(L.sga_loss_split16_tables(_p(z), s.A, s.J1, s.J2, _p(zb), st), 'sga_loss_split16_tables')
+                zbs.append(zb)
+            ev = None
+            if KERNEL_EVENTS is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            _lib.check(L.sga_loss_multi_sums_f16x2(_ptr_array(zbs), M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums),
+                                                   a_lo, a_hi, st), 'sga_loss_multi_sums_f16x2')
+            if ev is not None:
+                ev[1].record()
+                KERNEL_EVENTS.setdefault('loss_multi_sums_f16x2', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
+        elif M <= 3 and get_mfma_mode() == 'bf16x3':
             nb = L.sga_loss_split_bytes(s.A, s.J1, s.J2)
             for z in zs:
                 zb = torch.empty((nb,), device=dev, dtype=torch.uint8)
@@ -1217,6 +1242,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         ctx.s, ctx.alpha, ctx.M, ctx.shard, ctx.reduce = s, float(alpha), M, (a_lo, a_hi), reduce
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.n_zb = len(zbs)
+        ctx.split16 = split16
         ctx.onepass = onepass
         ctx.save_for_backward(sums, beta, zj, *zs, *nrms, *zbs, *extra)
         return out.float() + poison
@@ -1248,8 +1274,13 @@ class FusedContrastiveFn(torch.autograd.Function):
             dz_aa, gs_aa, gam_aa, hint = onepass_saved
             hh = torch.dot(hint, hint)
             u = torch.dot(coef, hint) / hh
+            # Always (VALIDATE or not), on the device and without a host sync: a mismatching gradient POISONS what this node returns --
+            # every table gradient, dL/d(sums) and dL/dbeta become NaN -- so the wrong gradients can never be consumed silently by an
+            # optimiser step that runs before the deferred error below is polled.
+            mismatch = (coef - u * hint).abs().max() > 1e-4 * hh.sqrt()
+            u = torch.where(mismatch, torch.full_like(u, float('nan')), u)
             if VALIDATE:
-                bad = ((coef - u * hint).abs().max() > 1e-4 * hh.sqrt()).to(torch.int32).reshape(1)
+                bad = mismatch.to(torch.int32).reshape(1)
                 DEFERRED_CHECKS.submit_fn(bad, lambda v: None if v[0] == 0 else (
                     'sgaligner_amd: the gradient that reached the loss terms is not a multiple of the one OverallLoss announced at forward time '
                     "(backward through something other than loss_dict['loss'] up to a factor); set sgaligner_amd.ops.FUSED_AA_ONEPASS = False"))
@@ -1313,7 +1344,10 @@ class FusedContrastiveFn(torch.autograd.Function):
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if ctx.n_zb:          # the forward ran in bf16x3 mode: its blocked bf16 planes are there
+        if ctx.n_zb and ctx.split16:          # the forward ran in f16x2 mode: its blocked fp16 hi/lo planes are there
+            _lib.check(L.sga_loss_multi_grad_f16x2(_ptr_array(zbs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
+                                                   _p(gam_neg), a_lo, a_hi, 1 if F16X2_COEF_LO else 0, st), 'sga_loss_multi_grad_f16x2')
+        elif ctx.n_zb:          # the forward ran in bf16x3 mode: its blocked bf16 planes are there
             _lib.check(L.sga_loss_multi_grad_bf16x3(_ptr_array(zbs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
                                                     _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad_bf16x3')
         else:
@@ -1321,7 +1355,7 @@ class FusedContrastiveFn(torch.autograd.Function):
                                              _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad')
         if ev is not None:
             ev[1].record()
-            KERNEL_EVENTS.setdefault('loss_multi_grad', []).append(ev + ((ns, A, s.J1, s.J2, M),))
+            KERNEL_EVENTS.setdefault('loss_multi_grad_f16x2' if (ctx.n_zb and ctx.split16) else 'loss_multi_grad', []).append(ev + ((ns, A, s.J1, s.J2, M),))
         grads = []
         same = all(sh == ctx.shapes[0] for sh in ctx.shapes)
         de_all = torch.zeros((M,) + tuple(ctx.shapes[0]), device=dev, dtype=torch.float32) if same else None   # one fill

@@ -290,3 +290,40 @@ def test_rccl_collectives_world_of_one(mods):
     kinds = set(summ['per_step_this_rank'])
     assert 'all_gather' in kinds and (('reduce_scatter' in kinds) == (len(mods) > 1)) and (('all_reduce' in kinds) == (len(mods) > 1))
     assert all(t['ms_each'] > 0 for t in summ['timed_alone'])
+
+
+def test_bench_gpus2_creates_its_two_ranks():
+    """`python bench.py --gpus 2` launched bare (no torchrun, the way the driver launches N = 1) must create its two ranks itself
+    and say so in the line: n_gpus == 2 and two distinct ranks in the self-certifying `collectives` object (round-3 review: it ran ONE
+    process and only warned).  One GPU on the box: the ranks share it and talk over gloo."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--config', 'c2',
+                        '--no-cpu-baseline', '--no-hits', '--no-scale-ref', '--no-bf16x3', '--no-split'], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2
+    seen = line['collectives']['ranks_seen']
+    assert sorted(x['rank'] for x in seen) == [0, 1]
+    assert line['collectives']['world_size'] == 2
+    assert line['config']['global_pairs'] == 1024 and line['config']['pairs_per_gpu'] == 512
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """WORLD_SIZE (set by a launcher) != --gpus is an error, not a warning."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--config', 'c2'],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert 'WORLD_SIZE=1' in (r.stderr + r.stdout)

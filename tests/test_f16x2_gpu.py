@@ -1,0 +1,165 @@
+"""Opt-in, fp32-FAITHFUL split-fp16 MFMA mode of the anchors x negatives loss sweeps (ops.set_mfma_mode('f16x2'), csrc/sweeph.hip; the default
+stays exact fp32; reference arithmetic src/aligner/losses.py:5-15,43-97).  The accuracy GATE of the round-3 review: the same tolerances as the
+exact-fp32 path everywhere, and an error against the fp64 oracle of at most 2x the exact-fp32 path's own error (the configs[2]-sized part of
+the gate -- every parameter's error against 4x the fp32 rerun noise -- is tests/test_c3_gpu.py::test_c3_f16x2_gate)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def f16x2():
+    from sgaligner_amd import ops
+    old = ops.set_mfma_mode('f16x2')
+    yield
+    ops.set_mfma_mode(old)
+
+
+def test_mode_switch_roundtrip():
+    from sgaligner_amd import ops
+    assert ops.get_mfma_mode() == 'f32'                       # the default
+    assert ops.set_mfma_mode('f16x2') == 'f32' and ops.get_mfma_mode() == 'f16x2'
+    assert ops.set_mfma_mode('f32') == 'f16x2' and ops.get_mfma_mode() == 'f32'
+
+
+@pytest.mark.parametrize('coef_lo', [True, False])
+@pytest.mark.parametrize('M,emb', [(3, 100), (2, 100), (3, 64)])
+def test_sweeps_vs_fp32_sweeps_and_anchor_shards(f16x2, M, emb, coef_lo):
+    """The split-fp16 loss sweeps against the exact-fp32 sweeps on the same tables (loss terms, dE, d fusion weight), unsharded and as
+    the sum of 3 anchor shards with cuts that are NOT multiples of the 32-row blocks (what ranks of a multi-GPU job own)."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    from test_c3_gpu import _replay_sharded
+    dd = make_batch(9, 30, 4, seed=40 + M, ragged=True, anchors='val')
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(M)
+    base = [torch.randn(T, emb, device='cuda', generator=g) for _ in range(M)]
+    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')[:M].contiguous()
+    cot = torch.randn(M + 1 + 2 * M, device='cuda', generator=g)
+    keep = ops.F16X2_COEF_LO
+    ops.F16X2_COEF_LO = coef_lo
+    try:
+        def run():
+            tabs = [b.clone().requires_grad_(True) for b in base]
+            w = w0.clone().requires_grad_(True)
+            sums, s = ops.fused_contrastive_terms(tabs, w, dd)
+            (sums * cot).sum().backward()
+            torch.cuda.synchronize()
+            return sums.detach(), [t.grad for t in tabs], w.grad, s
+        sb, gb, wb, s = run()
+        ops.set_mfma_mode('f32')
+        sf, gf, wf, _ = run()
+        ops.set_mfma_mode('f16x2')
+        assert torch.allclose(sb, sf, rtol=2e-6, atol=1e-7), (sb, sf)
+        tol = 5e-6 if coef_lo else 3e-4            # rounded coefficients: 2^-12 per pair over only ~100 pairs per row here
+        for m in range(M):
+            sc = gf[m].abs().max().item()
+            assert (gb[m] - gf[m]).abs().max().item() < tol * sc, (m, (gb[m] - gf[m]).abs().max().item(), sc)
+        assert (wb - wf).abs().max().item() < 10 * tol * max(1e-3, wf.abs().max().item())
+        A = s.A
+        cuts = [0, A // 3 + 5, 2 * A // 3 - 3, A]
+        _, gs, gw, all_sums = _replay_sharded(base, w0, cot, dd, cuts)
+        for sr in all_sums:
+            assert torch.allclose(sr, sb, rtol=1e-5, atol=1e-6)
+        for m in range(M):
+            sc = gb[m].abs().max().item()
+            assert (gs[m] - gb[m]).abs().max().item() < (2e-5 if coef_lo else 2e-4) * sc, m
+        assert (gw - wb).abs().max().item() < 2e-4 * max(1e-3, wb.abs().max().item())
+    finally:
+        ops.F16X2_COEF_LO = keep
+
+
+def _overall_vs_fp64(pairs, nobj, seed):
+    """The product OverallLoss on fused tables in both modes and the fp64 oracle: errors of every gradient against the oracle."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    from test_fullsize_gpu import _loss_setup, _run_overall
+    mods = ['point', 'gat', 'rel']
+    dd, T, base = _loss_setup(pairs, nobj, mods, seed=seed)
+    w0 = torch.tensor([[0.7], [1.2], [0.9]], device='cuda')
+    lv1 = torch.tensor([0.1, -0.2, 0.05], device='cuda')
+    lv2 = torch.tensor([-0.1, 0.15, 0.0], device='cuda')
+    eo = {k: base[i].cpu().double().requires_grad_(True) for i, k in enumerate(mods)}
+    wo = w0.cpu().double().requires_grad_(True)
+    lo1, lo2 = lv1.cpu().double().requires_grad_(True), lv2.cpu().double().requires_grad_(True)
+    out_o = dict(eo)
+    out_o['joint'] = O.fusion([eo[k] for k in mods], wo)
+    ref = O.overall_loss(out_o, dd, mods, lo1, lo2)
+    ref['loss'].backward()
+    errs = {}
+    for mode in ('f32', 'f16x2'):
+        old = ops.set_mfma_mode(mode)
+        try:
+            lf, gf, gwf, g1f, g2f = _run_overall(base, dd, mods, w0, lv1, lv2, fused=True)
+        finally:
+            ops.set_mfma_mode(old)
+        e = {'loss': abs(lf - ref['loss'].item()) / abs(ref['loss'].item())}
+        for k in mods:
+            gref = eo[k].grad
+            e['dE_' + k] = (gf[k].cpu().double() - gref).abs().max().item() / gref.abs().max().item()
+            # the column sums are what reaches the layers below (d bias): a cancellation over all rows
+            e['colsum_' + k] = (gf[k].cpu().double().sum(0) - gref.sum(0)).abs().max().item() / gref.sum(0).abs().max().item()
+        e['dw'] = (gwf.cpu().double() - wo.grad).abs().max().item() / max(1e-30, wo.grad.abs().max().item())
+        e['dlv1'] = (g1f.cpu().double() - lo1.grad).abs().max().item() / lo1.grad.abs().max().item()
+        e['dlv2'] = (g2f.cpu().double() - lo2.grad).abs().max().item() / lo2.grad.abs().max().item()
+        errs[mode] = e
+    return errs
+
+
+@pytest.mark.parametrize('pairs,nobj,seed', [(64, 64, 23), (16, 40, 5), (3, 30, 9)])
+def test_error_vs_fp64_oracle_at_most_twice_the_fp32_paths(pairs, nobj, seed):
+    """GATE: against the fp64 oracle (the largest batch-global losses it finishes in seconds and two small ones) the split-fp16 mode's error in
+    the loss, every table gradient (entries and column sums), d fusion weight and both d log_vars is at most 2x the exact-fp32 path's own
+    error (+ a floor of 2e-7 relative: single fp32 roundings of the result), and within the fp32 tests' tolerances (1e-4 loss, 1e-3 gradients)."""
+    errs = _overall_vs_fp64(pairs, nobj, seed)
+    a, b = errs['f32'], errs['f16x2']
+    for k in a:
+        assert b[k] <= 2.0 * a[k] + 2e-7, (k, a[k], b[k])
+        assert b[k] < (1e-4 if k == 'loss' else 1e-3), (k, b[k])
+
+
+def test_train_step_vs_oracle(f16x2):
+    from oracle import sga_oracle as O
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    mods = ['point', 'gat', 'rel']
+    dd = make_batch(3, 20, 96, seed=8, ragged=True)
+    steps = AlignerSteps(mods, device='cuda', seed=3)
+    params = {k: v.detach().cpu().clone() for k, v in steps.model.state_dict().items() if 'num_batches' not in k}
+    out_o, loss_o, grads_o = O.train_step(params, dd, mods)
+    out, loss = steps.forward_backward(to_device(dd, 'cuda'))
+    torch.cuda.synchronize()
+    for k in out_o:
+        assert (out[k].detach().cpu() - out_o[k].detach()).abs().max() < 1e-3, k
+    assert abs(loss['loss'].item() - loss_o['loss'].item()) < 1e-3 * max(1, abs(loss_o['loss'].item()))
+    for name, p in steps.model.named_parameters():
+        if name in grads_o and p.grad is not None:
+            ref = grads_o[name]
+            assert (p.grad.cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), name
+
+
+def test_loss_scale_independence(f16x2):
+    """The coefficient's power-of-two scale follows dL/d(sums): cotangents 1e-6 ... 1e+6 times larger give gradients exactly that much
+    larger (to fp32 rounding) -- no fp16 overflow or underflow of the coefficient whatever the loss scale."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(6, 24, 4, seed=3, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(1)
+    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(3)]
+    cot = torch.rand(3 + 1 + 6, device='cuda', generator=g) + 0.5
+    ref = None
+    for scale in (1.0, 1e-6, 1e6, 3e-12):
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        w = torch.ones(3, 1, device='cuda', requires_grad=True)
+        sums, _ = ops.fused_contrastive_terms(tabs, w, dd)
+        (sums * cot * scale).sum().backward()
+        gs = [t.grad / scale for t in tabs]
+        assert all(torch.isfinite(x).all() for x in gs)
+        if ref is None:
+            ref = gs
+        else:
+            for x, y in zip(gs, ref):
+                assert (x - y).abs().max().item() < 1e-5 * y.abs().max().item(), scale

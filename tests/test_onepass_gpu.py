@@ -83,12 +83,27 @@ def test_onepass_refuses_a_gradient_it_did_not_announce():
     from sgaligner_amd import ops
     dd, run = _setup(seed=9)
     ops.DEFERRED_CHECKS.flush()
-    run(True, key='icl_loss_unimodal')
+    _, g_bad = run(True, key='icl_loss_unimodal')
     with pytest.raises(RuntimeError, match='FUSED_AA_ONEPASS'):
         ops.DEFERRED_CHECKS.flush()
+    # ... and what it returned meanwhile cannot be consumed by an optimiser step: the table gradients are NaN (device-side poison,
+    # independent of VALIDATE and of when the deferred error is polled)
+    for g in g_bad[:3]:
+        assert torch.isnan(g).all()
     ops.DEFERRED_CHECKS.flush()
-    run(False, key='icl_loss_unimodal')
+    keep = ops.VALIDATE
+    ops.VALIDATE = False
+    try:
+        _, g_bad = run(True, key='ial_loss')
+    finally:
+        ops.VALIDATE = keep
+    for g in g_bad[:3]:
+        assert torch.isnan(g).all()
     ops.DEFERRED_CHECKS.flush()
+    _, g_ok = run(False, key='icl_loss_unimodal')
+    ops.DEFERRED_CHECKS.flush()
+    for g in g_ok[:3]:
+        assert torch.isfinite(g).all()
 
 
 def test_onepass_not_used_without_gradients():

@@ -19,17 +19,19 @@ for _ in range(reps + 2):
     sums, s = ops.fused_contrastive_terms(tabs, w, dd)
     sums.sum().backward()
 torch.cuda.synchronize()
-ev = ops.KERNEL_EVENTS['loss_multi_grad'][2:]
+sfx = '_f16x2' if ops.get_mfma_mode() == 'f16x2' else ''
+ev = ops.KERNEL_EVENTS['loss_multi_grad' + sfx][2:]
 ms = [a.elapsed_time(b) for a, b, _ in ev]
 ns, A, J1, J2, M = ev[0][2]
 alg = 2.0 * (2.0 * 200 * MT * 2.0 * ns * (J1 + J2))
-evf = ops.KERNEL_EVENTS.get('loss_multi_sums', [])[2:]
+evf = ops.KERNEL_EVENTS.get('loss_multi_sums' + sfx, [])[2:]
 msf = [a.elapsed_time(b) for a, b, _ in evf] or [float('nan')]
 print(f'sums {np.median(msf):.3f} ms | sweep grad: median {np.median(ms):.3f} ms (min {min(ms):.3f})  A={A} J={J1 + J2}  algorithmic {alg / np.median(ms) / 1e9:.1f} TFLOP/s = {alg / np.median(ms) / 1e9 / 157.3:.3f} of fp32 MFMA peak; grad checksum {float(tabs[0].grad.abs().sum()):.6e}')
 # accuracy of the opt-in mode against the exact-fp32 sweeps on the same inputs (run with SGA_BENCH_SWEEP_COMPARE=1)
 if os.environ.get('SGA_BENCH_SWEEP_COMPARE'):
     res = {}
-    for mode in ('f32', 'bf16x3'):
+    other = os.environ.get('SGA_BENCH_SWEEP_COMPARE') if os.environ.get('SGA_BENCH_SWEEP_COMPARE') in ('bf16x3', 'f16x2') else 'bf16x3'
+    for mode in ('f32', other):
         ops.set_mfma_mode(mode)
         for t in tabs:
             t.grad = None
@@ -39,7 +41,7 @@ if os.environ.get('SGA_BENCH_SWEEP_COMPARE'):
         torch.cuda.synchronize()
         res[mode] = (sums.detach().clone(), [t.grad.clone() for t in tabs], w.grad.clone())
     ops.set_mfma_mode('f32')
-    a, b = res['f32'], res['bf16x3']
+    a, b = res['f32'], res[other]
     print('loss terms rel err', ((a[0] - b[0]).abs() / a[0].abs().clamp_min(1e-30)).max().item())
     for k in range(3):
         print(f'dE[{k}] max abs err {(a[1][k] - b[1][k]).abs().max().item():.3e} / max |dE| {a[1][k].abs().max().item():.3e}')
