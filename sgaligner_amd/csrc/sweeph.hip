@@ -58,8 +58,12 @@ constexpr int SH_BLOCK = SH_TAIL + 2 * 1024;     // 14336 B
 constexpr int SH_NCH = SH_BLOCK / 1024;          // 14 DMA chunks
 constexpr float SH_PRE = 4096.f;                 // operand pre-scale 2^12: S accumulates 2^24 S
 constexpr float SH_UNPRE = 1.f / (4096.f * 4096.f);
-#ifndef SH_NBUF
 #define SH_NBUF 2
+#ifndef SH_TRANSPORT
+#define SH_TRANSPORT 1
+#endif
+#ifndef SH_TDEPTH
+#define SH_TDEPTH 1
 #endif
 constexpr int sh_min_chunks(int M) {             // fewest DMA chunks any wave issues per tile (wave w: chunks (w + m) % 4 + 4 k of table m)
     int best = 1 << 30;
@@ -76,8 +80,12 @@ constexpr int sh_min_chunks(int M) {             // fewest DMA chunks any wave i
 __device__ __forceinline__ void split_pair16(float v0, float v1, unsigned& hi, unsigned& lo) {
     const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);
     hi = __builtin_bit_cast(unsigned, h);
-    const f16x2 l = __builtin_convertvector(f32x2{v0 - (float)h[0], v1 - (float)h[1]}, f16x2);
-    lo = __builtin_bit_cast(unsigned, l);
+    // lo = fp16(v - hi), the difference exact in fp32: v_fma_mixlo / mixhi_f16 read the fp16 hi half directly and write the fp16 result
+    // (3 instead of 6 VALU per pair: no v_cvt_f32_f16 x 2, v_sub x 2, v_cvt_pk)
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v1));
+    lo = l;
 }
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -223,26 +231,27 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
         }
     }
 
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
-    auto issue = [&](int blk, unsigned char* buf) {
-#ifdef SH_DBG_NODMA
-        return;
-#endif
-        int l16 = threadIdx.x;
-        asm volatile("" : "+v"(l16));
-        l16 = (l16 & 63) * 16;
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const int rot = (wave_u + m) & (SH_WAVES - 1);
-            const unsigned char* src = a.Zb[m] + ((size_t)blk * SH_BLOCK + rot * 1024) + l16;
-            unsigned char* dst = buf + m * SH_BLOCK + rot * 1024;
-#pragma unroll
-            for (int k = 0; k * SH_WAVES < SH_NCH; ++k) {
-                if ((k + 1) * SH_WAVES > SH_NCH && rot + k * SH_WAVES >= SH_NCH) break;       // uniform; only the last k can fall off the block
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * SH_WAVES * 1024),
-                                                 (__attribute__((address_space(3))) void*)(dst + k * SH_WAVES * 1024), 16, 0, 0);
-            }
-        }
+    // Tile transport: the next tile travels HBM/L2 -> registers -> LDS in 1-KiB chunks (global_load_dwordx4 + ds_write_b128 per lane),
+    // slot s = (table m = s / 4, k = s % 4) -> chunk (wave + m) % 4 + 4 k of table m (k = 3 of the two waves whose chunk would fall off
+    // the 14-chunk block re-copies chunk 12 / 13: branch-free, the data is identical), ONE chunk in flight per wave, a slot's load issued
+    // and the previous slot's store retired between the MFMA groups of the tile.  Not the LDS-DMA path (global_load_lds) that sweepb uses:
+    // it moves ~1 KiB per ~57 cycles per CU and an issuing wave stalls while its queue is full (950 cycles per tile with the chunks issued
+    // back to back), and hipcc orders every ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA with s_waitcnt vmcnt(0) (the transpose-read
+    // intrinsic carries no alias information), which forbids spreading the chunks through the gradient phase.
+    const int lane16 = lane * 16;
+    __amdgpu_buffer_rsrc_t rsrc[M];                                   // raw buffer views of the tables' planes: the chunk address is
+#pragma unroll                                                        // (SGPR base, SGPR chunk offset, one VGPR lane offset) -- no 64-bit VGPR math
+    for (int m = 0; m < M; ++m) rsrc[m] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.Zb[m]), 0, 0x7fffffff, 0x00020000);
+    auto chunk_of = [&](int s_) {
+        const int c = __builtin_amdgcn_readfirstlane((wave + (s_ >> 2)) & (SH_WAVES - 1)) + SH_WAVES * (s_ & 3);
+        return c >= SH_NCH ? c - 2 : c;
+    };
+    auto t_load = [&](int blk, int s_) -> u32x4 {
+        const int m = s_ >> 2;
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc[m < M ? m : 0], lane16, blk * SH_BLOCK + chunk_of(s_) * 1024, 0);
+    };
+    auto t_store = [&](unsigned char* buf, int s_, u32x4 v) {
+        *reinterpret_cast<u32x4*>(buf + (s_ >> 2) * SH_BLOCK + chunk_of(s_) * 1024 + lane16) = v;
     };
 
     // lane-derived LDS offsets: S product (lane-linear up to the swizzle) and the transpose reads of the gradient GEMM's B operand:
@@ -272,23 +281,42 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
         for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
 
         __syncthreads();
+        if (seg.jt_lo + split < seg.jt_hi) {
 #pragma unroll
-        for (int d = 0; d < NBUF - 1; ++d)
-            if (seg.jt_lo + split + d * nsplit < seg.jt_hi) issue(seg.blk0 + seg.jt_lo + split + d * nsplit, ldsh + d * BUF);
+            for (int s_ = 0; s_ < 4 * M; ++s_) t_store(ldsh, s_, t_load(seg.blk0 + seg.jt_lo + split, s_));
+        }
         int it = 0;
 #pragma unroll 1
         for (int jt = seg.jt_lo + split; jt < seg.jt_hi; jt += nsplit, ++it) {
-            unsigned char* buf = ldsh + (it % NBUF) * BUF;
+            unsigned char* buf = ldsh + (it & 1) * BUF;
+            unsigned char* nbuf = ldsh + ((it + 1) & 1) * BUF;
             const int j0 = seg.old0 + 32 * jt;                 // old row of the tile's first row
-            if (NBUF == 2) {
-                __syncthreads();
-            } else {
-                constexpr int keep = sh_min_chunks(M) * (NBUF - 2);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep) : "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+            // the next tile's chunks travel through this tile (t_step); a segment's last tile re-copies its own block into the free buffer
+            // instead of branching around every site
+            const int nblk = seg.blk0 + (jt + nsplit < seg.jt_hi ? jt + nsplit : jt);
+            // SH_TRANSPORT 0: the whole next tile by LDS-DMA, issued here in one burst (as sweepb); 1: register-staged, SH_TDEPTH chunks in flight
+            constexpr int TD = SH_TDEPTH;
+            u32x4 tchunk[TD];
+            auto dma_all = [&]() {
+#pragma unroll
+                for (int s_ = 0; s_ < 4 * M; ++s_) {
+                    const int m_ = s_ >> 2;
+                    const unsigned char* src = a.Zb[m_] + ((size_t)nblk * SH_BLOCK + chunk_of(s_) * 1024) + lane16;
+                    unsigned char* dst = nbuf + m_ * SH_BLOCK + chunk_of(s_) * 1024;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            };
+            if (SH_TRANSPORT == 1) {
+#pragma unroll
+                for (int d = 0; d < TD; ++d) tchunk[d] = t_load(nblk, d);
             }
-            if (jt + (NBUF - 1) * nsplit < seg.jt_hi) issue(seg.blk0 + jt + (NBUF - 1) * nsplit, ldsh + ((it + NBUF - 1) % NBUF) * BUF);
+            auto t_step = [&](int s_) {                        // store slot s_ (requested SH_TDEPTH sites earlier), request slot s_ + SH_TDEPTH
+                if (SH_TRANSPORT != 1) return;
+                t_store(nbuf, s_, tchunk[s_ % TD]);
+                if (s_ + TD < 4 * M) tchunk[s_ % TD] = t_load(nblk, s_ + TD);
+            };
+            __syncthreads();                                   // tile `it` has landed (every wave waited for its own chunks), buffer it + 1 is free
+            if (SH_TRANSPORT == 0) dma_all();
             if (GRAD) {
                 // A segment's first / last tile may hold rows outside [lo, hi) (uniform test).  Zeroing those rows' 16-byte slots in the
                 // operand-order image (both planes + tail, all tables) makes their contributions vanish by themselves -- S = 0, c * 0 into the
@@ -311,61 +339,55 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                 }
             }
 
-            // ---- S^T tiles: sacc[m][oh][jh][r] = 2^24 S_m[own = 16 oh + lane&15, other = 8 g4 + 4 jh + r]
+            // ---- S^T tiles: sacc[m][oh][jh][r] = 2^24 S_m[own = 16 oh + lane&15, other = 8 g4 + 4 jh + r], one SUB-STEP = (table, other half):
+            // 7 A operands from LDS, two accumulator chains (the owner halves; a dependent v_mfma_f32_16x16x32_f16 issues back to back at
+            // 16 cycles, tools/micro/mfma_dep_chain.hip).  One wave per SIMD: nobody else covers an LDS read's latency, so the operands are
+            // prefetched on a ROLLING schedule inside the MFMA stream -- the next sub-step's tail + lo operands are requested once this
+            // one's tail / lo.hi products (their last readers) have issued, its hi operands after the hi.lo / hi.hi products.
             f32x4 sacc[M][2][2];
+            u32x4 at, al[3], ah[3];
+            auto ld_tl = [&](int ss) {
+                const unsigned char* ar = buf + (ss >> 1) * SH_BLOCK + (ss & 1) * 1024 + aoff;
+                at = *reinterpret_cast<const u32x4*>(ar + SH_TAIL);
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                // four independent accumulator chains (owner half x other half): a dependent MFMA is four issues away
-                const unsigned char* ar = buf + m * SH_BLOCK + aoff;
-                u32x4 ah[2][3], al[2][3], at[2];
+                for (int q = 0; q < 3; ++q) al[q] = *reinterpret_cast<const u32x4*>(ar + SH_PLANE + q * 2048);
+            };
+            auto ld_h = [&](int ss) {
+                const unsigned char* ar = buf + (ss >> 1) * SH_BLOCK + (ss & 1) * 1024 + aoff;
 #pragma unroll
-                for (int jh = 0; jh < 2; ++jh) {
-#ifdef SH_DBG_NOSREAD
-                    at[jh] = u32x4{(unsigned)it, (unsigned)jh, 0x3c003c00u, 0x3c003c00u};
+                for (int q = 0; q < 3; ++q) ah[q] = *reinterpret_cast<const u32x4*>(ar + q * 2048);
+            };
+            ld_tl(0);
+            ld_h(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) { al[jh][q] = at[jh]; ah[jh][q] = at[jh]; }
-#else
-                    at[jh] = *reinterpret_cast<const u32x4*>(ar + SH_TAIL + jh * 1024);
+            for (int ss = 0; ss < 2 * M; ++ss) {
+                const int m = ss >> 1, jh = ss & 1;
+                f32x4 acc[2];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        al[jh][q] = *reinterpret_cast<const u32x4*>(ar + SH_PLANE + q * 2048 + jh * 1024);
-                        ah[jh][q] = *reinterpret_cast<const u32x4*>(ar + q * 2048 + jh * 1024);
-                    }
-#endif
-                }
-                f32x4 acc[2][2];
-#ifdef SH_DBG_NOSMFMA
+                for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(at, otl[m][oh], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-                for (int oh = 0; oh < 2; ++oh)
+                for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int jh = 0; jh < 2; ++jh) { acc[oh][jh] = __builtin_bit_cast(f32x4, at[jh] ^ ah[jh][0] ^ al[jh][1] ^ ah[jh][2] ^ al[jh][0] ^ ah[jh][1] ^ al[jh][2] ^ otl[m][oh]); sacc[m][oh][jh] = acc[oh][jh]; }
-                continue;
-#endif
+                    for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(al[q], ohi[m][oh][q], acc[oh]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ss + 1 < 2 * M) ld_tl(ss + 1);
+                if (GRAD) { if (jh == 0) t_step(2 * m); } else t_step(4 * m + 2 * jh);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int oh = 0; oh < 2; ++oh)
+                for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(at[jh], otl[m][oh], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-#pragma unroll
-                    for (int oh = 0; oh < 2; ++oh)
-#pragma unroll
-                        for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(al[jh][q], ohi[m][oh][q], acc[oh][jh]);
-#pragma unroll
-                    for (int oh = 0; oh < 2; ++oh)
-#pragma unroll
-                        for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(ah[jh][q], olo[m][oh][q], acc[oh][jh]);
-                }
+                    for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(ah[q], olo[m][oh][q], acc[oh]);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)                    // the large hi.hi terms last
 #pragma unroll
-                    for (int oh = 0; oh < 2; ++oh)
+                    for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(ah[q], ohi[m][oh][q], acc[oh]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ss + 1 < 2 * M) ld_h(ss + 1);
+                if (GRAD) { if (jh == 1) t_step(2 * m + 1); } else t_step(4 * m + 2 * jh + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int jh = 0; jh < 2; ++jh) acc[oh][jh] = mfma_h(ah[jh][q], ohi[m][oh][q], acc[oh][jh]);
-#pragma unroll
-                for (int oh = 0; oh < 2; ++oh)
-#pragma unroll
-                    for (int jh = 0; jh < 2; ++jh) sacc[m][oh][jh] = acc[oh][jh];
+                for (int oh = 0; oh < 2; ++oh) sacc[m][oh][jh] = acc[oh];
             }
 
             if (!GRAD) {
@@ -401,6 +423,22 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
+                // Gradient GEMM B operands (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes,
+                // one STEP = (table, column tile): two accumulator chains (the owner halves); the operands of step k + 1 are requested before
+                // the MFMAs of step k issue (double-buffered: the first step's before the joint epilogue, a table's first step's before the
+                // previous table's last MFMAs), so their latency hides under matrix / VALU work of this wave itself.
+                u32x4 bh[2], bl[2];
+                auto ld_b = [&](int k) {
+                    const int m = k / NCT, ct = k % NCT, par = k & 1;
+                    const unsigned char* ph = ct < 6 ? buf + m * SH_BLOCK + tr_main + (ct >> 1) * 2048 + (ct & 1) * 512 : buf + m * SH_BLOCK + tr_tail;
+                    const unsigned char* pl = ct < 6 ? ph + SH_PLANE : ph + 512;
+                    const u32x2 h0 = tr_read16(ph), h1 = tr_read16(ph + 1024);
+                    const u32x2 l0 = tr_read16(pl), l1 = tr_read16(pl + 1024);
+                    bh[par] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                    bl[par] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                };
+                ld_b(0);
+                __builtin_amdgcn_sched_barrier(0);
                 // joint coefficient dL/dS_J (unscaled) for this lane's 2 x 8 pairs
                 float cj[2][2][4];
 #pragma unroll
@@ -454,54 +492,22 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                                 chi[oh][p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, f16x2));
                             }
                         }
-                    // B operand (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes
-                    const unsigned char* tb = buf + m * SH_BLOCK + tr_main;
-                    const unsigned char* tt = buf + m * SH_BLOCK + tr_tail;
 #pragma unroll
-                    for (int c0t = 0; c0t < NCT; c0t += 2) {       // two column tiles at a time: four independent accumulator chains
-                        u32x4 bh[2], bl[2];
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const int k = NCT * m + ct, par = k & 1;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k + 1 < NCT * M) ld_b(k + 1);
+                        // the transport's remaining 2 M slots, spread over the NCT M steps
+                        if ((k * 2 * M) / (NCT * M) != ((k + 1) * 2 * M) / (NCT * M)) t_step(2 * M + (k * 2 * M) / (NCT * M));
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int ct = c0t + u;
-#ifdef SH_DBG_NOTR
-                            if (ct < NCT) { bh[u] = u32x4{chi[0][0], (unsigned)ct, 0x3c003c00u, 0x3c003c00u}; bl[u] = bh[u]; }
-                            if (false) {
-#else
-                            if (ct < NCT) {
-#endif
-                                const unsigned char* ph = ct < 6 ? tb + (ct >> 1) * 2048 + (ct & 1) * 512 : tt;
-                                const unsigned char* pl = ct < 6 ? ph + SH_PLANE : tt + 512;
-                                const u32x2 h0 = tr_read16(ph), h1 = tr_read16(ph + 1024);
-                                const u32x2 l0 = tr_read16(pl), l1 = tr_read16(pl + 1024);
-                                bh[u] = u32x4{h0[0], h0[1], h1[0], h1[1]};
-                                bl[u] = u32x4{l0[0], l0[1], l1[0], l1[1]};
-                            }
+                        for (int oh = 0; oh < 2; ++oh) {
+                            f32x4 acc = gacc[GRAD ? m : 0][oh][ct];
+                            if (CLO) acc = mfma_h(clo[oh], bh[par], acc);
+                            acc = mfma_h(chi[oh], bl[par], acc);
+                            acc = mfma_h(chi[oh], bh[par], acc);
+                            gacc[GRAD ? m : 0][oh][ct] = acc;
                         }
-#ifdef SH_DBG_NOGMFMA
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int oh = 0; oh < 2; ++oh)
-                                if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] += __builtin_bit_cast(f32x4, chi[oh] ^ bh[u] ^ bl[u] ^ (CLO ? clo[oh] : chi[oh]));
-                        continue;
-#endif
-                        if (CLO) {
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                                for (int oh = 0; oh < 2; ++oh)
-                                    if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] = mfma_h(clo[oh], bh[u], gacc[GRAD ? m : 0][oh][c0t + u]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int oh = 0; oh < 2; ++oh)
-                                if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] = mfma_h(chi[oh], bl[u], gacc[GRAD ? m : 0][oh][c0t + u]);
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int oh = 0; oh < 2; ++oh)
-                                if (c0t + u < NCT) gacc[GRAD ? m : 0][oh][c0t + u] = mfma_h(chi[oh], bh[u], gacc[GRAD ? m : 0][oh][c0t + u]);
                     }
                 }
             }
