@@ -37,6 +37,7 @@
 //   8 (i>>2) + 4 jh + (i&3), so that a lane's 8 accumulator values (2 halves x 4) are the 8 CONSECUTIVE other rows 8 g4 .. 8 g4+7:
 //   exactly the k slots of the gradient MFMA  dZ[own] += C[own, other] Z[other, cols]  whose A operand is therefore the coefficient
 //   registers (split into fp16 hi/lo) and whose B operand comes from transpose reads of the same planes.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "loss_math.h"
@@ -50,7 +51,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SH_WAVES = 4, SH_THREADS = SH_WAVES * 64, SH_OWN = SH_WAVES * 32;
+constexpr int SH_OWN = 128;                      // owner rows per workgroup (8 waves x 16 or 4 waves x 32)
 constexpr int SH_DP = 104;
 constexpr int SH_PLANE = 3 * 2 * 1024;           // 6144 B
 constexpr int SH_TAIL = 2 * SH_PLANE;            // byte offset of the packed tail in a block
@@ -58,23 +59,6 @@ constexpr int SH_BLOCK = SH_TAIL + 2 * 1024;     // 14336 B
 constexpr int SH_NCH = SH_BLOCK / 1024;          // 14 DMA chunks
 constexpr float SH_PRE = 4096.f;                 // operand pre-scale 2^12: S accumulates 2^24 S
 constexpr float SH_UNPRE = 1.f / (4096.f * 4096.f);
-#define SH_NBUF 2
-#ifndef SH_TRANSPORT
-#define SH_TRANSPORT 1
-#endif
-#ifndef SH_TDEPTH
-#define SH_TDEPTH 1
-#endif
-constexpr int sh_min_chunks(int M) {             // fewest DMA chunks any wave issues per tile (wave w: chunks (w + m) % 4 + 4 k of table m)
-    int best = 1 << 30;
-    for (int w = 0; w < SH_WAVES; ++w) {
-        int n = 0;
-        for (int m = 0; m < M; ++m)
-            for (int c = (w + m) & (SH_WAVES - 1); c < SH_NCH; c += SH_WAVES) ++n;
-        best = n < best ? n : best;
-    }
-    return best;
-}
 
 // v0, v1 -> packed fp16 hi pair and lo pair (v = hi + lo to 22 bits)
 __device__ __forceinline__ void split_pair16(float v0, float v1, unsigned& hi, unsigned& lo) {
@@ -95,6 +79,9 @@ __device__ __forceinline__ u32x2 tr_read16(const unsigned char* p) {     // ds_r
 }
 __host__ __device__ constexpr int sh_slot(int g, int i) { return 16 * g + (i ^ (12 * (g & 1))); }
 
+#ifndef SH_BDEPTH
+#define SH_BDEPTH 2
+#endif
 struct HLayout { int nbA, nb1, nb2; };
 __host__ __device__ inline HLayout make_hlayout(int A, int J1, int J2) { return HLayout{(A + 31) / 32, (J1 + 31) / 32, (J2 + 31) / 32}; }
 
@@ -132,6 +119,12 @@ __global__ __launch_bounds__(256) void split16_tables_kernel(const float* __rest
     }
 }
 
+#ifdef SH_DBG_TIMING
+__device__ unsigned long long g_sh_dbg[16];
+#define SH_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; }
+#else
+#define SH_T(i)
+#endif
 struct HSeg { int blk0, jt_lo, jt_hi, old0, lo, hi, fam; };   // others: block blk0 + jt holds old rows old0 + 32 jt + w; valid rows in [lo, hi)
 struct HGroup { int own0, nown, own_old0, own_blk0, blk0, nsplit, nseg; HSeg seg[2]; };
 struct HArgs {
@@ -146,12 +139,19 @@ struct HArgs {
 
 // CLO: the coefficients' lo terms (C = hi + lo, third gradient MFMA).  Without them C is rounded to fp16's 11 bits: an independent,
 // unbiased rounding error of <= 2^-12 per (owner, other) pair.
-template <int M, bool GRAD, bool CLO>
-__global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
+// OH: owner halves (of 16 rows) per wave.  OH = 1: 8 waves x 16 rows, two waves per SIMD at <= 256 registers -- the CU's issue logic hands a
+// SIMD one instruction per TYPE per 4-cycle slot from DIFFERENT waves, so one wave's LDS / scalar / wait / DMA instructions (a third of the
+// instruction stream) issue in the shadow of the other's MFMAs and a parked wave costs nothing; OH = 2: 4 waves x 32 rows, one wave per SIMD
+// at <= 512 registers -- half the LDS reads per MFMA, but every instruction of the stream then takes its own 4-cycle issue slot (SQ
+// counters, profiles/r04_f_sweeph_sq.txt: 246 MFMAs = 3 936 matrix cycles + ~990 other instructions = 3 900 issue cycles per tile).
+template <int M, bool GRAD, bool CLO, int OH>
+__global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
     constexpr int NCT = 7;
+    constexpr int WAVES = 8 / OH, THREADS = WAVES * 64;
+    constexpr int KMAX = (SH_NCH + WAVES - 1) / WAVES;               // DMA chunk slots per table and wave
     constexpr int BUF = M * SH_BLOCK;
-    constexpr int NBUF = SH_NBUF;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsh[];      // [NBUF][M][SH_BLOCK]
+    constexpr bool PIPE = OH == 2;                                    // one wave per SIMD: operand prefetch pinned inside the MFMA stream
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsh[];      // [2][M][SH_BLOCK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
     int g = 0;
@@ -166,13 +166,17 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
     const int split = unit / n_ob;
     const int own0 = grp.own0 + (unit - split * n_ob) * SH_OWN;
     const int own_end = grp.own0 + grp.nown;
+    const int wrow0 = own0 + wave * 16 * OH;                          // this wave's first owner row
+#ifdef SH_DBG_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
 
-    // ---- owner rows (two halves of 16) as the S product's B operand: 3 K = 32 steps hi / lo + the packed tail (k group 0, 2: hi; 1, 3: lo)
-    u32x4 ohi[M][2][3], olo[M][2][3], otl[M][2];
+    // ---- owner rows (OH halves of 16) as the S product's B operand: 3 K = 32 steps hi / lo + the packed tail (k group 0, 2: hi; 1, 3: lo)
+    u32x4 ohi[M][OH][3], olo[M][OH][3], otl[M][OH];
     float beta[M];
 #pragma unroll
-    for (int oh = 0; oh < 2; ++oh) {
-        const int my_i = own0 + wave * 32 + oh * 16 + l15;
+    for (int oh = 0; oh < OH; ++oh) {
+        const int my_i = wrow0 + oh * 16 + l15;
         const bool iv = my_i < own_end;
         const int rel = (iv ? my_i : own0) - grp.own_old0;
         const int o = rel & 31, oi = 4 * (o >> 3) + (o & 3), ojh = (o >> 2) & 1;       // row o sits at (half ojh, operand row oi) of its block
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
 #pragma unroll
     for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
 
-    f32x4 gacc[GRAD ? M : 1][2][NCT];
+    f32x4 gacc[GRAD ? M : 1][OH][NCT];
 #pragma unroll
     for (int m = 0; m < (GRAD ? M : 1); ++m)
 #pragma unroll
-        for (int oh = 0; oh < 2; ++oh)
+        for (int oh = 0; oh < OH; ++oh)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) gacc[m][oh][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float gam[M];
@@ -231,27 +235,31 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
         }
     }
 
-    // Tile transport: the next tile travels HBM/L2 -> registers -> LDS in 1-KiB chunks (global_load_dwordx4 + ds_write_b128 per lane),
-    // slot s = (table m = s / 4, k = s % 4) -> chunk (wave + m) % 4 + 4 k of table m (k = 3 of the two waves whose chunk would fall off
-    // the 14-chunk block re-copies chunk 12 / 13: branch-free, the data is identical), ONE chunk in flight per wave, a slot's load issued
-    // and the previous slot's store retired between the MFMA groups of the tile.  Not the LDS-DMA path (global_load_lds) that sweepb uses:
-    // it moves ~1 KiB per ~57 cycles per CU and an issuing wave stalls while its queue is full (950 cycles per tile with the chunks issued
-    // back to back), and hipcc orders every ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA with s_waitcnt vmcnt(0) (the transpose-read
-    // intrinsic carries no alias information), which forbids spreading the chunks through the gradient phase.
-    const int lane16 = lane * 16;
-    __amdgpu_buffer_rsrc_t rsrc[M];                                   // raw buffer views of the tables' planes: the chunk address is
-#pragma unroll                                                        // (SGPR base, SGPR chunk offset, one VGPR lane offset) -- no 64-bit VGPR math
-    for (int m = 0; m < M; ++m) rsrc[m] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.Zb[m]), 0, 0x7fffffff, 0x00020000);
-    auto chunk_of = [&](int s_) {
-        const int c = __builtin_amdgcn_readfirstlane((wave + (s_ >> 2)) & (SH_WAVES - 1)) + SH_WAVES * (s_ & 3);
-        return c >= SH_NCH ? c - 2 : c;
-    };
-    auto t_load = [&](int blk, int s_) -> u32x4 {
-        const int m = s_ >> 2;
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc[m < M ? m : 0], lane16, blk * SH_BLOCK + chunk_of(s_) * 1024, 0);
-    };
-    auto t_store = [&](unsigned char* buf, int s_, u32x4 v) {
-        *reinterpret_cast<u32x4*>(buf + (s_ >> 2) * SH_BLOCK + chunk_of(s_) * 1024 + lane16) = v;
+    // Tile transport: ONE contiguous 14-KiB copy per table by LDS-DMA (global_load_lds, 1 KiB per wave instruction), slot (table m, k) ->
+    // chunk (wave + m) % WAVES + WAVES k: the table index of every DMA is a compile-time constant (no kernel-argument reload + s_waitcnt in
+    // front of it).  Issued in one burst at the top of a tile for the NEXT tile.  (Tried and dropped, profiles/r04_e_sweeph_transport.txt:
+    // the chunks through registers -- buffer_load_dwordx4 + ds_write_b128, 1-3 in flight, spread between the MFMA groups: 7.0-7.8 ms vs 6.9;
+    // the DMAs themselves spread through the tile: hipcc orders every ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA with vmcnt(0).)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
+    auto issue = [&](int blk, unsigned char* buf) {
+#ifdef SH_DBG_NODMA
+        return;
+#endif
+        int l16 = threadIdx.x;
+        asm volatile("" : "+v"(l16));
+        l16 = (l16 & 63) * 16;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int rot = (wave_u + m) & (WAVES - 1);
+            const unsigned char* src = a.Zb[m] + ((size_t)blk * SH_BLOCK + rot * 1024) + l16;
+            unsigned char* dst = buf + m * SH_BLOCK + rot * 1024;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if ((k + 1) * WAVES > SH_NCH && rot + k * WAVES >= SH_NCH) break;       // uniform; only the last k can fall off the block
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * WAVES * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + k * WAVES * 1024), 16, 0, 0);
+            }
+        }
     };
 
     // lane-derived LDS offsets: S product (lane-linear up to the swizzle) and the transpose reads of the gradient GEMM's B operand:
@@ -281,49 +289,24 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
         for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
 
         __syncthreads();
-        if (seg.jt_lo + split < seg.jt_hi) {
-#pragma unroll
-            for (int s_ = 0; s_ < 4 * M; ++s_) t_store(ldsh, s_, t_load(seg.blk0 + seg.jt_lo + split, s_));
-        }
+        if (seg.jt_lo + split < seg.jt_hi) issue(seg.blk0 + seg.jt_lo + split, ldsh);
         int it = 0;
 #pragma unroll 1
         for (int jt = seg.jt_lo + split; jt < seg.jt_hi; jt += nsplit, ++it) {
             unsigned char* buf = ldsh + (it & 1) * BUF;
-            unsigned char* nbuf = ldsh + ((it + 1) & 1) * BUF;
             const int j0 = seg.old0 + 32 * jt;                 // old row of the tile's first row
-            // the next tile's chunks travel through this tile (t_step); a segment's last tile re-copies its own block into the free buffer
-            // instead of branching around every site
-            const int nblk = seg.blk0 + (jt + nsplit < seg.jt_hi ? jt + nsplit : jt);
-            // SH_TRANSPORT 0: the whole next tile by LDS-DMA, issued here in one burst (as sweepb); 1: register-staged, SH_TDEPTH chunks in flight
-            constexpr int TD = SH_TDEPTH;
-            u32x4 tchunk[TD];
-            auto dma_all = [&]() {
-#pragma unroll
-                for (int s_ = 0; s_ < 4 * M; ++s_) {
-                    const int m_ = s_ >> 2;
-                    const unsigned char* src = a.Zb[m_] + ((size_t)nblk * SH_BLOCK + chunk_of(s_) * 1024) + lane16;
-                    unsigned char* dst = nbuf + m_ * SH_BLOCK + chunk_of(s_) * 1024;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                }
-            };
-            if (SH_TRANSPORT == 1) {
-#pragma unroll
-                for (int d = 0; d < TD; ++d) tchunk[d] = t_load(nblk, d);
-            }
-            auto t_step = [&](int s_) {                        // store slot s_ (requested SH_TDEPTH sites earlier), request slot s_ + SH_TDEPTH
-                if (SH_TRANSPORT != 1) return;
-                t_store(nbuf, s_, tchunk[s_ % TD]);
-                if (s_ + TD < 4 * M) tchunk[s_ % TD] = t_load(nblk, s_ + TD);
-            };
+            SH_T(5)
             __syncthreads();                                   // tile `it` has landed (every wave waited for its own chunks), buffer it + 1 is free
-            if (SH_TRANSPORT == 0) dma_all();
+            SH_T(0)
+            if (jt + nsplit < seg.jt_hi) issue(seg.blk0 + jt + nsplit, ldsh + ((it + 1) & 1) * BUF);
+            SH_T(1)
             if (GRAD) {
                 // A segment's first / last tile may hold rows outside [lo, hi) (uniform test).  Zeroing those rows' 16-byte slots in the
                 // operand-order image (both planes + tail, all tables) makes their contributions vanish by themselves -- S = 0, c * 0 into the
                 // owner gradient, 0 into Gamma -- so the gradient epilogue carries no validity mask.
                 const int vlo = max(seg.lo - j0, 0), vhi = min(seg.hi - j0, 32);
                 if (vlo > 0 || vhi < 32) {
-                    for (int x = tid; x < M * 32 * 28; x += SH_THREADS) {
+                    for (int x = tid; x < M * 32 * 28; x += THREADS) {
                         const int pc = x % 28, w = (x / 28) % 32, m = x / (28 * 32);
                         if (w >= vlo && w < vhi) continue;
                         const int wjh = (w >> 2) & 1, wi = 4 * (w >> 3) + (w & 3);
@@ -340,11 +323,11 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
             }
 
             // ---- S^T tiles: sacc[m][oh][jh][r] = 2^24 S_m[own = 16 oh + lane&15, other = 8 g4 + 4 jh + r], one SUB-STEP = (table, other half):
-            // 7 A operands from LDS, two accumulator chains (the owner halves; a dependent v_mfma_f32_16x16x32_f16 issues back to back at
-            // 16 cycles, tools/micro/mfma_dep_chain.hip).  One wave per SIMD: nobody else covers an LDS read's latency, so the operands are
-            // prefetched on a ROLLING schedule inside the MFMA stream -- the next sub-step's tail + lo operands are requested once this
-            // one's tail / lo.hi products (their last readers) have issued, its hi operands after the hi.lo / hi.hi products.
-            f32x4 sacc[M][2][2];
+            // 7 A operands from LDS, OH accumulator chains (a dependent v_mfma_f32_16x16x32_f16 issues back to back at 16 cycles,
+            // tools/micro/mfma_dep_chain.hip).  PIPE (one wave per SIMD: nobody else covers an LDS read's latency): the operands are prefetched
+            // on a ROLLING schedule inside the MFMA stream -- the next sub-step's tail + lo operands are requested once this one's tail /
+            // lo.hi products (their last readers) have issued, its hi operands after the hi.lo / hi.hi products.
+            f32x4 sacc[M][OH][2];
             u32x4 at, al[3], ah[3];
             auto ld_tl = [&](int ss) {
                 const unsigned char* ar = buf + (ss >> 1) * SH_BLOCK + (ss & 1) * 1024 + aoff;
@@ -357,39 +340,45 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) ah[q] = *reinterpret_cast<const u32x4*>(ar + q * 2048);
             };
-            ld_tl(0);
-            ld_h(0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (PIPE) {
+                ld_tl(0);
+                ld_h(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int ss = 0; ss < 2 * M; ++ss) {
                 const int m = ss >> 1, jh = ss & 1;
-                f32x4 acc[2];
+                if (!PIPE) { ld_tl(ss); ld_h(ss); }
+                f32x4 acc[OH];
 #pragma unroll
-                for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(at, otl[m][oh], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(al[q], ohi[m][oh][q], acc[oh]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ss + 1 < 2 * M) ld_tl(ss + 1);
-                if (GRAD) { if (jh == 0) t_step(2 * m); } else t_step(4 * m + 2 * jh);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(at, otl[m][oh], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(ah[q], olo[m][oh][q], acc[oh]);
+                    for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(al[q], ohi[m][oh][q], acc[oh]);
+                if (PIPE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ss + 1 < 2 * M) ld_tl(ss + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(ah[q], olo[m][oh][q], acc[oh]);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)                    // the large hi.hi terms last
 #pragma unroll
-                    for (int oh = 0; oh < 2; ++oh) acc[oh] = mfma_h(ah[q], ohi[m][oh][q], acc[oh]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ss + 1 < 2 * M) ld_h(ss + 1);
-                if (GRAD) { if (jh == 1) t_step(2 * m + 1); } else t_step(4 * m + 2 * jh + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(ah[q], ohi[m][oh][q], acc[oh]);
+                if (PIPE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ss + 1 < 2 * M) ld_h(ss + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
-                for (int oh = 0; oh < 2; ++oh) sacc[m][oh][jh] = acc[oh];
+                for (int oh = 0; oh < OH; ++oh) sacc[m][oh][jh] = acc[oh];
             }
 
+            SH_T(2)
             if (!GRAD) {
                 float p0[M + 1], p1[M + 1];
 #pragma unroll
@@ -398,8 +387,8 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                 auto sums_tile = [&](auto masked_c) {
                     constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-                    for (int oh = 0; oh < 2; ++oh) {
-                        const bool iv = own0 + wave * 32 + oh * 16 + l15 < own_end;
+                    for (int oh = 0; oh < OH; ++oh) {
+                        const bool iv = wrow0 + oh * 16 + l15 < own_end;
 #pragma unroll
                         for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
@@ -424,12 +413,13 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
                 // Gradient GEMM B operands (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes,
-                // one STEP = (table, column tile): two accumulator chains (the owner halves); the operands of step k + 1 are requested before
-                // the MFMAs of step k issue (double-buffered: the first step's before the joint epilogue, a table's first step's before the
-                // previous table's last MFMAs), so their latency hides under matrix / VALU work of this wave itself.
-                u32x4 bh[2], bl[2];
+                // one STEP = (table, column tile), OH accumulator chains.  PIPE: the operands of step k + 1 are requested before the MFMAs of
+                // step k issue (double-buffered: the first step's before the joint epilogue, a table's first step's before the previous
+                // table's last MFMAs), so their latency hides under matrix / VALU work of this wave itself.
+                constexpr int BD = PIPE ? SH_BDEPTH : 1;          // B operand ring: steps k .. k + BD - 1 requested
+                u32x4 bh[BD], bl[BD];
                 auto ld_b = [&](int k) {
-                    const int m = k / NCT, ct = k % NCT, par = k & 1;
+                    const int m = k / NCT, ct = k % NCT, par = k % BD;
                     const unsigned char* ph = ct < 6 ? buf + m * SH_BLOCK + tr_main + (ct >> 1) * 2048 + (ct & 1) * 512 : buf + m * SH_BLOCK + tr_tail;
                     const unsigned char* pl = ct < 6 ? ph + SH_PLANE : ph + 512;
                     const u32x2 h0 = tr_read16(ph), h1 = tr_read16(ph + 1024);
@@ -437,12 +427,17 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                     bh[par] = u32x4{h0[0], h0[1], h1[0], h1[1]};
                     bl[par] = u32x4{l0[0], l0[1], l1[0], l1[1]};
                 };
-                ld_b(0);
-                __builtin_amdgcn_sched_barrier(0);
-                // joint coefficient dL/dS_J (unscaled) for this lane's 2 x 8 pairs
-                float cj[2][2][4];
+                if (PIPE) {
 #pragma unroll
-                for (int oh = 0; oh < 2; ++oh)
+                    for (int k = 0; k + 1 < BD; ++k) ld_b(k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // joint coefficient dL/dS_J (unscaled) for this lane's OH x 8 pairs.  Plain VALU on purpose: beside MFMAs a v_pk_*_f32 costs 7.8
+                // cycles against 2.6 for v_fma / v_mul and 6.4 for v_exp (tools/micro/valu_issue.hip), so neither packed pairs nor
+                // e^{S/tau0} = (e^{S/tau1})^10 by four multiplies pay (both built and measured: profiles/r04_k_sweeph_final_variants.txt)
+                float cj[OH][2][4];
+#pragma unroll
+                for (int oh = 0; oh < OH; ++oh)
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
@@ -460,7 +455,7 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
 #pragma unroll
-                        for (int oh = 0; oh < 2; ++oh)
+                        for (int oh = 0; oh < OH; ++oh)
 #pragma unroll
                             for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
@@ -468,12 +463,13 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                         asm volatile("" : "+v"(gam[m]));
                     }
                 }
+                SH_T(3)
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     // sig_m c_m for this lane's 8 consecutive other rows (k slot j = 4 jh + r), split into fp16 hi / lo: the A operand
-                    u32x4 chi[2], clo[2];
+                    u32x4 chi[OH], clo[OH];
 #pragma unroll
-                    for (int oh = 0; oh < 2; ++oh)
+                    for (int oh = 0; oh < OH; ++oh)
 #pragma unroll
                         for (int p = 0; p < 4; ++p) {
                             const int jh = p >> 1, r = (p & 1) * 2;
@@ -494,14 +490,16 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                         }
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) {
-                        const int k = NCT * m + ct, par = k & 1;
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (k + 1 < NCT * M) ld_b(k + 1);
-                        // the transport's remaining 2 M slots, spread over the NCT M steps
-                        if ((k * 2 * M) / (NCT * M) != ((k + 1) * 2 * M) / (NCT * M)) t_step(2 * M + (k * 2 * M) / (NCT * M));
-                        __builtin_amdgcn_sched_barrier(0);
+                        const int k = NCT * m + ct, par = k % BD;
+                        if (PIPE) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (k + BD - 1 < NCT * M) ld_b(k + BD - 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+                            ld_b(k);
+                        }
 #pragma unroll
-                        for (int oh = 0; oh < 2; ++oh) {
+                        for (int oh = 0; oh < OH; ++oh) {
                             f32x4 acc = gacc[GRAD ? m : 0][oh][ct];
                             if (CLO) acc = mfma_h(clo[oh], bh[par], acc);
                             acc = mfma_h(chi[oh], bl[par], acc);
@@ -510,6 +508,7 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                         }
                     }
                 }
+                SH_T(4)
             }
         }
         if (!GRAD) {
@@ -522,19 +521,22 @@ __global__ __launch_bounds__(SH_THREADS, 1) void sweeph_kernel(HArgs a) {
                 }
         }
     }
+#ifdef SH_DBG_TIMING
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_sh_dbg[(GRAD ? 8 : 0) + i], tacc[i]);
+#endif
     if (GRAD) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             float* dz = a.dZ[m];
 #pragma unroll
-            for (int oh = 0; oh < 2; ++oh)
+            for (int oh = 0; oh < OH; ++oh)
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     const int d = ct * 16 + l15;
                     if (d < SH_DP) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int i = own0 + wave * 32 + oh * 16 + 4 * g4 + r;
+                            const int i = wrow0 + oh * 16 + 4 * g4 + r;
                             if (i < own_end) atomicAdd(dz + (size_t)i * SH_DP + d, gacc[GRAD ? m : 0][oh][ct][r] * isig[m]);
                         }
                     }
@@ -595,16 +597,26 @@ int fill_h(HArgs& a, const void* const* Zb, int M, const float* beta, int A, int
     return -nwg;                                                    // negative: number of workgroups (0 is a valid "nothing to do")
 }
 
+#ifndef SH_OH
+#define SH_OH 1
+#endif
 template <int M, bool GRAD, bool CLO>
 void launch_h(const HArgs& a, int nwg, hipStream_t s) {
-    const size_t lds = (size_t)SH_NBUF * M * SH_BLOCK;
-    auto k = sweeph_kernel<M, GRAD, CLO>;
+    const size_t lds = (size_t)2 * M * SH_BLOCK;
+    auto k = sweeph_kernel<M, GRAD, CLO, SH_OH>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(SH_THREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(512 / SH_OH), lds, s, a);
 }
 
 }  // namespace
 
+#ifdef SH_DBG_TIMING
+extern "C" int sga_dbg_sweeph(unsigned long long* host16) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_sh_dbg), sizeof(g_sh_dbg)) != hipSuccess) return 1;
+    static unsigned long long z[16];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sh_dbg), z, sizeof(z)) != hipSuccess;
+}
+#endif
 extern "C" size_t sga_loss_split16_bytes(int A, int J1, int J2) {
     const HLayout L = make_hlayout(A, J1, J2);
     return (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * SH_BLOCK;      // + one block of slack

@@ -483,9 +483,17 @@ BF16X3_COVERAGE = 'PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split 
 F16X2_COVERAGE = ('anchors x negatives loss sweeps (forward sums + gradient) on fp16 MFMA with operands split into fp16 hi + lo of 4096 x '
                   '(22 significand bits), fp32 accumulate; everything else exact fp32')
 # 'f16x2' gradient sweep: the coefficients dL/dS as fp16 hi + lo (True) or rounded to fp16 (False: an independent, unbiased 2^-12 rounding
-# per (anchor, negative) pair; 7 of 31 MFMAs and 1.5 VALU per pair less).  None = hi + lo unless every gradient row sums at least
-# F16X2_COEF_LO_MIN_TERMS pairs, where the rounding noise averages below fp32's own accumulation error.
-F16X2_COEF_LO = True
+# per (anchor, negative) pair; 7 of 31 MFMAs and 1.5 VALU per pair less).  None (default) = hi + lo unless EVERY gradient row sums at least
+# F16X2_COEF_LO_MIN_TERMS pairs: there the rounding noise of a row, 2^-12 / sqrt(terms) <= 6.7e-7 of its largest term, is below the
+# accumulation error the exact-fp32 sweep itself carries (8e-7 .. 2.5e-6 of a table gradient's maximum against fp64).
+F16X2_COEF_LO = {'1': True, '0': False}.get(_os.environ.get('SGA_F16X2_COEF_LO', ''), None)
+F16X2_COEF_LO_MIN_TERMS = 1 << 17
+
+
+def _f16x2_coef_lo(ns, J1, J2):
+    if F16X2_COEF_LO is not None:
+        return bool(F16X2_COEF_LO)
+    return min(J1 + J2, 2 * ns) < F16X2_COEF_LO_MIN_TERMS
 
 TAU_ICL = 0.1      # losses.py:39 (ctor argument ignored by the reference)
 TAU_IAL = 1.0      # losses.py:63
@@ -1346,7 +1354,7 @@ class FusedContrastiveFn(torch.autograd.Function):
             ev[0].record()
         if ctx.n_zb and ctx.split16:          # the forward ran in f16x2 mode: its blocked fp16 hi/lo planes are there
             _lib.check(L.sga_loss_multi_grad_f16x2(_ptr_array(zbs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
-                                                   _p(gam_neg), a_lo, a_hi, 1 if F16X2_COEF_LO else 0, st), 'sga_loss_multi_grad_f16x2')
+                                                   _p(gam_neg), a_lo, a_hi, 1 if _f16x2_coef_lo(ns, s.J1, s.J2) else 0, st), 'sga_loss_multi_grad_f16x2')
         elif ctx.n_zb:          # the forward ran in bf16x3 mode: its blocked bf16 planes are there
             _lib.check(L.sga_loss_multi_grad_bf16x3(_ptr_array(zbs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
                                                     _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad_bf16x3')
