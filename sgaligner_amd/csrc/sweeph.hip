@@ -85,9 +85,48 @@ __host__ __device__ constexpr int sh_slot(int g, int i) { return 16 * g + (i ^ (
 struct HLayout { int nbA, nb1, nb2; };
 __host__ __device__ inline HLayout make_hlayout(int A, int J1, int J2) { return HLayout{(A + 31) / 32, (J1 + 31) / 32, (J2 + 31) / 32}; }
 
-// fp32 packed table -> blocked fp16 hi/lo planes + packed tail (one workgroup per 32-row block)
-__global__ __launch_bounds__(256) void split16_tables_kernel(const float* __restrict__ Z, int A, int J1, int J2, unsigned char* __restrict__ Zb) {
+// ---- CENTRING.  The planes hold z' = z - zbar (zbar = the table's column mean over its R packed rows) plus two bookkeeping columns:
+//   column 100: b = zbar . z' + |zbar|^2 / 2        column 101: 1
+// so that with the owner's two columns SWAPPED (1, b_i) the K tail of the S product adds b_j + b_i and the MFMAs still deliver
+//   S_ij = z_i . z_j = z'_i . z'_j + zbar . z'_i + zbar . z'_j + |zbar|^2   exactly as before,
+// and the gradient GEMM's output column 101 is rowsum_i = sum_j c_ij, from which dZ_i = sum_j c_ij z'_j + rowsum_i zbar.
+// Why: a table whose rows are nearly identical (meta_embedding_rel: bag-of-words rows that are almost all alike, S ~ 1 for every pair) has a
+// loss gradient that is the small TANGENTIAL remainder of a large radial sum.  The 22-bit hi + lo image of z_j carries the same rounding
+// residue for every such row, so sum_j c_ij (z_j + eps_j) grows a coherent (sum_j c_ij) eps term with a tangential part of the remainder's own
+// size: at 1024 pairs x 128 objects the un-centred kernel missed d(meta_embedding_rel.weight) by 1.1 x its maximum against fp64 where the
+// exact-fp32 sweep misses it by 2.6 % (tests/test_fp64_chunked_gpu.py).  Centred, the residue is relative to |z'| (the spread of the rows),
+// the accumulators hold the small sums only, and the radial part enters once, exactly, through rowsum x zbar.
+// Statistics block of a table, behind its blocks and the slack block: float zbar[104] | float nbh (= |zbar|^2 / 2) ... | at +512 B: double colsum[104].
+constexpr int SH_STAT_BYTES = 2048;
+constexpr int SH_DREAL = 100;                    // data columns; 100, 101 are the bookkeeping columns (emb_dim <= 100 in this mode)
+
+__global__ __launch_bounds__(128) void split16_colsum_kernel(const float* __restrict__ Z, int R, double* __restrict__ colsum) {
+    const int c = threadIdx.x;
+    const int per = (R + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(R, r0 + per);
+    if (c >= SH_DP) return;
+    double acc = 0.0;
+    for (int r = r0; r < r1; ++r) acc += (double)Z[(size_t)r * SH_DP + c];
+    if (r1 > r0) atomicAdd(colsum + c, acc);
+}
+__global__ __launch_bounds__(128) void split16_stats_kernel(const double* __restrict__ colsum, int R, float* __restrict__ stat) {
+    __shared__ double sq[128];
+    const int c = threadIdx.x;
+    const float zb = (c < SH_DREAL && R > 0) ? (float)(colsum[c] / (double)R) : 0.f;
+    if (c < SH_DP) stat[c] = zb;
+    sq[c] = (double)zb * (double)zb;
+    __syncthreads();
+    if (c == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 128; ++i) t += sq[i];
+        stat[SH_DP] = (float)(0.5 * t);
+    }
+}
+
+// fp32 packed table -> blocked fp16 hi/lo planes + packed tail of the CENTRED rows (one workgroup per 32-row block)
+__global__ __launch_bounds__(256) void split16_tables_kernel(const float* __restrict__ Z, int A, int J1, int J2, unsigned char* __restrict__ Zb,
+                                                             const float* __restrict__ stat) {
     __shared__ float tile[32 * SH_DP];
+    __shared__ float zbar[SH_DP];
     const HLayout L = make_hlayout(A, J1, J2);
     int b = blockIdx.x, old0, len;
     if (b < L.nbA) { old0 = 0; len = A; }
@@ -96,7 +135,24 @@ __global__ __launch_bounds__(256) void split16_tables_kernel(const float* __rest
     else { b -= 2 * L.nbA + L.nb1; old0 = 2 * A + J1; len = J2; }
     const int nvalid = min(32, len - 32 * b);
     const float* src = Z + (size_t)(old0 + 32 * b) * SH_DP;
-    for (int e = threadIdx.x; e < 32 * SH_DP; e += 256) tile[e] = (e / SH_DP) < nvalid ? src[e] * SH_PRE : 0.f;
+    if (threadIdx.x < SH_DP) zbar[threadIdx.x] = stat[threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * SH_DP; e += 256) {
+        const int r = e / SH_DP, c = e - r * SH_DP;
+        tile[e] = (r < nvalid && c < SH_DREAL) ? src[e] - zbar[c] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {                       // the two bookkeeping columns of a valid row (a padding row stays all zero: S = 0 as before)
+        const int r = threadIdx.x;
+        if (r < nvalid) {
+            double a = 0.0;
+            for (int c = 0; c < SH_DREAL; ++c) a += (double)zbar[c] * (double)tile[r * SH_DP + c];
+            tile[r * SH_DP + SH_DREAL] = (float)(a + (double)stat[SH_DP]);
+            tile[r * SH_DP + SH_DREAL + 1] = 1.f;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * SH_DP; e += 256) tile[e] *= SH_PRE;
     __syncthreads();
     unsigned* out = reinterpret_cast<unsigned*>(Zb + (size_t)blockIdx.x * SH_BLOCK);
     // planes: dword e = (slot s of [q][jh][64], pair p of 4): stored slot (g, i ^ swz) <- logical (g, i)
@@ -134,6 +190,7 @@ struct HArgs {
     double* sums;                    // SUM out  [(M+1)][8] (+ slots)
     const double* gs;                // GRAD in  [(M+1)][8]
     float* dZ[4];                    // GRAD out (fp32, old row order), atomic accumulate
+    const float* stat[4];            // per table: zbar[104], |zbar|^2 / 2 (behind the blocks of Zb)
     double* gamma;                   // GRAD out [M] (+ slots)
 };
 
@@ -192,6 +249,7 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
             }
             // tail B operand: k group 0 -> own hi, 1 -> own lo, 2 -> own hi, 3 -> own lo (against A = other hi, hi, lo, lo)
             otl[m][oh] = iv ? *reinterpret_cast<const u32x4*>(base + SH_TAIL + (ojh * 64 + sh_slot((g4 & 1) * 2, oi)) * 16) : u32x4{0, 0, 0, 0};
+            otl[m][oh][2] = (otl[m][oh][2] >> 16) | (otl[m][oh][2] << 16);      // columns 100, 101: the owner holds (1, b_i) against the other's (b_j, 1)
         }
     }
 #pragma unroll
@@ -528,19 +586,27 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             float* dz = a.dZ[m];
+            float zb[NCT];                                     // zbar of this lane's columns
 #pragma unroll
-            for (int oh = 0; oh < OH; ++oh)
+            for (int ct = 0; ct < NCT; ++ct) zb[ct] = (ct * 16 + l15 < SH_DREAL) ? a.stat[m][ct * 16 + l15] : 0.f;
+#pragma unroll
+            for (int oh = 0; oh < OH; ++oh) {
+                // rowsum_i = sum_j c_ij: output column 101 = lane 5 of the last column tile (same row group g4)
+                float rs[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rs[r] = __shfl(gacc[GRAD ? m : 0][oh][NCT - 1][r], (lane & 48) | 5, 64);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     const int d = ct * 16 + l15;
-                    if (d < SH_DP) {
+                    if (d < SH_DREAL) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int i = wrow0 + oh * 16 + 4 * g4 + r;
-                            if (i < own_end) atomicAdd(dz + (size_t)i * SH_DP + d, gacc[GRAD ? m : 0][oh][ct][r] * isig[m]);
+                            if (i < own_end) atomicAdd(dz + (size_t)i * SH_DP + d, fmaf(rs[r], zb[ct], gacc[GRAD ? m : 0][oh][ct][r]) * isig[m]);
                         }
                     }
                 }
+            }
         }
         if (g < 2) {
 #pragma unroll
@@ -557,7 +623,15 @@ int fill_h(HArgs& a, const void* const* Zb, int M, const float* beta, int A, int
     if (M < 2 || M > 3) { sga_set_error("%s: M=%d (the split-fp16 sweeps are built for 2 or 3 modality tables)", who, M); return SGA_ERR_ARG; }
     if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("%s: anchor shard [%d,%d) outside [0,%d]", who, a_lo, a_hi, A); return SGA_ERR_ARG; }
     a.M = M;
-    for (int m = 0; m < M; ++m) { if (!Zb[m]) { sga_set_error("%s: null table", who); return SGA_ERR_ARG; } a.Zb[m] = static_cast<const unsigned char*>(Zb[m]); }
+    {
+        const HLayout L0 = make_hlayout(A, J1, J2);
+        const size_t stat_off = (size_t)(2 * L0.nbA + L0.nb1 + L0.nb2 + 1) * SH_BLOCK;
+        for (int m = 0; m < M; ++m) {
+            if (!Zb[m]) { sga_set_error("%s: null table", who); return SGA_ERR_ARG; }
+            a.Zb[m] = static_cast<const unsigned char*>(Zb[m]);
+            a.stat[m] = reinterpret_cast<const float*>(a.Zb[m] + stat_off);
+        }
+    }
     a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     const HLayout L = make_hlayout(A, J1, J2);
     const int ns = a_hi - a_lo;
@@ -619,7 +693,7 @@ extern "C" int sga_dbg_sweeph(unsigned long long* host16) {
 #endif
 extern "C" size_t sga_loss_split16_bytes(int A, int J1, int J2) {
     const HLayout L = make_hlayout(A, J1, J2);
-    return (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * SH_BLOCK;      // + one block of slack
+    return (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * SH_BLOCK + SH_STAT_BYTES;      // + one block of slack + the table's statistics
 }
 
 extern "C" int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream) {
@@ -629,8 +703,14 @@ extern "C" int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, vo
     if (nb == 0) return SGA_OK;
     SGA_CHECK_ARG(Z && Zb, "sga_loss_split16_tables: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(static_cast<unsigned char*>(Zb) + (size_t)nb * SH_BLOCK, 0, SH_BLOCK, s) != hipSuccess) { sga_set_error("sga_loss_split16_tables: memset failed"); return SGA_ERR_HIP; }
-    hipLaunchKernelGGL(split16_tables_kernel, dim3(nb), dim3(256), 0, s, Z, A, J1, J2, static_cast<unsigned char*>(Zb));
+    unsigned char* tail = static_cast<unsigned char*>(Zb) + (size_t)nb * SH_BLOCK;
+    if (hipMemsetAsync(tail, 0, SH_BLOCK + SH_STAT_BYTES, s) != hipSuccess) { sga_set_error("sga_loss_split16_tables: memset failed"); return SGA_ERR_HIP; }
+    float* stat = reinterpret_cast<float*>(tail + SH_BLOCK);
+    double* colsum = reinterpret_cast<double*>(tail + SH_BLOCK + 512);
+    const int R = 2 * A + J1 + J2;
+    hipLaunchKernelGGL(split16_colsum_kernel, dim3(R < 4096 ? (R + 63) / 64 : 1024), dim3(128), 0, s, Z, R, colsum);
+    hipLaunchKernelGGL(split16_stats_kernel, dim3(1), dim3(128), 0, s, colsum, R, stat);
+    hipLaunchKernelGGL(split16_tables_kernel, dim3(nb), dim3(256), 0, s, Z, A, J1, J2, static_cast<unsigned char*>(Zb), stat);
     SGA_CHECK_LAUNCH("sga_loss_split16_tables");
     return SGA_OK;
 }

@@ -112,11 +112,12 @@ def _overall_vs_fp64(pairs, nobj, seed):
 def test_error_vs_fp64_oracle_at_most_twice_the_fp32_paths(pairs, nobj, seed):
     """GATE: against the fp64 oracle (the largest batch-global losses it finishes in seconds and two small ones) the split-fp16 mode's error in
     the loss, every table gradient (entries and column sums), d fusion weight and both d log_vars is at most 2x the exact-fp32 path's own
-    error (+ a floor of 2e-7 relative: single fp32 roundings of the result), and within the fp32 tests' tolerances (1e-4 loss, 1e-3 gradients)."""
+    error (+ a floor of 1e-6 relative: a few fp32 roundings of the result -- the centred split adds rowsum x zbar to every gradient row), and
+    within the fp32 tests' tolerances (1e-4 loss, 1e-3 gradients)."""
     errs = _overall_vs_fp64(pairs, nobj, seed)
     a, b = errs['f32'], errs['f16x2']
     for k in a:
-        assert b[k] <= 2.0 * a[k] + 2e-7, (k, a[k], b[k])
+        assert b[k] <= 2.0 * a[k] + 1e-6, (k, a[k], b[k])
         assert b[k] < (1e-4 if k == 'loss' else 1e-3), (k, b[k])
 
 
@@ -163,3 +164,40 @@ def test_loss_scale_independence(f16x2):
         else:
             for x, y in zip(gs, ref):
                 assert (x - y).abs().max().item() < 1e-5 * y.abs().max().item(), scale
+
+
+def test_nearly_identical_rows_vs_fp64_oracle(f16x2):
+    """A table whose rows are nearly identical (what meta_embedding_rel makes of bag-of-words rows that are almost all alike): the loss gradient
+    is the small tangential remainder of a large radial sum.  The planes are CENTRED for this (csrc/sweeph.hip): against the fp64 oracle the
+    mode's error in the table gradient and in its column sums (= the bias gradient below it) stays within 2x the exact-fp32 path's own
+    (un-centred, the 22-bit image of the rows missed the column sums by 8x the fp32 path's error at this size)."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    from test_fullsize_gpu import _run_overall
+    mods = ['point', 'gat', 'rel']
+    dd = make_batch(64, 64, 1, seed=3)
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator().manual_seed(0)
+    base = [torch.randn(T, 100, generator=g, dtype=torch.float64) for _ in mods]
+    base[2] = torch.randn(1, 100, generator=g, dtype=torch.float64) + 1e-3 * torch.randn(T, 100, generator=g, dtype=torch.float64)
+    base = [b.float().double() for b in base]
+    w0 = torch.tensor([[0.7], [1.2], [0.9]], dtype=torch.float64)
+    lv1 = torch.tensor([0.1, -0.2, 0.05], dtype=torch.float64)
+    lv2 = torch.tensor([-0.1, 0.15, 0.0], dtype=torch.float64)
+    eo = {k: base[i].clone().requires_grad_(True) for i, k in enumerate(mods)}
+    wo = w0.clone().requires_grad_(True)
+    out_o = dict(eo)
+    out_o['joint'] = O.fusion([eo[k] for k in mods], wo)
+    O.overall_loss(out_o, dd, mods, lv1.clone().requires_grad_(True), lv2.clone().requires_grad_(True))['loss'].backward()
+    err = {}
+    for mode in ('f32', 'f16x2'):
+        ops.set_mfma_mode(mode)
+        _, gg, _, _, _ = _run_overall([b.float().cuda() for b in base], dd, mods, w0.float().cuda(), lv1.float().cuda(), lv2.float().cuda(), fused=True)
+        gref = eo['rel'].grad
+        got = gg['rel'].cpu().double()
+        err[mode] = ((got - gref).abs().max().item() / gref.abs().max().item(),
+                     (got.sum(0) - gref.sum(0)).abs().max().item() / gref.sum(0).abs().max().item())
+    ops.set_mfma_mode('f16x2')
+    assert err['f16x2'][0] <= 2.0 * err['f32'][0] + 1e-6, err
+    assert err['f16x2'][1] <= 2.0 * err['f32'][1] + 1e-6, err
