@@ -156,6 +156,15 @@ int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const float* bet
                                   double* gamma, int a_lo, int a_hi, double* out_terms, void* stream);
 int sga_loss_stash_grad_sym(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
                             void* stream);
+/* The same two entry points for ONE RANK of an anchor-sharded job (new design; the reference has no multi-GPU path:
+ * src/engine/base_trainer.py:70,146-158 is dead): rows [a_lo, a_hi) meet the columns [j_lo, j_hi) only; tiles at j >= mir also produce the
+ * mirrored element (j, i) (stash M2, rows j - mir), tiles left of mir are visited in the ordered way and must lie in the block's own
+ * square.  sga_loss_anchor_multi_bwd_sym == (j_lo, j_hi, mir) = (a_lo, A, a_hi).  M1[m]: [j_hi - j_lo, a_hi - a_lo], M2[m]: [j_hi - mir, a_hi - a_lo]. */
+int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
+                                   float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
+                                   double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir, double* out_terms, void* stream);
+int sga_loss_stash_grad_symx(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
+                             int j_lo, int j_hi, int mir, void* stream);
 /* ZJ[r, m*104+d] = sqrt(beta_m) Z_m[r,d] for the anchor rows (operand of the anchors x anchors kernels), and its adjoint */
 int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream);
 int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows, float* const* dZ,

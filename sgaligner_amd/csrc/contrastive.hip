@@ -1354,7 +1354,8 @@ struct AnchorMultiArgs {
     double* gs;                    // bwd: [(M+1)][8] (+ slots)
     double* gamma;                 // bwd: [M] (+ slots)
     int j_lo;                      // bwd: first column (a multiple of 16); stash rows are j - j_lo.  0 except in the symmetric mode
-    float* M2[4];                  // symmetric mode: M2[m][(j - i_hi)*ns + (i - i_lo)] = the MIRRORED coefficient dL/dS_m[j,i], j >= i_hi
+    float* M2[4];                  // symmetric mode: M2[m][(j - mir)*ns + (i - i_lo)] = the MIRRORED coefficient dL/dS_m[j,i], j >= mir
+    int j_hi, mir;                 // symmetric mode: columns [j_lo, j_hi); tiles at j >= mir also produce the mirrored element (one GPU: A, i_hi)
 };
 
 template <int M, bool BWD>
@@ -1515,6 +1516,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
     auto CF = [&](int e) { return a.coef[e]; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int A = a.A, ns = a.i_hi - a.i_lo;
+    const int JH = SYM ? a.j_hi : A;                                 // column end (the symmetric walk of a rank stops where another rank's starts)
     const int ib = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
     const int i0 = a.i_lo + ib * RB;
     const int ih = wave % NSUB, tw = wave / NSUB;                    // which 16 anchor rows of the block / which share of the J tiles
@@ -1573,7 +1575,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
     };
     const float* js = inv_s + M * 8;
 
-    const int ntile = (A + 15) / 16;
+    const int ntile = (JH + 15) / 16;
 #pragma unroll 1
     for (int jt = (a.j_lo >> 4) + split * TW + tw; jt < ntile; jt += a.nsplit * TW) {
         const int j0 = jt * 16;
@@ -1639,7 +1641,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + 4 * g + r;
-            const bool ok = !MASKED || (iv && (j < A));
+            const bool ok = !MASKED || (iv && (j < JH));
             const float okf = (!MASKED || ok) ? 1.f : 0.f;
             float xj = 0.f, yj = 0.f;
 #pragma unroll
@@ -1730,7 +1732,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + 4 * g + r;
-            const bool ok = iv && (j < A);
+            const bool ok = iv && (j < JH);
             const float okf = ok ? 1.f : 0.f;
             float xj = 0.f, yj = 0.f;
 #pragma unroll
@@ -1790,7 +1792,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
                 acc_gs[M][1] = fmaf(uA, MA.p, acc_gs[M][1]); acc_gs[M][3] = fmaf(uA, MA.r, acc_gs[M][3]);
                 acc_gs[M][5] = fmaf(uB, MB.p, acc_gs[M][5]); acc_gs[M][7] = fmaf(uB, MB.r, acc_gs[M][7]);
                 float* const* dst = dir ? a.M2 : a.M1;
-                const size_t off = (size_t)(j - (dir ? a.i_hi : a.j_lo)) * ns + (my_i - a.i_lo);
+                const size_t off = (size_t)(j - (dir ? a.mir : a.j_lo)) * ns + (my_i - a.i_lo);
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     acc_gam[m] = fmaf(gJ, dir ? Q[m][r] : P[m][r], acc_gam[m]);
@@ -1815,7 +1817,7 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
             for (int r = 0; r < 4; ++r) acc_gam[m] += P[m][r] * Q[m][r];
 #else
         if constexpr (SYM) {
-            if (j0 >= a.i_hi) epilogue_sym(0); else epilogue(std::true_type{});                               // uniform
+            if (j0 >= a.mir) epilogue_sym(0); else epilogue(std::true_type{});                               // uniform
         } else {
             if (j0 + 16 <= A && i0 + RB <= a.i_hi) epilogue(std::false_type{}); else epilogue(std::true_type{});   // uniform
         }
@@ -2270,31 +2272,37 @@ extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const flo
  *   M1[m][(j - a_lo) * ns + (i - a_lo)] = dL/dS_m[i, j],  j in [a_lo, A)          ([A - a_lo, ns] floats)
  *   M2[m][(j - a_hi) * ns + (i - a_lo)] = dL/dS_m[j, i],  j in [a_hi, A)          ([A - a_hi, ns] floats)
  * out_terms / gs / gamma as in sga_loss_anchor_multi_bwd: this block's share (both elements of every pair it visits). */
-extern "C" int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
-                                             float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
-                                             double* gs, double* gamma, int a_lo, int a_hi, double* out_terms, void* stream) {
-    SGA_CHECK_ARG(Z && beta && sums && coef && M1 && M2 && gs && gamma && out_terms && A >= 0, "sga_loss_anchor_multi_bwd_sym: bad argument");
-    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_anchor_multi_bwd_sym: M=%d (2 or 3; M = 4 runs sga_loss_anchor_multi_bwd)", M);
-    SGA_CHECK_ARG(a_lo % 32 == 0 && (a_hi % 32 == 0 || a_hi == A), "sga_loss_anchor_multi_bwd_sym: block [%d,%d) not on 32-row boundaries", a_lo, a_hi);
+extern "C" int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
+                                              float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
+                                              double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir, double* out_terms,
+                                              void* stream) {
+    SGA_CHECK_ARG(Z && beta && sums && coef && M1 && M2 && gs && gamma && out_terms && A >= 0, "sga_loss_anchor_multi_bwd_symx: bad argument");
+    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_anchor_multi_bwd_symx: M=%d (2 or 3; M = 4 runs sga_loss_anchor_multi_bwd)", M);
+    SGA_CHECK_ARG(a_lo % 32 == 0 && (a_hi % 32 == 0 || a_hi == A), "sga_loss_anchor_multi_bwd_symx: block [%d,%d) not on 32-row boundaries", a_lo, a_hi);
+    SGA_CHECK_ARG(j_lo >= 0 && j_lo % 16 == 0 && j_hi <= A && j_lo <= j_hi && (j_hi % 16 == 0 || j_hi == A) && mir >= j_lo && (mir % 16 == 0 || mir >= j_hi),
+                  "sga_loss_anchor_multi_bwd_symx: columns [%d,%d) / mirror start %d not on 16-column boundaries", j_lo, j_hi, mir);
+    // columns left of the mirror start are visited in the ordered way: they must lie in the block's own square
+    SGA_CHECK_ARG(mir <= j_lo || (j_lo >= a_lo && (mir < j_hi ? mir : j_hi) <= a_hi), "sga_loss_anchor_multi_bwd_symx: ordered columns [%d,%d) outside the block's square [%d,%d)",
+                  j_lo, mir, a_lo, a_hi);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int rc0 = zero_slots(gs, (M + 1) * 8, s, "sga_loss_anchor_multi_bwd_sym")) return rc0;
-    if (int rc1 = zero_slots(gamma, M, s, "sga_loss_anchor_multi_bwd_sym")) return rc1;
-    if (int rc2 = zero_slots(out_terms, (M + 1) + 2 * M, s, "sga_loss_anchor_multi_bwd_sym")) return rc2;
-    if (A == 0 || a_hi <= a_lo) return SGA_OK;
+    if (int rc0 = zero_slots(gs, (M + 1) * 8, s, "sga_loss_anchor_multi_bwd_symx")) return rc0;
+    if (int rc1 = zero_slots(gamma, M, s, "sga_loss_anchor_multi_bwd_symx")) return rc1;
+    if (int rc2 = zero_slots(out_terms, (M + 1) + 2 * M, s, "sga_loss_anchor_multi_bwd_symx")) return rc2;
+    if (A == 0 || a_hi <= a_lo || j_hi <= j_lo) return SGA_OK;
     AnchorMultiArgs a{};
     int rc = fill_anchor_multi(a, Z, M, beta, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
     if (rc) return rc;
-    a.coef = coef; a.gs = gs; a.gamma = gamma; a.out = out_terms; a.j_lo = a_lo;
+    a.coef = coef; a.gs = gs; a.gamma = gamma; a.out = out_terms; a.j_lo = j_lo; a.j_hi = j_hi; a.mir = mir;
     float* inv = reinterpret_cast<float*>(gs + (size_t)(1 + SGA_SLOTS) * (M + 1) * 8);
     hipLaunchKernelGGL(inv_sums_kernel, dim3(1), dim3(64), 0, s, sums, inv, (M + 1) * 8);
     a.inv = inv;
     for (int m = 0; m < M; ++m) {
-        SGA_CHECK_ARG(M1[m] && (M2[m] || a_hi == A), "sga_loss_anchor_multi_bwd_sym: null stash");
+        SGA_CHECK_ARG(M1[m] && (M2[m] || mir >= j_hi), "sga_loss_anchor_multi_bwd_symx: null stash");
         a.M1[m] = M1[m]; a.M2[m] = M2[m];
     }
     const int RB = 32, TW = 2;
     const size_t lds = (size_t)(M * 2 * RB * 104 + (M + 1) * 8) * sizeof(float);
-    const int nib = (a_hi - a_lo + RB - 1) / RB, ntile16 = (A - a_lo + 15) / 16;
+    const int nib = (a_hi - a_lo + RB - 1) / RB, ntile16 = (j_hi - j_lo + 15) / 16;
     int nsp = (6 * sga_num_cus() + nib - 1) / nib;
     if (nsp > (ntile16 + TW - 1) / TW) nsp = (ntile16 + TW - 1) / TW;
     if (nsp < 1) nsp = 1;
@@ -2307,26 +2315,37 @@ extern "C" int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const
     fold_slots(out_terms, (M + 1) + 2 * M, s);
     fold_slots(gs, (M + 1) * 8, s);
     fold_slots(gamma, M, s);
-    SGA_CHECK_LAUNCH("sga_loss_anchor_multi_bwd_sym");
+    SGA_CHECK_LAUNCH("sga_loss_anchor_multi_bwd_symx");
     return SGA_OK;
 }
 
-/* The four products of a symmetric block's two stashes for one table (Z = [X1 | X2 | ...] rows of width Dp; R = [a_lo, a_hi)):
- *   dX1[R] += M1^T X2[a_lo:A]     dX2[a_lo:A] += M1 X1[R]     dX1[a_hi:A] += M2 X2[R]     dX2[R] += M2^T X1[a_hi:A] */
-extern "C" int sga_loss_stash_grad_sym(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
-                                       void* stream) {
-    SGA_CHECK_ARG(M1 && Z && dZ && A >= 0 && Dp >= 8 && Dp % 8 == 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi && (M2 || a_hi == A),
-                  "sga_loss_stash_grad_sym: bad argument");
-    const int ns = a_hi - a_lo, c1 = A - a_lo, c2 = A - a_hi;
-    if (A == 0 || ns == 0) return SGA_OK;
+extern "C" int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
+                                             float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
+                                             double* gs, double* gamma, int a_lo, int a_hi, double* out_terms, void* stream) {
+    return sga_loss_anchor_multi_bwd_symx(Z, M, beta, A, sums, alpha, tau_icl, tau_ial, coef, M1, M2, gs, gamma, a_lo, a_hi, a_lo, A, a_hi, out_terms, stream);
+}
+
+/* The four products of a symmetric block's two stashes for one table (Z = [X1 | X2 | ...] rows of width Dp; R = [a_lo, a_hi), C = [j_lo, j_hi),
+ * C' = [mir, j_hi)):    dX1[R] += M1^T X2[C]     dX2[C] += M1 X1[R]     dX1[C'] += M2 X2[R]     dX2[R] += M2^T X1[C'] */
+extern "C" int sga_loss_stash_grad_symx(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
+                                        int j_lo, int j_hi, int mir, void* stream) {
+    SGA_CHECK_ARG(M1 && Z && dZ && A >= 0 && Dp >= 8 && Dp % 8 == 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi && j_lo >= 0 && j_lo <= j_hi && j_hi <= A &&
+                  mir >= j_lo && (M2 || mir >= j_hi), "sga_loss_stash_grad_symx: bad argument");
+    const int ns = a_hi - a_lo, c1 = j_hi - j_lo, c2 = mir < j_hi ? j_hi - mir : 0;
+    if (A == 0 || ns == 0 || c1 == 0) return SGA_OK;
     // (a last block whose row count is not a multiple of 4 takes sga_gemm's general kernel: correct, slower)
     const float* X1 = Z;
     const float* X2 = Z + (size_t)A * Dp;
     float* d1 = dZ;
     float* d2 = dZ + (size_t)A * Dp;
-    int rc = sga_gemm(1, 0, ns, Dp, c1, M1, ns, 0, X2 + (size_t)a_lo * Dp, Dp, d1 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
-    if (!rc) rc = sga_gemm(0, 0, c1, Dp, ns, M1, ns, 0, X1 + (size_t)a_lo * Dp, Dp, d2 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
-    if (!rc && c2 > 0) rc = sga_gemm(0, 0, c2, Dp, ns, M2, ns, 0, X2 + (size_t)a_lo * Dp, Dp, d1 + (size_t)a_hi * Dp, Dp, nullptr, 1, stream);
-    if (!rc && c2 > 0) rc = sga_gemm(1, 0, ns, Dp, c2, M2, ns, 0, X1 + (size_t)a_hi * Dp, Dp, d2 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
+    int rc = sga_gemm(1, 0, ns, Dp, c1, M1, ns, 0, X2 + (size_t)j_lo * Dp, Dp, d1 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
+    if (!rc) rc = sga_gemm(0, 0, c1, Dp, ns, M1, ns, 0, X1 + (size_t)a_lo * Dp, Dp, d2 + (size_t)j_lo * Dp, Dp, nullptr, 1, stream);
+    if (!rc && c2 > 0) rc = sga_gemm(0, 0, c2, Dp, ns, M2, ns, 0, X2 + (size_t)a_lo * Dp, Dp, d1 + (size_t)mir * Dp, Dp, nullptr, 1, stream);
+    if (!rc && c2 > 0) rc = sga_gemm(1, 0, ns, Dp, c2, M2, ns, 0, X1 + (size_t)mir * Dp, Dp, d2 + (size_t)a_lo * Dp, Dp, nullptr, 1, stream);
     return rc;
+}
+
+extern "C" int sga_loss_stash_grad_sym(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
+                                       void* stream) {
+    return sga_loss_stash_grad_symx(M1, M2, Z, A, Dp, dZ, a_lo, a_hi, a_lo, A, a_hi, stream);
 }

@@ -425,19 +425,29 @@ KERNEL_EVENTS = None   # bench.py sets this to {} to time the dominant kernel wi
 def _default_stash_bytes():
     """Bound on the transposed dL/dS stashes of the A x A backward (and the wide-table coefficient stashes): 16 GiB on a device with
     >= 128 GiB of memory (MI355X: 288 GB -- 18 anchor-row blocks instead of 69 at configs[2], +1.3 % step rate, 37.8 GiB peak),
-    4 GiB otherwise; env SGA_STASH_BYTES overrides."""
+    4 GiB otherwise; env SGA_STASH_BYTES overrides.  Resolved at FIRST USE from the process's current device (importing this module
+    neither initialises the HIP runtime nor looks at device 0 of a multi-GPU host)."""
     env = _os.environ.get('SGA_STASH_BYTES')
     if env:
         return int(env)
     try:
-        if torch.cuda.is_available() and torch.cuda.get_device_properties(0).total_memory >= (128 << 30):
+        if torch.cuda.is_available() and torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory >= (128 << 30):
             return 16 << 30
     except Exception:
         pass
     return 4 << 30
 
 
-STASH_BYTES = _default_stash_bytes()
+STASH_BYTES = None          # None: _default_stash_bytes() at first use; tests / callers may assign a number
+_stash_default = []
+
+
+def _stash_bytes():
+    if STASH_BYTES is not None:
+        return int(STASH_BYTES)
+    if not _stash_default:
+        _stash_default.append(_default_stash_bytes())
+    return _stash_default[0]
 
 
 def _anchor_chunks(a_lo, a_hi, A, n_tables):
@@ -448,7 +458,7 @@ def _anchor_chunks(a_lo, a_hi, A, n_tables):
     ns = a_hi - a_lo
     if ns <= 0 or A <= 0:
         return []
-    rows = max(32, (STASH_BYTES // (4 * A * max(1, n_tables))) // 32 * 32)
+    rows = max(32, (_stash_bytes() // (4 * A * max(1, n_tables))) // 32 * 32)
     return [(c, min(c + rows, a_hi)) for c in range(a_lo, a_hi, rows)]
 
 
@@ -456,14 +466,38 @@ def _sym_chunks(A, n_tables):
     """Blocks of the SYMMETRIC anchors x anchors walk (csrc/contrastive.hip, anchor_multi_bwd16_kernel<.., SYM>): block [lo, hi) meets
     the columns >= lo and keeps two stashes, [A - lo, hi - lo] and [A - hi, hi - lo] floats per table, bounded together by STASH_BYTES --
     so blocks get taller as the walk moves right.  32-row boundaries except the end."""
-    out, lo = [], 0
-    q = STASH_BYTES // (4 * max(1, n_tables))
-    while lo < A:
-        rows = max(32, (q // (2 * (A - lo))) // 32 * 32)
-        hi = min(lo + rows, A)
-        out.append((lo, hi))
+    return [(lo, hi) for lo, hi, _, _, _ in _sym_jobs([0, A], 0, n_tables)]
+
+
+def _sym_jobs(cuts, rank, n_tables):
+    """The symmetric walk of ONE RANK of an anchor-sharded job (new design): every UNORDERED pair of anchors is visited once
+    over all ranks, and every rank visits the same number of pairs.  cuts = [0, c_1, ..., A]: rank r owns the anchor rows
+    [c_r, c_r+1) (multiples of 32).  With R ranks, rank r evaluates its own diagonal square and the rectangles (its rows) x (the rows of
+    the next K ranks, cyclically), K = (R - 1) / 2 for odd R; for even R the ranks of the lower half take K = R / 2 and the upper half
+    R / 2 - 1 (a pair of blocks R / 2 apart is visited by its lower rank only).  Returns launches (lo, hi, j_lo, j_hi, mir) for
+    sga_loss_anchor_multi_bwd_symx / sga_loss_stash_grad_symx: rows [lo, hi) x columns [j_lo, j_hi), mirrored elements from column mir on;
+    the two stashes of a launch, (j_hi - j_lo) + (j_hi - mir) rows of hi - lo floats per table, stay within STASH_BYTES (blocks get
+    taller as the columns left to meet get fewer).  One rank, cuts = [0, A]: the single-GPU walk."""
+    R = len(cuts) - 1
+    A = cuts[-1]
+    lo_r, hi_r = cuts[rank], cuts[rank + 1]
+    if hi_r <= lo_r:
+        return []
+    K = (R - 1) // 2 if R % 2 else (R // 2 if rank < R // 2 else R // 2 - 1)
+    right_end = cuts[min(rank + K, R - 1) + 1]                     # contiguous columns right of the own square
+    wrap_end = cuts[(rank + K) % R + 1] if rank + K >= R else 0   # columns [0, wrap_end) of the ranks the cyclic order wraps to
+    q = _stash_bytes() // (4 * max(1, n_tables))
+    jobs, lo = [], lo_r
+    while lo < hi_r:
+        # columns this block meets: [lo, right_end) (own square ordered up to hi, mirrored from hi on) + [0, wrap_end) (all mirrored)
+        per_row = 2 * (right_end - lo) + 2 * wrap_end
+        rows = max(32, (q // max(1, per_row)) // 32 * 32)
+        hi = min(lo + rows, hi_r)
+        jobs.append((lo, hi, lo, right_end, hi))
+        if wrap_end > 0:
+            jobs.append((lo, hi, 0, wrap_end, 0))
         lo = hi
-    return out
+    return jobs
 
 
 # What sga_loss_multi_grad launches (bench.py's roofline line): two owner sweeps x M tables x (S with K = 100 + gradient
@@ -599,7 +633,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
             if zhs[k] is not None:
                 # opt-in fp16-input MFMA (configs[4]): S and both gradient GEMMs on v_mfma_f32_32x32x16_f16 (csrc/wide16.hip)
                 need = int(L.sga_loss_neg_grad_f16_bytes(A, s.J1, s.J2))
-                have = max(min(need, STASH_BYTES), int(L.sga_loss_neg_grad_f16_bytes(min(A, 128), s.J1, s.J2)))
+                have = max(min(need, _stash_bytes()), int(L.sga_loss_neg_grad_f16_bytes(min(A, 128), s.J1, s.J2)))
                 stash = torch.empty((have,), device=dev, dtype=torch.uint8)
                 ev16 = None
                 if KERNEL_EVENTS is not None:
@@ -614,7 +648,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
             elif dp > 128 and WIDE_STASH:
                 # wide rows: S is the expensive part -> coefficient stash + GEMMs, S computed once (csrc/contrastive.hip, sweep_coef_kernel)
                 need = int(L.sga_loss_neg_grad_wide_floats(A, s.J1, s.J2))
-                have = max(min(need, STASH_BYTES // 4), 2 * (s.J1 + s.J2) * min(A, 32))
+                have = max(min(need, _stash_bytes() // 4), 2 * (s.J1 + s.J2) * min(A, 32))
                 stash = torch.empty((have,), device=dev, dtype=torch.float32)
                 _lib.check(L.sga_loss_neg_grad_wide(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), _p(stash), have, st),
                            'sga_loss_neg_grad_wide')
@@ -1121,7 +1155,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         beta = _req(beta.contiguous(), 'beta')
         dev = tables[0].device
         s = index_sets
-        a_lo, a_hi = (0, s.A) if shard is None else (int(shard[0]), int(shard[1]))
+        a_lo, a_hi = (0, s.A) if shard is None else (int(shard[0]), int(shard[1]))     # shard = (a_lo, a_hi[, cuts, rank]): see _sym_jobs
         T = tables[0].shape[0]
         st = _stream()
         dp = 104
@@ -1200,30 +1234,35 @@ class FusedContrastiveFn(torch.autograd.Function):
             dz_all = torch.zeros((M, s.R, dp), device=dev, dtype=torch.float32)
             zz = torch.zeros((n_terms + nt * 8 + M,), device=dev, dtype=torch.float64)      # terms | gs | gamma: one fill
             out_acc, gs_aa, gam_aa = zz[:n_terms], zz[n_terms:n_terms + nt * 8].view(nt, 8), zz[n_terms + nt * 8:]
-            sym = AA_SYMMETRIC and M <= 3 and a_lo == 0 and a_hi == s.A
-            chunks = _sym_chunks(s.A, M) if sym else _anchor_chunks(a_lo, a_hi, s.A, M)
-            if sym and len(chunks) < 2:             # one block = one diagonal square: nothing to mirror, the ordered kernel (unmasked interior) does it
+            # symmetric walk: one GPU, or every rank of an anchor-sharded job when the caller passed all ranks' cuts (on 32-row boundaries)
+            cuts, crank = (shard[2], shard[3]) if (shard is not None and len(shard) >= 4) else (([0, s.A], 0) if (a_lo == 0 and a_hi == s.A) else (None, 0))
+            sym = AA_SYMMETRIC and M <= 3 and cuts is not None and all(c % 32 == 0 for c in cuts[:-1]) and cuts[-1] == s.A \
+                and cuts[crank] == a_lo and cuts[crank + 1] == a_hi
+            jobs = _sym_jobs(list(cuts), crank, M) if sym else []
+            chunks = jobs if sym else _anchor_chunks(a_lo, a_hi, s.A, M)
+            if sym and len(cuts) == 2 and len(jobs) < 2:             # one block = one diagonal square: nothing to mirror, the ordered kernel (unmasked interior) does it
                 sym, chunks = False, _anchor_chunks(a_lo, a_hi, s.A, M)
             if chunks:
                 gsc = torch.empty((slots + 1, nt, 8), device=dev, dtype=torch.float64)
                 gam2 = torch.empty((slots, M), device=dev, dtype=torch.float64)
             if chunks and sym:
-                # every unordered anchor pair once: a block also evaluates the mirrored elements right of it (second stash)
-                fl = max((2 * s.A - lo - hi) * (hi - lo) for lo, hi in chunks)
+                # every unordered anchor pair once over all ranks: a launch also evaluates the mirrored elements from column `mir` on (second stash)
+                fl = max(((jh - jl) + max(0, jh - mir)) * (hi - lo) for lo, hi, jl, jh, mir in chunks)
                 buf = [torch.empty((fl,), device=dev, dtype=torch.float32) for _ in range(M)]
-                for lo, hi in chunks:
-                    n1 = (s.A - lo) * (hi - lo)
+                for lo, hi, jl, jh, mir in chunks:
+                    n1 = (jh - jl) * (hi - lo)
                     m1 = [b[:n1] for b in buf]
                     m2 = [b[n1:] for b in buf]
-                    _lib.check(L.sga_loss_anchor_multi_bwd_sym(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(coef),
-                                                               _ptr_array(m1), _ptr_array(m2) if hi < s.A else (_ct.c_void_p * M)(), _p(gsc), _p(gam2),
-                                                               lo, hi, _p(out), st), 'sga_loss_anchor_multi_bwd_sym')
+                    has2 = mir < jh
+                    _lib.check(L.sga_loss_anchor_multi_bwd_symx(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(coef),
+                                                                _ptr_array(m1), _ptr_array(m2) if has2 else (_ct.c_void_p * M)(), _p(gsc), _p(gam2),
+                                                                lo, hi, jl, jh, mir, _p(out), st), 'sga_loss_anchor_multi_bwd_symx')
                     out_acc += out[:n_terms]
                     gs_aa += gsc[0]
                     gam_aa += gam2[0]
                     for k in range(M):
-                        _lib.check(L.sga_loss_stash_grad_sym(_p(m1[k]), _p(m2[k]) if hi < s.A else None, _p(zs[k]), s.A, dp, _p(dz_all[k]),
-                                                             lo, hi, st), 'sga_loss_stash_grad_sym')
+                        _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]) if has2 else None, _p(zs[k]), s.A, dp, _p(dz_all[k]),
+                                                              lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx')
                 del buf, m1, m2
             elif chunks:
                 cmax = max(hi - lo for lo, hi in chunks)

@@ -120,7 +120,10 @@ class AlignerSteps:
         else:
             gathered = sdist.gather_tables(output_dict, rows, reduce_grad=False)
         if sharded:
-            gdd['_sga_shard'] = (sum(anchors[:rank]), sum(anchors[:rank + 1]))
+            # (a_lo, a_hi) of this rank + every rank's cut and the rank: with all cuts on 32-row boundaries the anchors x anchors pairs are
+            # walked symmetrically ACROSS ranks (ops._sym_jobs: every unordered pair once, the same number on every rank)
+            cuts = [sum(anchors[:r]) for r in range(world + 1)]
+            gdd['_sga_shard'] = (cuts[rank], cuts[rank + 1], cuts, rank)
             def _reduce(t):                                                   # fp64 partial sums / loss terms / dL/d(sums)
                 sdist._log('all_reduce', t, t)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)

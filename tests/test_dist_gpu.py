@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mods, n_pairs, cuts, out):
+def _worker(rank, world, port, mods, n_pairs, cuts, out, nobj=14, ragged=True):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -37,13 +37,16 @@ def _worker(rank, world, port, mods, n_pairs, cuts, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         dev = torch.device('cuda', 0)
-        full = to_device(make_batch(n_pairs, 14, 48, seed=21, ragged=True), dev)
+        full = to_device(make_batch(n_pairs, nobj, 48, seed=21, ragged=ragged), dev)
         lo, hi = cuts[rank], cuts[rank + 1]
         mine = sdist.shard_data_dict(full, lo, hi)
+        from sgaligner_amd import ops as ops_mod
+        orig_jobs, ops_mod._sym_calls = ops_mod._sym_jobs, []
+        ops_mod._sym_jobs = lambda c, r, nt: (ops_mod._sym_calls.append((len(c) - 1, r)), orig_jobs(c, r, nt))[1]
         steps = AlignerSteps(mods, device=dev, seed=42)
         _, loss = steps.forward_backward(mine)
         torch.cuda.synchronize()
-        res = {'loss': float(loss['loss'].item())}
+        res = {'loss': float(loss['loss'].item()), 'sym_jobs': list(getattr(ops_mod, '_sym_calls', []))}
         for n, p in steps.model.named_parameters():
             if p.grad is not None:
                 res['g:' + n] = p.grad.detach().cpu()
@@ -56,10 +59,10 @@ def _worker(rank, world, port, mods, n_pairs, cuts, out):
         dist.destroy_process_group()
 
 
-def _single(mods, n_pairs):
+def _single(mods, n_pairs, nobj=14, ragged=True):
     from sgaligner_amd.synthetic import make_batch, to_device
     from sgaligner_amd.trainer import AlignerSteps
-    full = to_device(make_batch(n_pairs, 14, 48, seed=21, ragged=True), 'cuda')
+    full = to_device(make_batch(n_pairs, nobj, 48, seed=21, ragged=ragged), 'cuda')
     ref = AlignerSteps(mods, device='cuda', seed=42)
     _, loss = ref.forward_backward(full)
     torch.cuda.synchronize()
@@ -90,6 +93,26 @@ def test_two_ranks_equal_single_process(mods, n_pairs, cuts):
             for tag, layer in (('ial', ref.multi_loss_layer_ial), ('icl', ref.multi_loss_layer_icl)):
                 a = next(layer.parameters()).grad.cpu()
                 assert (r['lv:' + tag] - a).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), (rank, tag)
+
+
+def test_two_ranks_walk_the_anchor_pairs_symmetrically():
+    """Both ranks' anchor cuts on 32-row boundaries (32 anchors per pair): the one-pass anchors x anchors walk is SYMMETRIC across the ranks
+    (ops._sym_jobs with R = 2: rank 0 its square + the rectangle against rank 1's rows, rank 1 its square) -- loss and every parameter
+    gradient still equal the single process."""
+    mods, n_pairs, cuts, world = ['point', 'gat', 'rel'], 8, [0, 4, 8], 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), mods, n_pairs, cuts, out, 107, False), nprocs=world, join=True)
+    ref, loss = _single(mods, n_pairs, 107, False)
+    for rank in range(world):
+        r = out[rank]
+        assert (2, rank) in [tuple(x) for x in r['sym_jobs']], r['sym_jobs']          # the cross-rank symmetric plan ran on this rank
+        assert abs(r['loss'] - loss['loss'].item()) <= 1e-5 * max(1.0, abs(loss['loss'].item())), (rank, r['loss'], loss['loss'].item())
+        for n, p in ref.model.named_parameters():
+            if p.grad is None:
+                continue
+            sc = p.grad.abs().max().item()
+            assert (r['g:' + n] - p.grad.cpu()).abs().max().item() <= 1e-4 * max(1.0, sc), (rank, n)
 
 
 def _overlap_worker(rank, world, port, out):

@@ -50,3 +50,38 @@ def test_symmetric_walk_blocks_cover_the_anchors_within_the_stash_bound():
             assert heights == sorted(heights)
     finally:
         ops.STASH_BYTES = keep
+
+
+def test_symmetric_walk_over_ranks_visits_every_ordered_pair_once():
+    """ops._sym_jobs: over all ranks of an anchor-sharded job every ORDERED anchor pair (i, j) is produced exactly once -- directly (columns
+    left of `mir`: the block's own square), or as the direct / mirrored element of a tile right of it -- the ranks visit (nearly) the same
+    number of pairs, and every launch's two stashes stay inside STASH_BYTES."""
+    import numpy as np
+    from sgaligner_amd import ops
+    keep = ops.STASH_BYTES
+    try:
+        for R, per_rank, stash in ((1, 40, 1 << 16), (2, 12, 1 << 15), (3, 8, 1 << 14), (4, 6, 1 << 30), (5, 4, 1 << 13), (8, 3, 1 << 14), (8, 19, 1 << 17)):
+            ops.STASH_BYTES = stash
+            nb = R * per_rank                              # anchors in units of 32 rows
+            cuts = [32 * per_rank * r for r in range(R + 1)]
+            cover = np.zeros((nb, nb), dtype=np.int32)
+            work = []
+            for rank in range(R):
+                w = 0
+                for lo, hi, jl, jh, mir in ops._sym_jobs(cuts, rank, 3):
+                    assert lo % 32 == 0 and hi % 32 == 0 and jl % 32 == 0 and jh % 32 == 0 and mir % 32 == 0
+                    assert cuts[rank] <= lo < hi <= cuts[rank + 1]
+                    assert 4 * 3 * ((jh - jl) + max(0, jh - mir)) * (hi - lo) <= stash or hi - lo == 32
+                    bl, bh, cl, ch, bm = lo // 32, hi // 32, jl // 32, jh // 32, mir // 32
+                    for j in range(cl, ch):
+                        cover[bl:bh, j] += 1                       # (i, j) direct
+                        if j >= bm:
+                            cover[j, bl:bh] += 1                   # (j, i) mirrored
+                        else:
+                            assert bl <= j < bh                    # ordered columns only inside the block's own square
+                        w += (bh - bl)
+                work.append(w)
+            assert (cover == 1).all(), (R, per_rank, np.argwhere(cover != 1)[:5])
+            assert max(work) <= 1.35 * min(work) + 2 * per_rank * per_rank, (R, work)
+    finally:
+        ops.STASH_BYTES = keep

@@ -203,3 +203,68 @@ def test_symmetric_entry_refuses_blocks_off_the_32_row_grid():
     rc = L.sga_loss_anchor_multi_bwd_sym(_ptr_array(z), 2, _p(f), 64, _p(d), 0.5, 0.1, 1.0, _p(f), _ptr_array([f, f]), _ptr_array([f, f]),
                                          _p(d), _p(d), 8, 40, _p(d), _stream())
     assert rc != 0 and b'32-row' in L.sga_last_error()
+
+
+@pytest.mark.parametrize('R,M,stash', [(2, 3, None), (3, 3, 1 << 19), (4, 2, 1 << 19), (5, 3, 1 << 18), (8, 3, None)])
+def test_symmetric_walk_sharded_over_ranks_equals_unsharded(R, M, stash):
+    """The symmetric anchors x anchors walk on EVERY rank of an anchor-sharded job (ops._sym_jobs: own square + the rectangles against the
+    next ranks' rows, cyclically; csrc sga_loss_anchor_multi_bwd_symx / sga_loss_stash_grad_symx), simulated on one GPU with a deterministic
+    replay of the three all-reduces: every rank ends with the global term values, and the ranks' shares of dL/dE and dL/d(fusion weight)
+    sum to the unsharded one-pass result.  32 anchors per pair, so every pair cut is on a 32-row boundary; a small stash bound forces
+    several row blocks and the wrapped column ranges."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    pairs = 24
+    dd = make_batch(pairs, 107, 1, seed=5)
+    assert len(dd['e1i']) == 32 * pairs
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(R * 10 + M)
+    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(M)]
+    w0 = (torch.randn(M, 1, device='cuda', generator=g) * 0.5)
+    lv1, lv2 = 0.3 * torch.randn(M, device='cuda', generator=g), 0.3 * torch.randn(M, device='cuda', generator=g)
+    hint = ops.LossHeadFn.coef_hint(lv1, lv2, 32 * pairs, 0.1, 0.5, 0.1)
+    keep, calls = ops.STASH_BYTES, []
+    orig = ops._sym_jobs
+    ops._sym_jobs = lambda cuts, rank, nt: (calls.append((len(cuts) - 1, rank)), orig(cuts, rank, nt))[1]
+    if stash is not None:
+        ops.STASH_BYTES = stash
+    try:
+        def run(shard, reduce):
+            tabs = [b.clone().requires_grad_(True) for b in base]
+            w = w0.clone().requires_grad_(True)
+            sums, s = ops.fused_contrastive_terms(tabs, w, dict(dd), shard=shard, reduce=reduce, coef_hint=hint)
+            (sums * hint).sum().backward()
+            torch.cuda.synchronize()
+            return sums.detach(), [t.grad for t in tabs], w.grad
+        ref_sums, ref_g, ref_w = run(None, None)
+        per = [pairs // R + (1 if r < pairs % R else 0) for r in range(R)]
+        cuts = [32 * sum(per[:r]) for r in range(R + 1)]
+        totals, results = [], None
+        for rnd in range(4):
+            partial, results = [None] * R, []
+            for rank in range(R):
+                state = {'n': 0}
+
+                def reduce(t, rank=rank, state=state):
+                    n = state['n']
+                    state['n'] += 1
+                    if n < len(totals):
+                        t.copy_(totals[n])
+                    elif n == len(totals):
+                        partial[rank] = t.clone()
+                results.append(run((cuts[rank], cuts[rank + 1], cuts, rank), reduce))
+            if rnd < 3:
+                assert all(p is not None for p in partial), rnd
+                totals.append(sum(partial))
+        assert any(c == (R, r) for c in calls for r in range(R)), calls            # the sharded symmetric plan really ran
+        for sums_r, _, _ in results:
+            assert torch.allclose(sums_r, ref_sums, rtol=2e-5, atol=1e-6)
+        for m in range(M):
+            tot = sum(res[1][m] for res in results)
+            sc = ref_g[m].abs().max().item()
+            assert (tot - ref_g[m]).abs().max().item() < 2e-5 * sc, (m, (tot - ref_g[m]).abs().max().item(), sc)
+        totw = sum(res[2] for res in results)
+        assert (totw - ref_w).abs().max().item() < 2e-4 * max(1e-3, ref_w.abs().max().item())
+    finally:
+        ops.STASH_BYTES = keep
+        ops._sym_jobs = orig
