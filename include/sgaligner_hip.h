@@ -88,13 +88,18 @@ int sga_fusion_bwd(const float* const* embs, int M, const float* weight, const f
  * duplicate edges count with their multiplicity (as PyG's scatter does) up to 255 copies of one (source, target) pair -- the
  * multiplicity matrix is 8-bit and saturates there; when that happens bit 0 of *status (device int32, caller-zeroed, may be NULL)
  * is set, and the Python wrapper turns it into an exception (deferred by at most one step, like the edge range check).
- * A graph with more than 256 nodes is rejected with SGA_ERR_ARG. */
+ * A graph with more than 256 nodes is rejected with SGA_ERR_ARG.
+ * complete [G] uint8 (may be NULL): 1 = graph g lists every ordered pair i != j exactly once and nothing else -- what
+ * preprocessing/scan3r/preprocess.py:176-182 writes for every scene (annotated relations + the supplemented 'none' pairs); its
+ * multiplicities are all 1 and the kernels do not read its edges at all (16 B per edge: 2.13 GB at configs[2], eight times per step).
+ * sga_gat_complete_flags fills the array from the edge lists themselves (order-independent: an N x N bitmap per graph), once per batch. */
+int sga_gat_complete_flags(const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G, uint8_t* flags, void* stream);
 int sga_gat_attn_fwd(const float* H, const float* att_src, const float* att_dst, const float* bias,
                      const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G, int nmax,
-                     float* out, int32_t* status, void* stream);
+                     float* out, int32_t* status, const uint8_t* complete, void* stream);
 int sga_gat_attn_bwd(const float* H, const float* dO, const float* att_src, const float* att_dst, const int64_t* edges,
                      const int32_t* node_off, const int32_t* edge_off, int G, int nmax, float* dH, float* d_att_src,
-                     float* d_att_dst, void* stream);
+                     float* d_att_dst, const uint8_t* complete, void* stream);
 int sga_elu_fwd(const float* x, float* y, size_t n, void* stream);                    /* F.elu, gat.py:45-46 */
 int sga_elu_bwd(const float* x, const float* gy, float* gx, size_t n, void* stream);
 

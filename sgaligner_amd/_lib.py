@@ -37,8 +37,9 @@ SIGNATURES = {
     'sga_loss_head_bwd': (I, [P, P, I, P, P, I, c_double, c_double, c_double, c_double, P, P, P, P]),
     'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, P]),
     'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, P]),
-    'sga_gat_attn_fwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P]),
-    'sga_gat_attn_bwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
+    'sga_gat_complete_flags': (I, [P, P, P, I, P, P]),
+    'sga_gat_attn_fwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
+    'sga_gat_attn_bwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P, P]),
     'sga_elu_fwd': (I, [P, P, c_size_t, P]),
     'sga_elu_bwd': (I, [P, P, P, c_size_t, P]),
     'sga_simrank_workspace_bytes': (c_size_t, [I]),

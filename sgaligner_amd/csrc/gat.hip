@@ -75,7 +75,8 @@ struct Rows { const float* p; int stride; };
 template <int NJ, bool LDSF>
 __device__ __forceinline__ Rows gat_prologue(const GatLds& l, const float* __restrict__ H, const float* __restrict__ att_s,
                                              const float* __restrict__ att_d, const long long* __restrict__ edges,
-                                             int n0, int N, int e0, int E, int hd, int npad, int* status = nullptr) {
+                                             int n0, int N, int e0, int E, int hd, int npad, int* status = nullptr,
+                                             bool complete = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Hg = H + (size_t)n0 * (GAT_H * GAT_C) + hd * GAT_C;
     if (LDSF)
@@ -83,7 +84,17 @@ __device__ __forceinline__ Rows gat_prologue(const GatLds& l, const float* __res
             const int j = e >> 7, c = e & 127;
             l.hs[j * GAT_HS + c] = Hg[(size_t)j * (GAT_H * GAT_C) + c];
         }
-    for (int e = tid; e < N * (npad >> 2); e += GAT_THREADS) l.cnt[e] = 0u;
+    // COMPLETE graph (every ordered pair i != j listed exactly once: what preprocessing/scan3r/preprocess.py:176-182 writes for every
+    // scene, verified per batch by gat_complete_kernel): with the self loops GATConv adds, every multiplicity is 1 -- the 16-byte-per-edge
+    // list (2.13 GB at configs[2], read by 8 workgroup sets per step) is never touched.
+    if (complete) {
+        for (int e = tid; e < N * (npad >> 2); e += GAT_THREADS) {
+            const int j4 = (e % (npad >> 2)) * 4;
+            l.cnt[e] = (j4 + 0 < N ? 1u : 0u) | (j4 + 1 < N ? 0x100u : 0u) | (j4 + 2 < N ? 0x10000u : 0u) | (j4 + 3 < N ? 0x1000000u : 0u);
+        }
+    } else {
+        for (int e = tid; e < N * (npad >> 2); e += GAT_THREADS) l.cnt[e] = 0u;
+    }
     __syncthreads();
     const Rows hr = LDSF ? Rows{l.hs, GAT_HS} : Rows{Hg, GAT_H * GAT_C};
     const float s0 = att_s[hd * GAT_C + lane], s1 = att_s[hd * GAT_C + 64 + lane];
@@ -94,7 +105,7 @@ __device__ __forceinline__ Rows gat_prologue(const GatLds& l, const float* __res
         if (lane == 0) { l.as[j] = vs; l.ad[j] = vd; }
     }
     // edge list -> multiplicities (self loops dropped, out-of-range ids ignored, counts saturate at 255: reported through `status`)
-    for (int e = tid; e < E; e += GAT_THREADS) {
+    for (int e = tid; e < (complete ? 0 : E); e += GAT_THREADS) {
         const long long sj = edges[(size_t)(e0 + e) * 2 + 0], di = edges[(size_t)(e0 + e) * 2 + 1];
         if (sj != di && sj >= 0 && sj < N && di >= 0 && di < N) {
             const int idx = (int)di * npad + (int)sj;
@@ -145,7 +156,8 @@ template <int NJ, bool LDSF>
 __global__ __launch_bounds__(GAT_THREADS) void gat_attn_fwd_kernel(
     const float* __restrict__ H, const float* __restrict__ att_s, const float* __restrict__ att_d,
     const float* __restrict__ bias, const long long* __restrict__ edges, const int* __restrict__ node_off,
-    const int* __restrict__ edge_off, float* __restrict__ out, int nmax, int* __restrict__ status) {
+    const int* __restrict__ edge_off, float* __restrict__ out, int nmax, int* __restrict__ status,
+    const unsigned char* __restrict__ complete) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const GatLds l = carve<NJ, LDSF>(lds_raw, nmax, false);
     const int g = blockIdx.x, hd = blockIdx.y;
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_fwd_kernel(
     const int npad = (nmax + 3) & ~3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (N <= 0) return;
-    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad, status);
+    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad, status, complete && complete[g]);
     const float b0 = bias[hd * GAT_C + lane], b1 = bias[hd * GAT_C + 64 + lane];
     // GAT_TB targets per wave at a time: every h[j] row read feeds GAT_TB aggregates (the loop is LDS / L2 bound)
     for (int ib = wave * GAT_TB; ib < N; ib += (GAT_THREADS / 64) * GAT_TB) {
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_bwd_kernel(
     const float* __restrict__ H, const float* __restrict__ dO, const float* __restrict__ att_s,
     const float* __restrict__ att_d, const long long* __restrict__ edges, const int* __restrict__ node_off,
     const int* __restrict__ edge_off, float* __restrict__ dH, float* __restrict__ d_att_s,
-    float* __restrict__ d_att_d, int nmax) {
+    float* __restrict__ d_att_d, int nmax, const unsigned char* __restrict__ complete) {
     constexpr int MAXN = NJ * 64;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const GatLds l = carve<NJ, LDSF>(lds_raw, nmax, true);
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(GAT_THREADS) void gat_attn_bwd_kernel(
             l.dos[j * GAT_HS + c] = Dg[(size_t)j * (GAT_H * GAT_C) + c];
         }
     for (int j = tid; j < MAXN; j += GAT_THREADS) l.das[j] = 0.f;
-    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad);
+    const Rows hr = gat_prologue<NJ, LDSF>(l, H, att_s, att_d, edges, n0, N, e0, E, hd, npad, nullptr, complete && complete[g]);
     const Rows dr = LDSF ? Rows{l.dos, GAT_HS} : Rows{Dg, GAT_H * GAT_C};
 
     // ---- phase 1: per target row i -> d a_d[i], partial d a_s[j], row max / denom
@@ -342,7 +354,7 @@ int check_common(int G, int nmax, const char* who) {
 
 extern "C" int sga_gat_attn_fwd(const float* H, const float* att_src, const float* att_dst, const float* bias,
                                 const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G,
-                                int nmax, float* out, int32_t* status, void* stream) {
+                                int nmax, float* out, int32_t* status, const uint8_t* complete, void* stream) {
     int rc = check_common(G, nmax, "sga_gat_attn_fwd");
     if (rc) return rc;
     if (G == 0 || nmax == 0) return SGA_OK;
@@ -352,13 +364,13 @@ extern "C" int sga_gat_attn_fwd(const float* H, const float* att_src, const floa
         auto k = gat_attn_fwd_kernel<2, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, static_cast<hipStream_t>(stream), H, att_src,
-                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax, status);
+                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax, status, complete);
     } else {                                              // 129..256 nodes: features from global memory
         const size_t lds = gat_lds_bytes(nmax, false, 4, false);
         auto k = gat_attn_fwd_kernel<4, false>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, static_cast<hipStream_t>(stream), H, att_src,
-                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax, status);
+                           att_dst, bias, reinterpret_cast<const long long*>(edges), node_off, edge_off, out, nmax, status, complete);
     }
     SGA_CHECK_LAUNCH("sga_gat_attn_fwd");
     return SGA_OK;
@@ -366,7 +378,7 @@ extern "C" int sga_gat_attn_fwd(const float* H, const float* att_src, const floa
 
 extern "C" int sga_gat_attn_bwd(const float* H, const float* dO, const float* att_src, const float* att_dst,
                                 const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G,
-                                int nmax, float* dH, float* d_att_src, float* d_att_dst, void* stream) {
+                                int nmax, float* dH, float* d_att_src, float* d_att_dst, const uint8_t* complete, void* stream) {
     int rc = check_common(G, nmax, "sga_gat_attn_bwd");
     if (rc) return rc;
     SGA_CHECK_ARG(((G == 0 || nmax == 0) || (H && dO && node_off && edge_off && dH)) && att_src && att_dst && d_att_src && d_att_dst, "sga_gat_attn_bwd: null pointer");
@@ -383,15 +395,46 @@ extern "C" int sga_gat_attn_bwd(const float* H, const float* dO, const float* at
         auto k = gat_attn_bwd_kernel<2, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, s, H, dO, att_src, att_dst,
-                           reinterpret_cast<const long long*>(edges), node_off, edge_off, dH, d_att_src, d_att_dst, nmax);
+                           reinterpret_cast<const long long*>(edges), node_off, edge_off, dH, d_att_src, d_att_dst, nmax, complete);
     } else {
         const size_t lds = gat_lds_bytes(nmax, true, 4, false);
         auto k = gat_attn_bwd_kernel<4, false>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(G, GAT_H), dim3(GAT_THREADS), lds, s, H, dO, att_src, att_dst,
-                           reinterpret_cast<const long long*>(edges), node_off, edge_off, dH, d_att_src, d_att_dst, nmax);
+                           reinterpret_cast<const long long*>(edges), node_off, edge_off, dH, d_att_src, d_att_dst, nmax, complete);
     }
     SGA_CHECK_LAUNCH("sga_gat_attn_bwd");
+    return SGA_OK;
+}
+
+// flags[g] = 1 iff graph g lists every ordered pair i != j exactly once and nothing else (E = N (N - 1), every edge in range, no self
+// loop, no duplicate -- an N x N bitmap in LDS catches duplicates whatever the ORDER of the list: preprocess.py writes the annotated
+// relations first and the supplemented 'none' pairs after them).
+__global__ __launch_bounds__(GAT_THREADS) void gat_complete_kernel(const long long* __restrict__ edges, const int* __restrict__ node_off,
+                                                                   const int* __restrict__ edge_off, unsigned char* __restrict__ flags) {
+    __shared__ unsigned bits[GAT_MAXN_BIG * GAT_MAXN_BIG / 32];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int N = node_off[g + 1] - node_off[g], e0 = edge_off[g], E = edge_off[g + 1] - e0;
+    if (N <= 0 || N > GAT_MAXN_BIG || (long long)E != (long long)N * (N - 1)) { if (tid == 0) flags[g] = 0; return; }   // uniform
+    for (int w = tid; w < (N * N + 31) / 32; w += GAT_THREADS) bits[w] = 0u;
+    __syncthreads();
+    int bad = 0;
+    for (int e = tid; e < E; e += GAT_THREADS) {
+        const long long sj = edges[(size_t)(e0 + e) * 2 + 0], di = edges[(size_t)(e0 + e) * 2 + 1];
+        if (sj == di || sj < 0 || sj >= N || di < 0 || di >= N) { bad = 1; continue; }
+        const int idx = (int)di * N + (int)sj;
+        if (atomicOr(&bits[idx >> 5], 1u << (idx & 31)) & (1u << (idx & 31))) bad = 1;
+    }
+    bad = __syncthreads_or(bad);
+    if (tid == 0) flags[g] = bad ? 0 : 1;
+}
+
+extern "C" int sga_gat_complete_flags(const int64_t* edges, const int32_t* node_off, const int32_t* edge_off, int G, uint8_t* flags, void* stream) {
+    if (G == 0) return SGA_OK;
+    SGA_CHECK_ARG(node_off && edge_off && flags && G > 0, "sga_gat_complete_flags: bad argument");
+    hipLaunchKernelGGL(gat_complete_kernel, dim3(G), dim3(GAT_THREADS), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(edges), node_off, edge_off, flags);
+    SGA_CHECK_LAUNCH("sga_gat_complete_flags");
     return SGA_OK;
 }
 

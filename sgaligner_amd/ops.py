@@ -897,6 +897,17 @@ class GraphBatch:
         self.edges = edges if keep_edges else None
         offs = _h2d(_np.concatenate([[0], _np.cumsum(nc), [0], _np.cumsum(ec)]).astype(_np.int32), dev)     # one upload
         self.node_off, self.edge_off = offs[:self.G + 1], offs[self.G + 1:]
+        self.complete = self._complete_flags() if keep_edges else None
+
+    def _complete_flags(self):
+        """uint8 [G]: 1 = the graph is COMPLETE (every ordered pair once, nothing else); the attention kernels then never read its edge list.
+        Recomputed from the edge tensor's CONTENT on every call (one streaming pass; a caller may refill the same device buffer)."""
+        if not GAT_COMPLETE_FAST_PATH or self.G == 0 or self.edges is None or not self.edges.is_cuda:
+            return None
+        flags = torch.empty((self.G,), device=self.edges.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().sga_gat_complete_flags(_p(self.edges), _p(self.node_off), _p(self.edge_off), self.G, _p(flags), _stream()),
+                   'sga_gat_complete_flags')
+        return flags
 
     _cache = _SmallCache(2)
 
@@ -914,9 +925,11 @@ class GraphBatch:
         gb = GraphBatch.__new__(GraphBatch)
         gb.__dict__.update(proto.__dict__)
         gb.edges = edges if edges.dtype == torch.int64 and edges.is_contiguous() else edges.to(torch.int64).contiguous()
+        gb.complete = gb._complete_flags()
         return gb
 
 
+GAT_COMPLETE_FAST_PATH = _os.environ.get('SGA_GAT_COMPLETE', '1') != '0'     # complete graphs (what the reference's preprocessing writes) skip the edge list in the attention kernels
 _GAT_STATUS = {}          # device -> int32[1], bit 0 set by the GAT kernel when an edge multiplicity saturates (never reset by the kernel)
 
 
@@ -938,7 +951,7 @@ def _attn_fwd(h, att_s, att_d, bias, gb, check_status=False):
         if st is None:
             st = _GAT_STATUS[h.device] = torch.zeros((1,), device=h.device, dtype=torch.int32)
     _lib.check(_lib.lib().sga_gat_attn_fwd(_p(h), _p(att_s), _p(att_d), _p(bias), _p(gb.edges), _p(gb.node_off),
-                                           _p(gb.edge_off), gb.G, gb.nmax, _p(out), _p(st), _stream()), 'sga_gat_attn_fwd')
+                                           _p(gb.edge_off), gb.G, gb.nmax, _p(out), _p(st), _p(getattr(gb, 'complete', None)), _stream()), 'sga_gat_attn_fwd')
     if st is not None:            # read back without blocking; raises at the next batch's poll (or DEFERRED_CHECKS.flush())
         DEFERRED_CHECKS.submit_fn(st, _gat_status_verdict(h.device))
     return out
@@ -949,7 +962,7 @@ def _attn_bwd(h, d_o, att_s, att_d, gb):
     dboth = torch.empty((2,) + tuple(att_s.shape), device=att_s.device, dtype=att_s.dtype)      # adjacent: zeroed in one launch
     das, dad = dboth[0], dboth[1]
     _lib.check(_lib.lib().sga_gat_attn_bwd(_p(h), _p(d_o), _p(att_s), _p(att_d), _p(gb.edges), _p(gb.node_off),
-                                           _p(gb.edge_off), gb.G, gb.nmax, _p(dh), _p(das), _p(dad), _stream()),
+                                           _p(gb.edge_off), gb.G, gb.nmax, _p(dh), _p(das), _p(dad), _p(getattr(gb, 'complete', None)), _stream()),
                'sga_gat_attn_bwd')
     return dh, das, dad
 

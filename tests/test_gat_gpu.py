@@ -116,3 +116,54 @@ def test_gat_multiplicity_overflow_fails_loudly():
             with pytest.raises(RuntimeError, match='more than 255 times'):
                 ops.DEFERRED_CHECKS.flush()
     ops.DEFERRED_CHECKS.flush()                                    # the status word was reset: nothing pending raises again
+
+
+def test_complete_graph_fast_path_flags_and_equality():
+    """Complete graphs (every ordered pair once, in ANY order: preprocess.py:158-182 writes the annotated relations first, the supplemented 'none'
+    pairs after them) are recognised on the device per batch and never read their edge list; anything else -- a missing pair, a duplicate, an
+    explicit self loop, an out-of-range id -- takes the edge-list path.  Output and every gradient equal the edge-list kernels' exactly."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    rng = np.random.default_rng(0)
+    sizes = [40, 128, 1, 2, 57, 200, 33]
+    edges, ecnt = [], []
+    for gi, n in enumerate(sizes):
+        ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing='ij')
+        m = ii != jj
+        e = np.stack([ii[m], jj[m]], 1)
+        e = e[rng.permutation(e.shape[0])]                              # arbitrary order
+        if gi == 4:
+            e[3] = e[5]                                                  # one pair missing, another listed twice: same edge count
+        if gi == 6:
+            e = np.concatenate([e, [[2, 2]]])                            # an explicit self loop on top
+        edges.append(e)
+        ecnt.append(e.shape[0])
+    edges, ecnt = np.concatenate(edges).astype(np.int64), np.asarray(ecnt)
+    T = sum(sizes)
+    et = torch.from_numpy(edges).cuda()
+    gb = ops.GraphBatch(np.asarray(sizes), ecnt, et)
+    assert gb.complete is not None and gb.complete.cpu().tolist() == [1, 1, 1, 1, 0, 1, 0]
+    torch.manual_seed(1)
+    x = torch.randn(T, 3, dtype=torch.float64).cuda()
+    p = O.init_params(['point', 'gat'], dtype=torch.float64, seed=3)
+    layers = O._gat_layers(p)
+    cot = torch.randn(T, 256).cuda()
+
+    def run(fast):
+        keep = ops.GAT_COMPLETE_FAST_PATH
+        ops.GAT_COMPLETE_FAST_PATH = fast
+        try:
+            g2 = ops.GraphBatch(np.asarray(sizes), ecnt, et)
+            assert (g2.complete is None) == (not fast)
+            dl = [[l[k].detach().float().cuda().requires_grad_(True) for k in ('lin_w', 'att_src', 'att_dst', 'bias')] for l in layers]
+            out = ops.multi_gat(g2, x, dl[0], dl[1])
+            (out * cot).sum().backward()
+            torch.cuda.synchronize()
+            return out.detach(), [t.grad for li in dl for t in li]
+        finally:
+            ops.GAT_COMPLETE_FAST_PATH = keep
+    of, gf = run(True)
+    og, gg = run(False)
+    assert torch.equal(of, og)
+    for a, b in zip(gf, gg):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
