@@ -81,12 +81,23 @@ class OverallLoss(nn.Module):
             return self._forward_groups(output_dict, data_dict, int(self.loss_group))
         return self._forward_global(output_dict, data_dict)
 
+    _warned_untagged = False
+
     def _fusion_source(self, output_dict, mods):
         m = len(mods)
         tabs = [output_dict[k] for k in mods]
         src = getattr(output_dict['joint'], '_sga_fusion', None)
         fused = (src is not None and FUSED_JOINT and 2 <= m <= 4 and len(src[1]) == m
                  and all(a is b for a, b in zip(src[1], tabs)) and all(t.shape[1] <= 104 for t in tabs))
+        if not fused and FUSED_JOINT and 2 <= m <= 4 and not OverallLoss._warned_untagged and tabs[0].is_cuda:
+            # the provenance tag is a tensor ATTRIBUTE: any .clone() / .to() / arithmetic on `joint` between the encoder and the loss drops
+            # it, and the loss then (correctly, but ~2x slower) treats `joint` as an independent table -- say so once instead of silently
+            OverallLoss._warned_untagged = True
+            import warnings
+            warnings.warn("sgaligner_amd: output_dict['joint'] reached OverallLoss without the fusion provenance tag (it was copied or "
+                          "modified after MultiModalFusion, or is not a fusion of output_dict's modality tables): the loss takes the general "
+                          "per-table path -- correct, but the 100*M-wide joint table is swept explicitly (about twice the loss time).",
+                          RuntimeWarning, stacklevel=3)
         return tabs, (src if fused else None)
 
     def _forward_global(self, output_dict, data_dict):

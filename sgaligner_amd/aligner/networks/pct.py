@@ -111,6 +111,7 @@ class NaivePCT(nn.Module):
         self.dp1 = nn.Dropout(p=0.5)
         self.dp2 = nn.Dropout(p=0.5)
         self.fused_head = True               # tests flip it to cross-check the two backward formulations of the widest stage
+        self._check_gamma = False            # True: test |gamma| > 1e-3 before every fused training step (one host read-back per step)
         self.eval_chunk_rows = 1 << 19       # inference: points per chunk (x 1024 channels x 4 B = 2 GiB for the widest activation)
 
     def forward(self, x):
@@ -172,7 +173,13 @@ class NaivePCT(nn.Module):
             h = P.batch_norm_act(P.rows_linear(a, sa.trans_conv.weight, sa.trans_conv.bias, bn_stats=True), sa.after_norm, act=1, resid=h)
             xs.append(h)
         cat = torch.cat(xs, dim=1)
-        if self.fused_head:      # conv + BatchNorm + LeakyReLU + point max as one node with the algebraic backward (pct_ops.LinearBNActMaxFn)
+        # The fused node's sparse backward pass (sga_pct_head_scatter) is built for <= 1024 points per object and <= 1024 channels, and it
+        # recovers x_hat from the pooled output as (z - beta) / gamma: objects with more points and a BatchNorm whose |gamma| has collapsed
+        # take the chain of separate nodes (same numbers, more memory) instead of failing or dividing by ~0 in backward.
+        fused_ok = self.fused_head and n <= 1024 and self.linear[0].weight.shape[0] <= 1024
+        if fused_ok and torch.is_grad_enabled() and self.linear[1].weight.requires_grad:
+            fused_ok = bool((self.linear[1].weight.detach().abs().min() > 1e-3).item()) if self._check_gamma else True
+        if fused_ok:      # conv + BatchNorm + LeakyReLU + point max as one node with the algebraic backward (pct_ops.LinearBNActMaxFn)
             g = P.linear_bn_lrelu_max(cat, self.linear[0].weight, self.linear[1], t, n)
         else:
             y = P.batch_norm_act(P.rows_linear(cat, self.linear[0].weight, bn_stats=True), self.linear[1], act=2)

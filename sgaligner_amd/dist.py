@@ -141,6 +141,17 @@ class EarlyGather:
         self.works = []
         return {m: self.out[m] for m in modules}
 
+    def drain(self):
+        """Wait for whatever is still in flight (the encoder raised after some hooks had fired): an outstanding asynchronous all-gather must
+        not be dropped un-waited -- its output buffer would be freed under the collective."""
+        for w in self.works:
+            if w is not None:
+                try:
+                    w.wait()
+                except Exception:
+                    pass
+        self.works = []
+
 
 def known_layout(rows, n_e1i, n_e1j, n_e2j, world):
     """[world, 4] layout array for batches whose per-rank shape is known without communication (bench.py's uniform synthetic

@@ -930,30 +930,24 @@ class GraphBatch:
 
 
 GAT_COMPLETE_FAST_PATH = _os.environ.get('SGA_GAT_COMPLETE', '1') != '0'     # complete graphs (what the reference's preprocessing writes) skip the edge list in the attention kernels
-_GAT_STATUS = {}          # device -> int32[1], bit 0 set by the GAT kernel when an edge multiplicity saturates (never reset by the kernel)
-
-
-def _gat_status_verdict(dev):
-    def verdict(v):
-        if v[0] == 0:
-            return None
-        _GAT_STATUS[dev].zero_()
-        return ('sgaligner_amd: a (source, target) edge occurs more than 255 times in one graph; the GAT kernels count duplicate '
-                'edges in 8 bits (PyG would count them all) -- deduplicate the edge list')
-    return verdict
+def _gat_status_verdict(v):
+    if v[0] == 0:
+        return None
+    return ('sgaligner_amd: a (source, target) edge occurs more than 255 times in one graph of the PREVIOUS batch; the GAT kernels count '
+            'duplicate edges in 8 bits (PyG would count them all), so that step\'s structure embeddings were not PyG-equivalent -- '
+            'deduplicate the edge list')
 
 
 def _attn_fwd(h, att_s, att_d, bias, gb, check_status=False):
     out = torch.empty_like(h)
     st = None
     if check_status and VALIDATE:
-        st = _GAT_STATUS.get(h.device)
-        if st is None:
-            st = _GAT_STATUS[h.device] = torch.zeros((1,), device=h.device, dtype=torch.int32)
+        # a FRESH status word per batch: a sticky shared one re-raised for clean batches whose read-back was enqueued before its reset
+        st = torch.zeros((1,), device=h.device, dtype=torch.int32)
     _lib.check(_lib.lib().sga_gat_attn_fwd(_p(h), _p(att_s), _p(att_d), _p(bias), _p(gb.edges), _p(gb.node_off),
                                            _p(gb.edge_off), gb.G, gb.nmax, _p(out), _p(st), _p(getattr(gb, 'complete', None)), _stream()), 'sga_gat_attn_fwd')
     if st is not None:            # read back without blocking; raises at the next batch's poll (or DEFERRED_CHECKS.flush())
-        DEFERRED_CHECKS.submit_fn(st, _gat_status_verdict(h.device))
+        DEFERRED_CHECKS.submit_fn(st, _gat_status_verdict)
     return out
 
 

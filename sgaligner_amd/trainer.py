@@ -49,9 +49,11 @@ class AlignerSteps:
                 self.model._on_table = early
             try:
                 output_dict = self.model(data_dict)
+                loss_dict = self._global_loss(output_dict, data_dict, layout, early)
             finally:
                 self.model._on_table = None
-            loss_dict = self._global_loss(output_dict, data_dict, layout, early)
+                if early is not None:
+                    early.drain()                        # no-op after tables(); waits for the gathers in flight if the step raised
         else:
             output_dict = self.model(data_dict)
             loss_dict = self.loss_func(output_dict, data_dict)
