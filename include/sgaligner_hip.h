@@ -27,8 +27,9 @@ int sga_device_cus(void);
  * headline number), 1 = split-bf16 x3 (each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product into an fp32
  * accumulator; relative error ~1e-5), 2 = fp16 inputs for loss tables wider than 128 columns (configs[4]), 3 = split-fp16
  * (each fp32 operand as fp16 hi + lo of 4096 x, three fp16 MFMAs per product into an fp32 accumulator: the loss sweeps carry
- * fp32's own rounding error -- the mode ops.set_mfma_mode('f16x2') selects; everything else stays exact fp32).  Returns the
- * previous mode (-1 on a bad argument).  SGA_MFMA_MODE=bf16x3 | f16 | f16x2 in the environment selects the mode at first use. */
+ * fp32's own rounding error -- the mode ops.set_mfma_mode('f16x2') selects; everything else stays exact fp32), 4 = mode 3 + the PointNet
+ * forward in the same split ('f16x2p': values to 6e-7, but a point max that ties to fp32 rounding may pick the other point).  Returns the
+ * previous mode (-1 on a bad argument).  SGA_MFMA_MODE=bf16x3 | f16 | f16x2 | f16x2p in the environment selects the mode at first use. */
 int sga_set_mfma_mode(int mode);
 int sga_get_mfma_mode(void);
 

@@ -26,13 +26,13 @@ static int g_mfma_mode = -1;
 int sga_mfma_mode() {
     if (g_mfma_mode < 0) {
         const char* e = getenv("SGA_MFMA_MODE");
-        g_mfma_mode = (e && strcmp(e, "bf16x3") == 0) ? 1 : (e && strcmp(e, "f16") == 0) ? 2 : (e && strcmp(e, "f16x2") == 0) ? 3 : 0;
+        g_mfma_mode = (e && strcmp(e, "bf16x3") == 0) ? 1 : (e && strcmp(e, "f16") == 0) ? 2 : (e && strcmp(e, "f16x2") == 0) ? 3 : (e && strcmp(e, "f16x2p") == 0) ? 4 : 0;
     }
     return g_mfma_mode;
 }
 extern "C" int sga_set_mfma_mode(int mode) {
     const int old = sga_mfma_mode();
-    if (mode < 0 || mode > 3) { sga_set_error("sga_set_mfma_mode: mode %d (0 = fp32, 1 = bf16x3, 2 = f16 for wide tables, 3 = f16x2)", mode); return -1; }
+    if (mode < 0 || mode > 4) { sga_set_error("sga_set_mfma_mode: mode %d (0 = fp32, 1 = bf16x3, 2 = f16 for wide tables, 3 = f16x2, 4 = f16x2p)", mode); return -1; }
     g_mfma_mode = mode;
     return old;
 }

@@ -21,6 +21,7 @@
 //     and feeds 4 MFMAs.  That fills the CU's 160 KiB LDS: one persistent 8-wave workgroup per CU.
 //   * HBM traffic is the points once (12 B/point) + T*C3*(4+4) B out: the kernel is MFMA-bound
 //     (82 304 FLOP/point at C3 = 256).
+#include <stdlib.h>
 #include "sga_common.h"
 
 namespace {
@@ -229,8 +230,38 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// The same kernel in the split of the 'f16x2' loss sweeps (sga_set_mfma_mode(4), 'f16x2p'): operands as fp16 hi + lo -- 22 significand bits,
+// the products' fp32 accumulation rounding dominates -- of SCALED values, so that lo stays a normal fp16 number wherever it matters:
+// weights x 64 (|w| < 1023), activations x 8 (|h| < 8190; they are post-ReLU sums of at most 128 weighted inputs of metre-sized coordinates;
+// an activation beyond that overflows to inf and the object's output is NaN -- loud, never a wrong number).  Absolute representation error
+// <= 2^-25 / scale (4.7e-10 on a weight, 3.7e-9 on an activation) below the normal range.  The accumulators carry 512 x the pre-activation:
+// the bias enters pre-multiplied, the ReLU output is rescaled by an exact power of two on its way into the next split.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float PN_SW = 64.f, PN_SA = 8.f;
+__device__ __forceinline__ void split8h(const float (&v)[8], float scale, u32x4& hi, u32x4& lo, float& amax) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = v[2 * p] * scale, b = v[2 * p + 1] * scale;
+        amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));                 // fp16 range guard (free input modifiers): see PN_F16_MAX
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
+        unsigned l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp), "v"(a));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp), "v"(b));
+        hi[p] = hp;
+        lo[p] = l;
+    }
+}
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+constexpr float PN_F16_MAX = 6.0e4f;          // a scaled operand at or beyond this (fp16 max 65 504) poisons the object's output with NaN
+template <bool F16> __device__ __forceinline__ void split8x(const float (&v)[8], float scale, u32x4& hi, u32x4& lo, float& amax) {
+    if (F16) split8h(v, scale, hi, lo, amax); else split8(v, hi, lo);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma_x(u32x4 a, u32x4 b, f32x16 c) { return F16 ? mfma_f16(a, b, c) : mfma_bf16(a, b, c); }
 
-template <int C3, bool WITH_ARGMAX>
+template <int C3, bool WITH_ARGMAX, bool F16 = false>
 __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ y,
@@ -243,14 +274,15 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
     u32x4* w3lo = w3hi + NB3 * 8 * 64;
 
     const int tid = threadIdx.x;
-    // ---- split the weights into bf16 hi / lo planes in operand order (once per persistent workgroup)
+    float wmax = 0.f;
+    // ---- split the weights into bf16 (fp16) hi / lo planes in operand order (once per persistent workgroup)
     for (int d = tid; d < 16 * 64; d += PN_THREADS) {       // W2 as layer-2 A operand: row = out channel, k-slots = in channels 16 ks + 8 h + j
         const int ln = d & 63, ks = (d >> 6) & 3, cb = d >> 8;
         const float* src = w2 + (cb * 32 + (ln & 31)) * 64 + 16 * ks + 8 * (ln >> 5);
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[j];
-        split8(v, w2hi[d], w2lo[d]);
+        split8x<F16>(v, PN_SW, w2hi[d], w2lo[d], wmax);
     }
     for (int d = tid; d < NB3 * 8 * 64; d += PN_THREADS) {  // W3 as layer-3 B operand: column = out channel, k-slots follow layer 2's C layout
         const int ln = d & 63, ks3 = (d >> 6) & 7, cb = d >> 9;
@@ -259,9 +291,16 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[(j & 3) + 8 * (j >> 2)];
-        split8(v, w3hi[d], w3lo[d]);
+        split8x<F16>(v, PN_SW, w3hi[d], w3lo[d], wmax);
     }
     __syncthreads();
+    // fp16 range guard of the weights: every wave scans them itself (41 k floats from L2, once per persistent workgroup) -- the kernel's
+    // dynamic LDS is the CU's whole 160 KiB, so there is no room for a cross-wave flag
+    bool wbad = false;
+    if (F16) {
+        for (int d = tid & 63; d < 128 * 64 + C3 * 128; d += 64) wmax = fmaxf(wmax, fabsf(d < 128 * 64 ? w2[d] : w3[d - 128 * 64]) * PN_SW);
+        wbad = __any(!(wmax < PN_F16_MAX));
+    }
 
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
@@ -273,6 +312,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
         int bidx[NB3];
 #pragma unroll
         for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
+        float amax = 0.f;
 
         for (int tile = 0; tile < n_tiles; ++tile) {
             const int p0 = tile * 32;
@@ -299,7 +339,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
                     v[4 * half + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
                     v[4 * half + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
                 }
-                split8(v, h1hi[ks], h1lo[ks]);
+                split8x<F16>(v, PN_SA, h1hi[ks], h1lo[ks], amax);
             }
 
             // ---- layer 2: H2^T = W2 H1^T (A = W2 planes from LDS, B = H1 split), accumulators start at the bias
@@ -310,21 +350,22 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * g + 4 * h_o);
-                    acc[g * 4 + 0] = bb[0]; acc[g * 4 + 1] = bb[1]; acc[g * 4 + 2] = bb[2]; acc[g * 4 + 3] = bb[3];
+                    const float bs = F16 ? PN_SW * PN_SA : 1.f;
+                    acc[g * 4 + 0] = bb[0] * bs; acc[g * 4 + 1] = bb[1] * bs; acc[g * 4 + 2] = bb[2] * bs; acc[g * 4 + 3] = bb[3] * bs;
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const u32x4 wh = w2hi[(cb * 4 + ks) * 64 + lane_o], wl = w2lo[(cb * 4 + ks) * 64 + lane_o];
-                    acc = mfma_bf16(wh, h1hi[ks], acc);
-                    acc = mfma_bf16(wh, h1lo[ks], acc);
-                    acc = mfma_bf16(wl, h1hi[ks], acc);
+                    acc = mfma_x<F16>(wh, h1hi[ks], acc);
+                    acc = mfma_x<F16>(wh, h1lo[ks], acc);
+                    acc = mfma_x<F16>(wl, h1hi[ks], acc);
                 }
 #pragma unroll
                 for (int half8 = 0; half8 < 2; ++half8) {
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[half8 * 8 + j], 0.f);
-                    split8(v, h2hi[cb * 2 + half8], h2lo[cb * 2 + half8]);
+                    split8x<F16>(v, 1.f / PN_SW, h2hi[cb * 2 + half8], h2lo[cb * 2 + half8], amax);      // F16: 512 h2 -> 8 h2
                 }
             }
 
@@ -337,9 +378,9 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
 #pragma unroll
                 for (int ks3 = 0; ks3 < 8; ++ks3) {
                     const u32x4 wh = w3hi[(cb * 8 + ks3) * 64 + lane_o], wl = w3lo[(cb * 8 + ks3) * 64 + lane_o];
-                    acc = mfma_bf16(h2hi[ks3], wh, acc);
-                    acc = mfma_bf16(h2hi[ks3], wl, acc);
-                    acc = mfma_bf16(h2lo[ks3], wh, acc);
+                    acc = mfma_x<F16>(h2hi[ks3], wh, acc);
+                    acc = mfma_x<F16>(h2hi[ks3], wl, acc);
+                    acc = mfma_x<F16>(h2lo[ks3], wh, acc);
                 }
                 if (WITH_ARGMAX) {
 #pragma unroll
@@ -357,6 +398,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
             }
         }
 
+        const bool obad = F16 && (wbad || __any(!(amax < PN_F16_MAX)));       // an operand left the fp16 range: NaN, never a wrong number
 #pragma unroll
         for (int cb = 0; cb < NB3; ++cb) {
             const float ov = __shfl_xor(best[cb], 32, 64);
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
             }
             if (h == 0) {
                 const int c = cb * 32 + pt;
-                y[(size_t)t * C3 + c] = fmaxf(v + b3[c], 0.f);
+                y[(size_t)t * C3 + c] = obad ? __builtin_nanf("") : fmaxf((F16 ? v * (1.f / (PN_SW * PN_SA)) : v) + b3[c], 0.f);
                 if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
             }
         }
@@ -389,7 +431,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     const int ncu = sga_num_cus();
     if (grid > ncu) grid = ncu;
     // few objects: one object per workgroup, its tiles dealt to the 8 waves (exact fp32 kernel only; needs the partials workspace)
-    if (sga_mfma_mode() == 0 && workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32) {
+    if ((sga_mfma_mode() == 0 || sga_mfma_mode() == 2 || sga_mfma_mode() == 3) && workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32) {
         float2* part = static_cast<float2*>(workspace);
         const int g2 = T < ncu ? T : ncu;
         if (argmax) {
@@ -405,7 +447,17 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         SGA_CHECK_LAUNCH("sga_pointnet_fwd");
         return SGA_OK;
     }
-    if (sga_mfma_mode() == 1) {
+    if (sga_mfma_mode() == 4) {            // 'f16x2p': the split-fp16 sweeps AND this forward in the same split
+        if (argmax) {
+            auto k = pointnet_fwd_bf16x3_kernel<C3, true, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+        } else {
+            auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+        }
+    } else if (sga_mfma_mode() == 1) {
         if (argmax) {
             auto k = pointnet_fwd_bf16x3_kernel<C3, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -39,7 +39,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-MFMA_MODES = {'f32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3}
+MFMA_MODES = {'f32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'f16x2p': 4}
 _MFMA_NAMES = {v: k for k, v in MFMA_MODES.items()}
 
 
@@ -50,7 +50,9 @@ def set_mfma_mode(mode: str) -> str:
     128 columns and the similarity ranking take fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; 100-d tables
     and everything else stay exact fp32); 'f16x2' (opt-in, fp32-FAITHFUL: the fused 100-d loss sweeps with each fp32 operand as fp16
     hi + lo of 4096 x -- 22 significand bits, three fp16 MFMAs per product, fp32 accumulate: the similarities carry fp32's own rounding
-    error, csrc/sweeph.hip; everything else exact fp32).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial
+    error, csrc/sweeph.hip; everything else exact fp32); 'f16x2p' ('f16x2' + the PointNet forward in the same split, csrc/pointnet.hip:
+    outputs to 6e-7 of the fp32 kernel's, but where two points of an object tie for a channel's maximum to fp32 rounding the OTHER point may
+    win and take that channel's gradient -- a few 1e-5 of the (object, channel) pairs; not fp32-faithful for the conv weights' gradients).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial
     mode."""
     if mode not in MFMA_MODES:
         raise ValueError(f"sgaligner_amd: mfma mode must be one of {sorted(MFMA_MODES)} (got {mode!r})")
@@ -515,7 +517,8 @@ SWEEP_SUMS_INFO = {                             # sga_loss_multi_sums: one owner
 }
 BF16X3_COVERAGE = 'PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate'
 F16X2_COVERAGE = ('anchors x negatives loss sweeps (forward sums + gradient) on fp16 MFMA with operands split into fp16 hi + lo of 4096 x '
-                  '(22 significand bits), fp32 accumulate; everything else exact fp32')
+                  '(22 significand bits), rows centred, fp32 accumulate; everything else exact fp32')
+F16X2P_COVERAGE = F16X2_COVERAGE.replace('; everything else exact fp32', '') + ' + the PointNet forward in the same split (not faithful for near-tied point maxima); everything else exact fp32'
 # 'f16x2' gradient sweep: the coefficients dL/dS as fp16 hi + lo (True) or rounded to fp16 (False: an independent, unbiased 2^-12 rounding
 # per (anchor, negative) pair; 7 of 31 MFMAs and 1.5 VALU per pair less).  None (default) = hi + lo unless EVERY gradient row sums at least
 # F16X2_COEF_LO_MIN_TERMS pairs: there the rounding noise of a row, 2^-12 / sqrt(terms) <= 6.7e-7 of its largest term, is below the
@@ -1184,7 +1187,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         dmax = max(e.shape[1] for e in tables)          # real width: the K step that only covers zero padding is skipped
         # opt-in split-bf16 x3 sweeps: the tables additionally as blocked bf16 hi/lo planes (sweepb.hip)
         zbs = []
-        split16 = M in (2, 3) and dmax <= 100 and get_mfma_mode() == 'f16x2'      # columns 100, 101 of the planes carry the centring's bookkeeping
+        split16 = M in (2, 3) and dmax <= 100 and get_mfma_mode() in ('f16x2', 'f16x2p')      # columns 100, 101 of the planes carry the centring's bookkeeping
         if split16:
             nb = L.sga_loss_split16_bytes(s.A, s.J1, s.J2)
             for z in zs:

@@ -1,5 +1,5 @@
-"""Micro-benchmark of the PointNet forward kernel (HIP events on the launch stream): exact fp32 and the opt-in split-bf16 x3 mode,
-with the latter's error against the former."""
+"""Micro-benchmark of the PointNet forward kernel (HIP events on the launch stream): exact fp32 and the opt-in split modes
+(bf16x3; f16x2 = fp16 hi + lo, fp32-faithful), with their error against the former."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ w = [torch.randn(64, 3, device='cuda') * 0.2, torch.randn(64, device='cuda') * 0
      torch.randn(128, 64, device='cuda') * 0.1, torch.randn(128, device='cuda') * 0.1,
      torch.randn(256, 128, device='cuda') * 0.1, torch.randn(256, device='cuda') * 0.1]
 ref = None
-for mode in (0, 1):
+for mode in (0, 1, 4):
     _lib.lib().sga_set_mfma_mode(mode)
     for am in (False, True):
         for _ in range(2):
@@ -30,11 +30,11 @@ for mode in (0, 1):
         extra = ''
         if mode == 0 and am:
             ref = (y.clone(), a.clone())
-        if mode == 1 and am:
+        if mode in (1, 4) and am:
             err = (y - ref[0]).abs().max().item()
             rel = err / ref[0].abs().max().item()
             same = (a == ref[1]).float().mean().item()
             extra = f'  max|y - y_fp32| {err:.3e} (rel {rel:.2e}), same arg-max point {same * 100:.3f} %'
-        print(f'pointnet_fwd mode={"bf16x3" if mode else "fp32"} argmax={am} T={T} P={P}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s algorithmic '
+        print(f'pointnet_fwd mode={ {0: "fp32", 1: "bf16x3", 4: "f16x2p"}[mode]} argmax={am} T={T} P={P}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s algorithmic '
               f'({fl/ms/1e9/157.3*100:.1f}% of the fp32 MFMA peak){extra}')
 _lib.lib().sga_set_mfma_mode(0)
