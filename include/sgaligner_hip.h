@@ -197,11 +197,13 @@ int sga_loss_multi_grad_bf16x3(const void* const* Zb, int M, const float* beta, 
  * sga_loss_multi_sums_f16x2 / _grad_f16x2: same arguments and outputs as sga_loss_multi_sums / sga_loss_multi_grad with the M tables
  * given as Zb; every product is hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16 into fp32 (22 significand bits per operand).
  * coef_lo != 0: the coefficients enter the gradient GEMM as hi + lo as well; 0: rounded to fp16 (11 bits, independent per pair).
+ * s_lo != 0: the forward sums use the full three-product similarities; 0: hi.hi only on the 96 main columns (the K tail with the centring's
+ * bookkeeping columns stays complete) -- for sums of >= 2^24 terms, where the unbiased 1e-5 error per similarity averages out.
  * M in {2,3}. */
 size_t sga_loss_split16_bytes(int A, int J1, int J2);
 int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
 int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                              double* sums, int a_lo, int a_hi, void* stream);
+                              double* sums, int a_lo, int a_hi, int s_lo, void* stream);
 int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                               const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, int coef_lo, void* stream);
 

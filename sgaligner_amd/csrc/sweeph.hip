@@ -208,6 +208,11 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
     constexpr int KMAX = (SH_NCH + WAVES - 1) / WAVES;               // DMA chunk slots per table and wave
     constexpr int BUF = M * SH_BLOCK;
     constexpr bool PIPE = OH == 2;                                    // one wave per SIMD: operand prefetch pinned inside the MFMA stream
+    // Forward sums (GRAD = false) with CLO = false: the S product's lo terms are dropped for the 96 main columns (4 instead of 10 MFMAs per
+    // 16 x 16 tile; the K tail -- columns 96..103 and the centring's bookkeeping columns -- keeps all four products).  A sum of >= 2^24
+    // exponentials only needs every S to ~1e-5 with an UNBIASED error: the 11-bit rounding of the centred rows is random per element, the
+    // sum's relative error is that of one term (3e-5) over the root of the term count, and the second-order bias 50 dS^2 ~ 6e-10.
+    constexpr bool SLO = GRAD || CLO;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsh[];      // [2][M][SH_BLOCK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
@@ -390,8 +395,10 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
             auto ld_tl = [&](int ss) {
                 const unsigned char* ar = buf + (ss >> 1) * SH_BLOCK + (ss & 1) * 1024 + aoff;
                 at = *reinterpret_cast<const u32x4*>(ar + SH_TAIL);
+                if (SLO) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) al[q] = *reinterpret_cast<const u32x4*>(ar + SH_PLANE + q * 2048);
+                    for (int q = 0; q < 3; ++q) al[q] = *reinterpret_cast<const u32x4*>(ar + SH_PLANE + q * 2048);
+                }
             };
             auto ld_h = [&](int ss) {
                 const unsigned char* ar = buf + (ss >> 1) * SH_BLOCK + (ss & 1) * 1024 + aoff;
@@ -410,19 +417,23 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
                 f32x4 acc[OH];
 #pragma unroll
                 for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(at, otl[m][oh], f32x4{0.f, 0.f, 0.f, 0.f});
+                if (SLO) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                    for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(al[q], ohi[m][oh][q], acc[oh]);
+                        for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(al[q], ohi[m][oh][q], acc[oh]);
+                }
                 if (PIPE) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (ss + 1 < 2 * M) ld_tl(ss + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (SLO) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                    for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(ah[q], olo[m][oh][q], acc[oh]);
+                        for (int oh = 0; oh < OH; ++oh) acc[oh] = mfma_h(ah[q], olo[m][oh][q], acc[oh]);
+                }
 #pragma unroll
                 for (int q = 0; q < 3; ++q)                    // the large hi.hi terms last
 #pragma unroll
@@ -716,7 +727,7 @@ extern "C" int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, vo
 }
 
 extern "C" int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                                         double* sums, int a_lo, int a_hi, void* stream) {
+                                         double* sums, int a_lo, int a_hi, int s_lo, void* stream) {
     SGA_CHECK_ARG(Zb && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums_f16x2: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums_f16x2")) return rc0;
@@ -725,7 +736,8 @@ extern "C" int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const flo
     const int r = fill_h(a, Zb, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi, "sga_loss_multi_sums_f16x2");
     if (r > 0) return r;
     a.sums = sums;
-    if (M == 2) launch_h<2, false, true>(a, -r, s); else launch_h<3, false, true>(a, -r, s);
+    if (M == 2) { if (s_lo) launch_h<2, false, true>(a, -r, s); else launch_h<2, false, false>(a, -r, s); }
+    else { if (s_lo) launch_h<3, false, true>(a, -r, s); else launch_h<3, false, false>(a, -r, s); }
     fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums_f16x2");
     return SGA_OK;

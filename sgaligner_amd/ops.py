@@ -527,6 +527,18 @@ F16X2_COEF_LO = {'1': True, '0': False}.get(_os.environ.get('SGA_F16X2_COEF_LO',
 F16X2_COEF_LO_MIN_TERMS = 1 << 17
 
 
+# 'f16x2' forward sums: full three-product similarities (True) or hi.hi only on the 96 main columns (False: 4 instead of 10 MFMAs per tile).
+# None (default) = full unless the smallest of the four global sums has at least F16X2_SUMS_LO_MIN_TERMS terms.
+F16X2_SUMS_LO = {'1': True, '0': False}.get(_os.environ.get('SGA_F16X2_SUMS_LO', ''), None)
+F16X2_SUMS_LO_MIN_TERMS = 1 << 24
+
+
+def _f16x2_sums_lo(ns, J1, J2):
+    if F16X2_SUMS_LO is not None:
+        return bool(F16X2_SUMS_LO)
+    return ns * min(J1, J2) < F16X2_SUMS_LO_MIN_TERMS
+
+
 def _f16x2_coef_lo(ns, J1, J2):
     if F16X2_COEF_LO is not None:
         return bool(F16X2_COEF_LO)
@@ -1199,7 +1211,7 @@ class FusedContrastiveFn(torch.autograd.Function):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             _lib.check(L.sga_loss_multi_sums_f16x2(_ptr_array(zbs), M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums),
-                                                   a_lo, a_hi, st), 'sga_loss_multi_sums_f16x2')
+                                                   a_lo, a_hi, 1 if _f16x2_sums_lo(a_hi - a_lo, s.J1, s.J2) else 0, st), 'sga_loss_multi_sums_f16x2')
             if ev is not None:
                 ev[1].record()
                 KERNEL_EVENTS.setdefault('loss_multi_sums_f16x2', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))

@@ -253,3 +253,32 @@ def test_pointnet_forward_large_values_are_loud_not_wrong(f16x2p):
     assert ok[[0, 1, 2, 4, 5, 6, 7]].all() and torch.isfinite(y0).all()
     assert (y[ok] - y0[ok]).abs().max().item() < 1e-5 * y0[ok].abs().max().item()
     assert not ok[3] or (y[3] - y0[3]).abs().max().item() < 1e-5 * y0[3].abs().max().item()
+
+
+def test_forward_sums_hi_only_products(f16x2):
+    """The forward sums with the lo terms of the similarity dropped on the 96 main columns (what configs[2]-sized sums use: >= 2^24 terms each):
+    at 64 pairs x 64 objects (A x J = 1.2 M x 2.8 M terms per sum ... small, so the averaging is weakest here) every loss term stays within
+    3e-6 of the exact-fp32 path's, and a table of nearly identical rows -- where un-centred 11-bit rows would shift every similarity by the
+    same 1e-5 -- within 3e-6 as well."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(64, 64, 1, seed=3)
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(5)
+    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(3)]
+    base[2] = torch.randn(1, 100, device='cuda', generator=g) + 1e-2 * torch.randn(T, 100, device='cuda', generator=g)
+    w = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')
+    keep = ops.F16X2_SUMS_LO
+    try:
+        res = {}
+        for tag, mode, lo in (('f32', 'f32', None), ('full', 'f16x2', True), ('hi', 'f16x2', False)):
+            ops.set_mfma_mode(mode)
+            ops.F16X2_SUMS_LO = lo
+            with torch.no_grad():
+                res[tag] = ops.fused_contrastive_terms(base, w, dd)[0].double()
+        ops.set_mfma_mode('f16x2')
+        for tag in ('full', 'hi'):
+            rel = ((res[tag] - res['f32']).abs() / res['f32'].abs()).max().item()
+            assert rel < (1e-6 if tag == 'full' else 3e-6), (tag, rel)
+    finally:
+        ops.F16X2_SUMS_LO = keep
