@@ -1503,7 +1503,7 @@ __global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restri
 // column range (the diagonal square) run the ordinary epilogue.
 template <int M, bool TERMS = false, int RB = (M <= 3 ? 32 : 16), bool SYM = false>
 __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
-    static_assert(!SYM || (TERMS && M <= 3), "symmetric mode: one-pass build, M <= 3");
+    static_assert(!SYM || TERMS, "symmetric mode: one-pass build");
     constexpr int DP = 104, NT = M + 1, NSUB = RB / 16, TW = 4 / NSUB;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][RB][DP] own rows
     // The (M+1)*8 sum coefficients and the 3M+1 upstream coefficients are read from global memory at uniform addresses, per element
@@ -1600,15 +1600,17 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
 #pragma unroll
             for (int t = 0; t < 2; ++t) { o.pt[t] = gp[96 + 4 * t + g]; o.qt[t] = gq[96 + 4 * t + g]; }
         };
-        JOps jb[2];
+        constexpr bool JDB = true;        // (M = 4, symmetric: 54 VGPRs go to scratch with or without the second buffer -- cold values, 2 reloads per element)
+        JOps jb[JDB ? 2 : 1];
         jload(0, jb[0]);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            if (m + 1 < M) jload(m + 1, jb[(m + 1) & 1]);
+            if (JDB) { if (m + 1 < M) jload(m + 1, jb[JDB ? (m + 1) & 1 : 0]); }
+            else if (m > 0) jload(m, jb[0]);
             __builtin_amdgcn_sched_barrier(0);
             P[m] = f32x4{0.f, 0.f, 0.f, 0.f};
             Q[m] = P[m];
-            const JOps& o = jb[m & 1];
+            const JOps& o = jb[JDB ? m & 1 : 0];
             const float* bp = lds + lofs + ((m * 2 + 0) * RB + ih * 16 + l15) * DP;   // X1[i]
             const float* bq = lds + lofs + ((m * 2 + 1) * RB + ih * 16 + l15) * DP;   // X2[i]
 #pragma unroll
@@ -2277,7 +2279,7 @@ extern "C" int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, cons
                                               double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir, double* out_terms,
                                               void* stream) {
     SGA_CHECK_ARG(Z && beta && sums && coef && M1 && M2 && gs && gamma && out_terms && A >= 0, "sga_loss_anchor_multi_bwd_symx: bad argument");
-    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_anchor_multi_bwd_symx: M=%d (2 or 3; M = 4 runs sga_loss_anchor_multi_bwd)", M);
+    SGA_CHECK_ARG(M >= 2 && M <= 4, "sga_loss_anchor_multi_bwd_symx: M=%d (2, 3 or 4)", M);
     SGA_CHECK_ARG(a_lo % 32 == 0 && (a_hi % 32 == 0 || a_hi == A), "sga_loss_anchor_multi_bwd_symx: block [%d,%d) not on 32-row boundaries", a_lo, a_hi);
     SGA_CHECK_ARG(j_lo >= 0 && j_lo % 16 == 0 && j_hi <= A && j_lo <= j_hi && (j_hi % 16 == 0 || j_hi == A) && mir >= j_lo && (mir % 16 == 0 || mir >= j_hi),
                   "sga_loss_anchor_multi_bwd_symx: columns [%d,%d) / mirror start %d not on 16-column boundaries", j_lo, j_hi, mir);
@@ -2300,7 +2302,7 @@ extern "C" int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, cons
         SGA_CHECK_ARG(M1[m] && (M2[m] || mir >= j_hi), "sga_loss_anchor_multi_bwd_symx: null stash");
         a.M1[m] = M1[m]; a.M2[m] = M2[m];
     }
-    const int RB = 32, TW = 2;
+    const int RB = M <= 3 ? 32 : 16, TW = M <= 3 ? 2 : 4;
     const size_t lds = (size_t)(M * 2 * RB * 104 + (M + 1) * 8) * sizeof(float);
     const int nib = (a_hi - a_lo + RB - 1) / RB, ntile16 = (j_hi - j_lo + 15) / 16;
     int nsp = (6 * sga_num_cus() + nib - 1) / nib;
@@ -2311,7 +2313,9 @@ extern "C" int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, cons
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
     };
-    if (M == 2) go(anchor_multi_bwd16_kernel<2, true, 32, true>); else go(anchor_multi_bwd16_kernel<3, true, 32, true>);
+    if (M == 2) go(anchor_multi_bwd16_kernel<2, true, 32, true>);
+    else if (M == 3) go(anchor_multi_bwd16_kernel<3, true, 32, true>);
+    else go(anchor_multi_bwd16_kernel<4, true, 16, true>);
     fold_slots(out_terms, (M + 1) + 2 * M, s);
     fold_slots(gs, (M + 1) * 8, s);
     fold_slots(gamma, M, s);

@@ -416,9 +416,10 @@ class IndexSets:
 
 FUSED_ANCHOR_BWD = True
 FUSED_AA_ONEPASS = True      # training: A x A terms + gradients from one pass in forward() when the loss head announces dL/d(terms)
-# One-pass mode, unsharded anchors, M <= 3: walk the anchors x anchors pairs SYMMETRICALLY -- a block evaluates (i, j) and (j, i) from the
-# same two similarities, every unordered pair once (sga_loss_anchor_multi_bwd_sym: -34 % per ordered pair, tools/bench_aa.py).
+# One-pass mode: walk the anchors x anchors pairs SYMMETRICALLY -- a block evaluates (i, j) and (j, i) from the same two similarities, every
+# unordered pair once (sga_loss_anchor_multi_bwd_sym: -34 % per ordered pair, tools/bench_aa.py); across ranks by _sym_jobs.
 AA_SYMMETRIC = True
+AA_SYMMETRIC_MAX_M = int(_os.environ.get('SGA_AA_SYM_MAX_M', '4'))     # tools flip this to 3 to time M = 4 on the ordered walk
 ONEPASS_MIN_ANCHORS = 256    # below this the A x A work is negligible and the saved gradients' bookkeeping is not worth its launches
 WIDE_STASH = True         # tables wider than 128 columns: coefficient stash + GEMMs instead of the multi-pass gradient sweep (tests flip it)
 FUSED_ANCHOR_FWD = True   # tests flip this to cross-check the two anchors x anchors forward kernels
@@ -1258,7 +1259,7 @@ class FusedContrastiveFn(torch.autograd.Function):
             out_acc, gs_aa, gam_aa = zz[:n_terms], zz[n_terms:n_terms + nt * 8].view(nt, 8), zz[n_terms + nt * 8:]
             # symmetric walk: one GPU, or every rank of an anchor-sharded job when the caller passed all ranks' cuts (on 32-row boundaries)
             cuts, crank = (shard[2], shard[3]) if (shard is not None and len(shard) >= 4) else (([0, s.A], 0) if (a_lo == 0 and a_hi == s.A) else (None, 0))
-            sym = AA_SYMMETRIC and M <= 3 and cuts is not None and all(c % 32 == 0 for c in cuts[:-1]) and cuts[-1] == s.A \
+            sym = AA_SYMMETRIC and M <= AA_SYMMETRIC_MAX_M and cuts is not None and all(c % 32 == 0 for c in cuts[:-1]) and cuts[-1] == s.A \
                 and cuts[crank] == a_lo and cuts[crank + 1] == a_hi
             jobs = _sym_jobs(list(cuts), crank, M) if sym else []
             chunks = jobs if sym else _anchor_chunks(a_lo, a_hi, s.A, M)

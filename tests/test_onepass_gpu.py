@@ -118,7 +118,8 @@ def test_onepass_not_used_without_gradients():
     assert abs(float(l_train['loss']) - float(l_eval['loss'])) <= 1e-6 * abs(float(l_eval['loss']))
 
 
-@pytest.mark.parametrize('mods,stash_rows', [(('point', 'gat', 'rel'), None), (('point', 'rel'), 64), (('point', 'gat', 'rel'), 32)])
+@pytest.mark.parametrize('mods,stash_rows', [(('point', 'gat', 'rel'), None), (('point', 'rel'), 64), (('point', 'gat', 'rel'), 32),
+                                             (('point', 'gat', 'rel', 'attr'), None), (('point', 'gat', 'rel', 'attr'), 32)])
 def test_symmetric_walk_equals_ordered_walk(mods, stash_rows):
     """ops.AA_SYMMETRIC: every unordered anchor pair evaluated once (a block also produces the mirrored elements right of it) --
     same terms and gradients as the walk that visits both orders; several blocks of growing height with a small stash."""
@@ -143,7 +144,7 @@ def test_symmetric_walk_equals_ordered_walk(mods, stash_rows):
         assert (a - b).abs().max().item() <= 2e-5 * max(1e-12, b.abs().max().item()), ((a - b).abs().max().item(), b.abs().max().item())
 
 
-@pytest.mark.parametrize('A,rows,M', [(2100, 512, 3), (1000, 96, 2), (333, 160, 3)])
+@pytest.mark.parametrize('A,rows,M', [(2100, 512, 3), (1000, 96, 2), (333, 160, 3), (1500, 480, 4), (333, 96, 4)])
 def test_symmetric_kernel_walk_at_the_c_abi(A, rows, M):
     """sga_loss_anchor_multi_bwd_sym + sga_loss_stash_grad_sym over a whole walk == sga_loss_anchor_multi_bwd + sga_loss_stash_grad:
     terms, dL/d(sums), dL/dbeta and dZ; ragged last block, A not a multiple of 16, stashes poisoned with NaN beforehand."""
@@ -205,7 +206,7 @@ def test_symmetric_entry_refuses_blocks_off_the_32_row_grid():
     assert rc != 0 and b'32-row' in L.sga_last_error()
 
 
-@pytest.mark.parametrize('R,M,stash', [(2, 3, None), (3, 3, 1 << 19), (4, 2, 1 << 19), (5, 3, 1 << 18), (8, 3, None)])
+@pytest.mark.parametrize('R,M,stash', [(2, 3, None), (3, 3, 1 << 19), (4, 2, 1 << 19), (5, 3, 1 << 18), (8, 3, None), (3, 4, 1 << 19)])
 def test_symmetric_walk_sharded_over_ranks_equals_unsharded(R, M, stash):
     """The symmetric anchors x anchors walk on EVERY rank of an anchor-sharded job (ops._sym_jobs: own square + the rectangles against the
     next ranks' rows, cyclically; csrc sga_loss_anchor_multi_bwd_symx / sga_loss_stash_grad_symx), simulated on one GPU with a deterministic

@@ -44,7 +44,7 @@ el = float(NS) * A
 print(f'A x A kernel (M={M}, {NS} rows x {A} anchors): {np.median(tk):.3f} ms = {np.median(tk) * 1e6 / el:.4f} ns per (i, j) pair; stash GEMMs {np.median(tg):.3f} ms '
       f'({2.0 * 2 * M * el * 104 / np.median(tg) / 1e9:.1f} TFLOP/s); checksum {float(out[:nt + 2 * M].sum()):.6e} {float(m1[0].abs().sum()):.6e}')
 # symmetric block: rows [0, NS) x columns [0, A), both elements of every pair -> compare HALF its time with the ordinary block above
-if M <= 3 and NS % 32 == 0:
+if M <= 4 and NS % 32 == 0:
     m1s = [torch.empty(A * NS, device=dev) for _ in range(M)]
     m2s = [torch.empty((A - NS) * NS, device=dev) for _ in range(M)]
     ts, tgs = [], []
