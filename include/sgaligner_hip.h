@@ -46,6 +46,11 @@ int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const flo
  * (max, arg-max) pairs are folded by a second small kernel -- identical results, per-object latency / 8.  workspace may be NULL
  * (then this is sga_pointnet_fwd). */
 size_t sga_pointnet_fwd_ws_bytes(int T, int C3);
+/* MFMA mode 'f16x2' (3) with argmax != NULL: the forward runs in the fp16 hi + lo split and needs workspace >= 4 (T + 1) bytes; it leaves
+ * [count | object ids] (int32) there: the objects in which some channel's two largest layer-3 values were distinct and within
+ * eps * (|a| + |b| + max|z| / 8) -- they were re-run on the exact-fp32 kernel, their values and arg-maxes are that kernel's bits.  sga_pointnet_tie_eps sets eps (default 2^-17) and returns the
+ * previous value; a negative argument only reads.  pointnet.py:140-161 (the max-pool's arg-max routes the backward). */
+float sga_pointnet_tie_eps(float eps);
 int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
                         void* workspace, size_t ws_bytes, void* stream);

@@ -25,6 +25,7 @@ SIGNATURES = {
     'sga_get_mfma_mode': (I, []),
     'sga_pointnet_fwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
     'sga_pointnet_fwd_ws_bytes': (c_size_t, [I, I]),
+    'sga_pointnet_tie_eps': (F, [F]),
     'sga_set_group_valu': (I, [I]),
     'sga_loss_neg_grad_wide_floats': (c_size_t, [I, I, I]),
     'sga_loss_neg_grad_wide': (I, [P, I, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     const float* __restrict__ b3,  // [C3]
     float* __restrict__ y,         // [T, C3]
     int* __restrict__ argmax,      // [T, C3] or nullptr
-    int T, int P, float2* __restrict__ part) {             // part: SPLIT only, [T][PN_WAVES][C3] (value, index as float bits)
+    int T, int P, float2* __restrict__ part,               // part: SPLIT only, [T][PN_WAVES][C3] (value, index as float bits)
+    const int* __restrict__ only = nullptr) {              // !SPLIT: if given, only the only[0] objects listed in only[1..] run (the 'f16x2' near-tie re-run)
     constexpr int NB3 = C3 / 32;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w2s = lds;             // [4 cb][8 q][64 lane][4]        = 8192 floats
@@ -68,7 +69,9 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     const int h = lane >> 5, pt = lane & 31;
     const int n_tiles = (P + 31) >> 5;
 
-    for (int t = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * PN_WAVES + wave; t < T; t += SPLIT ? (int)gridDim.x : (int)gridDim.x * PN_WAVES) {
+    const int n_obj = (!SPLIT && only) ? min(only[0], T) : T;
+    for (int it = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * PN_WAVES + wave; it < n_obj; it += SPLIT ? (int)gridDim.x : (int)gridDim.x * PN_WAVES) {
+        const int t = (!SPLIT && only) ? only[1 + it] : it;
         const float* xt = x + (size_t)t * P * 3;
         float best[NB3];
         int bidx[NB3];
@@ -261,11 +264,20 @@ template <bool F16> __device__ __forceinline__ void split8x(const float (&v)[8],
 }
 template <bool F16> __device__ __forceinline__ f32x16 mfma_x(u32x4 a, u32x4 b, f32x16 c) { return F16 ? mfma_f16(a, b, c) : mfma_bf16(a, b, c); }
 
-template <int C3, bool WITH_ARGMAX, bool F16 = false>
+// TIE ('f16x2', training): the arg-max of the max-pool decides where the backward routes an object's gradient, and a different arithmetic
+// flips it wherever the two largest values of a channel lie closer than the arithmetics differ (1 in ~18 000 arg-maxes at the split's
+// ~1e-6; the conv-weight gradients of a 4096-pair step then differ by 100 x their rerun noise).  The kernel therefore also tracks each
+// channel's SECOND largest value (one v_med3 per element) and appends the object to the list `redo` when any channel's two leaders are
+// within tie_eps of each other, or its output's pre-activation is within tie_eps of zero (the backward's y > 0 mask -- the same
+// kind of discontinuity: ~300 flipped masks in a 4096-pair step move the conv3 weight gradient by sqrt(300) terms of a random-sign sum of
+// 1e6, 1e-3..1e-2 of its maximum); launch_fwd then re-runs exactly those objects on the exact-fp32 kernel (`only`), so every arg-max the
+// split could have moved -- and that object's values -- are the fp32 kernel's own bits.
+template <int C3, bool WITH_ARGMAX, bool F16 = false, bool TIE = false>
 __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ y,
-    int* __restrict__ argmax, int T, int P) {
+    int* __restrict__ argmax, int T, int P, int* __restrict__ redo = nullptr, float tie_eps = 0.f) {
+    static_assert(!TIE || (WITH_ARGMAX && F16), "near-tie tracking: the training build of the fp16 split");
     constexpr int NB3 = C3 / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];
     u32x4* w2hi = reinterpret_cast<u32x4*>(ldsu);            // [4 cb2][4 ks][64 lane]   16 KiB
@@ -308,10 +320,10 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
 
     for (int t = blockIdx.x * PN_WAVES + wave; t < T; t += gridDim.x * PN_WAVES) {
         const float* xt = x + (size_t)t * P * 3;
-        float best[NB3];
+        float best[NB3], sec[TIE ? NB3 : 1];
         int bidx[NB3];
 #pragma unroll
-        for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
+        for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; if (TIE) sec[TIE ? c : 0] = -INFINITY; }
         float amax = 0.f;
 
         for (int tile = 0; tile < n_tiles; ++tile) {
@@ -385,6 +397,11 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
                 if (WITH_ARGMAX) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
+                        if (TIE) {            // second largest so far (sec <= best).  The ragged last tile's replicated rows are no candidates, for
+                            // either place: they are copies of point P - 1, which the strict > below prefers anyway (same value, same arg-max)
+                            if (p0 + 32 > P && p0 + mfma32_row(r, h) >= P) acc[r] = -INFINITY;
+                            sec[TIE ? cb : 0] = __builtin_amdgcn_fmed3f(best[cb], sec[TIE ? cb : 0], acc[r]);
+                        }
                         const bool gt = acc[r] > best[cb];
                         best[cb] = gt ? acc[r] : best[cb];
                         bidx[cb] = gt ? (p0 + mfma32_row(r, h)) : bidx[cb];
@@ -399,11 +416,32 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
         }
 
         const bool obad = F16 && (wbad || __any(!(amax < PN_F16_MAX)));       // an operand left the fp16 range: NaN, never a wrong number
+        bool near = false;
+        float zfloor = 0.f;                              // TIE: absolute part of the margin -- the split's error on z follows sum |h2||w3|, about the same for
+        if (TIE) {                                       // every channel of an object, not |z|: a channel whose leaders are small still errs like the large ones
+#pragma unroll
+            for (int cb = 0; cb < NB3; ++cb) zfloor = fmaxf(zfloor, fabsf(best[cb]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) zfloor = fmaxf(zfloor, __shfl_xor(zfloor, o, 64));
+            zfloor *= 0.125f * tie_eps;
+        }
 #pragma unroll
         for (int cb = 0; cb < NB3; ++cb) {
             const float ov = __shfl_xor(best[cb], 32, 64);
             float v = best[cb];
             int bi = bidx[cb];
+            if (TIE) {
+                // the channel's two leaders over both lane halves.  Equal leaders count: two distinct points a few 1e-8 apart in one arithmetic
+                // coincide in the other (54 of 2.7e8 arg-maxes at configs[2] while only distinct values were marked)
+                const float os = __shfl_xor(sec[TIE ? cb : 0], 32, 64);
+                const float b1v = fmaxf(v, ov), s1v = fmaxf(fminf(v, ov), fmaxf(sec[TIE ? cb : 0], os));
+                const float gap = b1v - s1v;
+                near = near || (gap <= fmaf(tie_eps, fabsf(b1v) + fabsf(s1v), zfloor));
+                // ... and the ReLU mask of the output (y > 0 gates the channel's whole gradient in the backward): a pre-activation within the
+                // margin of zero could land on the other side in exact fp32
+                const float zs = b1v * (1.f / (PN_SW * PN_SA)), bc = b3[cb * 32 + pt];
+                near = near || (fabsf(zs + bc) <= fmaf(tie_eps, fabsf(zs) + fabsf(bc), zfloor * (1.f / (PN_SW * PN_SA))));
+            }
             if (WITH_ARGMAX) {
                 const int oi = __shfl_xor(bidx[cb], 32, 64);
                 const bool take = (ov > v) || (ov == v && oi < bi);
@@ -419,8 +457,13 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
                 if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
             }
         }
+        if (TIE) {
+            if ((obad || __any(near)) && lane == 0) redo[1 + atomicAdd(redo, 1)] = t;          // redo[0] = count, then the object ids (any order)
+        }
     }
 }
+
+static float g_tie_eps = 1.0f / 131072.f;      // 2^-17 of |leader| + |runner-up| (+ 2^-20 of the object's largest |z|): none of the 2.7e8 arg-maxes / masks of a configs[2] batch differs from the fp32 kernel's at 2^-18 already; 9 % of the objects re-run (tools/dbg/f16x2_pointnet_flips.py)
 
 template <int C3>
 int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -437,44 +480,59 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         if (argmax) {
             auto k = pointnet_fwd_kernel<C3, true, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part);
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr));
         } else {
             auto k = pointnet_fwd_kernel<C3, false, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part);
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr));
         }
         hipLaunchKernelGGL(pointnet_combine_kernel, dim3((T * C3 + 255) / 256), dim3(256), 0, stream, part, b3, y, argmax, T, C3, P);
         SGA_CHECK_LAUNCH("sga_pointnet_fwd");
         return SGA_OK;
     }
-    if (sga_mfma_mode() == 4) {            // 'f16x2p': the split-fp16 sweeps AND this forward in the same split
+    if (sga_mfma_mode() == 3 && argmax) {  // 'f16x2', training: the forward in the fp16 split, objects with a near-tied arg-max re-run in exact fp32
+        if (!workspace || ws_bytes < (size_t)(T + 1) * sizeof(int)) { sga_set_error("sga_pointnet_fwd: mode 'f16x2' needs a workspace of 4 (T + 1) bytes, T = %d (sga_pointnet_fwd_ws)", T); return SGA_ERR_ARG; }
+        int* redo = static_cast<int*>(workspace);
+        if (hipMemsetAsync(redo, 0, sizeof(int), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd: memset failed"); return SGA_ERR_HIP; }
+        auto k = pointnet_fwd_bf16x3_kernel<C3, true, true, true>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, redo, g_tie_eps);
+        auto k2 = pointnet_fwd_kernel<C3, true>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k2, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr),
+                           static_cast<const int*>(redo));
+    } else if (sga_mfma_mode() == 3) {     // 'f16x2', inference: values only -- nothing to flip
+        auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
+    } else if (sga_mfma_mode() == 4) {     // 'f16x2p': the split-fp16 sweeps AND this forward in the same split, arg-maxes as the split finds them
         if (argmax) {
             auto k = pointnet_fwd_bf16x3_kernel<C3, true, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
         } else {
             auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
         }
     } else if (sga_mfma_mode() == 1) {
         if (argmax) {
             auto k = pointnet_fwd_bf16x3_kernel<C3, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
         } else {
             auto k = pointnet_fwd_bf16x3_kernel<C3, false>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
         }
     } else if (argmax) {
         auto k = pointnet_fwd_kernel<C3, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr));
     } else {
         auto k = pointnet_fwd_kernel<C3, false>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr));
     }
     SGA_CHECK_LAUNCH("sga_pointnet_fwd");
     return SGA_OK;
@@ -483,6 +541,14 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
 }  // namespace
 
 extern "C" size_t sga_pointnet_fwd_ws_bytes(int T, int C3) { return (size_t)(T > 0 ? T : 0) * PN_WAVES * (C3 > 0 ? C3 : 0) * sizeof(float2); }
+
+/* 'f16x2' forward with arg-max: relative distance of a channel's two largest layer-3 values below which the object is re-run in exact fp32
+ * (eps * (|leader| + |runner-up|)).  Returns the previous value; eps < 0 only reads.  After the call the int workspace holds [count | object ids]. */
+extern "C" float sga_pointnet_tie_eps(float eps) {
+    const float old = g_tie_eps;
+    if (eps >= 0.f) g_tie_eps = eps;
+    return old;
+}
 
 static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                              const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,

@@ -65,6 +65,7 @@ def get_mfma_mode() -> str:
 
 
 # ------------------------------------------------------------------------------------------ PointNet
+POINTNET_LAST_REDO = None              # 'f16x2': [count | object ids] re-run in exact fp32 by the last training forward (diagnostics: tests, bench)
 POINTNET_SPLIT_MAX_OBJECTS = 1023      # the library uses the split form below 4 x CUs objects; above that a workspace is not allocated
 def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     """x_tp3 [T,P,3] (point-major, as in data_dict['tot_obj_pts']).  Returns (y [T,C3], argmax|None)."""
@@ -81,6 +82,11 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     if 0 < T <= POINTNET_SPLIT_MAX_OBJECTS:      # few objects: split every object over a workgroup's 8 waves (needs a partials buffer)
         ws_bytes = int(L.sga_pointnet_fwd_ws_bytes(T, C3))
         ws = torch.empty((ws_bytes,), device=x_tp3.device, dtype=torch.uint8)
+    elif T > 0 and want_argmax and get_mfma_mode() == 'f16x2':
+        # 'f16x2' training forward: [count | ids] of the objects with a near-tied arg-max -> those again on the exact-fp32 kernel
+        global POINTNET_LAST_REDO
+        ws_bytes = 4 * (T + 1)
+        ws = POINTNET_LAST_REDO = torch.empty((T + 1,), device=x_tp3.device, dtype=torch.int32)
     rc = L.sga_pointnet_fwd_ws(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
                                T, P, C3, _p(ws), ws_bytes, _stream())
     _lib.check(rc, 'sga_pointnet_fwd')
@@ -518,8 +524,10 @@ SWEEP_SUMS_INFO = {                             # sga_loss_multi_sums: one owner
 }
 BF16X3_COVERAGE = 'PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate'
 F16X2_COVERAGE = ('anchors x negatives loss sweeps (forward sums + gradient) on fp16 MFMA with operands split into fp16 hi + lo of 4096 x '
-                  '(22 significand bits), rows centred, fp32 accumulate; everything else exact fp32')
-F16X2P_COVERAGE = F16X2_COVERAGE.replace('; everything else exact fp32', '') + ' + the PointNet forward in the same split (not faithful for near-tied point maxima); everything else exact fp32'
+                  '(22 significand bits), rows centred, fp32 accumulate; the PointNet forward in the same split with every object whose point '
+                  'max is near-tied (2^-17) re-run on the exact-fp32 kernel (same arg-max points as exact fp32); everything else exact fp32')
+F16X2P_COVERAGE = ('the f16x2 loss sweeps + the PointNet forward in the same split WITHOUT the near-tie re-run (a tied point max may pick the other '
+                   'point: not faithful); everything else exact fp32')
 # 'f16x2' gradient sweep: the coefficients dL/dS as fp16 hi + lo (True) or rounded to fp16 (False: an independent, unbiased 2^-12 rounding
 # per (anchor, negative) pair; 7 of 31 MFMAs and 1.5 VALU per pair less).  None (default) = hi + lo unless EVERY gradient row sums at least
 # F16X2_COEF_LO_MIN_TERMS pairs: there the rounding noise of a row, 2^-12 / sqrt(terms) <= 6.7e-7 of its largest term, is below the

@@ -203,6 +203,39 @@ def test_nearly_identical_rows_vs_fp64_oracle(f16x2):
     assert err['f16x2'][1] <= 2.0 * err['f32'][1] + 1e-6, err
 
 
+def test_pointnet_forward_same_argmax_points_as_fp32(f16x2):
+    """'f16x2' training forward of the object encoder (more objects than the few-object form takes): fp16 hi + lo split, and every object in
+    which some channel's two largest layer-3 values are distinct and within 2^-16 of each other -- or an operand left the fp16 range --
+    re-run on the exact-fp32 kernel (csrc/pointnet.hip, TIE).  Result: the SAME arg-max point as the exact-fp32 mode for every
+    (object, channel) -- the backward routes gradients through them (pointnet.py:140-161) --, values within fp32 rounding, the re-run objects
+    bit-identical; an object whose coordinates overflow the split (millimetres instead of metres) is re-run, not NaN."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    p = O.init_params(['point'])
+    g = torch.Generator(device='cuda').manual_seed(3)
+    ws = [p['object_encoder.conv1.weight'].reshape(64, 3).contiguous().cuda(), 0.1 * torch.randn(64, device='cuda', generator=g),
+          p['object_encoder.conv2.weight'].reshape(128, 64).contiguous().cuda(), 0.1 * torch.randn(128, device='cuda', generator=g),
+          p['object_encoder.conv3.weight'].reshape(256, 128).contiguous().cuda(), 0.1 * torch.randn(256, device='cuda', generator=g)]
+    T, P = 6000, 77                                     # ragged last tile: replicated points tie exactly and must NOT count as near ties
+    x = torch.randn(T, P, 3, device='cuda', generator=g)
+    x[17] *= 3.0e4
+    y, am = ops.pointnet_forward(x, *ws, want_argmax=True)
+    redo = ops.POINTNET_LAST_REDO.clone()
+    ops.set_mfma_mode('f32')
+    y0, am0 = ops.pointnet_forward(x, *ws, want_argmax=True)
+    ops.set_mfma_mode('f16x2')
+    n = int(redo[0])
+    ids = redo[1:1 + n].long()
+    assert 0 < n < T // 3, n
+    assert 17 in ids.tolist() and torch.isfinite(y).all()
+    assert torch.equal(y[ids], y0[ids]) and torch.equal(am[ids], am0[ids])
+    assert (y - y0).abs().max().item() < 2e-6 * y0[:17].abs().max().item()
+    assert torch.equal(am, am0), int((am != am0).sum())
+    # inference (no arg-max wanted): the split alone, values within fp32 rounding
+    yi, _ = ops.pointnet_forward(x[18:], *ws, want_argmax=False)
+    assert (yi - y0[18:]).abs().max().item() < 2e-6 * y0[18:].abs().max().item()
+
+
 @pytest.fixture
 def f16x2p():
     from sgaligner_amd import ops
