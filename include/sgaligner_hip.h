@@ -176,6 +176,16 @@ int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, const float* be
                                    double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir, double* out_terms, void* stream);
 int sga_loss_stash_grad_symx(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
                              int j_lo, int j_hi, int mir, void* stream);
+
+/* MFMA mode 'f16x2': the four stash products of sga_loss_stash_grad_symx on fp16 MFMA with both operands split into fp16 hi + lo of scaled
+ * values (22 significand bits, fp32 accumulate; csrc/stashh.hip).  `planes` = sga_loss_stash_planes(Z = the table's unit rows [X1 | X2 | ...],
+ * width 104) -- sga_loss_stash_planes_bytes(A) bytes, built once per step and table; cmax = one uint32 on the device: the float bits of
+ * the largest |value| in M1 / M2 (the products scale the stash by it).  dZ [>= 2A, 104] is accumulated into (atomics).  The block's rows,
+ * a_lo, j_lo and mir must be multiples of 8 (a ragged last block: use sga_loss_stash_grad_symx).  losses.py:6,50-57,81-94 (autograd). */
+size_t sga_loss_stash_planes_bytes(int A);
+int sga_loss_stash_planes(const float* Z, int A, int Dp, void* planes, void* stream);
+int sga_loss_stash_grad_symx_f16x2(const float* M1, const float* M2, const void* planes, const uint32_t* cmax, int A, float* dZ,
+                                   int a_lo, int a_hi, int j_lo, int j_hi, int mir, void* stream);
 /* ZJ[r, m*104+d] = sqrt(beta_m) Z_m[r,d] for the anchor rows (operand of the anchors x anchors kernels), and its adjoint */
 int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream);
 int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows, float* const* dZ,

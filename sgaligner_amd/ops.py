@@ -532,6 +532,10 @@ F16X2P_COVERAGE = ('the f16x2 loss sweeps + the PointNet forward in the same spl
 # per (anchor, negative) pair; 7 of 31 MFMAs and 1.5 VALU per pair less).  None (default) = hi + lo unless EVERY gradient row sums at least
 # F16X2_COEF_LO_MIN_TERMS pairs: there the rounding noise of a row, 2^-12 / sqrt(terms) <= 6.7e-7 of its largest term, is below the
 # accumulation error the exact-fp32 sweep itself carries (8e-7 .. 2.5e-6 of a table gradient's maximum against fp64).
+# 'f16x2': the A x A stash products on split-fp16 MFMA (csrc/stashh.hip).  OFF by default: 7.4 vs 8.4 ms per 2048 x 155 648 block for the exact-fp32
+# GEMMs (tools/bench_aa.py; plus one pass over the stash for its largest |value|) -- at best -0.04 s of a 2.9 s configs[2] step -- while the gate's margin on meta_embedding_rel.bias shrinks from 3.7 to 4.0 x
+# the rerun noise (profiles/r04_v_bench_c3.json).  Kept as a measured experiment with its C-ABI test.
+F16X2_STASH = _os.environ.get('SGA_F16X2_STASH', '0') == '1'
 F16X2_COEF_LO = {'1': True, '0': False}.get(_os.environ.get('SGA_F16X2_COEF_LO', ''), None)
 F16X2_COEF_LO_MIN_TERMS = 1 << 17
 
@@ -1280,6 +1284,13 @@ class FusedContrastiveFn(torch.autograd.Function):
                 # every unordered anchor pair once over all ranks: a launch also evaluates the mirrored elements from column `mir` on (second stash)
                 fl = max(((jh - jl) + max(0, jh - mir)) * (hi - lo) for lo, hi, jl, jh, mir in chunks)
                 buf = [torch.empty((fl,), device=dev, dtype=torch.float32) for _ in range(M)]
+                # 'f16x2': the stash products on split-fp16 MFMA (csrc/stashh.hip) -- transposed fp16 hi / lo planes of every table's unit rows,
+                # once per step; each launch's stash scaled by its largest |coefficient|
+                split_st = F16X2_STASH and dp == 104 and get_mfma_mode() in ('f16x2', 'f16x2p')
+                if split_st:
+                    planes = [torch.empty((int(L.sga_loss_stash_planes_bytes(s.A)),), device=dev, dtype=torch.uint8) for _ in range(M)]
+                    for k in range(M):
+                        _lib.check(L.sga_loss_stash_planes(_p(zs[k]), s.A, dp, _p(planes[k]), st), 'sga_loss_stash_planes')
                 for lo, hi, jl, jh, mir in chunks:
                     n1 = (jh - jl) * (hi - lo)
                     m1 = [b[:n1] for b in buf]
@@ -1291,10 +1302,18 @@ class FusedContrastiveFn(torch.autograd.Function):
                     out_acc += out[:n_terms]
                     gs_aa += gsc[0]
                     gam_aa += gam2[0]
+                    on8 = (hi - lo) % 8 == 0 and lo % 8 == 0 and jl % 8 == 0 and (not has2 or mir % 8 == 0)      # (a ragged last block: exact fp32)
                     for k in range(M):
-                        _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]) if has2 else None, _p(zs[k]), s.A, dp, _p(dz_all[k]),
-                                                              lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx')
+                        if split_st and on8:
+                            cmx = torch.maximum(m1[k].abs().max(), m2[k][:(jh - mir) * (hi - lo)].abs().max()) if has2 else m1[k].abs().max()
+                            _lib.check(L.sga_loss_stash_grad_symx_f16x2(_p(m1[k]), _p(m2[k]) if has2 else None, _p(planes[k]), cmx.data_ptr(), s.A,
+                                                                        _p(dz_all[k]), lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx_f16x2')
+                        else:
+                            _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]) if has2 else None, _p(zs[k]), s.A, dp, _p(dz_all[k]),
+                                                                  lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx')
                 del buf, m1, m2
+                if split_st:
+                    del planes
             elif chunks:
                 cmax = max(hi - lo for lo, hi in chunks)
                 m1 = [torch.empty((s.A * cmax,), device=dev, dtype=torch.float32) for _ in range(M)]
