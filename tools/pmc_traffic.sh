@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the two dominant kernels: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over
 # `python bench.py --config <c2|c3> --steps 2 --warmup 1` (counters only, no trace domains).
-# usage: tools/pmc_traffic.sh <c2|c3> <out.csv>   (rows are APPENDED; bench.py reads profiles/r03_pmc_traffic.csv)
+# usage: tools/pmc_traffic.sh <c2|c3> <out.csv>   (rows are APPENDED; bench.py reads profiles/r04_pmc_traffic.csv)
 # row: kernel;workload_key;sha16(kernel source);counter;avg KiB per dispatch;launches  -- bench.py uses a row only when the
 # workload key matches what it runs and the source file is unchanged since the pass.
 set -u
@@ -15,7 +15,7 @@ if [ ! -f "$out" ]; then
   echo "kernel;workload_key;source_sha16;counter;avg_kib_per_launch;launches" >> $out
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, (true|false)|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, (true|false)|pointnet_fwd_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct --no-split < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
   python - $c $cfg >> $out <<'PY'
 import csv, glob, sys, collections, hashlib
 c, cfg = sys.argv[1], sys.argv[2]
