@@ -171,16 +171,27 @@ def roofline_objects(events, world):
     evs = events.get('pointnet_fwd_kernel', [])
     if evs:
         durs = [a.elapsed_time(b) for a, b, _ in evs]
-        T, P, C1, C2, C3 = evs[0][2]
+        T, P, C1, C2, C3 = evs[0][2][:5]
+        pmode = evs[0][2][5] if len(evs[0][2]) > 5 else 'f32'
         alg = 2.0 * T * P * (3 * C1 + C1 * C2 + C2 * C3)           # three per-point layers
         avg_ms = float(np.mean(durs))
         ach = alg / (avg_ms * 1e-3) / 1e12
-        roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                      'frac': round(ach / PEAK_F32_TFLOPS, 4),
-                      'traffic': pmc_traffic_bytes('pointnet_fwd_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
-                      'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object)',
-                      'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
-                      'algorithmic_flops_per_launch': alg})
+        if pmode == 'f32':
+            roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': round(ach / PEAK_F32_TFLOPS, 4),
+                          'traffic': pmc_traffic_bytes('pointnet_fwd_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
+                          'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object)',
+                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
+                          'algorithmic_flops_per_launch': alg})
+        else:
+            # modes 'f16x2' / 'f16': the fp16 hi + lo split (3 fp16 MFMAs per product) + the exact-fp32 re-run of the near-tied objects; one
+            # event pair around both launches.  Priced against the fp16 peak on ALGORITHMIC FLOPs (the executed count is ~3.3 x that).
+            roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': None,
+                          'kernel': 'pointnet_fwd_bf16x3_kernel<256,true,F16,TIE> + pointnet_fwd_kernel<256,true> on the near-tied objects (object encoder forward, '
+                                    'fp32-faithful fp16 hi + lo split)',
+                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
+                          'algorithmic_flops_per_launch': alg, 'executed_over_algorithmic': '3 fp16 MFMAs per product + ~9-17 % of the objects again in fp32'})
     for key, grad in (('loss_multi_grad', True), ('loss_multi_sums', False)):
         evs = events.get(key, [])
         if not evs:

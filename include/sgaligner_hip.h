@@ -46,7 +46,7 @@ int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const flo
  * (max, arg-max) pairs are folded by a second small kernel -- identical results, per-object latency / 8.  workspace may be NULL
  * (then this is sga_pointnet_fwd). */
 size_t sga_pointnet_fwd_ws_bytes(int T, int C3);
-/* MFMA mode 'f16x2' (3) with argmax != NULL: the forward runs in the fp16 hi + lo split and needs workspace >= 4 (T + 1) bytes; it leaves
+/* MFMA modes 'f16x2' (3) and 'f16' (2) with argmax != NULL: the forward runs in the fp16 hi + lo split and needs workspace >= 4 (T + 1) bytes; it leaves
  * [count | object ids] (int32) there: the objects in which some channel's two largest layer-3 values were distinct and within
  * eps * (|a| + |b| + max|z| / 8) -- they were re-run on the exact-fp32 kernel, their values and arg-maxes are that kernel's bits.  sga_pointnet_tie_eps sets eps (default 2^-17) and returns the
  * previous value; a negative argument only reads.  pointnet.py:140-161 (the max-pool's arg-max routes the backward). */
@@ -167,6 +167,16 @@ int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const float* bet
                                   double* gamma, int a_lo, int a_hi, double* out_terms, void* stream);
 int sga_loss_stash_grad_sym(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
                             void* stream);
+/* MFMA mode 'f16x2': sga_loss_anchor_multi_bwd_symx with the similarities S = X1 X2^T on fp16 MFMA from rows held as fp16 hi + lo of 4096 x
+ * (22 significand bits, hi.hi + hi.lo + lo.hi, fp32 accumulate: fp32's own error on S; rows centred on their column mean, the mean's share
+ * carried by two bookkeeping columns).  Zh[m] = sga_loss_aa_planes(Z[m], rows = 2A, out): out holds rows + 1 rows of 104 floats (the last one
+ * receives the column mean), same row pitch as the fp32 table.  losses.py:6,50-57,81-94. */
+int sga_loss_aa_planes(const float* Z, size_t rows, float* out, void* stream);
+int sga_loss_anchor_multi_bwd_symx_h16(const float* const* Zh, int M, const float* beta, int A, const double* sums, float alpha,
+                                       float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
+                                       double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir,
+                                       double* out_terms, void* stream);
+
 /* The same two entry points for ONE RANK of an anchor-sharded job (new design; the reference has no multi-GPU path:
  * src/engine/base_trainer.py:70,146-158 is dead): rows [a_lo, a_hi) meet the columns [j_lo, j_hi) only; tiles at j >= mir also produce the
  * mirrored element (j, i) (stash M2, rows j - mir), tiles left of mir are visited in the ordered way and must lie in the block's own

@@ -89,6 +89,8 @@ SIGNATURES = {
     'sga_loss_anchor_multi_bwd_sym': (I, [P, I, P, I, P, F, F, F, P, P, P, P, P, I, I, P, P]),
     'sga_loss_stash_grad_sym': (I, [P, P, P, I, I, P, I, I, P]),
     'sga_loss_anchor_multi_bwd_symx': (I, [P, I, P, I, P, F, F, F, P, P, P, P, P, I, I, I, I, I, P, P]),
+    'sga_loss_anchor_multi_bwd_symx_h16': (I, [P, I, P, I, P, F, F, F, P, P, P, P, P, I, I, I, I, I, P, P]),
+    'sga_loss_aa_planes': (I, [P, c_size_t, P, P]),
     'sga_loss_stash_planes_bytes': (c_size_t, [I]),
     'sga_loss_stash_planes': (I, [P, I, I, P, P]),
     'sga_loss_stash_grad_symx_f16x2': (I, [P, P, P, P, I, P, I, I, I, I, I, P]),

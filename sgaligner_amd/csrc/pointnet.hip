@@ -490,8 +490,10 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         SGA_CHECK_LAUNCH("sga_pointnet_fwd");
         return SGA_OK;
     }
-    if (sga_mfma_mode() == 3 && argmax) {  // 'f16x2', training: the forward in the fp16 split, objects with a near-tied arg-max re-run in exact fp32
-        if (!workspace || ws_bytes < (size_t)(T + 1) * sizeof(int)) { sga_set_error("sga_pointnet_fwd: mode 'f16x2' needs a workspace of 4 (T + 1) bytes, T = %d (sga_pointnet_fwd_ws)", T); return SGA_ERR_ARG; }
+    // ('f16', the configs[4] mode -- fp16 inputs for the loss GEMMs of wide tables -- takes the same fp32-faithful forward: PointNet is 46 % of its step)
+    const bool split_fwd = sga_mfma_mode() == 3 || sga_mfma_mode() == 2;
+    if (split_fwd && argmax) {             // 'f16x2', training: the forward in the fp16 split, objects with a near-tied arg-max re-run in exact fp32
+        if (!workspace || ws_bytes < (size_t)(T + 1) * sizeof(int)) { sga_set_error("sga_pointnet_fwd: modes 'f16x2' / 'f16' need a workspace of 4 (T + 1) bytes, T = %d (sga_pointnet_fwd_ws)", T); return SGA_ERR_ARG; }
         int* redo = static_cast<int*>(workspace);
         if (hipMemsetAsync(redo, 0, sizeof(int), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd: memset failed"); return SGA_ERR_HIP; }
         auto k = pointnet_fwd_bf16x3_kernel<C3, true, true, true>;
@@ -501,7 +503,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL(k2, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr),
                            static_cast<const int*>(redo));
-    } else if (sga_mfma_mode() == 3) {     // 'f16x2', inference: values only -- nothing to flip
+    } else if (split_fwd) {                // 'f16x2', inference: values only -- nothing to flip
         auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);

@@ -47,12 +47,14 @@ def set_mfma_mode(mode: str) -> str:
     """Arithmetic of the MFMA kernels that have a reduced-precision variant: 'f32' (exact fp32 MFMA: the default and every
     headline number); 'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate; ~1e-5
     relative error; PointNet forward + the fused 100-d loss sweeps); 'f16' (opt-in, BASELINE.json configs[4]: loss tables WIDER than
-    128 columns and the similarity ranking take fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; 100-d tables
-    and everything else stay exact fp32); 'f16x2' (opt-in, fp32-FAITHFUL: the fused 100-d loss sweeps with each fp32 operand as fp16
-    hi + lo of 4096 x -- 22 significand bits, three fp16 MFMAs per product, fp32 accumulate: the similarities carry fp32's own rounding
-    error, csrc/sweeph.hip; everything else exact fp32); 'f16x2p' ('f16x2' + the PointNet forward in the same split, csrc/pointnet.hip:
-    outputs to 6e-7 of the fp32 kernel's, but where two points of an object tie for a channel's maximum to fp32 rounding the OTHER point may
-    win and take that channel's gradient -- a few 1e-5 of the (object, channel) pairs; not fp32-faithful for the conv weights' gradients).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial
+    128 columns and the similarity ranking take fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; the PointNet
+    training forward as in 'f16x2'; 100-d tables and everything else stay exact fp32); 'f16x2' (opt-in, fp32-FAITHFUL: the fused 100-d loss
+    sweeps with each fp32 operand as fp16 hi + lo of 4096 x -- 22 significand bits, three fp16 MFMAs per product, fp32 accumulate: the
+    similarities carry fp32's own rounding error, csrc/sweeph.hip -- and the PointNet training forward in the same split with every
+    near-tied object re-run on the exact-fp32 kernel: same arg-max points and ReLU masks as exact fp32, csrc/pointnet.hip; everything else
+    exact fp32); 'f16x2p' (the 'f16x2' sweeps + the PointNet forward in the split WITHOUT the re-run: outputs to 6e-7 of the fp32 kernel's,
+    but where two points of an object tie for a channel's maximum to fp32 rounding the OTHER point may win and take that channel's
+    gradient -- a few 1e-6 of the (object, channel) pairs; not fp32-faithful for the conv weights' gradients).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial
     mode."""
     if mode not in MFMA_MODES:
         raise ValueError(f"sgaligner_amd: mfma mode must be one of {sorted(MFMA_MODES)} (got {mode!r})")
@@ -82,7 +84,7 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     if 0 < T <= POINTNET_SPLIT_MAX_OBJECTS:      # few objects: split every object over a workgroup's 8 waves (needs a partials buffer)
         ws_bytes = int(L.sga_pointnet_fwd_ws_bytes(T, C3))
         ws = torch.empty((ws_bytes,), device=x_tp3.device, dtype=torch.uint8)
-    elif T > 0 and want_argmax and get_mfma_mode() == 'f16x2':
+    elif T > 0 and want_argmax and get_mfma_mode() in ('f16x2', 'f16'):
         # 'f16x2' training forward: [count | ids] of the objects with a near-tied arg-max -> those again on the exact-fp32 kernel
         global POINTNET_LAST_REDO
         ws_bytes = 4 * (T + 1)
@@ -92,7 +94,7 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
     _lib.check(rc, 'sga_pointnet_fwd')
     if ev is not None:
         ev[1].record()
-        KERNEL_EVENTS.setdefault('pointnet_fwd_kernel', []).append(ev + ((T, P, w1.shape[0], w2.shape[0], C3),))
+        KERNEL_EVENTS.setdefault('pointnet_fwd_kernel', []).append(ev + ((T, P, w1.shape[0], w2.shape[0], C3, get_mfma_mode() if (ws is not None and ws_bytes == 4 * (T + 1)) else 'f32'),))
     return y, am
 
 
@@ -524,7 +526,7 @@ SWEEP_SUMS_INFO = {                             # sga_loss_multi_sums: one owner
 }
 BF16X3_COVERAGE = 'PointNet forward + loss sweeps on bf16 MFMA with hi/lo-split operands, fp32 accumulate'
 F16X2_COVERAGE = ('anchors x negatives loss sweeps (forward sums + gradient) on fp16 MFMA with operands split into fp16 hi + lo of 4096 x '
-                  '(22 significand bits), rows centred, fp32 accumulate; the PointNet forward in the same split with every object whose point '
+                  '(22 significand bits), rows centred, fp32 accumulate; the similarities of the symmetric anchors x anchors kernel in the same split; the PointNet forward in the same split with every object whose point '
                   'max is near-tied (2^-17) re-run on the exact-fp32 kernel (same arg-max points as exact fp32); everything else exact fp32')
 F16X2P_COVERAGE = ('the f16x2 loss sweeps + the PointNet forward in the same split WITHOUT the near-tie re-run (a tied point max may pick the other '
                    'point: not faithful); everything else exact fp32')
@@ -536,6 +538,7 @@ F16X2P_COVERAGE = ('the f16x2 loss sweeps + the PointNet forward in the same spl
 # GEMMs (tools/bench_aa.py; plus one pass over the stash for its largest |value|) -- at best -0.04 s of a 2.9 s configs[2] step -- while the gate's margin on meta_embedding_rel.bias shrinks from 3.7 to 4.0 x
 # the rerun noise (profiles/r04_v_bench_c3.json).  Kept as a measured experiment with its C-ABI test.
 F16X2_STASH = _os.environ.get('SGA_F16X2_STASH', '0') == '1'
+F16X2_AA = _os.environ.get('SGA_F16X2_AA', '1') != '0'       # 'f16x2': the symmetric A x A kernel's similarities on split-fp16 MFMA (tools / tests flip it)
 F16X2_COEF_LO = {'1': True, '0': False}.get(_os.environ.get('SGA_F16X2_COEF_LO', ''), None)
 F16X2_COEF_LO_MIN_TERMS = 1 << 17
 
@@ -1291,14 +1294,22 @@ class FusedContrastiveFn(torch.autograd.Function):
                     planes = [torch.empty((int(L.sga_loss_stash_planes_bytes(s.A)),), device=dev, dtype=torch.uint8) for _ in range(M)]
                     for k in range(M):
                         _lib.check(L.sga_loss_stash_planes(_p(zs[k]), s.A, dp, _p(planes[k]), st), 'sga_loss_stash_planes')
+                # 'f16x2': the A x A similarities on fp16 MFMA from fp16 hi + lo rows (same bytes per row; the epilogue is the exact-fp32 code)
+                h16 = F16X2_AA and dp == 104 and get_mfma_mode() in ('f16x2', 'f16x2p')
+                if h16:
+                    zh = [torch.empty((2 * s.A + 1, dp), device=dev, dtype=torch.float32) for _ in range(M)]
+                    for k in range(M):
+                        _lib.check(L.sga_loss_aa_planes(_p(zs[k]), 2 * s.A, _p(zh[k]), st), 'sga_loss_aa_planes')
+                    zharr = _ptr_array(zh)
+                aa_fn = L.sga_loss_anchor_multi_bwd_symx_h16 if h16 else L.sga_loss_anchor_multi_bwd_symx
                 for lo, hi, jl, jh, mir in chunks:
                     n1 = (jh - jl) * (hi - lo)
                     m1 = [b[:n1] for b in buf]
                     m2 = [b[n1:] for b in buf]
                     has2 = mir < jh
-                    _lib.check(L.sga_loss_anchor_multi_bwd_symx(zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(coef),
-                                                                _ptr_array(m1), _ptr_array(m2) if has2 else (_ct.c_void_p * M)(), _p(gsc), _p(gam2),
-                                                                lo, hi, jl, jh, mir, _p(out), st), 'sga_loss_anchor_multi_bwd_symx')
+                    _lib.check(aa_fn(zharr if h16 else zarr, M, _p(beta), s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(coef),
+                                     _ptr_array(m1), _ptr_array(m2) if has2 else (_ct.c_void_p * M)(), _p(gsc), _p(gam2),
+                                     lo, hi, jl, jh, mir, _p(out), st), 'sga_loss_anchor_multi_bwd_symx')
                     out_acc += out[:n_terms]
                     gs_aa += gsc[0]
                     gam_aa += gam2[0]
@@ -1314,6 +1325,8 @@ class FusedContrastiveFn(torch.autograd.Function):
                 del buf, m1, m2
                 if split_st:
                     del planes
+                if h16:
+                    del zh, zharr
             elif chunks:
                 cmax = max(hi - lo for lo, hi in chunks)
                 m1 = [torch.empty((s.A * cmax,), device=dev, dtype=torch.float32) for _ in range(M)]
