@@ -466,6 +466,36 @@ def main():
                           'value': round(CONFIGS['c2']['pairs_per_gpu'] * n4 / el4, 2), 'unit': 'pairs/s',
                           'ms_per_step': round(el4 / n4 * 1e3, 3), 'steps': n4, 'warmup': 2, 'dtype': 'f32',
                           'roofline': roofline_objects(ev4, world)}
+            if not args.no_split:
+                # the same M = 4 step in the fp32-faithful 'f16x2' mode (sweeph_kernel<4, ...>: four waves per workgroup, one per SIMD), with its
+                # gradient error against the exact-fp32 step and that step's own rerun noise -- as extra_f16x2 does at configs[2]
+                ref4 = {n: p.grad.detach().clone() for n, p in steps4.model.named_parameters() if p.grad is not None}
+                noise4 = {}
+                for _ in range(2):
+                    steps4.forward_backward(dd2)
+                    torch.cuda.synchronize()
+                    for n, p in steps4.model.named_parameters():
+                        if p.grad is not None and n in ref4:
+                            noise4[n] = max(noise4.get(n, 0.0), float((p.grad - ref4[n]).abs().max()) / max(1e-30, float(ref4[n].abs().max())))
+                ops.set_mfma_mode('f16x2')
+                try:
+                    el4h, _, _ = timed(steps4, dd2, 2, n4)
+                    ratio4, name4, own4 = 0.0, None, 0.0
+                    for n, p in steps4.model.named_parameters():
+                        if p.grad is None or n not in ref4:
+                            continue
+                        own = float((p.grad - ref4[n]).abs().max()) / max(1e-30, float(ref4[n].abs().max()))
+                        r = own / max(noise4.get(n, 0.0), NOISE_FLOOR)
+                        own4 = max(own4, own)
+                        if r > ratio4:
+                            ratio4, name4 = r, n
+                    extra_attr['f16x2'] = {'value': round(CONFIGS['c2']['pairs_per_gpu'] * n4 / el4h, 2), 'unit': 'pairs/s',
+                                           'ms_per_step': round(el4h / n4 * 1e3, 3), 'max_grad_err_rel_to_own_max': own4,
+                                           'max_err_over_f32_rerun_noise': round(ratio4, 3), 'max_err_over_noise_param': name4,
+                                           'gate_4x_noise': bool(ratio4 <= 4.0), 'noise_floor_rel_to_own_max': NOISE_FLOOR}
+                finally:
+                    ops.set_mfma_mode('f32')
+                del ref4
             del steps4
         except Exception as e:
             extra_attr = {'error': f'{type(e).__name__}: {e}'}

@@ -201,10 +201,13 @@ struct HArgs {
 // instruction stream) issue in the shadow of the other's MFMAs and a parked wave costs nothing; OH = 2: 4 waves x 32 rows, one wave per SIMD
 // at <= 512 registers -- half the LDS reads per MFMA, but every instruction of the stream then takes its own 4-cycle issue slot (SQ
 // counters, profiles/r04_f_sweeph_sq.txt: 246 MFMAs = 3 936 matrix cycles + ~990 other instructions = 3 900 issue cycles per tile).
-template <int M, bool GRAD, bool CLO, int OH>
-__global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
+// WV: waves per workgroup.  8 / OH (128 owner rows) for M <= 3; M = 4 runs OH = 1 with FOUR waves (64 owner rows, one wave per SIMD at up to
+// 512 registers): four tables of owner operands (112) and gradient accumulators (112) do not fit the 256 registers of a two-wave SIMD.
+template <int M, bool GRAD, bool CLO, int OH, int WV = 8 / OH>
+__global__ __launch_bounds__(WV * 64, (WV * OH == 8) ? 2 / OH : 1) void sweeph_kernel(HArgs a) {
     constexpr int NCT = 7;
-    constexpr int WAVES = 8 / OH, THREADS = WAVES * 64;
+    constexpr int WAVES = WV, THREADS = WAVES * 64;
+    constexpr int OWN = WV * 16 * OH;                                 // owner rows per workgroup
     constexpr int KMAX = (SH_NCH + WAVES - 1) / WAVES;               // DMA chunk slots per table and wave
     constexpr int BUF = M * SH_BLOCK;
     constexpr bool PIPE = OH == 2;                                    // one wave per SIMD: operand prefetch pinned inside the MFMA stream
@@ -222,11 +225,11 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
     const HGroup& grp = a.grp[g];
     // XCD-aware work order (as sweepb / sweep16): the group's (split major, owner block minor) work list in 8 contiguous per-XCD chunks
     const int wg_in_grp = (int)blockIdx.x - grp.blk0;
-    const int nsplit = grp.nsplit, n_ob = (grp.nown + SH_OWN - 1) / SH_OWN, n_units = n_ob * nsplit;
+    const int nsplit = grp.nsplit, n_ob = (grp.nown + OWN - 1) / OWN, n_units = n_ob * nsplit;
     const int unit = (wg_in_grp & 7) * ((n_units + 7) >> 3) + (wg_in_grp >> 3);
     if ((wg_in_grp >> 3) >= ((n_units + 7) >> 3) || unit >= n_units) return;
     const int split = unit / n_ob;
-    const int own0 = grp.own0 + (unit - split * n_ob) * SH_OWN;
+    const int own0 = grp.own0 + (unit - split * n_ob) * OWN;
     const int own_end = grp.own0 + grp.nown;
     const int wrow0 = own0 + wave * 16 * OH;                          // this wave's first owner row
 #ifdef SH_DBG_TIMING
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
                             }
                     }
                 };
-                if (j0 >= seg.lo && j0 + 32 <= seg.hi && own0 + SH_OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
+                if (j0 >= seg.lo && j0 + 32 <= seg.hi && own0 + OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
 #pragma unroll
                 for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
             } else {
@@ -631,7 +634,8 @@ __global__ __launch_bounds__(512 / OH, 2 / OH) void sweeph_kernel(HArgs a) {
 
 int fill_h(HArgs& a, const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1, bool grad,
            int a_lo, int a_hi, const char* who) {
-    if (M < 2 || M > 3) { sga_set_error("%s: M=%d (the split-fp16 sweeps are built for 2 or 3 modality tables)", who, M); return SGA_ERR_ARG; }
+    if (M < 2 || M > 4) { sga_set_error("%s: M=%d (the split-fp16 sweeps are built for 2, 3 or 4 modality tables)", who, M); return SGA_ERR_ARG; }
+    const int own_rows = M <= 3 ? SH_OWN : SH_OWN / 2;               // owner rows per workgroup (sweeph_kernel: WV)
     if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("%s: anchor shard [%d,%d) outside [0,%d]", who, a_lo, a_hi, A); return SGA_ERR_ARG; }
     a.M = M;
     {
@@ -677,7 +681,7 @@ int fill_h(HArgs& a, const void* const* Zb, int M, const float* beta, int A, int
         if (nsp < 1) nsp = 1;
         G.nsplit = nsp;
         G.blk0 = nwg;
-        nwg += (((G.nown + SH_OWN - 1) / SH_OWN) * nsp + 7) / 8 * 8;
+        nwg += (((G.nown + own_rows - 1) / own_rows) * nsp + 7) / 8 * 8;
     }
     return -nwg;                                                    // negative: number of workgroups (0 is a valid "nothing to do")
 }
@@ -688,9 +692,15 @@ int fill_h(HArgs& a, const void* const* Zb, int M, const float* beta, int A, int
 template <int M, bool GRAD, bool CLO>
 void launch_h(const HArgs& a, int nwg, hipStream_t s) {
     const size_t lds = (size_t)2 * M * SH_BLOCK;
-    auto k = sweeph_kernel<M, GRAD, CLO, SH_OH>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(512 / SH_OH), lds, s, a);
+    if constexpr (M == 4) {
+        auto k = sweeph_kernel<M, GRAD, CLO, 1, 4>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, s, a);
+    } else {
+        auto k = sweeph_kernel<M, GRAD, CLO, SH_OH>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(nwg), dim3(512 / SH_OH), lds, s, a);
+    }
 }
 
 }  // namespace
@@ -737,7 +747,8 @@ extern "C" int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const flo
     if (r > 0) return r;
     a.sums = sums;
     if (M == 2) { if (s_lo) launch_h<2, false, true>(a, -r, s); else launch_h<2, false, false>(a, -r, s); }
-    else { if (s_lo) launch_h<3, false, true>(a, -r, s); else launch_h<3, false, false>(a, -r, s); }
+    else if (M == 3) { if (s_lo) launch_h<3, false, true>(a, -r, s); else launch_h<3, false, false>(a, -r, s); }
+    else { if (s_lo) launch_h<4, false, true>(a, -r, s); else launch_h<4, false, false>(a, -r, s); }
     fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums_f16x2");
     return SGA_OK;
@@ -755,7 +766,8 @@ extern "C" int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const flo
     a.gs = gs; a.gamma = gamma;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad_f16x2: null dZ"); a.dZ[m] = dZ[m]; }
     if (M == 2) { if (coef_lo) launch_h<2, true, true>(a, -r, s); else launch_h<2, true, false>(a, -r, s); }
-    else { if (coef_lo) launch_h<3, true, true>(a, -r, s); else launch_h<3, true, false>(a, -r, s); }
+    else if (M == 3) { if (coef_lo) launch_h<3, true, true>(a, -r, s); else launch_h<3, true, false>(a, -r, s); }
+    else { if (coef_lo) launch_h<4, true, true>(a, -r, s); else launch_h<4, true, false>(a, -r, s); }
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad_f16x2");
     return SGA_OK;

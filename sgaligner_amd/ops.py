@@ -1215,7 +1215,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         dmax = max(e.shape[1] for e in tables)          # real width: the K step that only covers zero padding is skipped
         # opt-in split-bf16 x3 sweeps: the tables additionally as blocked bf16 hi/lo planes (sweepb.hip)
         zbs = []
-        split16 = M in (2, 3) and dmax <= 100 and get_mfma_mode() in ('f16x2', 'f16x2p')      # columns 100, 101 of the planes carry the centring's bookkeeping
+        split16 = M in (2, 3, 4) and dmax <= 100 and get_mfma_mode() in ('f16x2', 'f16x2p')      # columns 100, 101 of the planes carry the centring's bookkeeping
         if split16:
             nb = L.sga_loss_split16_bytes(s.A, s.J1, s.J2)
             for z in zs:

@@ -25,7 +25,7 @@ def test_mode_switch_roundtrip():
 
 
 @pytest.mark.parametrize('coef_lo', [True, False])
-@pytest.mark.parametrize('M,emb', [(3, 100), (2, 100), (3, 64)])
+@pytest.mark.parametrize('M,emb', [(3, 100), (2, 100), (3, 64), (4, 100)])
 def test_sweeps_vs_fp32_sweeps_and_anchor_shards(f16x2, M, emb, coef_lo):
     """The split-fp16 loss sweeps against the exact-fp32 sweeps on the same tables (loss terms, dE, d fusion weight), unsharded and as
     the sum of 3 anchor shards with cuts that are NOT multiples of the 32-row blocks (what ranks of a multi-GPU job own)."""
@@ -36,7 +36,7 @@ def test_sweeps_vs_fp32_sweeps_and_anchor_shards(f16x2, M, emb, coef_lo):
     T = int(dd['tot_obj_count'].sum())
     g = torch.Generator(device='cuda').manual_seed(M)
     base = [torch.randn(T, emb, device='cuda', generator=g) for _ in range(M)]
-    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')[:M].contiguous()
+    w0 = torch.tensor([[0.3], [1.1], [-0.4], [0.6]], device='cuda')[:M].contiguous()
     cot = torch.randn(M + 1 + 2 * M, device='cuda', generator=g)
     keep = ops.F16X2_COEF_LO
     ops.F16X2_COEF_LO = coef_lo
