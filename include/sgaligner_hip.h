@@ -154,7 +154,7 @@ int sga_loss_anchor_multi_fwd(const float* const* Z, int M, const float* beta, i
 int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
                               float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, double* gamma,
                               int a_lo, int a_hi, double* out_terms, void* stream);
-/* Symmetric walk of the anchors x anchors terms for an UNSHARDED anchor set (M in {2,3}; reference arithmetic losses.py:43-97, where
+/* Symmetric walk of the anchors x anchors terms for an UNSHARDED anchor set (M in {2,3,4}; reference arithmetic losses.py:43-97, where
  * term (i,j) and term (j,i) are made of the same two similarities S[i,j], S[j,i]): block [a_lo, a_hi) meets the columns j >= a_lo only
  * and also evaluates the mirrored elements (j, i), j >= a_hi -- every unordered anchor pair once over the whole walk instead of twice.
  * a_lo % 32 == 0; a_hi % 32 == 0 or a_hi == A.  M1[m]: [A - a_lo, a_hi - a_lo] floats, M1[m][(j-a_lo)*ns + (i-a_lo)] = dL/dS_m[i,j];
@@ -224,7 +224,7 @@ int sga_loss_multi_grad_bf16x3(const void* const* Zb, int M, const float* beta, 
  * coef_lo != 0: the coefficients enter the gradient GEMM as hi + lo as well; 0: rounded to fp16 (11 bits, independent per pair).
  * s_lo != 0: the forward sums use the full three-product similarities; 0: hi.hi only on the 96 main columns (the K tail with the centring's
  * bookkeeping columns stays complete) -- for sums of >= 2^24 terms, where the unbiased 1e-5 error per similarity averages out.
- * M in {2,3}. */
+ * M in {2,3,4} (M = 4: four waves per workgroup, one per SIMD). */
 size_t sga_loss_split16_bytes(int A, int J1, int J2);
 int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
 int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
