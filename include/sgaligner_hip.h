@@ -133,6 +133,15 @@ int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, con
                         float tau_icl, float tau_ial, const float* coef, float* const* M1, double* gs, int a_lo, int a_hi,
                         void* stream);
 
+/* MFMA mode 'f16' (configs[4]: tables wider than 128 columns): the same two launches with fp16 INPUTS for the similarities of every table k
+ * whose Zh[k] != NULL -- Zh[k] = the fp16 copy of Z[k]'s rows that sga_wide16_prepare writes (row pitch Dp[k] halfs); fp32 accumulate, the
+ * epilogue unchanged.  Zh == NULL or Zh[k] == NULL: exact fp32 for that table.  1e-2 tolerance, like the mode's sweeps. */
+int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
+                            float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream);
+int sga_loss_anchor_bwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
+                            float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
+                            double* gs, int a_lo, int a_hi, void* stream);
+
 /* dZ[a_lo:a_hi,:] += M1^T Z[A:2A,:] ; dZ[A:2A,:] += M1 Z[a_lo:a_hi,:]  (M1 [A, a_hi-a_lo] from sga_loss_anchor_bwd; dZ zero-initialised) */
 int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi, void* stream);
 /* fused variants for the normal pipeline, where the last table is the fusion of the M others: every joint

@@ -77,6 +77,8 @@ SIGNATURES = {
     'sga_loss_neg_grad': (I, [P, I, I, I, I, F, F, P, P, P]),
     'sga_loss_anchor_fwd': (I, [P, P, I, I, P, F, F, F, P, I, I, P]),
     'sga_loss_anchor_bwd': (I, [P, P, I, I, P, F, F, F, P, P, P, I, I, P]),
+    'sga_loss_anchor_fwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, I, I, P]),
+    'sga_loss_anchor_bwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, P, P, I, I, P]),
     'sga_loss_multi_sums': (I, [P, I, I, P, I, I, I, F, F, P, I, I, P]),
     'sga_loss_multi_grad': (I, [P, I, I, P, I, I, I, F, F, P, P, P, I, I, P]),
     'sga_loss_build_joint': (I, [P, I, P, I, P, P]),

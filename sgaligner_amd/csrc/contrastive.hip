@@ -1101,12 +1101,46 @@ __global__ void check_norms_kernel(const float* __restrict__ nrm, int n, float* 
         if (!(nrm[i] >= 1e-12f)) *poison = __builtin_nanf("");
 }
 
+// fp16 staging of the general-width anchors x anchors kernel: the same LDS tiles hold [rows][64 halfs + 8 pad] (144 B = the fp32 tiles' 36
+// floats per row: conflict-free ds_read_b128), a K chunk is 64 columns = 4 steps of v_mfma_f32_32x32x16_f16 (lane: row lane & 31, k slots
+// 8 (lane >> 5) .. + 7 of each step)
+typedef _Float16 ak_f16x8 __attribute__((ext_vector_type(8)));
+template <int NROWS, int NTHREADS>
+__device__ __forceinline__ void lds_load_rows_h(float* __restrict__ tile, const _Float16* __restrict__ g, int ld, int row0, int nrows, int k0,
+                                                int ncols, int tid) {
+    unsigned char* t8 = reinterpret_cast<unsigned char*>(tile);
+#pragma unroll
+    for (int e = tid; e < NROWS * 8; e += NTHREADS) {
+        const int r = e >> 3, c = (e & 7) * 8;
+        ak_f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int gr = row0 + r, gc = k0 + c;
+        if (gr < nrows && gc < ncols) v = *reinterpret_cast<const ak_f16x8*>(g + (size_t)gr * ld + gc);     // ncols % 8 == 0
+        *reinterpret_cast<ak_f16x8*>(t8 + r * 144 + c * 2) = v;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mfma_chunk_h(f32x16 (&acc)[NT], const float* __restrict__ a_tile, const float* __restrict__ b_row, int lane) {
+    const unsigned char* ap = reinterpret_cast<const unsigned char*>(a_tile) + (lane & 31) * 144 + (lane >> 5) * 16;
+    const unsigned char* bp = reinterpret_cast<const unsigned char*>(b_row) + (lane >> 5) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const ak_f16x8 b = *reinterpret_cast<const ak_f16x8*>(bp + 32 * q);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const ak_f16x8 av = *reinterpret_cast<const ak_f16x8*>(ap + t * 32 * 144 + 32 * q);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b, acc[t], 0, 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // anchors x anchors: loss terms (fwd) and dL/dS + dL/d(sums) (bwd), all tables in one pass
 // ------------------------------------------------------------------------------------------------
 struct AnchorArgs {
     int NT, A, i_lo, i_hi;           // anchor rows [i_lo, i_hi) are this process's shard of block I
     const float* Z[CT_MAXT]; int Dp[CT_MAXT];
+    const _Float16* Zh[CT_MAXT];   // optional (MFMA mode 'f16', tables wider than 128 columns): fp16 copy of table k's rows -- its similarities then run
+                                   // on v_mfma_f32_32x32x16_f16 (fp16 inputs, fp32 accumulate: the arithmetic of wide16.hip's sweeps)
     const double* sums;            // [NT][8]
     float alpha, kc, ki, itc, iti; // ICL alpha; log2e/tau and 1/tau for ICL (c) and IAL (i)
     double* out;                   // fwd: [NT] icl sums, [M] iala, [M] ialb
@@ -1146,6 +1180,20 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
         f32x16 P[NJT], Q[NJT];
         zero_acc<NJT>(P);
         zero_acc<NJT>(Q);
+        const _Float16* Zh = a.Zh[k];
+        if (Zh) {                                               // uniform: fp16 inputs, 64 columns per chunk
+            for (int k0 = 0; k0 < Dp; k0 += 64) {
+                __syncthreads();
+                lds_load_rows_h<128, CT_THREADS>(own1, Zh, Dp, i0, A, k0, Dp, tid);
+                lds_load_rows_h<128, CT_THREADS>(own2, Zh, Dp, A + i0, 2 * A, k0, Dp, tid);
+                lds_load_rows_h<OT, CT_THREADS>(oth1, Zh, Dp, A + j0, 2 * A, k0, Dp, tid);
+                lds_load_rows_h<OT, CT_THREADS>(oth2, Zh, Dp, j0, A, k0, Dp, tid);
+                __syncthreads();
+                const int ro = (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE;
+                mfma_chunk_h<NJT>(P, oth1, own1 + ro, lane);
+                mfma_chunk_h<NJT>(Q, oth2, own2 + ro, lane);
+            }
+        } else
         for (int k0 = 0; k0 < Dp; k0 += SGA_KC) {
             __syncthreads();
             lds_load_rows<128, CT_THREADS>(own1, Z, Dp, i0, A, k0, Dp, tid);
@@ -2105,6 +2153,11 @@ static int fill_anchor(AnchorArgs& a, const float* const* Z, const int* Dp, int 
 
 extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
                                    float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream) {
+    return sga_loss_anchor_fwd_f16(Z, nullptr, Dp, NT, A, sums, alpha, tau_icl, tau_ial, out, a_lo, a_hi, stream);
+}
+
+extern "C" int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
+                                       float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && Dp && sums && out && A >= 0, "sga_loss_anchor_fwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = NT > 1 ? NT - 1 : 0;
@@ -2114,6 +2167,7 @@ extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT,
     int rc = fill_anchor(a, Z, Dp, NT, A, sums, alpha, tau_icl, tau_ial, a_lo, a_hi);
     if (rc) return rc;
     a.out = out;
+    for (int k = 0; k < NT; ++k) a.Zh[k] = Zh ? static_cast<const _Float16*>(Zh[k]) : nullptr;
     hipLaunchKernelGGL(anchor_kernel<false>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(out, NT + 2 * M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_fwd");
@@ -2123,6 +2177,12 @@ extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT,
 extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
                                    float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
                                    double* gs, int a_lo, int a_hi, void* stream) {
+    return sga_loss_anchor_bwd_f16(Z, nullptr, Dp, NT, A, sums, alpha, tau_icl, tau_ial, coef, M1, gs, a_lo, a_hi, stream);
+}
+
+extern "C" int sga_loss_anchor_bwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
+                                       float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
+                                       double* gs, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && Dp && sums && coef && M1 && gs && A >= 0, "sga_loss_anchor_bwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(gs, NT * 8, s, "sga_loss_anchor_bwd")) return rc0;
@@ -2132,6 +2192,7 @@ extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT,
     if (rc) return rc;
     a.coef = coef; a.gs = gs;
     for (int k = 0; k < NT; ++k) { SGA_CHECK_ARG(M1[k], "sga_loss_anchor_bwd: null stash %d", k); a.M1[k] = M1[k]; }
+    for (int k = 0; k < NT; ++k) a.Zh[k] = Zh ? static_cast<const _Float16*>(Zh[k]) : nullptr;
     hipLaunchKernelGGL(anchor_kernel<true>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(gs, NT * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_bwd");

@@ -214,7 +214,7 @@ import ctypes as _ct
 
 
 def _ptr_array(tensors):
-    arr = (_ct.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    arr = (_ct.c_void_p * len(tensors))(*[(t.data_ptr() if t is not None else None) for t in tensors])
     return arr
 
 
@@ -615,7 +615,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
         out = torch.empty((slots * (nt + 2 * m),), device=dev, dtype=torch.float64)
         zarr = _ptr_array(zs)
         dparr = (_ct.c_int * nt)(*dps)
-        _lib.check(L.sga_loss_anchor_fwd(zarr, dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), 0, s.A, st),
+        # (mode 'f16': the wide tables' anchors x anchors similarities take their fp16 copies as well -- fp16 inputs, fp32 accumulate)
+        _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), 0, s.A, st),
                    'sga_loss_anchor_fwd')
         ctx.s, ctx.alpha, ctx.dps, ctx.nt = s, float(alpha), dps, nt
         ctx.shapes = [tuple(t.shape) for t in tables]
@@ -647,8 +648,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
             m1 = [torch.empty((A * cmax,), device=dev, dtype=torch.float32) for _ in range(nt)]
             gsc = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
             for lo, hi in chunks:          # bounded stash: one anchor-row block at a time
-                _lib.check(L.sga_loss_anchor_bwd(_ptr_array(zs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
-                                                 _ptr_array(m1), _p(gsc), lo, hi, st), 'sga_loss_anchor_bwd')
+                _lib.check(L.sga_loss_anchor_bwd_f16(_ptr_array(zs), _ptr_array(zhs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
+                                                     _ptr_array(m1), _p(gsc), lo, hi, st), 'sga_loss_anchor_bwd')
                 gs += gsc[0]
                 for k in range(nt):
                     # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]

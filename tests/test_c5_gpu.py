@@ -138,7 +138,8 @@ F16_TOL = 1e-2          # stated tolerance of the fp16-input path (11-bit operan
 
 @pytest.mark.parametrize('D,stash_rows', [(264, None), (1024, None), (1024, 128), (136, None)])
 def test_f16_wide_loss_equals_fp32_wide_loss(D, stash_rows):
-    """The fp16-input kernels (S, coefficient stashes in both orientations, both gradient GEMMs on v_mfma_f32_32x32x16_f16) against
+    """The fp16-input kernels (S, coefficient stashes in both orientations, both gradient GEMMs on v_mfma_f32_32x32x16_f16; the anchors x
+    anchors similarities of the general-width kernel on the same fp16 copies: sga_loss_anchor_fwd_f16 / _bwd_f16) against
     the exact-fp32 wide-table path on the same ragged batch: loss terms within 1e-2 (observed ~1e-3), gradients within 1e-2 of their
     maximum; also with a workspace that forces several anchor-row blocks."""
     from sgaligner_amd import ops
