@@ -532,15 +532,17 @@ F16X2P_COVERAGE = ('the f16x2 loss sweeps + the PointNet forward in the same spl
                    'point: not faithful); everything else exact fp32')
 # 'f16x2' gradient sweep: the coefficients dL/dS as fp16 hi + lo (True) or rounded to fp16 (False: an independent, unbiased 2^-12 rounding
 # per (anchor, negative) pair; 7 of 31 MFMAs and 1.5 VALU per pair less).  None (default) = hi + lo unless EVERY gradient row sums at least
-# F16X2_COEF_LO_MIN_TERMS pairs: there the rounding noise of a row, 2^-12 / sqrt(terms) <= 6.7e-7 of its largest term, is below the
-# accumulation error the exact-fp32 sweep itself carries (8e-7 .. 2.5e-6 of a table gradient's maximum against fp64).
+# F16X2_COEF_LO_MIN_TERMS pairs: there the rounding noise of a row, 2^-12 / sqrt(terms), is below the accumulation error the exact-fp32
+# sweep itself carries (8e-7 .. 2.5e-6 of a table gradient's maximum against fp64).  2^20: configs[2] (311 296 pairs per row)
+# keeps hi + lo -- dropping lo there is +6 % pairs/s (1 447 vs 1 360) but puts meta_embedding_rel.* (the small remainder of cancelling sums
+# over a table of nearly identical rows) at 2.9 .. 4.3 x its fp32 rerun noise from run to run instead of 2.3 .. 2.9 x.
 # 'f16x2': the A x A stash products on split-fp16 MFMA (csrc/stashh.hip).  OFF by default: 7.4 vs 8.4 ms per 2048 x 155 648 block for the exact-fp32
 # GEMMs (tools/bench_aa.py; plus one pass over the stash for its largest |value|) -- at best -0.04 s of a 2.9 s configs[2] step -- while the gate's margin on meta_embedding_rel.bias shrinks from 3.7 to 4.0 x
 # the rerun noise (profiles/r04_v_bench_c3.json).  Kept as a measured experiment with its C-ABI test.
 F16X2_STASH = _os.environ.get('SGA_F16X2_STASH', '0') == '1'
 F16X2_AA = _os.environ.get('SGA_F16X2_AA', '1') != '0'       # 'f16x2': the symmetric A x A kernel's similarities on split-fp16 MFMA (tools / tests flip it)
 F16X2_COEF_LO = {'1': True, '0': False}.get(_os.environ.get('SGA_F16X2_COEF_LO', ''), None)
-F16X2_COEF_LO_MIN_TERMS = 1 << 17
+F16X2_COEF_LO_MIN_TERMS = 1 << 20
 
 
 # 'f16x2' forward sums: full three-product similarities (True) or hi.hi only on the 96 main columns (False: 4 instead of 10 MFMAs per tile).
