@@ -121,11 +121,13 @@ def test_error_vs_fp64_oracle_at_most_twice_the_fp32_paths(pairs, nobj, seed):
         assert b[k] < (1e-4 if k == 'loss' else 1e-3), (k, b[k])
 
 
-def test_train_step_vs_oracle(f16x2):
+@pytest.mark.parametrize('mods', [['point', 'gat', 'rel'], ['point', 'gat', 'rel', 'attr']])
+def test_train_step_vs_oracle(f16x2, mods):
+    """One training step in the mode against the oracle, for the three-module list of the headline and the reference's full module list
+    (M = 4: sweeph_kernel<4, ...>, the symmetric A x A kernel with 16 anchor rows per workgroup)."""
     from oracle import sga_oracle as O
     from sgaligner_amd.synthetic import make_batch, to_device
     from sgaligner_amd.trainer import AlignerSteps
-    mods = ['point', 'gat', 'rel']
     dd = make_batch(3, 20, 96, seed=8, ragged=True)
     steps = AlignerSteps(mods, device='cuda', seed=3)
     params = {k: v.detach().cpu().clone() for k, v in steps.model.state_dict().items() if 'num_batches' not in k}
