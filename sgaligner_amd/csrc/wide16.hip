@@ -57,12 +57,13 @@ __device__ __forceinline__ float coef_bound(const double* gs, int fam, float k0,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(W_THREADS, 2) void wide16_kernel(W16Args a) {
+__device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
     __shared__ __attribute__((aligned(16))) f16 As[W_T * W_LS];
     __shared__ __attribute__((aligned(16))) f16 Bs[W_T * W_LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * W_T, n0 = blockIdx.x * W_T;
-    const int kb = blockIdx.z * a.kper, ke = min(a.K, kb + a.kper);
+    if (m0 >= a.M || n0 >= a.N) return;                      // (batched launches: the grid is the largest family's)
+    const int kb = bz * a.kper, ke = min(a.K, kb + a.kper);
     if (kb >= ke) return;
 
     f32x16 acc[4];
@@ -152,6 +153,19 @@ __global__ __launch_bounds__(W_THREADS, 2) void wide16_kernel(W16Args a) {
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(W_THREADS, 2) void wide16_kernel(W16Args a) { wide16_body<MODE>(a, blockIdx.z); }
+
+// The four sum families of a table in ONE launch (blockIdx.z = family * zper + K split): 16 launches of ~85 us per table and backward at
+// configs[4] -- grids of a few hundred tiles each -- become 4.
+struct W16Batch { W16Args a[4]; int n, zper; };
+template <int MODE>
+__global__ __launch_bounds__(W_THREADS, 2) void wide16_batch_kernel(W16Batch b) {
+    const int q = blockIdx.z / b.zper;
+    if (q >= b.n) return;
+    wide16_body<MODE>(b.a[q], blockIdx.z - q * b.zper);
+}
+
 // Z fp32 [R][Dp] -> Zh fp16 [R][Dp] and ZhT fp16 [Dp][ldt] (column of packed row r: r + shift of its segment)
 struct PrepArgs { const float* Z; int R, Dp; f16* Zh; f16* ZhT; long ldt; int seg_end[4]; int shift[4]; };
 __global__ __launch_bounds__(256) void wide16_prepare_kernel(PrepArgs a) {
@@ -191,6 +205,15 @@ inline SegCols seg_cols(int A, int J1, int J2) {
 template <int MODE>
 void launch(const W16Args& a, int ksplit, hipStream_t s) {
     hipLaunchKernelGGL(wide16_kernel<MODE>, dim3((a.N + W_T - 1) / W_T, (a.M + W_T - 1) / W_T, ksplit), dim3(W_THREADS), 0, s, a);
+}
+template <int MODE>
+void launch_batch(W16Batch& b, const int* ksplit, hipStream_t s) {
+    int gx = 1, gy = 1, kz = 1;
+    for (int q = 0; q < b.n; ++q) {
+        gx = max(gx, (b.a[q].N + W_T - 1) / W_T); gy = max(gy, (b.a[q].M + W_T - 1) / W_T); kz = max(kz, ksplit[q]);
+    }
+    b.zper = kz;
+    hipLaunchKernelGGL(wide16_batch_kernel<MODE>, dim3(gx, gy, kz * b.n), dim3(W_THREADS), 0, s, b);
 }
 
 }  // namespace
@@ -234,6 +257,8 @@ extern "C" int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int 
     Blk b[4];
     four_blocks(b, A, J1, J2);
     const f16* Z = static_cast<const f16*>(Zh);
+    W16Batch bs{};
+    int ones[4] = {1, 1, 1, 1};
     for (int q = 0; q < 4; ++q) {
         if (b[q].n_own == 0 || b[q].n_oth == 0) continue;
         W16Args a{};
@@ -241,8 +266,9 @@ extern "C" int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int 
         a.B = Z + (size_t)b[q].oth_row * Dp; a.ldb = Dp; a.N = b[q].n_oth;
         a.K = Dp; a.kper = (Dp + W_KC - 1) / W_KC * W_KC;
         a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.fam = b[q].fam; a.sums = sums8;
-        launch<W_SUMS>(a, 1, s);
+        bs.a[bs.n++] = a;
     }
+    if (bs.n) launch_batch<W_SUMS>(bs, ones, s);               // the four families in one launch
     fold_slots(sums8, 8, s);
     SGA_CHECK_LAUNCH("sga_loss_neg_sums_f16");
     return SGA_OK;
@@ -251,7 +277,7 @@ extern "C" int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int 
 // bytes of stash for anchor-row blocks of `rows` anchors (one (X, N) block at a time: C [rows][pad8(J)] + C^T [J][pad8(rows)], fp16)
 extern "C" size_t sga_loss_neg_grad_f16_bytes(int A, int J1, int J2) {
     const int J = J1 > J2 ? J1 : J2;
-    return sizeof(f16) * ((size_t)A * pad8(J) + (size_t)J * pad8(A)) + 256;
+    return 4 * (sizeof(f16) * ((size_t)A * pad8(J) + (size_t)J * pad8(A)) + 256);     // four stash pairs: the four families share their launches
 }
 
 extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, int A, int J1, int J2, float tau0, float tau1,
@@ -281,12 +307,16 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
         kper = ((K + ks - 1) / ks + W_KC - 1) / W_KC * W_KC;
         return (K + kper - 1) / kper;
     };
+    // one stash pair per family if the workspace holds four (then the four families share every launch), else family by family
+    const bool batched = 4 * need(rows) <= stash_bytes;
     for (int lo = 0; lo < A; lo += (int)rows) {
         const int ns = (lo + (int)rows < A ? (int)rows : A - lo);
+        W16Batch bc{}, bct{}, bg1{}, bg2{};
+        int k1s[4], k2s[4], ones[4] = {1, 1, 1, 1};
         for (int q = 0; q < 4; ++q) {
             const int J = b[q].n_oth;
             if (J == 0) continue;
-            f16* C = static_cast<f16*>(stash);                               // [ns][pad8(J)]   anchor-major
+            f16* C = reinterpret_cast<f16*>(static_cast<unsigned char*>(stash) + (batched ? (size_t)q * (need(rows) / 16 * 16) : 0));   // [ns][pad8(J)]   anchor-major
             f16* CT = C + ((size_t)ns * pad8(J) + 7) / 8 * 8;                // [J][pad8(ns)]   negative-major
             W16Args a{};
             a.K = Dp; a.kper = (Dp + W_KC - 1) / W_KC * W_KC;
@@ -295,12 +325,12 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
             a.A = Z + (size_t)(b[q].own_row + lo) * Dp; a.lda = Dp; a.M = ns;
             a.B = Z + (size_t)b[q].oth_row * Dp; a.ldb = Dp; a.N = J;
             a.cout = C; a.ldc = pad8(J);
-            launch<W_COEF>(a, 1, s);
+            if (batched) bc.a[bc.n++] = a; else launch<W_COEF>(a, 1, s);
             // C^T: rows = negatives, lanes along the anchors
             a.A = Z + (size_t)b[q].oth_row * Dp; a.M = J;
             a.B = Z + (size_t)(b[q].own_row + lo) * Dp; a.N = ns;
             a.cout = CT; a.ldc = pad8(ns);
-            launch<W_COEF>(a, 1, s);
+            if (batched) bct.a[bct.n++] = a; else launch<W_COEF>(a, 1, s);
             // dZ[anchors] += alpha C Z[negatives]          (B operand: ZhT rows = columns d, k = negative)
             W16Args g{};
             g.k0 = a.k0; g.k1 = a.k1; g.it0 = a.it0; g.it1 = a.it1; g.gs = gs8; g.fam = b[q].fam;
@@ -309,14 +339,20 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
             g.K = J;
             g.out = dZ + (size_t)(b[q].own_row + lo) * Dp; g.ldo = Dp;
             int ks = ksplit_for(g.M, g.N, g.K, g.kper);
-            launch<W_GEMM>(g, ks, s);
+            if (batched) { k1s[bg1.n] = ks; bg1.a[bg1.n++] = g; } else launch<W_GEMM>(g, ks, s);
             // dZ[negatives] += alpha C^T Z[anchors of the block]
             g.A = CT; g.lda = pad8(ns); g.M = J;
             g.B = ZT + b[q].own_col + lo; g.N = Dp;
             g.K = ns;
             g.out = dZ + (size_t)b[q].oth_row * Dp;
             ks = ksplit_for(g.M, g.N, g.K, g.kper);
-            launch<W_GEMM>(g, ks, s);
+            if (batched) { k2s[bg2.n] = ks; bg2.a[bg2.n++] = g; } else launch<W_GEMM>(g, ks, s);
+        }
+        if (batched && bc.n) {
+            launch_batch<W_COEF>(bc, ones, s);
+            launch_batch<W_COEF>(bct, ones, s);
+            launch_batch<W_GEMM>(bg1, k1s, s);
+            launch_batch<W_GEMM>(bg2, k2s, s);
         }
     }
     SGA_CHECK_LAUNCH("sga_loss_neg_grad_f16");
