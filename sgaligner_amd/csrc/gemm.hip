@@ -164,16 +164,19 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_small_kernel(const TA* __rest
 // K % 4 == 0, no split-K): the next K chunk travels global -> registers while the MFMAs of the current one run, so a
 // workgroup does not alternate between "everybody loads" and "everybody multiplies" (the generic kernel above: 59
 // TFLOP/s on the PCT per-point layers).
+template <int MT>
 __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __restrict__ A, long lda,
                                                              const float* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc,
                                                              const float* __restrict__ bias, int M, int N, int K,
                                                              int accumulate, int act, const float* __restrict__ resid,
                                                              long ldr, double* __restrict__ colstats) {
-    __shared__ __attribute__((aligned(16))) float As[128 * SGA_LDS_STRIDE];
+    // MT = rows of A per workgroup (128, or 64 when the 128-row grid would leave most of the chip idle in its last round: gemm_launch)
+    constexpr int NTA = MT / 32;
+    __shared__ __attribute__((aligned(16))) float As[MT * SGA_LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Bs[128 * SGA_LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int m0 = blockIdx.x * MT, n0 = blockIdx.y * 128;
     constexpr int V = SGA_KC / 4;                       // quads per tile row
     f32x4 ra[4], rb[4];
     auto gload = [&](int k0) {
@@ -182,24 +185,24 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
             const int e = i * GM_THREADS + tid, r = e / V, c = (e % V) * 4;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const bool kin = k0 + c < K;                // K % 4 == 0: a quad is inside or outside as a whole
-            ra[i] = (m0 + r < M && kin) ? *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * lda + k0 + c) : z;
+            if (i < NTA) ra[i] = (m0 + r < M && kin) ? *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * lda + k0 + c) : z;
             rb[i] = (n0 + r < N && kin) ? *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + r) * ldb + k0 + c) : z;
         }
     };
-    f32x16 acc[4];
-    zero_acc<4>(acc);
+    f32x16 acc[NTA];
+    zero_acc<NTA>(acc);
     gload(0);
     for (int k0 = 0; k0 < K; k0 += SGA_KC) {
         __syncthreads();                                // the previous chunk's operand reads are done
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = i * GM_THREADS + tid, r = e / V, c = (e % V) * 4;
-            *reinterpret_cast<f32x4*>(As + r * SGA_LDS_STRIDE + c) = ra[i];
+            if (i < NTA) *reinterpret_cast<f32x4*>(As + r * SGA_LDS_STRIDE + c) = ra[i];
             *reinterpret_cast<f32x4*>(Bs + r * SGA_LDS_STRIDE + c) = rb[i];
         }
         __syncthreads();
         if (k0 + SGA_KC < K) gload(k0 + SGA_KC);       // in flight under the MFMAs below
-        mfma_chunk<4>(acc, As, Bs + (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE, lane);
+        mfma_chunk<NTA>(acc, As, Bs + (wave * 32 + (lane & 31)) * SGA_LDS_STRIDE, lane);
     }
     const int n = n0 + wave * 32 + (lane & 31);
     const bool nv = n < N;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
     const int h = lane >> 5;
     float cs = 0.f, cq = 0.f;                           // column sum / sum of squares of what is written (colstats != null)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTA; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + t * 32 + mfma32_row(r, h);
@@ -445,7 +448,16 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
         return SGA_OK;
     }
     if (!a_is_f64 && !transA && transB && splits == 1 && a_al && b_al && K % 4 == 0) {
-        hipLaunchKernelGGL(gemm_nt_kernel, dim3(gx, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
+        // 64-row tiles when the 128-row grid ends in a mostly idle round (4 workgroups per CU: 163 840 rows x 128 columns = 1 280 tiles on
+        // 1 024 slots run two rounds for 1.25 rounds of work; 2 560 half tiles run 2.5)
+        const int slots = 4 * ncu, tiles = gx * gy, last = tiles % slots;
+        if (tiles > slots && tiles < 3 * slots && last > 0 && last * 2 < slots) {
+            hipLaunchKernelGGL(gemm_nt_kernel<64>, dim3((M + 63) / 64, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
+                               bias, M, N, K, accumulate, act, resid, ldr, colstats);
+            SGA_CHECK_LAUNCH("sga_gemm");
+            return SGA_OK;
+        }
+        hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3(gx, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
                            bias, M, N, K, accumulate, act, resid, ldr, colstats);
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;
