@@ -23,15 +23,10 @@ extern "C" {
 int sga_version(void);                 /* 100 * major + minor */
 const char* sga_last_error(void);
 int sga_device_cus(void);
-/* Arithmetic of the MFMA kernels that have a split-precision variant (sga_pointnet_fwd): 0 = exact fp32 (default; every
- * headline number), 1 = split-bf16 x3 (each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product into an fp32
- * accumulator; relative error ~1e-5), 2 = fp16 inputs for loss tables wider than 128 columns (configs[4]), 3 = split-fp16
- * (each fp32 operand as fp16 hi + lo of 4096 x, three fp16 MFMAs per product into an fp32 accumulator: the loss sweeps carry
- * fp32's own rounding error -- the mode ops.set_mfma_mode('f16x2') selects; everything else stays exact fp32), 4 = mode 3 + the PointNet
- * forward in the same split ('f16x2p': values to 6e-7, but a point max that ties to fp32 rounding may pick the other point).  Returns the
- * previous mode (-1 on a bad argument).  SGA_MFMA_MODE=bf16x3 | f16 | f16x2 | f16x2p in the environment selects the mode at first use. */
-int sga_set_mfma_mode(int mode);
-int sga_get_mfma_mode(void);
+/* The library is STATELESS (SURVEY 8(b) "Threading"): no entry point reads or writes a process-global setting.  Which arithmetic a
+ * call uses is either in its name (sga_loss_multi_sums = exact fp32 MFMA, _bf16x6 = three exact bf16 planes, _f16x2 = two fp16 planes,
+ * _bf16x3 = two bf16 planes, *_f16 = fp16 inputs for wide tables) or an explicit argument (sga_pointnet_fwd_ws: mode).  The policy --
+ * which of them a training step calls -- lives in the caller (sgaligner_amd.ops.set_mfma_mode, SGA_MFMA_MODE). */
 
 /* ---- PointNet object encoder ------------------------------------------------------------------------
  * replaces PointNetfeat.forward, src/aligner/networks/pointnet.py:120-175 (called sg_aligner.py:115):
@@ -46,14 +41,15 @@ int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const flo
  * (max, arg-max) pairs are folded by a second small kernel -- identical results, per-object latency / 8.  workspace may be NULL
  * (then this is sga_pointnet_fwd). */
 size_t sga_pointnet_fwd_ws_bytes(int T, int C3);
-/* MFMA modes 'f16x2' (3) and 'f16' (2) with argmax != NULL: the forward runs in the fp16 hi + lo split and needs workspace >= 4 (T + 1) bytes; it leaves
- * [count | object ids] (int32) there: the objects in which some channel's two largest layer-3 values were distinct and within
- * eps * (|a| + |b| + max|z| / 8) -- they were re-run on the exact-fp32 kernel, their values and arg-maxes are that kernel's bits.  sga_pointnet_tie_eps sets eps (default 2^-17) and returns the
- * previous value; a negative argument only reads.  pointnet.py:140-161 (the max-pool's arg-max routes the backward). */
-float sga_pointnet_tie_eps(float eps);
+/* mode: the forward's arithmetic.  0 = exact fp32 (sga_pointnet_fwd is this); 1 = every operand as bf16 hi + lo, three bf16 MFMAs per
+ * product; 2 = fp16 hi + lo of scaled operands (values within 6e-7 of mode 0) and, with argmax != NULL, an exact-fp32 re-run of every
+ * object in which some channel's two largest layer-3 values lie within tie_eps * (|a| + |b| + max|z| / 8) of each other or a pre-activation
+ * within that margin of zero: needs workspace >= 4 (T + 1) bytes and leaves [count | object ids] (int32) there; the listed objects carry
+ * the fp32 kernel's own bits (values and arg-maxes), so the max-pool's arg-max routes the backward exactly as in mode 0
+ * (pointnet.py:140-161); 3 = mode 2 without the re-run.  tie_eps < 0: the default 2^-17. */
 int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
-                        void* workspace, size_t ws_bytes, void* stream);
+                        void* workspace, size_t ws_bytes, int mode, float tie_eps, void* stream);
 /* autograd of the above wrt the six parameters (sparse through the max-pool); gy [T,C3]; C3 == 256. */
 int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy, const float* w1,
                      const float* b1, const float* w2, const float* b2, const float* w3, float* gw1, float* gb1,
@@ -241,6 +237,22 @@ int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, i
 int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                               const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, int coef_lo, void* stream);
 
+/* ---- the two fused sweeps with every fp32 operand split EXACTLY into three bf16 terms (ops.set_mfma_mode('bf16x6'); sweep3.hip) ------
+ * replaces src/aligner/losses.py:5-15 (calculate_prob_dist's anchors x negatives products) and its autograd, like sga_loss_multi_sums /
+ * sga_loss_multi_grad, in fp32 arithmetic on the bf16 matrix pipe: x = h + m + l (8 + 8 + 8 significand bits, fp32's exponent range: every
+ * fp32 value exactly), a product = the six partial products down to 2^-16 relative on v_mfma_f32_16x16x32_bf16 into one fp32 accumulator
+ * (the dropped three are <= 2^-23 of the product), i.e. 6/16 of the fp32 MFMA's matrix time at fp32's own accuracy ("fp32 MFMA
+ * or split-bf16 x3").  M = 2 or 3 tables, emb_dim <= 100 (columns 100, 101 of the planes carry the row centring's bookkeeping).
+ * sga_loss_split3_tables: packed fp32 table Z [R(+32), 104] -> Zb, 32-row blocks of bf16 h / m / l planes in MFMA operand order + two
+ * packed K-tail images (sga_loss_split3_bytes bytes; segments X1 | X2 | N1 | N2 each padded to whole blocks; column means summed in a
+ * fixed order: the planes are bitwise reproducible).  The other arguments and every output: as sga_loss_multi_sums / sga_loss_multi_grad. */
+size_t sga_loss_split3_bytes(int A, int J1, int J2);
+int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
+int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                               double* sums, int a_lo, int a_hi, void* stream);
+int sga_loss_multi_grad_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                               const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
+
 /* ---- loss_group = b: the same loss on G independent groups of b consecutive pairs ------------------------
  * replaces the reference trainer feeding b pairs per iteration (configs/scan3r/scan3r_ground_truth.yaml:27,
  * src/engine/epoch_based_trainer.py:91-93 -> src/aligner/losses.py:114-152) for all B/b groups of a device batch at once:
@@ -250,13 +262,14 @@ int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, i
  * row, #N2, 0, 0} (contiguous ranges inside [0,A) / [0,J1) / [0,J2)); s_off [G+1] int64 float offsets of the groups'
  * similarity blocks [2 na, na+nj1+nj2] inside one table's slab of S [M][s_total].  sums [G][NT][8], out [G][NT+2M]
  * (NT = M+1, or 1 and no IAL columns when M == 1).  bwd: coef [G][NT+2M] = dL/d(out); S (as left by fwd) is overwritten
- * with dL/dS; dZ[m] += this batch's gradient (every packed row has one writer); gamma [G][M] = dL/dbeta per group. */
+ * with dL/dS; dZ[m] += this batch's gradient (every packed row has one writer); gamma [G][M] = dL/dbeta per group.
+ * use_valu: 1 = the VALU forms of the similarity / gradient kernels (kept for cross-checks), 0 = MFMA (what the product passes). */
 int sga_group_loss_fwd(const float* const* Z, int M, const float* beta, int A, int J1, const int32_t* groups, int G,
                        const int64_t* s_off, int64_t s_total, float alpha, float tau_icl, float tau_ial, float* S,
-                       double* sums, double* out, void* stream);
+                       double* sums, double* out, int use_valu, void* stream);
 int sga_group_loss_bwd(const float* const* Z, int M, const float* beta, int A, int J1, const int32_t* groups, int G,
                        const int64_t* s_off, int64_t s_total, float alpha, float tau_icl, float tau_ial, float* S,
-                       const double* sums, const float* coef, float* const* dZ, double* gamma, void* stream);
+                       const double* sums, const float* coef, float* const* dZ, double* gamma, int use_valu, void* stream);
 
 /* ---- per-pair similarity + ranking --------------------------------------------------------------------
  * replaces eval_step's emb/||emb||, sim = 1 - emb emb^T, argsort (src/inference/sgaligner/inference_align_reg.py:
@@ -362,9 +375,6 @@ int sga_hull_candidates(const float* pts, const int32_t* offsets, int n_obj, uns
  * must run Qhull on that object (utils/point_cloud.py does).  preprocessing/scan3r/preprocess.py:93-96. */
 int sga_hull_max_candidates(void);
 int sga_hull_vertices(const double* pts, const int32_t* offsets, int n_obj, unsigned char* is_vertex, int32_t* status, void* stream);
-
-/* loss_group kernels: 1 = the VALU forms of the similarity / gradient kernels (kept for cross-checks), 0 = MFMA (default); returns the old value. */
-int sga_set_group_valu(int on);
 
 /* Wide tables (Dp > 128) of sga_loss_neg_grad: one anchor-owner sweep writes c_ij = dL/dS_ij to a caller-owned stash (anchor-row blocks
  * sized to stash_floats; sga_loss_neg_grad_wide_floats() = everything in one block), both gradients are GEMMs on it: the K = Dp

@@ -31,6 +31,7 @@ def _newer(src_list, target):
 FILE_FLAGS = {'contrastive.hip': ['-fno-slp-vectorize'],
               'sweepb.hip': ['-fno-slp-vectorize'],     # bf16x3 gradient sweep 7.58 -> 7.21 ms, sums 2.51 -> 2.62 ms at configs[1]
               'sweeph.hip': ['-fno-slp-vectorize'],
+              'sweep3.hip': ['-fno-slp-vectorize'],
               'stashh.hip': ['-fno-slp-vectorize']}
 
 

@@ -21,12 +21,8 @@ SIGNATURES = {
     'sga_version': (I, []),
     'sga_last_error': (c_char_p, []),
     'sga_device_cus': (I, []),
-    'sga_set_mfma_mode': (I, [I]),
-    'sga_get_mfma_mode': (I, []),
     'sga_pointnet_fwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
     'sga_pointnet_fwd_ws_bytes': (c_size_t, [I, I]),
-    'sga_pointnet_tie_eps': (F, [F]),
-    'sga_set_group_valu': (I, [I]),
     'sga_loss_neg_grad_wide_floats': (c_size_t, [I, I, I]),
     'sga_loss_neg_grad_wide': (I, [P, I, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
     'sga_wide16_ldt': (c_long, [I, I, I]),
@@ -36,7 +32,7 @@ SIGNATURES = {
     'sga_loss_neg_grad_f16': (I, [P, P, I, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
     'sga_loss_head_fwd': (I, [P, I, P, P, I, c_double, c_double, c_double, c_double, P, P]),
     'sga_loss_head_bwd': (I, [P, P, I, P, P, I, c_double, c_double, c_double, c_double, P, P, P, P]),
-    'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, P]),
+    'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, I, F, P]),
     'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, P]),
     'sga_gat_complete_flags': (I, [P, P, P, I, P, P]),
     'sga_gat_attn_fwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
@@ -105,8 +101,12 @@ SIGNATURES = {
     'sga_loss_split16_tables': (I, [P, I, I, I, P, P]),
     'sga_loss_multi_sums_f16x2': (I, [P, I, P, I, I, I, F, F, P, I, I, I, P]),
     'sga_loss_multi_grad_f16x2': (I, [P, I, P, I, I, I, F, F, P, P, P, I, I, I, P]),
-    'sga_group_loss_fwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, P]),
-    'sga_group_loss_bwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, P, P, P]),
+    'sga_loss_split3_bytes': (c_size_t, [I, I, I]),
+    'sga_loss_split3_tables': (I, [P, I, I, I, P, P]),
+    'sga_loss_multi_sums_bf16x6': (I, [P, I, P, I, I, I, F, F, P, I, I, P]),
+    'sga_loss_multi_grad_bf16x6': (I, [P, I, P, I, I, I, F, F, P, P, P, I, I, P]),
+    'sga_group_loss_fwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, I, P]),
+    'sga_group_loss_bwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, P, P, I, P]),
     'sga_fusion_fwd': (I, [P, I, P, P, I, I, P]),
     'sga_fusion_bwd_workspace_bytes': (c_size_t, [I]),
     'sga_fusion_bwd': (I, [P, I, P, P, P, P, I, I, P, c_size_t, P]),

@@ -22,18 +22,6 @@
 #include "loss_math.h"
 #include "mfma_tiles.h"
 
-static int g_group_grad_valu = -1;
-static int sga_group_grad_valu() {
-    if (g_group_grad_valu < 0) { const char* e = getenv("SGA_GROUP_GRAD_VALU"); g_group_grad_valu = (e && e[0] == '1') ? 1 : 0; }
-    return g_group_grad_valu;
-}
-
-extern "C" int sga_set_group_valu(int on) {          // 1: the VALU forms of group_sim / group_grad (cross-checks); returns the old value
-    const int old = sga_group_grad_valu();
-    g_group_grad_valu = on ? 1 : 0;
-    return old;
-}
-
 namespace {
 
 constexpr int GL_THREADS = 256;
@@ -493,14 +481,14 @@ __global__ __launch_bounds__(GL_THREADS) void group_grad_mfma_kernel(GroupArgs a
 
 extern "C" int sga_group_loss_fwd(const float* const* Z, int M, const float* beta, int A, int J1, const int32_t* groups, int G,
                                   const int64_t* s_off, int64_t s_total, float alpha, float tau_icl, float tau_ial, float* S,
-                                  double* sums, double* out, void* stream) {
+                                  double* sums, double* out, int use_valu, void* stream) {
     if (G == 0) return SGA_OK;
     GroupArgs a{};
     if (int rc = fill_group_args(a, Z, M, beta, A, J1, groups, G, s_off, s_total, alpha, tau_icl, tau_ial, S, "sga_group_loss_fwd")) return rc;
     SGA_CHECK_ARG(sums && out, "sga_group_loss_fwd: null output");
     a.sums = sums; a.out = out;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sga_group_grad_valu()) {
+    if (use_valu) {
         hipLaunchKernelGGL(group_sim_kernel, dim3(G, M), dim3(GL_THREADS), 0, s, a);
     } else {
         int gz = (8 * sga_num_cus()) / (G * M > 0 ? G * M : 1);
@@ -518,7 +506,7 @@ extern "C" int sga_group_loss_fwd(const float* const* Z, int M, const float* bet
 
 extern "C" int sga_group_loss_bwd(const float* const* Z, int M, const float* beta, int A, int J1, const int32_t* groups, int G,
                                   const int64_t* s_off, int64_t s_total, float alpha, float tau_icl, float tau_ial, float* S,
-                                  const double* sums, const float* coef, float* const* dZ, double* gamma, void* stream) {
+                                  const double* sums, const float* coef, float* const* dZ, double* gamma, int use_valu, void* stream) {
     if (G == 0) return SGA_OK;
     GroupArgs a{};
     if (int rc = fill_group_args(a, Z, M, beta, A, J1, groups, G, s_off, s_total, alpha, tau_icl, tau_ial, S, "sga_group_loss_bwd")) return rc;
@@ -530,7 +518,7 @@ extern "C" int sga_group_loss_bwd(const float* const* Z, int M, const float* bet
     else if (M == 2) hipLaunchKernelGGL(group_bwd_kernel<2>, dim3(G), dim3(GL_THREADS), 0, s, a);
     else if (M == 3) hipLaunchKernelGGL(group_bwd_kernel<3>, dim3(G), dim3(GL_THREADS), 0, s, a);
     else hipLaunchKernelGGL(group_bwd_kernel<4>, dim3(G), dim3(GL_THREADS), 0, s, a);
-    if (sga_group_grad_valu()) {
+    if (use_valu) {
         hipLaunchKernelGGL(group_grad_kernel, dim3(G, M), dim3(GL_THREADS), 0, s, a);
     } else {
         int gz = (8 * sga_num_cus()) / (G * M > 0 ? G * M : 1);          // tiles of a group are spread over gz workgroups of 4 waves

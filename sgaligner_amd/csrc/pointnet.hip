@@ -463,18 +463,21 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
     }
 }
 
-static float g_tie_eps = 1.0f / 131072.f;      // 2^-17 of |leader| + |runner-up| (+ 2^-20 of the object's largest |z|): none of the 2.7e8 arg-maxes / masks of a configs[2] batch differs from the fp32 kernel's at 2^-18 already; 9 % of the objects re-run (tools/dbg/f16x2_pointnet_flips.py)
+// Forward arithmetic, chosen PER CALL (the library keeps no mode): 0 = exact fp32; 1 = bf16 hi + lo (three bf16 MFMAs per product);
+// 2 = fp16 hi + lo split with every near-tied object re-run on the exact-fp32 kernel (needs the [count | ids] workspace with argmax);
+// 3 = the fp16 split without the re-run.
+constexpr float PN_TIE_EPS_DEFAULT = 1.0f / 131072.f;      // 2^-17 of |leader| + |runner-up| (+ 2^-20 of the object's largest |z|): none of the 2.7e8 arg-maxes / masks of a configs[2] batch differs from the fp32 kernel's at 2^-18 already; 9 % of the objects re-run (tools/dbg/f16x2_pointnet_flips.py)
 
 template <int C3>
 int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                const float* w3, const float* b3, float* y, int* argmax, int T, int P, hipStream_t stream,
-               void* workspace = nullptr, size_t ws_bytes = 0) {
+               void* workspace, size_t ws_bytes, int mode, float tie_eps) {
     const size_t lds_bytes = (size_t)(8192 + C3 * 128) * sizeof(float);
     int grid = (T + PN_WAVES - 1) / PN_WAVES;
     const int ncu = sga_num_cus();
     if (grid > ncu) grid = ncu;
     // few objects: one object per workgroup, its tiles dealt to the 8 waves (exact fp32 kernel only; needs the partials workspace)
-    if ((sga_mfma_mode() == 0 || sga_mfma_mode() == 2 || sga_mfma_mode() == 3) && workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32) {
+    if ((mode == 0 || mode == 2) && workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32) {
         float2* part = static_cast<float2*>(workspace);
         const int g2 = T < ncu ? T : ncu;
         if (argmax) {
@@ -491,14 +494,14 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         return SGA_OK;
     }
     // ('f16', the configs[4] mode -- fp16 inputs for the loss GEMMs of wide tables -- takes the same fp32-faithful forward: PointNet is 46 % of its step)
-    const bool split_fwd = sga_mfma_mode() == 3 || sga_mfma_mode() == 2;
+    const bool split_fwd = mode == 2;
     if (split_fwd && argmax) {             // 'f16x2', training: the forward in the fp16 split, objects with a near-tied arg-max re-run in exact fp32
         if (!workspace || ws_bytes < (size_t)(T + 1) * sizeof(int)) { sga_set_error("sga_pointnet_fwd: modes 'f16x2' / 'f16' need a workspace of 4 (T + 1) bytes, T = %d (sga_pointnet_fwd_ws)", T); return SGA_ERR_ARG; }
         int* redo = static_cast<int*>(workspace);
         if (hipMemsetAsync(redo, 0, sizeof(int), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd: memset failed"); return SGA_ERR_HIP; }
         auto k = pointnet_fwd_bf16x3_kernel<C3, true, true, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, redo, g_tie_eps);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, redo, tie_eps >= 0.f ? tie_eps : PN_TIE_EPS_DEFAULT);
         auto k2 = pointnet_fwd_kernel<C3, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL(k2, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr),
@@ -507,7 +510,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
-    } else if (sga_mfma_mode() == 4) {     // 'f16x2p': the split-fp16 sweeps AND this forward in the same split, arg-maxes as the split finds them
+    } else if (mode == 3) {     // 'f16x2p': the split-fp16 sweeps AND this forward in the same split, arg-maxes as the split finds them
         if (argmax) {
             auto k = pointnet_fwd_bf16x3_kernel<C3, true, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -517,7 +520,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
         }
-    } else if (sga_mfma_mode() == 1) {
+    } else if (mode == 1) {
         if (argmax) {
             auto k = pointnet_fwd_bf16x3_kernel<C3, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -544,46 +547,36 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
 
 extern "C" size_t sga_pointnet_fwd_ws_bytes(int T, int C3) { return (size_t)(T > 0 ? T : 0) * PN_WAVES * (C3 > 0 ? C3 : 0) * sizeof(float2); }
 
-/* 'f16x2' forward with arg-max: relative distance of a channel's two largest layer-3 values below which the object is re-run in exact fp32
- * (eps * (|leader| + |runner-up|)).  Returns the previous value; eps < 0 only reads.  After the call the int workspace holds [count | object ids]. */
-extern "C" float sga_pointnet_tie_eps(float eps) {
-    const float old = g_tie_eps;
-    if (eps >= 0.f) g_tie_eps = eps;
-    return old;
-}
-
 static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                              const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,
-                             void* stream);
-
-extern "C" int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                                   const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
-                                   void* workspace, size_t ws_bytes, void* stream) {
-    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, stream);
-}
-
-extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const float* w2,
-                                const float* b2, const float* w3, const float* b3, float* y,
-                                int32_t* argmax, int T, int P, int C3, void* stream) {
-    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, nullptr, 0, stream);
-}
-
-static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
-                             const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,
-                             void* stream) {
+                             int mode, float tie_eps, void* stream) {
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_fwd: need T >= 0 and P >= 1 (got T=%d P=%d)", T, P);
+    SGA_CHECK_ARG(mode >= 0 && mode <= 3, "sga_pointnet_fwd: mode %d (0 = exact fp32, 1 = bf16 hi + lo, 2 = fp16 hi + lo with the exact re-run of near-ties, 3 = fp16 hi + lo)", mode);
     // a zero-object shard (T == 0: empty tensors carry null data pointers) is a valid no-op
     SGA_CHECK_ARG((T == 0 || (x && y)) && w1 && b1 && w2 && b2 && w3 && b3, "sga_pointnet_fwd: null pointer");
     if (T == 0) return SGA_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (C3) {
-        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes);
-        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes);
-        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes);
+        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps);
+        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps);
+        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps);
         default:
             sga_set_error("sga_pointnet_fwd: out_size C3=%d unsupported (64, 128 or 256: W3 must fit the 160 KiB LDS)", C3);
             return SGA_ERR_ARG;
     }
+}
+
+extern "C" int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
+                                   void* workspace, size_t ws_bytes, int mode, float tie_eps, void* stream) {
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, mode, tie_eps, stream);
+}
+
+/* the no-workspace entry: always the exact-fp32 kernel */
+extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, float* y,
+                                int32_t* argmax, int T, int P, int C3, void* stream) {
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, nullptr, 0, 0, -1.f, stream);
 }
 
 // =================================================================================================

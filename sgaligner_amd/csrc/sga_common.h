@@ -37,8 +37,6 @@ void sga_set_error(const char* fmt, ...);
         }                                                                           \
     } while (0)
 
-int sga_mfma_mode();     // capi.hip: 0 = exact fp32 (default), 1 = split-bf16 x3 (opt-in)
-
 static inline int sga_num_cus() {
     static int n = 0;
     if (!n) {

@@ -1,0 +1,819 @@
+// The anchors x negatives loss sweeps with every fp32 operand split EXACTLY into three bf16 terms (ops.set_mfma_mode('bf16x6'); SURVEY 7:
+// "parity configs use fp32 MFMA or split-bf16 x3").  Same mathematics and the same two-owner-sweep structure as sweep16_kernel
+// (contrastive.hip, exact-fp32 MFMA) and sweeph.hip (two fp16 planes):
+//     pass 1 (sums)   s_fam,temp[table] = sum exp(S / tau)                 S = X_own . X_other^T per modality table,
+//     backward (grad) dZ[own] += C . Z[other],  C = dL/dS_m + beta_m dL/dS_J    S_J = sum_m beta_m S_m (joint table derived)
+// (reference src/aligner/losses.py:5-15 and its autograd).
+//
+// Arithmetic.  x = h + m + l with h = bf16(x), m = bf16(x - h), l = x - h - m: 8 + 8 + 8 significand bits (round to nearest at every step,
+// so |m| <= 2^-8 |x|, |l| <= 2^-16 |x|), and bf16 has fp32's exponent range -- the three terms represent EVERY fp32 value exactly, no
+// pre-scale, no range condition (the fp16 planes of sweeph.hip hold 22 bits of 4096 x).  A product x y is the six partial products
+//     h h' + (h m' + m h') + (m m' + h l' + l h')
+// on v_mfma_f32_16x16x32_bf16 into ONE fp32 accumulator (a bf16 x bf16 product is exact in fp32); the three dropped ones (m l', l m', l l')
+// are <= 2^-23 |x y| in the worst case, 2^-27 typically -- below the rounding of the fp32 accumulation that both this kernel and the
+// fp32 MFMA perform.  So the similarities and the gradient sums are fp32 arithmetic on the exact fp32 operands: six bf16 MFMAs of 16 cycles
+// where v_mfma_f32_16x16x4_f32 needs eight of 32 cycles for the same 32 k slots (6/16 of the matrix time).
+// The coefficient C = dL/dS (A operand of the gradient GEMM) is an fp32 value computed in fp32 exactly as in sweep16_kernel and is split the
+// same way inside the loop: v_cvt_pk_bf16_f32 + two v_dot2c_f32_bf16 (residual = x - h, exact) per plane and pair, 7 VALU per pair.
+//
+// Rows are CENTRED like sweeph.hip's planes (z' = z - zbar, bookkeeping columns 100: b = zbar . z' + |zbar|^2 / 2, 101: 1; the owner holds
+// (1, b_i) so that the K tail adds b_i + b_j: the MFMAs deliver S_ij = z_i . z_j; the gradient GEMM's column 101 is rowsum_i = sum_j c_ij
+// and dZ_i = sum_j c_ij z'_j + rowsum_i zbar).  With exact operands this is not needed for correctness; it keeps the accumulators of a
+// table of nearly identical rows (meta_embedding_rel) small, so that its tangential gradient is not the rounding residue of a large radial
+// sum -- there the centred sweep is MORE accurate than the plain fp32 one (tests/test_fp64_chunked_gpu.py).
+//
+// Data layout.  sga_loss_split3_tables turns a packed fp32 table Z [X1 | X2 | N1 | N2] into 32-row BLOCKS (each segment padded to whole
+// blocks) of 22 528 B: [h plane 6 144 | m plane | l plane | tail image T0 2 048 | tail image T1 2 048]; a plane = [K step q (3)][half jh (2)]
+// [64 slots][8 bf16], slot(g, i) = 16 g + (i ^ 12 (g & 1)) holds columns 32 q + 8 g .. + 7 of row 8 (i >> 2) + 4 jh + (i & 3) (the XOR
+// swizzle makes both the lane-linear ds_read_b128 of the S product and the ds_read_b64_tr_b16 transpose reads of the gradient GEMM bank-
+// conflict free); a tail image = [jh][64 slots][8 bf16] of columns 96 .. 103 with k groups T0 = (h, h, m, m), T1 = (l, h, l, m): against the
+// owner's (h, m, h, m) and (h, l, m, l) two MFMAs give eight of the nine partial products of the K tail.
+// MFMA bookkeeping as in sweeph.hip: S^T tile with A = other rows from LDS, B = owner rows (registers); half jh of a 32-row tile uses A row
+// i <-> other row 8 (i >> 2) + 4 jh + (i & 3), so a lane's 8 accumulator values are the 8 consecutive other rows 8 g4 .. 8 g4 + 7 = the k
+// slots of the gradient MFMA, whose A operand is therefore the coefficient registers (split into three planes) and whose B operand
+// comes from transpose reads of the same planes.
+//
+// Geometry.  Per 16 owner rows a wave holds 44 operand + 28 gradient-accumulator + 8 S registers PER TABLE; with three tables (240) plus the
+// operands in flight that is more than the 256 registers of a two-wave SIMD, so the M = 3 gradient sweep runs ONE wave per SIMD (4 waves x
+// 16 owner rows, <= 512 registers) with every LDS operand requested a group of MFMAs ahead inside the matrix stream (sched_barrier-pinned,
+// as sweeph.hip's OH = 2 build); M = 2 and the forward sums (no accumulators) run 8 waves, two per SIMD.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "loss_math.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int S3_DP = 104;
+constexpr int S3_PLANE = 3 * 2 * 1024;           // 6144 B
+constexpr int S3_TAIL = 3 * S3_PLANE;            // byte offset of the two tail images in a block
+constexpr int S3_BLOCK = S3_TAIL + 2 * 2048;     // 22528 B
+constexpr int S3_NCH = S3_BLOCK / 1024;          // 22 DMA chunks
+constexpr int S3_ROWSLOTS = 3 * 12 + 8;          // 16-byte slots that hold one row: 3 planes x (3 K steps x 4 k groups) + 2 tail images x 4
+
+// v0, v1 -> three packed bf16 pairs, v = h + m + l EXACTLY (round to nearest at each step; the residuals are exact in fp32, the last one has
+// at most 8 significant bits).  Residual = v - float(bf16): the bf16 pair is unpacked by a shift / a mask (plain VALU: beside MFMAs they cost
+// their issue slot only, where v_dot2c_f32_bf16 -- "v - h" in one instruction -- costs ~10 cycles, MI355X_MICROARCH.md; S3_SPLIT_DOT2 builds
+// that form.  NB hipcc 7.2 folds the packed constant 0x0000BF80 = (-1, 0) into the inline constant "-1.0", which the hardware reads as
+// 0xBF800000 = (0, -1): the constants must stay opaque in SGPRs).
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    const bf16x2 H = __builtin_convertvector(f32x2{v0, v1}, bf16x2);
+    const unsigned hu = __builtin_bit_cast(unsigned, H);
+#ifdef S3_SPLIT_DOT2
+    unsigned c0 = 0x0000BF80u, c1 = 0xBF800000u;
+    asm("" : "+s"(c0), "+s"(c1));
+    const bf16x2 n0 = __builtin_bit_cast(bf16x2, c0), n1 = __builtin_bit_cast(bf16x2, c1);
+    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(H, n0, v0, false);
+    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(H, n1, v1, false);
+#else
+    const float r0 = v0 - __builtin_bit_cast(float, hu << 16);
+    const float r1 = v1 - __builtin_bit_cast(float, hu & 0xffff0000u);
+#endif
+    const bf16x2 Mi = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+    const unsigned mu = __builtin_bit_cast(unsigned, Mi);
+#ifdef S3_SPLIT_DOT2
+    const float s0 = __builtin_amdgcn_fdot2_f32_bf16(Mi, n0, r0, false);
+    const float s1 = __builtin_amdgcn_fdot2_f32_bf16(Mi, n1, r1, false);
+#else
+    const float s0 = r0 - __builtin_bit_cast(float, mu << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, mu & 0xffff0000u);
+#endif
+    const bf16x2 Lo = __builtin_convertvector(f32x2{s0, s1}, bf16x2);
+    h = hu; m = mu; l = __builtin_bit_cast(unsigned, Lo);
+}
+__device__ __forceinline__ f32x4 mfma_b(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x2 tr_read16(const unsigned char* p) {     // ds_read_b64_tr_b16
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p)));
+}
+__device__ __forceinline__ unsigned long long sreg64(unsigned long long v) {       // a wave-uniform 64-bit value, provably in SGPRs
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__host__ __device__ constexpr int s3_slot(int g, int i) { return 16 * g + (i ^ (12 * (g & 1))); }
+
+struct TLayout { int nbA, nb1, nb2; };
+__host__ __device__ inline TLayout make_tlayout(int A, int J1, int J2) { return TLayout{(A + 31) / 32, (J1 + 31) / 32, (J2 + 31) / 32}; }
+
+// Statistics block of a table, behind its blocks and the slack block: float zbar[104] | float nbh (= |zbar|^2 / 2) ... | at +512 B: double colsum[104].
+constexpr int S3_STAT_BYTES = 2048;
+constexpr int S3_DREAL = 100;                    // data columns; 100, 101 are the bookkeeping columns (emb_dim <= 100 in this mode)
+
+// column sums in a FIXED order (deterministic, unlike the atomic form of sweeph.hip): block b sums its row range into part[b][c], one
+// workgroup folds the partials in index order.
+constexpr int S3_CS_BLOCKS = 256;
+__global__ __launch_bounds__(128) void split3_colsum_kernel(const float* __restrict__ Z, int R, double* __restrict__ part) {
+    const int c = threadIdx.x;
+    const int per = (R + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(R, r0 + per);
+    if (c >= S3_DP) return;
+    double acc = 0.0;
+    for (int r = r0; r < r1; ++r) acc += (double)Z[(size_t)r * S3_DP + c];
+    part[(size_t)blockIdx.x * S3_DP + c] = acc;
+}
+__global__ __launch_bounds__(128) void split3_stats_kernel(const double* __restrict__ part, int nblocks, int R, float* __restrict__ stat) {
+    __shared__ double sq[128];
+    const int c = threadIdx.x;
+    double cs = 0.0;
+    if (c < S3_DP) for (int b = 0; b < nblocks; ++b) cs += part[(size_t)b * S3_DP + c];
+    float zb = (c < S3_DREAL && R > 0) ? (float)(cs / (double)R) : 0.f;
+    sq[c] = (double)zb * (double)zb;
+    __syncthreads();
+    __shared__ double tot;
+    if (c == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 128; ++i) t += sq[i];
+        tot = t;
+    }
+    __syncthreads();
+    // Centre only a table whose rows point the same way (|mean row|^2 >= 1/4: meta_embedding_rel's nearly identical rows have ~1).  For any
+    // other table zbar = 0: the planes then hold the fp32 operands themselves -- z - zbar would round each of them once more (2^-25 |z|,
+    // the same for every owner row, which the column sums of the gradient see), for no gain when the rows are spread out.
+    const bool centre = tot >= 0.25;
+    if (!centre) zb = 0.f;
+    if (c < S3_DP) stat[c] = zb;
+    if (c == 0) stat[S3_DP] = centre ? (float)(0.5 * tot) : 0.f;
+}
+
+// fp32 packed table -> blocked bf16 h / m / l planes + the two tail images of the CENTRED rows (one workgroup per 32-row block)
+__global__ __launch_bounds__(256) void split3_tables_kernel(const float* __restrict__ Z, int A, int J1, int J2, unsigned char* __restrict__ Zb,
+                                                            const float* __restrict__ stat) {
+    __shared__ float tile[32 * S3_DP];
+    __shared__ float zbar[S3_DP];
+    const TLayout L = make_tlayout(A, J1, J2);
+    int b = blockIdx.x, old0, len;
+    if (b < L.nbA) { old0 = 0; len = A; }
+    else if (b < 2 * L.nbA) { b -= L.nbA; old0 = A; len = A; }
+    else if (b < 2 * L.nbA + L.nb1) { b -= 2 * L.nbA; old0 = 2 * A; len = J1; }
+    else { b -= 2 * L.nbA + L.nb1; old0 = 2 * A + J1; len = J2; }
+    const int nvalid = min(32, len - 32 * b);
+    const float* src = Z + (size_t)(old0 + 32 * b) * S3_DP;
+    if (threadIdx.x < S3_DP) zbar[threadIdx.x] = stat[threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * S3_DP; e += 256) {
+        const int r = e / S3_DP, c = e - r * S3_DP;
+        tile[e] = (r < nvalid && c < S3_DREAL) ? src[e] - zbar[c] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {                       // the two bookkeeping columns of a valid row (a padding row stays all zero: S = 0)
+        const int r = threadIdx.x;
+        if (r < nvalid) {
+            double a = 0.0;
+            for (int c = 0; c < S3_DREAL; ++c) a += (double)zbar[c] * (double)tile[r * S3_DP + c];
+            tile[r * S3_DP + S3_DREAL] = (float)(a + (double)stat[S3_DP]);
+            tile[r * S3_DP + S3_DREAL + 1] = 1.f;
+        }
+    }
+    __syncthreads();
+    unsigned* out = reinterpret_cast<unsigned*>(Zb + (size_t)blockIdx.x * S3_BLOCK);
+    // planes: dword e = (slot s of [q][jh][64], pair p of 4): stored slot (g, i ^ swz) <- logical (g, i)
+    for (int e = threadIdx.x; e < 3 * 2 * 64 * 4; e += 256) {
+        const int p = e & 3, st = (e >> 2) & 63, jh = (e >> 8) & 1, q = e >> 9;
+        const int g = st >> 4, i = (st & 15) ^ (12 * (g & 1));
+        const int row = 8 * (i >> 2) + 4 * jh + (i & 3), col = 32 * q + 8 * g + 2 * p;
+        unsigned h, m, l;
+        split3_pair(tile[row * S3_DP + col], tile[row * S3_DP + col + 1], h, m, l);
+        out[e] = h; out[S3_PLANE / 4 + e] = m; out[2 * S3_PLANE / 4 + e] = l;
+    }
+    // tail images: dword e = (image, slot of [jh][64], pair p of 4) of columns 96 + 2 p, + 1; k groups T0 = (h, h, m, m), T1 = (l, h, l, m)
+    for (int e = threadIdx.x; e < 2 * 2 * 64 * 4; e += 256) {
+        const int p = e & 3, st = (e >> 2) & 63, jh = (e >> 8) & 1, img = e >> 9;
+        const int g = st >> 4, i = (st & 15) ^ (12 * (g & 1));
+        const int row = 8 * (i >> 2) + 4 * jh + (i & 3), col = 96 + 2 * p;
+        unsigned h, m, l;
+        split3_pair(tile[row * S3_DP + col], tile[row * S3_DP + col + 1], h, m, l);
+        const unsigned v = img == 0 ? (g < 2 ? h : m) : ((g & 1) == 0 ? l : (g == 1 ? h : m));
+        out[S3_TAIL / 4 + e] = v;
+    }
+}
+
+#ifdef S3_DBG_TIMING
+__device__ unsigned long long g_s3_dbg[16];
+#define S3_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; }
+#else
+#define S3_T(i)
+#endif
+struct TSeg { int blk0, jt_lo, jt_hi, old0, lo, hi, fam; };   // others: block blk0 + jt holds old rows old0 + 32 jt + w; valid rows in [lo, hi)
+struct TGroup { int own0, nown, own_old0, own_blk0, blk0, nsplit, nseg; TSeg seg[2]; };
+struct TArgs {
+    int M; const unsigned char* Zb[4]; int ngroups; TGroup grp[4];
+    float k0, k1, it0, it1;
+    const float* beta;
+    double* sums;                    // SUM out  [(M+1)][8] (+ slots)
+    const double* gs;                // GRAD in  [(M+1)][8]
+    float* dZ[4];                    // GRAD out (fp32, old row order), atomic accumulate
+    const float* stat[4];            // per table: zbar[104], |zbar|^2 / 2 (behind the blocks of Zb)
+    double* gamma;                   // GRAD out [M] (+ slots)
+};
+
+// WV: waves per workgroup, each owning 16 owner rows.  8: two waves per SIMD (<= 256 registers), operands requested at the top of a
+// sub-step and covered by the partner wave.  4: one wave per SIMD (<= 512 registers), PIPE: operands requested a group of MFMAs ahead.
+template <int M, bool GRAD, int WV>
+__global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs a) {
+    constexpr int NCT = 7;
+    constexpr int WAVES = WV, THREADS = WAVES * 64;
+    constexpr int OWN = WV * 16;                                     // owner rows per workgroup
+    constexpr int KMAX = (S3_NCH + WAVES - 1) / WAVES;              // DMA chunk slots per table and wave
+    constexpr int BUF = M * S3_BLOCK;
+    constexpr bool PIPE = WV == 4;
+#ifndef S3_OWN_IN_S
+#define S3_OWN_IN_S 1
+#endif
+    constexpr bool OWN_IN_S = GRAD && PIPE && S3_OWN_IN_S;          // the own coefficient part of table m - 1 under table m's S-phase MFMAs
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];      // [2][M][S3_BLOCK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
+    const TGroup& grp = a.grp[g];
+    // XCD-aware work order (as sweeph / sweep16): the group's (split major, owner block minor) work list in 8 contiguous per-XCD chunks
+    const int wg_in_grp = (int)blockIdx.x - grp.blk0;
+    const int nsplit = grp.nsplit, n_ob = (grp.nown + OWN - 1) / OWN, n_units = n_ob * nsplit;
+    const int unit = (wg_in_grp & 7) * ((n_units + 7) >> 3) + (wg_in_grp >> 3);
+    if ((wg_in_grp >> 3) >= ((n_units + 7) >> 3) || unit >= n_units) return;
+    const int split = unit / n_ob;
+    const int own0 = grp.own0 + (unit - split * n_ob) * OWN;
+    const int own_end = grp.own0 + grp.nown;
+    const int wrow0 = own0 + wave * 16;                               // this wave's first owner row
+#ifdef S3_DBG_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
+
+    // ---- owner rows as the S product's B operand: 3 planes x 3 K = 32 steps + the two tail operands O0 = (h, m, h, m), O1 = (h, l, m, l)
+    u32x4 opl[M][3][3], otl[M][2];
+    float beta[M];
+    const bool iv = wrow0 + l15 < own_end;
+    {
+        const int my_i = wrow0 + l15;
+        const int rel = (iv ? my_i : own0) - grp.own_old0;
+        const int o = rel & 31, oi = 4 * (o >> 3) + (o & 3), ojh = (o >> 2) & 1;       // row o sits at (half ojh, operand row oi) of its block
+        const size_t off = (size_t)(grp.own_blk0 + (rel >> 5)) * S3_BLOCK;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const unsigned char* base = a.Zb[m] + off;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int so = ((q * 2 + ojh) * 64 + s3_slot(g4, oi)) * 16;
+                    opl[m][p][q] = iv ? *reinterpret_cast<const u32x4*>(base + p * S3_PLANE + so) : u32x4{0, 0, 0, 0};
+                }
+            // O0: k group g4 -> h, m, h, m = T0 group 2 (g4 & 1);  O1: h, l, m, l = image (g4 & 1), group (g4 & 2)
+            otl[m][0] = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot((g4 & 1) * 2, oi)) * 16) : u32x4{0, 0, 0, 0};
+            otl[m][1] = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (g4 & 1) * 2048 + (ojh * 64 + s3_slot(g4 & 2, oi)) * 16) : u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)                               // columns 100, 101: the owner holds (1, b_i) against the other's (b_j, 1)
+                otl[m][t][2] = (otl[m][t][2] >> 16) | (otl[m][t][2] << 16);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
+
+    // Gradient accumulators, TWO per output: gacc takes the h h products, gsm the five small partial products (<= 2^-8 of them).  Why: the
+    // 16-bit MFMAs align their 32 products and C to the largest exponent and CHOP what falls ~7 bits below the result's last place --
+    // toward minus infinity whatever the sign (tools/micro/mfma_round_probe.hip: -0.09 ulp per MFMA whose products are 2^-8 .. 2^-16 of C;
+    // the fp32 MFMA chops too, but toward zero).  Small products added straight onto the large accumulator would give every gradient entry
+    // the same one-sided bias, which the column sums over 10^6 rows (the bias gradients of the layers below) would collect coherently; in
+    // their own accumulator nothing is chopped, and the two are added once, in fp32, at the end.
+    f32x4 gacc[GRAD ? M : 1][NCT], gsm[GRAD ? M : 1][NCT];
+#pragma unroll
+    for (int m = 0; m < (GRAD ? M : 1); ++m)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { gacc[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; gsm[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float gam[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) gam[m] = 0.f;
+
+    // Tile transport: ONE contiguous 22-KiB copy per table by LDS-DMA (global_load_lds, 1 KiB per wave instruction), slot (table m, k) ->
+    // chunk (wave + m) % WAVES + WAVES k: the table index of every DMA is a compile-time constant.  Issued in one burst at the top of a
+    // tile for the NEXT tile.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // M0 (the DMA's LDS address) must be provably uniform
+    unsigned l16 = threadIdx.x;                                     // (unsigned: base + zext(offset) is what selects the saddr form)
+    asm volatile("" : "+v"(l16));
+    l16 = (l16 & 63u) * 16u;
+    // flat copy slots [f_lo, f_hi) of the M * KMAX (table, k) slots.  The copies of the NEXT tile are spread over this tile's first S
+    // sub-steps (a burst of all of them at the top of the tile queues up behind the CU's one texture-address unit -- 16 cycles per 1-KiB
+    // instruction, 66 of them per tile from the four waves -- and stalled every wave's in-order stream for ~12 % of the tile,
+    // S3_DBG_TIMING); BRANCH-FREE: a slot past the block's last chunk copies the wave's previous chunk again (same bytes to the same
+    // place), a tile without successor copies itself into the idle buffer -- a branch here splits the MFMA stream into basic blocks, and
+    // hipcc opens every block that follows a join with s_waitcnt lgkmcnt(0) right behind the operand requests it has just issued.
+    unsigned long long tb[M];                                                      // scalar base of the tile being copied, per table
+    auto set_tile = [&](int blk) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) tb[m] = sreg64(reinterpret_cast<unsigned long long>(a.Zb[m]) + (unsigned long long)blk * S3_BLOCK);
+    };
+    auto issue_slots = [&](unsigned char* buf, int f_lo, int f_hi) {
+#ifdef S3_DBG_NODMA
+        return;
+#endif
+#pragma unroll
+        for (int f = f_lo; f < f_hi; ++f) {
+            if (f >= M * KMAX) break;                                               // compile time
+            const int m = f / KMAX, k = f % KMAX;
+            const int rot = (wave_u + m) & (WAVES - 1);
+            int c = rot + k * WAVES;
+            if ((k + 1) * WAVES > S3_NCH) c = c >= S3_NCH ? c - WAVES : c;          // only the last k can fall off the block (scalar select)
+            // scalar base + 32-bit lane offset (the saddr form: no 64-bit VALU address per copy)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(tb[m] + (unsigned)(c * 1024)) + l16),
+                                             (__attribute__((address_space(3))) void*)(buf + m * S3_BLOCK + c * 1024), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int blk, unsigned char* buf) { set_tile(blk); issue_slots(buf, 0, M * KMAX); };
+
+    // lane-derived LDS offsets: S product (lane-linear up to the swizzle) and the transpose reads of the gradient GEMM's B operand:
+    // lane i of a 16-lane group addresses the 8-byte piece (row 8 g4 + 4 rd + (i >> 2), columns 16 ct + 4 (i & 3) ..)
+    const int aoff = s3_slot(g4, l15) * 16;
+    const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
+    const int tr_main = s3_slot(tr_cs >> 1, tr_io) * 16 + (tr_cs & 1) * 8;       // + p * PLANE + (ct >> 1) * 2048 + rd * 1024 + (ct & 1) * 512
+    const int tr_tail = S3_TAIL + tr_io * 16 + (tr_cs & 1) * 8;                   // h: T0 group 0; m: + 512 (T0 group 2); l: + 2048 (T1 group 0); + rd * 1024
+
+#pragma unroll 1
+    for (int sg = 0; sg < 2; ++sg) {
+        if (sg >= grp.nseg) break;
+        const TSeg seg = grp.seg[sg];
+        float c0[M + 1], c1[M + 1];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) {
+            c0[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
+            c1[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
+        }
+        const float k0 = a.k0, k1 = a.k1;
+        double dsum[M + 1][2];
+#pragma unroll
+        for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
+
+        __syncthreads();
+        if (seg.jt_lo + split < seg.jt_hi) issue(seg.blk0 + seg.jt_lo + split, lds3);
+        int it = 0;
+#pragma unroll 1
+        for (int jt = seg.jt_lo + split; jt < seg.jt_hi; jt += nsplit, ++it) {
+            unsigned char* buf = lds3 + (it & 1) * BUF;
+            const int j0 = seg.old0 + 32 * jt;                 // old row of the tile's first row
+            S3_T(5)
+            __syncthreads();                                   // tile `it` has landed (every wave waited for its own chunks), buffer it + 1 is free
+            S3_T(0)
+            const int next_blk = seg.blk0 + (jt + nsplit < seg.jt_hi ? jt + nsplit : jt);      // (the last tile re-copies itself: see issue_slots)
+            unsigned char* next_buf = lds3 + ((it + 1) & 1) * BUF;
+            set_tile(next_blk);
+            S3_T(1)
+            if (GRAD) {
+                // A segment's first / last tile may hold rows outside [lo, hi) (uniform test).  Zeroing those rows' 16-byte slots in the
+                // operand-order image (all planes + tails, all tables) makes their contributions vanish by themselves -- S = 0, c * 0 into the
+                // owner gradient, 0 into Gamma -- so the gradient epilogue carries no validity mask.
+                const int vlo = max(seg.lo - j0, 0), vhi = min(seg.hi - j0, 32);
+                if (vlo > 0 || vhi < 32) {
+                    for (int x = tid; x < M * 32 * S3_ROWSLOTS; x += THREADS) {
+                        const int pc = x % S3_ROWSLOTS, w = (x / S3_ROWSLOTS) % 32, m = x / (S3_ROWSLOTS * 32);
+                        if (w >= vlo && w < vhi) continue;
+                        const int wjh = (w >> 2) & 1, wi = 4 * (w >> 3) + (w & 3);
+                        unsigned char* base = buf + m * S3_BLOCK;
+                        if (pc < 36) {
+                            const int pl = pc / 12, q = (pc % 12) >> 2, gq = pc & 3;
+                            *reinterpret_cast<u32x4*>(base + pl * S3_PLANE + ((q * 2 + wjh) * 64 + s3_slot(gq, wi)) * 16) = u32x4{0, 0, 0, 0};
+                        } else {
+                            const int img = (pc - 36) >> 2, gq = (pc - 36) & 3;
+                            *reinterpret_cast<u32x4*>(base + S3_TAIL + img * 2048 + (wjh * 64 + s3_slot(gq, wi)) * 16) = u32x4{0, 0, 0, 0};
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+
+            // ---- S^T tiles: sacc[m][jh][r] = S_m[own = lane & 15, other = 8 g4 + 4 jh + r]; one SUB-STEP = (table, other half): 11 A operands
+            // from LDS, 20 MFMAs in one accumulator chain, the small partial products first:
+            //   tails | l h | m m | m h | h l | h m | h h      (other plane x owner plane).
+            // PIPE: the next sub-step's operands are requested once their registers' last readers have issued (tails + l after "l h", m after
+            // "m h", h after "h h"): every operand has >= 10 MFMAs to arrive.
+            f32x4 sacc[M][2];
+            float own[M][2][4];                                // c0 e^{S/tau0} + c1 e^{S/tau1} of the table's own similarities (GRAD)
+            // A operands of a sub-step: two tail images, l, m, h planes x 3 K steps.  PIPE: two register sets; the whole set of sub-step
+            // ss + 1 is requested right behind the FIRST MFMA of sub-step ss -- hipcc waits with s_waitcnt lgkmcnt(0) (never a counted wait:
+            // the LDS-DMAs in flight make the counter "out of order" in its model) in front of the first MFMA that reads requested data, so
+            // that one wait per sub-step must sit where nothing younger than 19 MFMAs is outstanding.
+            constexpr int NSET = PIPE ? 2 : 1;
+            u32x4 at[NSET][2], ap[NSET][3][3];                 // ap[.][0]: h, [1]: m, [2]: l
+            auto ld_one = [&](int ss, int idx) {               // idx 0, 1: tail images T1, T0; 2 + 3 p' + q: plane l, m, h (p' = 0, 1, 2) K step q
+                const int e = ss % NSET;
+                const unsigned char* ar = buf + (ss >> 1) * S3_BLOCK + (ss & 1) * 1024 + aoff;
+                if (idx < 2) at[e][1 - idx] = *reinterpret_cast<const u32x4*>(ar + S3_TAIL + (1 - idx) * 2048);
+                else ap[e][2 - (idx - 2) / 3][(idx - 2) % 3] = *reinterpret_cast<const u32x4*>(ar + (2 - (idx - 2) / 3) * S3_PLANE + ((idx - 2) % 3) * 2048);
+            };
+            auto ld_set = [&](int ss) {
+#pragma unroll
+                for (int idx = 0; idx < 11; ++idx) ld_one(ss, idx);
+            };
+            if (PIPE) {
+                ld_set(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0) HERE, not behind the requests of set 1 (see above)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ss = 0; ss < 2 * M; ++ss) {
+                const int m = ss >> 1, jh = ss & 1, e = ss % NSET;
+                if (!PIPE) ld_set(ss);
+                // 20 products, the small ones first, dealt alternately to TWO accumulator chains: between MFMAs on different accumulators
+                // another instruction costs its issue slot, between two dependent ones it breaks the back-to-back forwarding (+43 cycles,
+                // MI355X_MICROARCH.md) -- and a wave that is alone on its SIMD has to place 11 operand requests and up to 5 copies per
+                // sub-step: one request per MFMA gap, a copy every third (program order pinned: an LDS-DMA ends a scheduling region, so
+                // sched_group_barrier cannot spread across it).
+                // The next tile's copies go over the first NDS sub-steps: the compiler puts s_waitcnt vmcnt(0) in front of the first transpose
+                // read that follows an LDS-DMA (it cannot tell the two buffers apart), so they must have landed by the gradient phase.
+                constexpr int NDS = GRAD ? (2 * M - 2) : 2 * M, PER = (M * KMAX + NDS - 1) / NDS;
+                f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                float ownt[2] = {0.f, 0.f};
+                // (A plane, owner plane): l h | m m | m h | h l | h m | h h
+                constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+                for (int x = 0; x < 20; ++x) {
+                    if (x == 0) acc2[0] = mfma_b(at[e][1], otl[m][1], acc2[0]);
+                    else if (x == 1) acc2[1] = mfma_b(at[e][0], otl[m][0], acc2[1]);
+                    else acc2[x & 1] = mfma_b(ap[e][PA[(x - 2) / 3]][(x - 2) % 3], opl[m][PB[(x - 2) / 3]][(x - 2) % 3], acc2[x & 1]);
+                    if (PIPE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ss + 1 < 2 * M && x < 11) ld_one(ss + 1, x);
+                        if (ss < NDS && (x % 3) == 1 && (x / 3) < PER) issue_slots(next_buf, ss * PER + (x / 3), ss * PER + (x / 3) + 1);
+                        // the previous table's own coefficient part under this table's MFMAs (half jh here): three VALU per gap 11 .. 18
+                        if (OWN_IN_S && m > 0 && x >= 11 && x < 19) {
+                            const int r = (x - 11) >> 1;
+                            const float sv = sacc[m - 1][jh][r];
+                            if (((x - 11) & 1) == 0) {
+                                ownt[0] = fexp2(sv * k0);
+                                ownt[1] = sv * k1;
+                            } else {
+                                own[m - 1][jh][r] = fmaf(c0[m - 1], ownt[0], c1[m - 1] * fexp2(ownt[1]));
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (x == 1 && ss < NDS) {
+                        issue_slots(next_buf, ss * PER, (ss + 1) * PER);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[m][jh][r] = acc2[0][r] + acc2[1][r];       // (element-wise: a vector add becomes v_pk_add_f32, 3 x the price beside MFMAs)
+            }
+
+            S3_T(2)
+            if (!GRAD) {
+                float p0[M + 1], p1[M + 1];
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+                // forward sums: exp2(0) = 1 of a padded / foreign row would count, so edge tiles are masked; interior tiles add unmasked
+                auto sums_tile = [&](auto masked_c) {
+                    constexpr bool MASKED = decltype(masked_c)::value;
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = j0 + 8 * g4 + 4 * jh + r;
+                            const float okf = (!MASKED || (iv && row >= seg.lo && row < seg.hi)) ? 1.f : 0.f;
+                            float sj = 0.f;
+#pragma unroll
+                            for (int m = 0; m < M; ++m) {
+                                const float sv = sacc[m][jh][r];
+                                sj = fmaf(beta[m], sv, sj);
+                                p0[m] = MASKED ? fmaf(okf, fexp2(sv * k0), p0[m]) : p0[m] + fexp2(sv * k0);
+                                p1[m] = MASKED ? fmaf(okf, fexp2(sv * k1), p1[m]) : p1[m] + fexp2(sv * k1);
+                            }
+                            p0[M] = MASKED ? fmaf(okf, fexp2(sj * k0), p0[M]) : p0[M] + fexp2(sj * k0);
+                            p1[M] = MASKED ? fmaf(okf, fexp2(sj * k1), p1[M]) : p1[M] + fexp2(sj * k1);
+                        }
+                };
+                if (j0 >= seg.lo && j0 + 32 <= seg.hi && own0 + OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
+#pragma unroll
+                for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
+            } else {
+                // Gradient GEMM B operands (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes,
+                // one STEP = (table, column tile): 6 transpose reads, 6 MFMAs: five small partial products into gsm, h h into gacc
+                //   l h | h l | m m | m h | h m || h h      (coefficient plane x row plane).
+                // PIPE (one wave per SIMD: nobody else fills the issue slots a VALU instruction leaves, ~5 cycles each when a wave runs them
+                // back to back, 2.6 beside MFMAs): the operands of step k + 1 are requested before the MFMAs of step k, and the coefficient
+                // planes of table m + 1 are computed UNDER the MFMAs of table m (two VALU per MFMA, sched_group_barrier).
+                constexpr int BD = PIPE ? 4 : 1;
+                u32x4 bp[BD][3];
+                auto ld_b = [&](int k) {
+                    const int m = k / NCT, ct = k % NCT, par = k % BD;
+                    const unsigned char* pb = buf + m * S3_BLOCK;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned char* ph = ct < 6 ? pb + p * S3_PLANE + tr_main + (ct >> 1) * 2048 + (ct & 1) * 512
+                                                         : pb + tr_tail + (p == 0 ? 0 : (p == 1 ? 512 : 2048));
+                        const u32x2 x0 = tr_read16(ph), x1 = tr_read16(ph + 1024);
+                        bp[par][p] = u32x4{x0[0], x0[1], x1[0], x1[1]};
+                    }
+                };
+                // own coefficient parts not computed under the S phase's MFMAs: the last table's (PIPE), all of them otherwise
+#pragma unroll
+                for (int m = OWN_IN_S ? M - 1 : 0; m < M; ++m)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sv = sacc[m][jh][r];
+#ifdef S3_DBG_NOEPI
+                            own[m][jh][r] = sv;
+#else
+                            own[m][jh][r] = fmaf(c0[m], fexp2(sv * k0), c1[m] * fexp2(sv * k1));
+#endif
+                        }
+                // joint coefficient dL/dS_J for this lane's 8 pairs (plain VALU: beside MFMAs a v_pk_*_f32 costs 3 x a v_fma, tools/micro/valu_issue.hip)
+                float cj[2][4];
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float sj = 0.f;
+#pragma unroll
+                        for (int m = 0; m < M; ++m) sj = fmaf(beta[m], sacc[m][jh][r], sj);
+#ifdef S3_DBG_NOEPI
+                        cj[jh][r] = sj;
+#else
+                        cj[jh][r] = c0[M] * fexp2(sj * k0) + c1[M] * fexp2(sj * k1);
+#endif
+                    }
+                auto gamma_acc = [&]() {                        // Gamma_m = sum dL/dS_J * S_m (used from the anchor-owner sweeps only: each pair once;
+#pragma unroll                                                 //  no branch here -- it would cut the gradient phase's scheduling region in two)
+                    for (int m = 0; m < M; ++m) {
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[jh][r], sacc[m][jh][r], gam[m]);
+                    }
+                };
+                if (!PIPE) gamma_acc();
+                S3_T(3)
+                // c_m for this lane's 8 consecutive other rows (k slot j = 4 jh + r), split into three bf16 planes: the A operand
+                u32x4 ch[2], cm[2], cl[2];                     // double-buffered by table parity
+                auto planes = [&](int m) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int jh = p >> 1, r = (p & 1) * 2;
+#ifdef S3_DBG_NOEPI
+                        const float v0 = own[m][jh][r] + cj[jh][r], v1 = own[m][jh][r + 1] + cj[jh][r + 1];
+#else
+                        const float v0 = fmaf(beta[m], cj[jh][r], own[m][jh][r]), v1 = fmaf(beta[m], cj[jh][r + 1], own[m][jh][r + 1]);
+#endif
+                        unsigned h_, m_, l_;
+                        split3_pair(v0, v1, h_, m_, l_);
+                        ch[m & 1][p] = h_; cm[m & 1][p] = m_; cl[m & 1][p] = l_;
+                    }
+                };
+                planes(0);
+                // (coefficient plane, row plane) of the five small products, in accumulation order
+                auto step_small = [&](int m, int ct, int par, int i) {
+                    const int e = m & 1;
+                    const u32x4 ca = i == 0 ? cl[e] : (i == 1 || i == 4) ? ch[e] : cm[e];
+                    const int pb_ = i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 1 : i == 3 ? 0 : 1;
+                    gsm[GRAD ? m : 0][ct] = mfma_b(ca, bp[par][pb_], gsm[GRAD ? m : 0][ct]);
+                };
+                if (!PIPE) {
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        if (m > 0) planes(m);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) {
+                            ld_b(NCT * m + ct);
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) step_small(m, ct, 0, i);
+                            gacc[GRAD ? m : 0][ct] = mfma_b(ch[m & 1], bp[0][0], gacc[GRAD ? m : 0][ct]);
+                        }
+                    }
+                } else {
+                    // column tiles in PAIRS (0,1) (2,3) (4,5) (6): the MFMAs of a pair alternate between its two tiles, so that consecutive
+                    // MFMAs never share an accumulator and the fillers between them -- the next group's 6 or 12 transpose reads, two VALU of
+                    // the next table's coefficients per MFMA -- cost their issue slots only
+                    __builtin_amdgcn_sched_barrier(0);
+                    ld_b(0); ld_b(1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g4i = 0; g4i < 4 * M; ++g4i) {
+                        const int m = g4i >> 2, ct0 = (g4i & 3) * 2, n = (g4i & 3) == 3 ? 1 : 2, k0_ = NCT * m + ct0;
+                        if ((g4i & 3) == 0 && m + 1 < M) planes(m + 1);        // source order only: spread under this table's MFMAs below
+                        if (g4i == (M > 1 ? 4 : 0)) gamma_acc();               // ... and Gamma under the second table's (the first carries planes(1))
+                        const int kn = k0_ + n;                               // the next group's first step
+                        const int nn = kn >= NCT * M ? 0 : ((kn % NCT) == 6 ? 1 : 2);
+#pragma unroll
+                        for (int j = 0; j < nn; ++j) ld_b(kn + j);
+                        if (n == 2) {
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) { step_small(m, ct0, k0_ % BD, i); step_small(m, ct0 + 1, (k0_ + 1) % BD, i); }
+                            gacc[GRAD ? m : 0][ct0] = mfma_b(ch[m & 1], bp[k0_ % BD][0], gacc[GRAD ? m : 0][ct0]);
+                            gacc[GRAD ? m : 0][ct0 + 1] = mfma_b(ch[m & 1], bp[(k0_ + 1) % BD][0], gacc[GRAD ? m : 0][ct0 + 1]);
+                        } else {
+                            step_small(m, ct0, k0_ % BD, 0);
+                            gacc[GRAD ? m : 0][ct0] = mfma_b(ch[m & 1], bp[k0_ % BD][0], gacc[GRAD ? m : 0][ct0]);
+#pragma unroll
+                            for (int i = 1; i < 5; ++i) step_small(m, ct0, k0_ % BD, i);
+                        }
+                        // directives: per MFMA one transpose read (while there are any) and two VALU
+#pragma unroll
+                        for (int x = 0; x < 6 * n; ++x) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (x < 6 * nn) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            if (n == 2 || x < 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        }
+                        if ((g4i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                S3_T(4)
+            }
+        }
+        if (!GRAD) {
+#pragma unroll
+            for (int m = 0; m <= M; ++m)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const double v = wave_sum_d(dsum[m][tt]);
+                    if (lane == 0 && v != 0.0) atomicAdd(a.sums + (M + 1) * 8 * (1 + my_slot()) + m * 8 + seg.fam * 2 + tt, v);
+                }
+        }
+    }
+#ifdef S3_DBG_TIMING
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_s3_dbg[(GRAD ? 8 : 0) + i], tacc[i]);
+#endif
+    if (GRAD) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float* dz = a.dZ[m];
+            float zb[NCT];                                     // zbar of this lane's columns
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) zb[ct] = (ct * 16 + l15 < S3_DREAL) ? a.stat[m][ct * 16 + l15] : 0.f;
+            // rowsum_i = sum_j c_ij: output column 101 = lane 5 of the last column tile (same row group g4)
+            float rs[4];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) gacc[GRAD ? m : 0][ct] += gsm[GRAD ? m : 0][ct];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs[r] = __shfl(gacc[GRAD ? m : 0][NCT - 1][r], (lane & 48) | 5, 64);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int d = ct * 16 + l15;
+                if (d < S3_DREAL) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = wrow0 + 4 * g4 + r;
+                        if (i < own_end) atomicAdd(dz + (size_t)i * S3_DP + d, fmaf(rs[r], zb[ct], gacc[GRAD ? m : 0][ct][r]));
+                    }
+                }
+            }
+        }
+        if (g < 2) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const float v = wave_sum(gam[m]);
+                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + m, (double)v);
+            }
+        }
+    }
+}
+
+int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1, bool grad,
+           int a_lo, int a_hi, int own_rows, const char* who) {
+    if (M < 2 || M > 3) { sga_set_error("%s: M=%d (the three-plane bf16 sweeps are built for 2 or 3 modality tables)", who, M); return SGA_ERR_ARG; }
+    if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("%s: anchor shard [%d,%d) outside [0,%d]", who, a_lo, a_hi, A); return SGA_ERR_ARG; }
+    a.M = M;
+    const TLayout L = make_tlayout(A, J1, J2);
+    {
+        const size_t stat_off = (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * S3_BLOCK;
+        for (int m = 0; m < M; ++m) {
+            if (!Zb[m]) { sga_set_error("%s: null table", who); return SGA_ERR_ARG; }
+            a.Zb[m] = static_cast<const unsigned char*>(Zb[m]);
+            a.stat[m] = reinterpret_cast<const float*>(a.Zb[m] + stat_off);
+        }
+    }
+    a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
+    const int ns = a_hi - a_lo;
+    const int bx1 = 0, bx2 = L.nbA, bn1 = 2 * L.nbA, bn2 = 2 * L.nbA + L.nb1;
+    const int ox1 = 0, ox2 = A, on1 = 2 * A, on2 = 2 * A + J1;
+    const TSeg N1a{bn1, 0, L.nb1, on1, on1, on1 + J1, 0}, N2a{bn2, 0, L.nb2, on2, on2, on2 + J2, 1};
+    const TSeg N2b{bn2, 0, L.nb2, on2, on2, on2 + J2, 2}, N1b{bn1, 0, L.nb1, on1, on1, on1 + J1, 3};
+    int g = 0;
+    auto add = [&](int own0, int nown, int own_old0, int own_blk0, TSeg s0, TSeg s1) {
+        if (nown <= 0) return;
+        TGroup& G = a.grp[g++];
+        G.own0 = own0; G.nown = nown; G.own_old0 = own_old0; G.own_blk0 = own_blk0; G.nseg = 2; G.seg[0] = s0; G.seg[1] = s1; G.nsplit = 1; G.blk0 = 0;
+    };
+    add(ox1 + a_lo, ns, ox1, bx1, N1a, N2a);                       // s11, s12
+    add(ox2 + a_lo, ns, ox2, bx2, N2b, N1b);                       // s22, s21
+    if (grad) {
+        const int jl = a_lo / 32, jh = (a_hi + 31) / 32;
+        const TSeg X1f0{bx1, jl, jh, ox1, ox1 + a_lo, ox1 + a_hi, 0}, X2f3{bx2, jl, jh, ox2, ox2 + a_lo, ox2 + a_hi, 3};
+        const TSeg X1f1{bx1, jl, jh, ox1, ox1 + a_lo, ox1 + a_hi, 1}, X2f2{bx2, jl, jh, ox2, ox2 + a_lo, ox2 + a_hi, 2};
+        add(on1, J1, on1, bn1, X1f0, X2f3);
+        add(on2, J2, on2, bn2, X1f1, X2f2);
+    }
+    a.ngroups = g;
+    // uniform ~160-step work units; see sweepb.hip for the XCD argument
+    int nwg = 0;
+    for (int i = 0; i < g; ++i) {
+        TGroup& G = a.grp[i];
+        int steps = 0;
+        for (int sg = 0; sg < G.nseg; ++sg) steps += G.seg[sg].jt_hi - G.seg[sg].jt_lo;
+        int nsp = (steps + 159) / 160;
+        if (nsp > steps) nsp = steps;
+        if (nsp < 1) nsp = 1;
+        G.nsplit = nsp;
+        G.blk0 = nwg;
+        nwg += (((G.nown + own_rows - 1) / own_rows) * nsp + 7) / 8 * 8;
+    }
+    return -nwg;                                                    // negative: number of workgroups (0 is a valid "nothing to do")
+}
+
+#ifndef S3_WV_SUMS
+#define S3_WV_SUMS 8
+#endif
+#ifndef S3_WV_GRAD3
+#define S3_WV_GRAD3 4
+#endif
+#ifndef S3_WV_GRAD2
+#define S3_WV_GRAD2 4
+#endif
+template <int M, bool GRAD> constexpr int s3_wv() { return GRAD ? (M == 3 ? S3_WV_GRAD3 : S3_WV_GRAD2) : S3_WV_SUMS; }
+
+template <int M, bool GRAD>
+void launch_t(const TArgs& a, int nwg, hipStream_t s) {
+    constexpr int WV = s3_wv<M, GRAD>();
+    const size_t lds = (size_t)2 * M * S3_BLOCK;
+    auto k = sweep3_kernel<M, GRAD, WV>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(WV * 64), lds, s, a);
+}
+
+}  // namespace
+
+#ifdef S3_DBG_TIMING
+extern "C" int sga_dbg_sweep3(unsigned long long* host16) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_s3_dbg), sizeof(g_s3_dbg)) != hipSuccess) return 1;
+    static unsigned long long z[16];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_s3_dbg), z, sizeof(z)) != hipSuccess;
+}
+#endif
+
+extern "C" size_t sga_loss_split3_bytes(int A, int J1, int J2) {
+    const TLayout L = make_tlayout(A, J1, J2);
+    // blocks + one block of slack + the table's statistics + the column-sum partials
+    return (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * S3_BLOCK + S3_STAT_BYTES + (size_t)S3_CS_BLOCKS * S3_DP * sizeof(double);
+}
+
+extern "C" int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream) {
+    SGA_CHECK_ARG(A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_split3_tables: bad sizes");
+    const TLayout L = make_tlayout(A, J1, J2);
+    const int nb = 2 * L.nbA + L.nb1 + L.nb2;
+    if (nb == 0) return SGA_OK;
+    SGA_CHECK_ARG(Z && Zb, "sga_loss_split3_tables: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned char* tail = static_cast<unsigned char*>(Zb) + (size_t)nb * S3_BLOCK;
+    if (hipMemsetAsync(tail, 0, S3_BLOCK + S3_STAT_BYTES, s) != hipSuccess) { sga_set_error("sga_loss_split3_tables: memset failed"); return SGA_ERR_HIP; }
+    float* stat = reinterpret_cast<float*>(tail + S3_BLOCK);
+    double* part = reinterpret_cast<double*>(tail + S3_BLOCK + S3_STAT_BYTES);
+    const int R = 2 * A + J1 + J2;
+    const int ncs = R < 64 * S3_CS_BLOCKS ? (R + 63) / 64 : S3_CS_BLOCKS;
+    hipLaunchKernelGGL(split3_colsum_kernel, dim3(ncs), dim3(128), 0, s, Z, R, part);
+    hipLaunchKernelGGL(split3_stats_kernel, dim3(1), dim3(128), 0, s, part, ncs, R, stat);
+    hipLaunchKernelGGL(split3_tables_kernel, dim3(nb), dim3(256), 0, s, Z, A, J1, J2, static_cast<unsigned char*>(Zb), stat);
+    SGA_CHECK_LAUNCH("sga_loss_split3_tables");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                                          double* sums, int a_lo, int a_hi, void* stream) {
+    SGA_CHECK_ARG(Zb && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums_bf16x6: bad argument");
+    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_multi_sums_bf16x6: M=%d (2 or 3 modality tables)", M);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums_bf16x6")) return rc0;
+    if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
+    TArgs a{};
+    const int own_rows = 16 * (M == 3 ? s3_wv<3, false>() : s3_wv<2, false>());
+    const int r = fill_t(a, Zb, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi, own_rows, "sga_loss_multi_sums_bf16x6");
+    if (r > 0) return r;
+    a.sums = sums;
+    if (M == 2) launch_t<2, false>(a, -r, s); else launch_t<3, false>(a, -r, s);
+    fold_slots(sums, (M + 1) * 8, s);
+    SGA_CHECK_LAUNCH("sga_loss_multi_sums_bf16x6");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_multi_grad_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                                          const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream) {
+    SGA_CHECK_ARG(Zb && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad_bf16x6: bad argument");
+    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_multi_grad_bf16x6: M=%d (2 or 3 modality tables)", M);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rcz = zero_slots(gamma, M, s, "sga_loss_multi_grad_bf16x6")) return rcz;
+    if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
+    TArgs a{};
+    const int own_rows = 16 * (M == 3 ? s3_wv<3, true>() : s3_wv<2, true>());
+    const int r = fill_t(a, Zb, M, beta, A, J1, J2, tau0, tau1, true, a_lo, a_hi, own_rows, "sga_loss_multi_grad_bf16x6");
+    if (r > 0) return r;
+    a.gs = gs; a.gamma = gamma;
+    for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad_bf16x6: null dZ"); a.dZ[m] = dZ[m]; }
+    if (M == 2) launch_t<2, true>(a, -r, s); else launch_t<3, true>(a, -r, s);
+    fold_slots(gamma, M, s);
+    SGA_CHECK_LAUNCH("sga_loss_multi_grad_bf16x6");
+    return SGA_OK;
+}

@@ -39,31 +39,45 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-MFMA_MODES = {'f32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'f16x2p': 4}
-_MFMA_NAMES = {v: k for k, v in MFMA_MODES.items()}
+import os as _os_mode
+
+MFMA_MODES = ('f32', 'bf16x6', 'bf16x3', 'f16', 'f16x2', 'f16x2p')
+# Which arithmetic the MFMA kernels with more than one variant use is a POLICY OF THIS LAYER: the C-ABI library is stateless (every entry
+# point's arithmetic is in its name or an explicit argument, include/sgaligner_hip.h).  One setting per process, like the reference's
+# torch.backends flags; initial value from SGA_MFMA_MODE.
+_MODE = _os_mode.environ.get('SGA_MFMA_MODE', 'f32')
+if _MODE not in MFMA_MODES:
+    raise ValueError(f"sgaligner_amd: SGA_MFMA_MODE must be one of {MFMA_MODES} (got {_MODE!r})")
 
 
 def set_mfma_mode(mode: str) -> str:
-    """Arithmetic of the MFMA kernels that have a reduced-precision variant: 'f32' (exact fp32 MFMA: the default and every
-    headline number); 'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate; ~1e-5
-    relative error; PointNet forward + the fused 100-d loss sweeps); 'f16' (opt-in, BASELINE.json configs[4]: loss tables WIDER than
-    128 columns and the similarity ranking take fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; the PointNet
-    training forward as in 'f16x2'; 100-d tables and everything else stay exact fp32); 'f16x2' (opt-in, fp32-FAITHFUL: the fused 100-d loss
-    sweeps with each fp32 operand as fp16 hi + lo of 4096 x -- 22 significand bits, three fp16 MFMAs per product, fp32 accumulate: the
-    similarities carry fp32's own rounding error, csrc/sweeph.hip -- and the PointNet training forward in the same split with every
-    near-tied object re-run on the exact-fp32 kernel: same arg-max points and ReLU masks as exact fp32, csrc/pointnet.hip; everything else
-    exact fp32); 'f16x2p' (the 'f16x2' sweeps + the PointNet forward in the split WITHOUT the re-run: outputs to 6e-7 of the fp32 kernel's,
-    but where two points of an object tie for a channel's maximum to fp32 rounding the OTHER point may win and take that channel's
-    gradient -- a few 1e-6 of the (object, channel) pairs; not fp32-faithful for the conv weights' gradients).  Returns the previous mode.  SGA_MFMA_MODE in the environment sets the initial
-    mode."""
+    """Arithmetic of the MFMA kernels that have more than one variant.
+    'f32': exact fp32 MFMA everywhere (v_mfma_f32_*_f32).
+    'bf16x6': the fused 100-d loss sweeps (anchors x negatives: forward sums + gradient) with every fp32 operand split EXACTLY into three
+    bf16 terms (8 + 8 + 8 significand bits, fp32's exponent range) and six bf16 MFMAs per product into one fp32 accumulator -- fp32
+    arithmetic on the exact operands at 6/16 of the fp32 MFMA's matrix time (csrc/sweep3.hip; SURVEY 7 "fp32 MFMA or split-bf16 x3");
+    everything else exact fp32.  M = 2, 3 tables of emb_dim <= 100; other shapes take the 'f32' kernels.
+    'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, 16 bits, three bf16 MFMAs per product; ~1e-5 relative error; PointNet forward +
+    the fused loss sweeps); 'f16' (opt-in, BASELINE.json configs[4]: loss tables WIDER than 128 columns and the similarity ranking take
+    fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; the PointNet training forward as in 'f16x2'; 100-d tables and
+    everything else stay exact fp32); 'f16x2' (opt-in: the fused loss sweeps with each operand as fp16 hi + lo of 4096 x -- 22 significand
+    bits, three fp16 MFMAs per product, csrc/sweeph.hip -- and the PointNet training forward in the same split with every near-tied object
+    re-run on the exact-fp32 kernel); 'f16x2p' (the same without the re-run).  Returns the previous mode."""
+    global _MODE
     if mode not in MFMA_MODES:
         raise ValueError(f"sgaligner_amd: mfma mode must be one of {sorted(MFMA_MODES)} (got {mode!r})")
-    old = _lib.lib().sga_set_mfma_mode(MFMA_MODES[mode])
-    return _MFMA_NAMES.get(old, 'f32')
+    old, _MODE = _MODE, mode
+    return old
 
 
 def get_mfma_mode() -> str:
-    return _MFMA_NAMES.get(_lib.lib().sga_get_mfma_mode(), 'f32')
+    return _MODE
+
+
+# PointNet forward arithmetic per mode (sga_pointnet_fwd_ws `mode`): 0 exact fp32, 1 bf16 hi + lo, 2 fp16 hi + lo + exact re-run of near-ties, 3 without
+_POINTNET_MODE = {'f32': 0, 'bf16x6': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 2, 'f16x2p': 3}
+POINTNET_TIE_EPS = -1.0                # 'f16x2' forward: < 0 = the library default 2^-17 (tools/dbg/f16x2_pointnet_flips.py sweeps it)
+GROUP_LOSS_VALU = _os_mode.environ.get('SGA_GROUP_GRAD_VALU', '0') == '1'      # loss_group kernels: the VALU forms (cross-checks) instead of MFMA
 
 
 # ------------------------------------------------------------------------------------------ PointNet
@@ -90,7 +104,7 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
         ws_bytes = 4 * (T + 1)
         ws = POINTNET_LAST_REDO = torch.empty((T + 1,), device=x_tp3.device, dtype=torch.int32)
     rc = L.sga_pointnet_fwd_ws(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
-                               T, P, C3, _p(ws), ws_bytes, _stream())
+                               T, P, C3, _p(ws), ws_bytes, _POINTNET_MODE[get_mfma_mode()], float(POINTNET_TIE_EPS), _stream())
     _lib.check(rc, 'sga_pointnet_fwd')
     if ev is not None:
         ev[1].record()
@@ -837,7 +851,7 @@ class GroupedContrastiveFn(torch.autograd.Function):
         sums = torch.empty((max(gr.G, 1), nt, 8), device=dev, dtype=torch.float64)
         out = torch.zeros((max(gr.G, 1), no), device=dev, dtype=torch.float64)
         _lib.check(L.sga_group_loss_fwd(_ptr_array(zs), M, _p(beta), s.A, s.J1, _p(gr.groups), gr.G, _p(gr.soff), gr.s_total,
-                                        float(alpha), TAU_ICL, TAU_IAL, _p(S), _p(sums), _p(out), st), 'sga_group_loss_fwd')
+                                        float(alpha), TAU_ICL, TAU_IAL, _p(S), _p(sums), _p(out), int(GROUP_LOSS_VALU), st), 'sga_group_loss_fwd')
         ctx.s, ctx.gr, ctx.alpha, ctx.M = s, gr, float(alpha), M
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.has_beta = beta is not None
@@ -861,7 +875,7 @@ class GroupedContrastiveFn(torch.autograd.Function):
         dzs = [torch.zeros((max(s.R, 1), dp), device=dev, dtype=torch.float32) for _ in range(M)]
         gamma = torch.zeros((max(gr.G, 1), M), device=dev, dtype=torch.float64)
         _lib.check(L.sga_group_loss_bwd(_ptr_array(zs), M, _p(beta), s.A, s.J1, _p(gr.groups), gr.G, _p(gr.soff), gr.s_total,
-                                        ctx.alpha, TAU_ICL, TAU_IAL, _p(C), _p(sums), _p(coef), _ptr_array(dzs), _p(gamma), st),
+                                        ctx.alpha, TAU_ICL, TAU_IAL, _p(C), _p(sums), _p(coef), _ptr_array(dzs), _p(gamma), int(GROUP_LOSS_VALU), st),
                    'sga_group_loss_bwd')
         grads = []
         for k in range(M):
@@ -1218,6 +1232,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         dmax = max(e.shape[1] for e in tables)          # real width: the K step that only covers zero padding is skipped
         # opt-in split-bf16 x3 sweeps: the tables additionally as blocked bf16 hi/lo planes (sweepb.hip)
         zbs = []
+        split3 = False
         split16 = M in (2, 3, 4) and dmax <= 100 and get_mfma_mode() in ('f16x2', 'f16x2p')      # columns 100, 101 of the planes carry the centring's bookkeeping
         if split16:
             nb = L.sga_loss_split16_bytes(s.A, s.J1, s.J2)
@@ -1234,6 +1249,23 @@ class FusedContrastiveFn(torch.autograd.Function):
             if ev is not None:
                 ev[1].record()
                 KERNEL_EVENTS.setdefault('loss_multi_sums_f16x2', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
+        elif M in (2, 3) and dmax <= 100 and get_mfma_mode() == 'bf16x6':
+            # three exact bf16 planes per table (csrc/sweep3.hip): blocked h / m / l planes of the centred rows, once per step
+            split3 = True
+            nb = L.sga_loss_split3_bytes(s.A, s.J1, s.J2)
+            for z in zs:
+                zb = torch.empty((nb,), device=dev, dtype=torch.uint8)
+                _lib.check(L.sga_loss_split3_tables(_p(z), s.A, s.J1, s.J2, _p(zb), st), 'sga_loss_split3_tables')
+                zbs.append(zb)
+            ev = None
+            if KERNEL_EVENTS is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            _lib.check(L.sga_loss_multi_sums_bf16x6(_ptr_array(zbs), M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums),
+                                                    a_lo, a_hi, st), 'sga_loss_multi_sums_bf16x6')
+            if ev is not None:
+                ev[1].record()
+                KERNEL_EVENTS.setdefault('loss_multi_sums_bf16x6', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
         elif M <= 3 and get_mfma_mode() == 'bf16x3':
             nb = L.sga_loss_split_bytes(s.A, s.J1, s.J2)
             for z in zs:
@@ -1356,6 +1388,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.n_zb = len(zbs)
         ctx.split16 = split16
+        ctx.split3 = split3
         ctx.onepass = onepass
         ctx.save_for_backward(sums, beta, zj, *zs, *nrms, *zbs, *extra)
         return out.float() + poison
@@ -1457,7 +1490,10 @@ class FusedContrastiveFn(torch.autograd.Function):
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if ctx.n_zb and ctx.split16:          # the forward ran in f16x2 mode: its blocked fp16 hi/lo planes are there
+        if ctx.n_zb and ctx.split3:           # the forward ran in bf16x6 mode: its blocked bf16 h / m / l planes are there
+            _lib.check(L.sga_loss_multi_grad_bf16x6(_ptr_array(zbs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
+                                                    _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad_bf16x6')
+        elif ctx.n_zb and ctx.split16:        # the forward ran in f16x2 mode: its blocked fp16 hi/lo planes are there
             _lib.check(L.sga_loss_multi_grad_f16x2(_ptr_array(zbs), M, _p(beta), A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(gs), _ptr_array(dzs),
                                                    _p(gam_neg), a_lo, a_hi, 1 if _f16x2_coef_lo(ns, s.J1, s.J2) else 0, st), 'sga_loss_multi_grad_f16x2')
         elif ctx.n_zb:          # the forward ran in bf16x3 mode: its blocked bf16 planes are there
@@ -1468,7 +1504,7 @@ class FusedContrastiveFn(torch.autograd.Function):
                                              _p(gam_neg), a_lo, a_hi, st), 'sga_loss_multi_grad')
         if ev is not None:
             ev[1].record()
-            KERNEL_EVENTS.setdefault('loss_multi_grad_f16x2' if (ctx.n_zb and ctx.split16) else 'loss_multi_grad', []).append(ev + ((ns, A, s.J1, s.J2, M),))
+            KERNEL_EVENTS.setdefault('loss_multi_grad_bf16x6' if (ctx.n_zb and ctx.split3) else 'loss_multi_grad_f16x2' if (ctx.n_zb and ctx.split16) else 'loss_multi_grad', []).append(ev + ((ns, A, s.J1, s.J2, M),))
         grads = []
         same = all(sh == ctx.shapes[0] for sh in ctx.shapes)
         de_all = torch.zeros((M,) + tuple(ctx.shapes[0]), device=dev, dtype=torch.float32) if same else None   # one fill

@@ -1,0 +1,274 @@
+"""The anchors x negatives loss sweeps with every fp32 operand split EXACTLY into three bf16 planes (ops.set_mfma_mode('bf16x6'),
+csrc/sweep3.hip; reference arithmetic src/aligner/losses.py:5-15,43-97; SURVEY 7: "parity configs use fp32 MFMA or split-bf16 x3").
+What makes the mode fp32 arithmetic and not a narrower one is tested first: h + m + l of every stored plane element IS the fp32 operand,
+bit for bit.  Then the same tolerances as the exact-fp32 MFMA path everywhere, and an error against the fp64 oracle no larger than that
+path's own."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16x6():
+    from sgaligner_amd import ops
+    old = ops.set_mfma_mode('bf16x6')
+    yield
+    ops.set_mfma_mode(old)
+
+
+def _bf16_to_f64(u16):
+    return (u16.to(torch.int32) << 16).view(torch.float32).double()
+
+
+@pytest.mark.parametrize('parallel_rows', [False, True])
+def test_planes_represent_every_fp32_operand_exactly(parallel_rows):
+    """sga_loss_split3_tables: for every row and column of a packed table (values over 60 binades, incl. exact zeros) the three stored bf16
+    terms sum to the fp32 operand EXACTLY, |m| <= 2^-8 |h|, |l| <= 2^-16 |h|.  The operand is the table entry z itself (zbar = 0) unless
+    the table's rows are nearly parallel (|mean row|^2 >= 1/4), then it is the fp32 difference z - zbar and the bookkeeping columns hold
+    b = zbar . z' + |zbar|^2 / 2 and 1; the two K-tail images repeat the planes' columns 96..103 in the documented k-group order; the column
+    means are bitwise reproducible (fixed summation order)."""
+    from sgaligner_amd import _lib, ops
+    L = _lib.lib()
+    A, J1, J2 = 37, 70, 45
+    R = 2 * A + J1 + J2
+    g = torch.Generator(device='cuda').manual_seed(0)
+    z = torch.randn(R + 32, 104, device='cuda', generator=g) * torch.exp2(torch.randint(-40, 0, (R + 32, 104), device='cuda', generator=g).float())
+    if parallel_rows:
+        z = 1e-3 * torch.randn(R + 32, 104, device='cuda', generator=g) + 0.1 * torch.randn(1, 104, device='cuda', generator=g)
+    z[3, 7] = 0.0
+    z[:, 100:] = 0.0
+    z[R:] = 0.0
+    nb = L.sga_loss_split3_bytes(A, J1, J2)
+    outs = []
+    for _ in range(2):
+        zb = torch.zeros((nb,), device='cuda', dtype=torch.uint8)
+        _lib.check(L.sga_loss_split3_tables(z.data_ptr(), A, J1, J2, zb.data_ptr(), ops._stream()), 'sga_loss_split3_tables')
+        torch.cuda.synchronize()
+        outs.append(zb.clone())
+    assert torch.equal(outs[0], outs[1])
+    zb = outs[0]
+    nblk = [(A + 31) // 32, (A + 31) // 32, (J1 + 31) // 32, (J2 + 31) // 32]
+    seg0 = [0, A, 2 * A, 2 * A + J1]
+    seglen = [A, A, J1, J2]
+    BLOCK, PLANE, TAIL = 22528, 6144, 18432
+    stat = zb[(sum(nblk) + 1) * BLOCK:(sum(nblk) + 1) * BLOCK + 4 * 105].view(torch.float32)
+    zbar = stat[:104]
+    ref_mean = (z[:R, :100].double().sum(0) / R).float()
+    centred = float((ref_mean.double() ** 2).sum()) >= 0.25
+    assert centred == parallel_rows
+    if not centred:
+        ref_mean = torch.zeros_like(ref_mean)
+    assert torch.equal(zbar[:100], ref_mean) and float(zbar[100:].abs().max()) == 0.0
+    cen = torch.zeros((R, 104), device='cuda')
+    cen[:, :100] = z[:R, :100] - zbar[:100]
+    assert centred or torch.equal(cen[:, :100], z[:R, :100])
+    cen[:, 100] = ((zbar[:100].double() * cen[:, :100].double()).sum(1) + stat[104].double()).float()
+    cen[:, 101] = 1.0
+    u16 = zb.view(torch.int16).to(torch.int32) & 0xFFFF
+
+    def slot(gk, i):
+        return 16 * gk + (i ^ (12 * (gk & 1)))
+    blk = 0
+    worst_m, worst_l = 0.0, 0.0
+    for sgm in range(4):
+        for b in range(nblk[sgm]):
+            base = blk * BLOCK // 2
+            for w in range(32):
+                row = 32 * b + w
+                jh, i = (w >> 2) & 1, 4 * (w >> 3) + (w & 3)
+                want = cen[seg0[sgm] + row] if row < seglen[sgm] else torch.zeros(104, device='cuda')
+                planes = []
+                for p in range(3):
+                    cols = torch.zeros(104, device='cuda', dtype=torch.float64)
+                    for q in range(3):
+                        for gk in range(4):
+                            o = base + (p * PLANE + ((q * 2 + jh) * 64 + slot(gk, i)) * 16) // 2
+                            cols[32 * q + 8 * gk:32 * q + 8 * gk + 8] = _bf16_to_f64(u16[o:o + 8])
+                    planes.append(cols)
+                # tail images: T0 = (h, h, m, m), T1 = (l, h, l, m)
+                t0 = [_bf16_to_f64(u16[base + (TAIL + (jh * 64 + slot(gk, i)) * 16) // 2:][:8]) for gk in range(4)]
+                t1 = [_bf16_to_f64(u16[base + (TAIL + 2048 + (jh * 64 + slot(gk, i)) * 16) // 2:][:8]) for gk in range(4)]
+                planes[0][96:104], planes[1][96:104], planes[2][96:104] = t0[0], t0[2], t1[0]
+                assert torch.equal(t0[1], t0[0]) and torch.equal(t0[3], t0[2]) and torch.equal(t1[1], t0[0]) and torch.equal(t1[2], t1[0]) and torch.equal(t1[3], t0[2])
+                tot = planes[0] + planes[1] + planes[2]
+                assert torch.equal(tot, want.double()), (sgm, b, w, (tot - want.double()).abs().max().item())
+                nz = planes[0] != 0
+                if nz.any():
+                    worst_m = max(worst_m, float((planes[1][nz] / planes[0][nz]).abs().max()))
+                    worst_l = max(worst_l, float((planes[2][nz] / planes[0][nz]).abs().max()))
+            blk += 1
+    assert worst_m <= 2.0 ** -8 * 1.01 and worst_l <= 2.0 ** -16 * 1.01, (worst_m, worst_l)
+
+
+@pytest.mark.parametrize('M,emb', [(3, 100), (2, 100), (3, 64)])
+def test_sweeps_vs_fp32_sweeps_and_anchor_shards(bf16x6, M, emb):
+    """The three-plane sweeps against the exact-fp32 MFMA sweeps on the same tables (loss terms, dE, d fusion weight), unsharded and as the
+    sum of 3 anchor shards with cuts that are NOT multiples of the 32-row blocks (what ranks of a multi-GPU job own)."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    from test_c3_gpu import _replay_sharded
+    dd = make_batch(9, 30, 4, seed=40 + M, ragged=True, anchors='val')
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(M)
+    base = [torch.randn(T, emb, device='cuda', generator=g) for _ in range(M)]
+    w0 = torch.tensor([[0.3], [1.1], [-0.4], [0.6]], device='cuda')[:M].contiguous()
+    cot = torch.randn(M + 1 + 2 * M, device='cuda', generator=g)
+
+    def run():
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        w = w0.clone().requires_grad_(True)
+        sums, s = ops.fused_contrastive_terms(tabs, w, dd)
+        (sums * cot).sum().backward()
+        torch.cuda.synchronize()
+        return sums.detach(), [t.grad for t in tabs], w.grad, s
+    sb, gb, wb, s = run()
+    ops.set_mfma_mode('f32')
+    sf, gf, wf, _ = run()
+    ops.set_mfma_mode('bf16x6')
+    assert torch.allclose(sb, sf, rtol=2e-6, atol=1e-7), (sb, sf)
+    for m in range(M):
+        sc = gf[m].abs().max().item()
+        assert (gb[m] - gf[m]).abs().max().item() < 5e-6 * sc, (m, (gb[m] - gf[m]).abs().max().item(), sc)
+    assert (wb - wf).abs().max().item() < 5e-5 * max(1e-3, wf.abs().max().item())
+    A = s.A
+    cuts = [0, A // 3 + 5, 2 * A // 3 - 3, A]
+    _, gs, gw, all_sums = _replay_sharded(base, w0, cot, dd, cuts)
+    for sr in all_sums:
+        assert torch.allclose(sr, sb, rtol=1e-5, atol=1e-6)
+    for m in range(M):
+        sc = gb[m].abs().max().item()
+        assert (gs[m] - gb[m]).abs().max().item() < 2e-5 * sc, m
+    assert (gw - wb).abs().max().item() < 2e-4 * max(1e-3, wb.abs().max().item())
+
+
+def _overall_vs_fp64(pairs, nobj, seed, modes=('f32', 'bf16x6')):
+    """The product OverallLoss on fused tables in both modes and the fp64 oracle: errors of every gradient against the oracle."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    from test_fullsize_gpu import _loss_setup, _run_overall
+    mods = ['point', 'gat', 'rel']
+    dd, T, base = _loss_setup(pairs, nobj, mods, seed=seed)
+    w0 = torch.tensor([[0.7], [1.2], [0.9]], device='cuda')
+    lv1 = torch.tensor([0.1, -0.2, 0.05], device='cuda')
+    lv2 = torch.tensor([-0.1, 0.15, 0.0], device='cuda')
+    eo = {k: base[i].cpu().double().requires_grad_(True) for i, k in enumerate(mods)}
+    wo = w0.cpu().double().requires_grad_(True)
+    lo1, lo2 = lv1.cpu().double().requires_grad_(True), lv2.cpu().double().requires_grad_(True)
+    out_o = dict(eo)
+    out_o['joint'] = O.fusion([eo[k] for k in mods], wo)
+    ref = O.overall_loss(out_o, dd, mods, lo1, lo2)
+    ref['loss'].backward()
+    errs = {}
+    for mode in modes:
+        old = ops.set_mfma_mode(mode)
+        try:
+            lf, gf, gwf, g1f, g2f = _run_overall(base, dd, mods, w0, lv1, lv2, fused=True)
+        finally:
+            ops.set_mfma_mode(old)
+        e = {'loss': abs(lf - ref['loss'].item()) / abs(ref['loss'].item())}
+        for k in mods:
+            gref = eo[k].grad
+            e['dE_' + k] = (gf[k].cpu().double() - gref).abs().max().item() / gref.abs().max().item()
+            e['colsum_' + k] = (gf[k].cpu().double().sum(0) - gref.sum(0)).abs().max().item() / gref.sum(0).abs().max().item()
+        e['dw'] = (gwf.cpu().double() - wo.grad).abs().max().item() / max(1e-30, wo.grad.abs().max().item())
+        e['dlv1'] = (g1f.cpu().double() - lo1.grad).abs().max().item() / lo1.grad.abs().max().item()
+        e['dlv2'] = (g2f.cpu().double() - lo2.grad).abs().max().item() / lo2.grad.abs().max().item()
+        errs[mode] = e
+    return errs
+
+
+@pytest.mark.parametrize('pairs,nobj,seed', [(64, 64, 23), (16, 40, 5), (3, 30, 9)])
+def test_error_vs_fp64_oracle_no_larger_than_the_fp32_mfma_paths(pairs, nobj, seed):
+    """Against the fp64 oracle (the largest batch-global losses it finishes in seconds and two small ones): the mode's error in the loss,
+    every table gradient (entries and column sums), d fusion weight and both d log_vars is that of fp32 arithmetic -- at most 1.25 x the
+    exact-fp32 MFMA path's own error + 5e-7 relative (two different fp32 summation orders differ by that much among themselves), and
+    within the fp32 tests' tolerances (1e-4 loss, 1e-3 gradients)."""
+    errs = _overall_vs_fp64(pairs, nobj, seed)
+    a, b = errs['f32'], errs['bf16x6']
+    for k in a:
+        assert b[k] <= 1.25 * a[k] + 5e-7, (k, a[k], b[k])
+        assert b[k] < (1e-4 if k == 'loss' else 1e-3), (k, b[k])
+
+
+def test_train_step_vs_oracle(bf16x6):
+    from oracle import sga_oracle as O
+    from sgaligner_amd.synthetic import make_batch, to_device
+    from sgaligner_amd.trainer import AlignerSteps
+    mods = ['point', 'gat', 'rel']
+    dd = make_batch(3, 20, 96, seed=8, ragged=True)
+    steps = AlignerSteps(mods, device='cuda', seed=3)
+    params = {k: v.detach().cpu().clone() for k, v in steps.model.state_dict().items() if 'num_batches' not in k}
+    out_o, loss_o, grads_o = O.train_step(params, dd, mods)
+    out, loss = steps.forward_backward(to_device(dd, 'cuda'))
+    torch.cuda.synchronize()
+    for k in out_o:
+        assert (out[k].detach().cpu() - out_o[k].detach()).abs().max() < 1e-3, k
+    assert abs(loss['loss'].item() - loss_o['loss'].item()) < 1e-3 * max(1, abs(loss_o['loss'].item()))
+    for name, p in steps.model.named_parameters():
+        if name in grads_o and p.grad is not None:
+            ref = grads_o[name]
+            assert (p.grad.cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), name
+
+
+def test_loss_scale_independence(bf16x6):
+    """bf16 has fp32's exponent range: cotangents 1e-30 ... 1e+20 times larger give gradients exactly that much larger (to fp32 rounding) --
+    no scaling logic, no overflow or underflow of a coefficient plane whatever the loss scale."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(6, 24, 4, seed=3, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(1)
+    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(3)]
+    cot = torch.rand(3 + 1 + 6, device='cuda', generator=g) + 0.5
+    ref = None
+    for scale in (1.0, 1e-6, 1e6, 1e-24, 1e20):
+        tabs = [b.clone().requires_grad_(True) for b in base]
+        w = torch.ones(3, 1, device='cuda', requires_grad=True)
+        sums, _ = ops.fused_contrastive_terms(tabs, w, dd)
+        (sums * cot * scale).sum().backward()
+        gs = [t.grad.double() / scale for t in tabs]
+        assert all(torch.isfinite(x).all() for x in gs)
+        if ref is None:
+            ref = gs
+        else:
+            for x, y in zip(gs, ref):
+                assert (x - y).abs().max().item() < 1e-5 * y.abs().max().item(), scale
+
+
+def test_nearly_identical_rows_vs_fp64_oracle(bf16x6):
+    """A table whose rows are nearly identical (what meta_embedding_rel makes of bag-of-words rows that are almost all alike): the loss gradient
+    is the small tangential remainder of a large radial sum.  With exact operands AND centred rows the mode is at least as accurate as the
+    exact-fp32 MFMA sweep against the fp64 oracle, in the table gradient and in its column sums (= the bias gradient below it)."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    from test_fullsize_gpu import _run_overall
+    mods = ['point', 'gat', 'rel']
+    dd = make_batch(64, 64, 1, seed=3)
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator().manual_seed(0)
+    base = [torch.randn(T, 100, generator=g, dtype=torch.float64) for _ in mods]
+    base[2] = torch.randn(1, 100, generator=g, dtype=torch.float64) + 1e-3 * torch.randn(T, 100, generator=g, dtype=torch.float64)
+    base = [b.float().double() for b in base]
+    w0 = torch.tensor([[0.7], [1.2], [0.9]], dtype=torch.float64)
+    lv1 = torch.tensor([0.1, -0.2, 0.05], dtype=torch.float64)
+    lv2 = torch.tensor([-0.1, 0.15, 0.0], dtype=torch.float64)
+    eo = {k: base[i].clone().requires_grad_(True) for i, k in enumerate(mods)}
+    wo = w0.clone().requires_grad_(True)
+    out_o = dict(eo)
+    out_o['joint'] = O.fusion([eo[k] for k in mods], wo)
+    O.overall_loss(out_o, dd, mods, lv1.clone().requires_grad_(True), lv2.clone().requires_grad_(True))['loss'].backward()
+    err = {}
+    for mode in ('f32', 'bf16x6'):
+        ops.set_mfma_mode(mode)
+        _, gg, _, _, _ = _run_overall([b.float().cuda() for b in base], dd, mods, w0.float().cuda(), lv1.float().cuda(), lv2.float().cuda(), fused=True)
+        gref = eo['rel'].grad
+        got = gg['rel'].cpu().double()
+        err[mode] = ((got - gref).abs().max().item() / gref.abs().max().item(),
+                     (got.sum(0) - gref.sum(0)).abs().max().item() / gref.sum(0).abs().max().item())
+    ops.set_mfma_mode('bf16x6')
+    print('nearly identical rows, (max entry, max column sum) error vs fp64:', err)
+    assert err['bf16x6'][0] <= 1.25 * err['f32'][0] + 5e-7, err
+    assert err['bf16x6'][1] <= 1.25 * err['f32'][1] + 5e-7, err

@@ -14,10 +14,10 @@ w = [torch.randn(64, 3, device='cuda') * 0.2, torch.randn(64, device='cuda') * 0
      torch.randn(256, 128, device='cuda') * 0.1, torch.randn(256, device='cuda') * 0.1]
 ref = None
 EPS = [float(e) for e in os.environ.get('PN_TIE_EPS', '').split(',') if e] or [None]
+NAMES = {0: 'f32', 1: 'bf16x3', 3: 'f16x2', 4: 'f16x2p'}
 for mode, eps in [(0, None), (1, None), (4, None)] + [(3, e) for e in EPS]:
-    if eps is not None:
-        _lib.lib().sga_pointnet_tie_eps(eps)
-    _lib.lib().sga_set_mfma_mode(mode)
+    ops.POINTNET_TIE_EPS = -1.0 if eps is None else eps
+    ops.set_mfma_mode(NAMES[mode])
     for am in (False, True):
         for _ in range(2):
             y, a = ops.pointnet_forward(x, *w, want_argmax=am)
@@ -39,7 +39,7 @@ for mode, eps in [(0, None), (1, None), (4, None)] + [(3, e) for e in EPS]:
             same = (a == ref[1]).float().mean().item()
             extra = f'  max|y - y_fp32| {err:.3e} (rel {rel:.2e}), same arg-max point {same * 100:.5f} % ({int((a != ref[1]).sum())} of {a.numel()} differ, {int(((a != ref[1]) & (ref[0] > 0)).sum())} of them with y > 0)'
             if mode == 3:
-                extra += f'; tie eps {_lib.lib().sga_pointnet_tie_eps(-1.0):.3g}: {int(ops.POINTNET_LAST_REDO[0]) / T * 100:.2f} % of the objects re-run in fp32'
+                extra += f'; tie eps {ops.POINTNET_TIE_EPS if ops.POINTNET_TIE_EPS >= 0 else 2.0 ** -17:.3g}: {int(ops.POINTNET_LAST_REDO[0]) / T * 100:.2f} % of the objects re-run in fp32'
         print(f'pointnet_fwd mode={ {0: "fp32", 1: "bf16x3", 3: "f16x2", 4: "f16x2p"}[mode]} argmax={am} T={T} P={P}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s algorithmic '
               f'({fl/ms/1e9/157.3*100:.1f}% of the fp32 MFMA peak){extra}')
-_lib.lib().sga_set_mfma_mode(0)
+ops.set_mfma_mode('f32')

@@ -19,8 +19,7 @@ ops.set_mfma_mode('f32')
 y0, a0 = ops.pointnet_forward(x, *ws, want_argmax=True)
 print('objects', tuple(x.shape), 'y > 0 fraction', float((y0 > 0).float().mean()))
 for eps in eps_list:
-    if eps is not None:
-        _lib.lib().sga_pointnet_tie_eps(eps)
+    ops.POINTNET_TIE_EPS = -1.0 if eps is None else eps
     for mode in ('f16x2p', 'f16x2'):
         ops.set_mfma_mode(mode)
         y1, a1 = ops.pointnet_forward(x, *ws, want_argmax=True)
@@ -28,7 +27,7 @@ for eps in eps_list:
         dm = (y0 > 0) != (y1 > 0)
         extra = ''
         if mode == 'f16x2':
-            extra = f'; eps {_lib.lib().sga_pointnet_tie_eps(-1.0):.3g}: {int(ops.POINTNET_LAST_REDO[0]) / x.shape[0] * 100:.2f} % of the objects re-run'
+            extra = f'; eps {ops.POINTNET_TIE_EPS if ops.POINTNET_TIE_EPS >= 0 else 2.0 ** -17:.3g}: {int(ops.POINTNET_LAST_REDO[0]) / x.shape[0] * 100:.2f} % of the objects re-run'
         print(f'{mode}: arg-max differs (live channels) {int(da.sum())}, ReLU mask differs {int(dm.sum())} of {a0.numel()}; max |dy| {float((y0 - y1).abs().max()):.3e} '
               f'(max |y| {float(y0.abs().max()):.3e}){extra}')
         if mode == 'f16x2' and da.any():

@@ -21,14 +21,14 @@ while time.time() < t_end:
     w0 = torch.randn(M, 1, device='cuda', generator=g)
     res = {}
     for valu in (0, 1):
-        L.sga_set_group_valu(valu)
+        ops.GROUP_LOSS_VALU = bool(valu)
         tabs = [t.clone().requires_grad_(True) for t in base]
         w = w0.clone().requires_grad_(True)
         out, gr = ops.grouped_contrastive_terms(tabs, w if M > 1 else None, dict(dd), b)
         cot = torch.linspace(0.5, 1.5, out.numel(), device='cuda', dtype=out.dtype).view_as(out)
         (out * cot).sum().backward()
         res[valu] = (out.detach().double(), [t.grad for t in tabs], w.grad if M > 1 else None)
-    L.sga_set_group_valu(0)
+    ops.GROUP_LOSS_VALU = False
     a, c = res[0], res[1]
     e = float(((a[0] - c[0]).abs() / c[0].abs().clamp_min(1e-3)).max()) if a[0].numel() else 0.0
     for x, y in zip(a[1], c[1]):
