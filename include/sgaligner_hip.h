@@ -245,13 +245,21 @@ int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, i
  * or split-bf16 x3").  M = 2 or 3 tables, emb_dim <= 100 (columns 100, 101 of the planes carry the row centring's bookkeeping).
  * sga_loss_split3_tables: packed fp32 table Z [R(+32), 104] -> Zb, 32-row blocks of bf16 h / m / l planes in MFMA operand order + two
  * packed K-tail images (sga_loss_split3_bytes bytes; segments X1 | X2 | N1 | N2 each padded to whole blocks; column means summed in a
- * fixed order: the planes are bitwise reproducible).  The other arguments and every output: as sga_loss_multi_sums / sga_loss_multi_grad. */
+ * fixed order: the planes are bitwise reproducible).  The other arguments and every output: as sga_loss_multi_sums / sga_loss_multi_grad,
+ * except that the gradient arrives in TWO parts: dZ[r, 0..100) += sum_j c_rj (z_j - zbar) and dZ[r, 101] += sum_j c_rj (zbar = 0 unless the
+ * table's rows are nearly parallel, |mean row|^2 >= 1/4).  Zc (optional) receives the anchor rows as fp32 [2A, 104] = z - zbar with column
+ * 101 = 1: the B operand that makes sga_loss_stash_grad* deliver the A x A part in the same two-part form.
+ * sga_loss_scatter_tangent = sga_loss_scatter (the autograd of F.normalize + the row gather, losses.py:44-48) for that form: it projects
+ * G - rho (z_r - zbar) instead of the summed gradient -- identical in exact arithmetic (P_r z_r = 0), and free of the cancellation that
+ * costs a table of nearly parallel rows 3e-4 of its gradient when the radial part is formed in fp32 first. */
 size_t sga_loss_split3_bytes(int A, int J1, int J2);
-int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
+int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, void* Zb, float* Zc, void* stream);
 int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                double* sums, int a_lo, int a_hi, void* stream);
 int sga_loss_multi_grad_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
+int sga_loss_scatter_tangent(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int A, int J1, int J2, int D,
+                             const void* Zb, float* dE, void* stream);
 
 /* ---- loss_group = b: the same loss on G independent groups of b consecutive pairs ------------------------
  * replaces the reference trainer feeding b pairs per iteration (configs/scan3r/scan3r_ground_truth.yaml:27,

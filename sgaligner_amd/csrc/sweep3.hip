@@ -139,12 +139,12 @@ __global__ __launch_bounds__(128) void split3_stats_kernel(const double* __restr
     const bool centre = tot >= 0.25;
     if (!centre) zb = 0.f;
     if (c < S3_DP) stat[c] = zb;
-    if (c == 0) stat[S3_DP] = centre ? (float)(0.5 * tot) : 0.f;
+    if (c == 0) { stat[S3_DP] = centre ? (float)(0.5 * tot) : 0.f; stat[S3_DP + 1] = centre ? 1.f : 0.f; }
 }
 
 // fp32 packed table -> blocked bf16 h / m / l planes + the two tail images of the CENTRED rows (one workgroup per 32-row block)
 __global__ __launch_bounds__(256) void split3_tables_kernel(const float* __restrict__ Z, int A, int J1, int J2, unsigned char* __restrict__ Zb,
-                                                            const float* __restrict__ stat) {
+                                                            const float* __restrict__ stat, float* __restrict__ Zc) {
     __shared__ float tile[32 * S3_DP];
     __shared__ float zbar[S3_DP];
     const TLayout L = make_tlayout(A, J1, J2);
@@ -160,6 +160,9 @@ __global__ __launch_bounds__(256) void split3_tables_kernel(const float* __restr
     for (int e = threadIdx.x; e < 32 * S3_DP; e += 256) {
         const int r = e / S3_DP, c = e - r * S3_DP;
         tile[e] = (r < nvalid && c < S3_DREAL) ? src[e] - zbar[c] : 0.f;
+        // the anchor rows once more as fp32 [2A, 104]: z - zbar, column 101 = 1 -- the B operand of the A x A stash products, whose output
+        // column 101 is then the row sum of the coefficients (sga_loss_scatter_tangent)
+        if (Zc && old0 < 2 * A && r < nvalid) Zc[(size_t)(old0 + 32 * b) * S3_DP + e] = c == S3_DREAL + 1 ? 1.f : tile[e];
     }
     __syncthreads();
     if (threadIdx.x < 32) {                       // the two bookkeeping columns of a valid row (a padding row stays all zero: S = 0)
@@ -209,7 +212,6 @@ struct TArgs {
     double* sums;                    // SUM out  [(M+1)][8] (+ slots)
     const double* gs;                // GRAD in  [(M+1)][8]
     float* dZ[4];                    // GRAD out (fp32, old row order), atomic accumulate
-    const float* stat[4];            // per table: zbar[104], |zbar|^2 / 2 (behind the blocks of Zb)
     double* gamma;                   // GRAD out [M] (+ slots)
 };
 
@@ -642,23 +644,18 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             float* dz = a.dZ[m];
-            float zb[NCT];                                     // zbar of this lane's columns
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) zb[ct] = (ct * 16 + l15 < S3_DREAL) ? a.stat[m][ct * 16 + l15] : 0.f;
-            // rowsum_i = sum_j c_ij: output column 101 = lane 5 of the last column tile (same row group g4)
-            float rs[4];
+            // dZ[i, 0..99] += sum_j c_ij z'_j and dZ[i, 101] += rowsum_i = sum_j c_ij (output column 101 of the last column tile): the true
+            // gradient is the first + rowsum x zbar, but it is never formed -- sga_loss_scatter_tangent takes the two apart (see there)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) gacc[GRAD ? m : 0][ct] += gsm[GRAD ? m : 0][ct];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rs[r] = __shfl(gacc[GRAD ? m : 0][NCT - 1][r], (lane & 48) | 5, 64);
-#pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int d = ct * 16 + l15;
-                if (d < S3_DREAL) {
+                if (d < S3_DREAL || d == S3_DREAL + 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = wrow0 + 4 * g4 + r;
-                        if (i < own_end) atomicAdd(dz + (size_t)i * S3_DP + d, fmaf(rs[r], zb[ct], gacc[GRAD ? m : 0][ct][r]));
+                        if (i < own_end) atomicAdd(dz + (size_t)i * S3_DP + d, gacc[GRAD ? m : 0][ct][r]);
                     }
                 }
             }
@@ -679,13 +676,9 @@ int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int
     if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("%s: anchor shard [%d,%d) outside [0,%d]", who, a_lo, a_hi, A); return SGA_ERR_ARG; }
     a.M = M;
     const TLayout L = make_tlayout(A, J1, J2);
-    {
-        const size_t stat_off = (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * S3_BLOCK;
-        for (int m = 0; m < M; ++m) {
-            if (!Zb[m]) { sga_set_error("%s: null table", who); return SGA_ERR_ARG; }
-            a.Zb[m] = static_cast<const unsigned char*>(Zb[m]);
-            a.stat[m] = reinterpret_cast<const float*>(a.Zb[m] + stat_off);
-        }
+    for (int m = 0; m < M; ++m) {
+        if (!Zb[m]) { sga_set_error("%s: null table", who); return SGA_ERR_ARG; }
+        a.Zb[m] = static_cast<const unsigned char*>(Zb[m]);
     }
     a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     const int ns = a_hi - a_lo;
@@ -761,7 +754,7 @@ extern "C" size_t sga_loss_split3_bytes(int A, int J1, int J2) {
     return (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * S3_BLOCK + S3_STAT_BYTES + (size_t)S3_CS_BLOCKS * S3_DP * sizeof(double);
 }
 
-extern "C" int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream) {
+extern "C" int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, void* Zb, float* Zc, void* stream) {
     SGA_CHECK_ARG(A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_split3_tables: bad sizes");
     const TLayout L = make_tlayout(A, J1, J2);
     const int nb = 2 * L.nbA + L.nb1 + L.nb2;
@@ -776,8 +769,62 @@ extern "C" int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, voi
     const int ncs = R < 64 * S3_CS_BLOCKS ? (R + 63) / 64 : S3_CS_BLOCKS;
     hipLaunchKernelGGL(split3_colsum_kernel, dim3(ncs), dim3(128), 0, s, Z, R, part);
     hipLaunchKernelGGL(split3_stats_kernel, dim3(1), dim3(128), 0, s, part, ncs, R, stat);
-    hipLaunchKernelGGL(split3_tables_kernel, dim3(nb), dim3(256), 0, s, Z, A, J1, J2, static_cast<unsigned char*>(Zb), stat);
+    hipLaunchKernelGGL(split3_tables_kernel, dim3(nb), dim3(256), 0, s, Z, A, J1, J2, static_cast<unsigned char*>(Zb), stat, Zc);
     SGA_CHECK_LAUNCH("sga_loss_split3_tables");
+    return SGA_OK;
+}
+
+// dE[idx[r], :] += J_normalize^T dZ[r, :] for a gradient that arrives in two parts: G = dZ[r, 0..D) = sum_j c_rj (z_j - zbar) and
+// rho = dZ[r, 101] = sum_j c_rj (the true gradient of the unit row z_r is G + rho zbar).  The normalisation's Jacobian projects the
+// component along z_r out: P_r (G + rho zbar) = P_r (G - rho (z_r - zbar)) because P_r z_r = 0 -- and THAT is what is evaluated.  For a table
+// of nearly parallel rows (the only kind that is centred: meta_embedding_rel's bag-of-words rows) the true gradient is almost radial,
+// |P_r dZ| ~ 1e-3 .. 1e-4 |dZ|: formed in fp32 first, the tangential remainder is what is left of dZ's rounding (3e-4 of the table
+// gradient's maximum, 1.5-4.7 % of d meta_embedding_rel.{weight, bias} at 1024-4096 pairs against fp64 -- with fp32 MFMA sweeps and with
+// exact planes alike); G and rho (z_r - zbar) are both small, nothing cancels.  An un-centred table (zbar = 0: flag at stat[105]) holds
+// the true gradient in dZ[r, 0..D) and takes the plain path.
+__global__ void scatter_tangent_kernel(const float* __restrict__ dZ, const float* __restrict__ Z, const float* __restrict__ nrm,
+                                       const int* __restrict__ idx, int R, int D, const float* __restrict__ stat, float* __restrict__ dE) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const bool centred = stat[S3_DP + 1] != 0.f;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
+        const float* g = dZ + (size_t)r * S3_DP;
+        const float* z = Z + (size_t)r * S3_DP;
+        const float rho = centred ? g[S3_DREAL + 1] : 0.f;
+        float gv[2], zv[2];
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int d = lane + 64 * t;
+            zv[t] = d < D ? z[d] : 0.f;
+            gv[t] = d < D ? (centred ? fmaf(-rho, zv[t] - stat[d], g[d]) : g[d]) : 0.f;
+            dot = fmaf(gv[t], zv[t], dot);
+        }
+        dot = wave_sum(dot);
+        const float n = nrm[r];
+        const bool clamped = n < 1e-12f;
+        const float inv = 1.f / fmaxf(n, 1e-12f);
+        if (clamped) dot = 0.f;
+        float* o = dE + (size_t)idx[r] * D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int d = lane + 64 * t;
+            if (d < D) atomicAdd(o + d, (gv[t] - zv[t] * dot) * inv);
+        }
+    }
+}
+
+extern "C" int sga_loss_scatter_tangent(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int A, int J1, int J2, int D,
+                                        const void* Zb, float* dE, void* stream) {
+    SGA_CHECK_ARG(D >= 1 && D <= S3_DREAL && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_scatter_tangent: bad argument (emb_dim <= 100)");
+    const int R = 2 * A + J1 + J2;
+    if (R == 0) return SGA_OK;
+    SGA_CHECK_ARG(dZ && Z && nrm && idx && dE && Zb, "sga_loss_scatter_tangent: null pointer");
+    const TLayout L = make_tlayout(A, J1, J2);
+    const float* stat = reinterpret_cast<const float*>(static_cast<const unsigned char*>(Zb) + (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * S3_BLOCK);
+    int grid = (R + 3) / 4;
+    if (grid > 8 * sga_num_cus()) grid = 8 * sga_num_cus();
+    hipLaunchKernelGGL(scatter_tangent_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), dZ, Z, nrm, idx, R, D, stat, dE);
+    SGA_CHECK_LAUNCH("sga_loss_scatter_tangent");
     return SGA_OK;
 }
 

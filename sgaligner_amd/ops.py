@@ -45,15 +45,16 @@ MFMA_MODES = ('f32', 'bf16x6', 'bf16x3', 'f16', 'f16x2', 'f16x2p')
 # Which arithmetic the MFMA kernels with more than one variant use is a POLICY OF THIS LAYER: the C-ABI library is stateless (every entry
 # point's arithmetic is in its name or an explicit argument, include/sgaligner_hip.h).  One setting per process, like the reference's
 # torch.backends flags; initial value from SGA_MFMA_MODE.
-_MODE = _os_mode.environ.get('SGA_MFMA_MODE', 'f32')
+DEFAULT_MFMA_MODE = 'bf16x6'
+_MODE = _os_mode.environ.get('SGA_MFMA_MODE', DEFAULT_MFMA_MODE)
 if _MODE not in MFMA_MODES:
     raise ValueError(f"sgaligner_amd: SGA_MFMA_MODE must be one of {MFMA_MODES} (got {_MODE!r})")
 
 
 def set_mfma_mode(mode: str) -> str:
     """Arithmetic of the MFMA kernels that have more than one variant.
-    'f32': exact fp32 MFMA everywhere (v_mfma_f32_*_f32).
-    'bf16x6': the fused 100-d loss sweeps (anchors x negatives: forward sums + gradient) with every fp32 operand split EXACTLY into three
+    'f32': fp32 MFMA everywhere (v_mfma_f32_*_f32).
+    'bf16x6' (THE DEFAULT): the fused 100-d loss sweeps (anchors x negatives: forward sums + gradient) with every fp32 operand split EXACTLY into three
     bf16 terms (8 + 8 + 8 significand bits, fp32's exponent range) and six bf16 MFMAs per product into one fp32 accumulator -- fp32
     arithmetic on the exact operands at 6/16 of the fp32 MFMA's matrix time (csrc/sweep3.hip; SURVEY 7 "fp32 MFMA or split-bf16 x3");
     everything else exact fp32.  M = 2, 3 tables of emb_dim <= 100; other shapes take the 'f32' kernels.
@@ -1231,7 +1232,7 @@ class FusedContrastiveFn(torch.autograd.Function):
         sums = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
         dmax = max(e.shape[1] for e in tables)          # real width: the K step that only covers zero padding is skipped
         # opt-in split-bf16 x3 sweeps: the tables additionally as blocked bf16 hi/lo planes (sweepb.hip)
-        zbs = []
+        zbs, zcs = [], []
         split3 = False
         split16 = M in (2, 3, 4) and dmax <= 100 and get_mfma_mode() in ('f16x2', 'f16x2p')      # columns 100, 101 of the planes carry the centring's bookkeeping
         if split16:
@@ -1249,14 +1250,18 @@ class FusedContrastiveFn(torch.autograd.Function):
             if ev is not None:
                 ev[1].record()
                 KERNEL_EVENTS.setdefault('loss_multi_sums_f16x2', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
-        elif M in (2, 3) and dmax <= 100 and get_mfma_mode() == 'bf16x6':
+        elif M in (2, 3) and dmax <= 100 and FUSED_ANCHOR_BWD and get_mfma_mode() == 'bf16x6':
             # three exact bf16 planes per table (csrc/sweep3.hip): blocked h / m / l planes of the centred rows, once per step
             split3 = True
             nb = L.sga_loss_split3_bytes(s.A, s.J1, s.J2)
             for z in zs:
                 zb = torch.empty((nb,), device=dev, dtype=torch.uint8)
-                _lib.check(L.sga_loss_split3_tables(_p(z), s.A, s.J1, s.J2, _p(zb), st), 'sga_loss_split3_tables')
-                zbs.append(zb)
+                # + the anchor rows as fp32 z - zbar with a ones column: the stash products' B operand (gradient in two parts, see
+                # sga_loss_scatter_tangent)
+                zc = torch.empty((2 * s.A + 32, dp), device=dev, dtype=torch.float32)
+                zc[2 * s.A:].zero_()
+                _lib.check(L.sga_loss_split3_tables(_p(z), s.A, s.J1, s.J2, _p(zb), _p(zc), st), 'sga_loss_split3_tables')
+                zbs.append(zb); zcs.append(zc)
             ev = None
             if KERNEL_EVENTS is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -1355,8 +1360,8 @@ class FusedContrastiveFn(torch.autograd.Function):
                             _lib.check(L.sga_loss_stash_grad_symx_f16x2(_p(m1[k]), _p(m2[k]) if has2 else None, _p(planes[k]), cmx.data_ptr(), s.A,
                                                                         _p(dz_all[k]), lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx_f16x2')
                         else:
-                            _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]) if has2 else None, _p(zs[k]), s.A, dp, _p(dz_all[k]),
-                                                                  lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx')
+                            _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]) if has2 else None, _p(zcs[k] if split3 else zs[k]), s.A, dp,
+                                                                  _p(dz_all[k]), lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx')
                 del buf, m1, m2
                 if split_st:
                     del planes
@@ -1372,7 +1377,7 @@ class FusedContrastiveFn(torch.autograd.Function):
                     gs_aa += gsc[0]
                     gam_aa += gam2[0]
                     for k in range(M):
-                        _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), s.A, dp, _p(dz_all[k]), lo, hi, st), 'sga_loss_stash_grad')
+                        _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zcs[k] if split3 else zs[k]), s.A, dp, _p(dz_all[k]), lo, hi, st), 'sga_loss_stash_grad')
                 del m1
             out = _allreduce_sum(out_acc.clone(), reduce)
             extra = [dz_all, gs_aa.clone(), gam_aa.clone(), coef]
@@ -1390,7 +1395,8 @@ class FusedContrastiveFn(torch.autograd.Function):
         ctx.split16 = split16
         ctx.split3 = split3
         ctx.onepass = onepass
-        ctx.save_for_backward(sums, beta, zj, *zs, *nrms, *zbs, *extra)
+        ctx.n_zc = len(zcs)
+        ctx.save_for_backward(sums, beta, zj, *zs, *nrms, *zbs, *zcs, *extra)
         return out.float() + poison
 
     @staticmethod
@@ -1404,7 +1410,8 @@ class FusedContrastiveFn(torch.autograd.Function):
         onepass_saved = None
         if ctx.onepass:
             rest, onepass_saved = rest[:-4], rest[-4:]
-        zs, nrms, zbs = rest[:M], rest[M:2 * M], rest[2 * M:]
+        zs, nrms, zbs = rest[:M], rest[M:2 * M], rest[2 * M:2 * M + ctx.n_zb]
+        zcs = rest[2 * M + ctx.n_zb:]
         dev = sums.device
         st = _stream()
         dp = 104
@@ -1473,7 +1480,7 @@ class FusedContrastiveFn(torch.autograd.Function):
                 _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), lo, hi, st), 'sga_loss_stash_grad')
             gs += gsc[0]
             for k in range(M):
-                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dp, _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
+                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zcs[k] if ctx.split3 else zs[k]), A, dp, _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
         if chunks:
             del m1
             if fused:
@@ -1511,7 +1518,11 @@ class FusedContrastiveFn(torch.autograd.Function):
         for k in range(M):
             t, d = ctx.shapes[k]
             de = de_all[k] if same else torch.zeros((t, d), device=dev, dtype=torch.float32)
-            _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
+            if ctx.n_zb and ctx.split3:       # the gradient is in two parts (sum c (z - zbar) | sum c): projected without forming their sum
+                _lib.check(L.sga_loss_scatter_tangent(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), A, s.J1, s.J2, d, _p(zbs[k]), _p(de), st),
+                           'sga_loss_scatter_tangent')
+            else:
+                _lib.check(L.sga_loss_scatter(_p(dzs[k]), _p(zs[k]), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
             grads.append(de)
         # d/dbeta_m: through the negatives (gamma) + through sqrt(beta_m) in the anchor rows of ZJ
         gbeta = (gam_neg[0] + gam_anc).float()

@@ -20,9 +20,11 @@ def bf16x3():
 
 def test_mode_switch_roundtrip():
     from sgaligner_amd import ops
-    assert ops.get_mfma_mode() == 'f32'                       # the default
-    assert ops.set_mfma_mode('bf16x3') == 'f32' and ops.get_mfma_mode() == 'bf16x3'
+    d = ops.get_mfma_mode()
+    assert d == ops.DEFAULT_MFMA_MODE == 'bf16x6'            # the default: fp32 arithmetic on three exact bf16 planes (tests/test_bf16x6_gpu.py)
+    assert ops.set_mfma_mode('bf16x3') == d and ops.get_mfma_mode() == 'bf16x3'
     assert ops.set_mfma_mode('f32') == 'bf16x3' and ops.get_mfma_mode() == 'f32'
+    assert ops.set_mfma_mode(d) == 'f32'
     with pytest.raises(ValueError):
         ops.set_mfma_mode('fp8')
 

@@ -44,7 +44,8 @@ def test_planes_represent_every_fp32_operand_exactly(parallel_rows):
     outs = []
     for _ in range(2):
         zb = torch.zeros((nb,), device='cuda', dtype=torch.uint8)
-        _lib.check(L.sga_loss_split3_tables(z.data_ptr(), A, J1, J2, zb.data_ptr(), ops._stream()), 'sga_loss_split3_tables')
+        zc = torch.full((2 * A, 104), float('nan'), device='cuda')
+        _lib.check(L.sga_loss_split3_tables(z.data_ptr(), A, J1, J2, zb.data_ptr(), zc.data_ptr(), ops._stream()), 'sga_loss_split3_tables')
         torch.cuda.synchronize()
         outs.append(zb.clone())
     assert torch.equal(outs[0], outs[1])
@@ -66,6 +67,10 @@ def test_planes_represent_every_fp32_operand_exactly(parallel_rows):
     assert centred or torch.equal(cen[:, :100], z[:R, :100])
     cen[:, 100] = ((zbar[:100].double() * cen[:, :100].double()).sum(1) + stat[104].double()).float()
     cen[:, 101] = 1.0
+    # the fp32 copy of the anchor rows for the stash products: the same centred values, zero in column 100, one in column 101
+    want_c = cen[:2 * A].clone()
+    want_c[:, 100] = 0.0
+    assert torch.equal(zc, want_c)
     u16 = zb.view(torch.int16).to(torch.int32) & 0xFFFF
 
     def slot(gk, i):

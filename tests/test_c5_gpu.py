@@ -151,6 +151,7 @@ def test_f16_wide_loss_equals_fp32_wide_loss(D, stash_rows):
     cot = torch.rand(2 + 2, device='cuda') + 0.5
     res = {}
     keep = ops.STASH_BYTES
+    mode0 = ops.get_mfma_mode()
     for mode in ('f32', 'f16'):
         tabs = [b.clone().requires_grad_(True) for b in base]
         old = ops.set_mfma_mode(mode)
@@ -165,7 +166,7 @@ def test_f16_wide_loss_equals_fp32_wide_loss(D, stash_rows):
             ops.set_mfma_mode(old)
             ops.STASH_BYTES = keep
         res[mode] = (sums.detach().double(), [t.grad.double() for t in tabs])
-    assert ops.get_mfma_mode() == 'f32'
+    assert ops.get_mfma_mode() == mode0
     rel = ((res['f16'][0] - res['f32'][0]).abs() / res['f32'][0].abs().clamp_min(1e-12)).max().item()
     assert rel < F16_TOL, rel
     for a, b in zip(res['f16'][1], res['f32'][1]):

@@ -19,9 +19,11 @@ def f16x2():
 
 def test_mode_switch_roundtrip():
     from sgaligner_amd import ops
-    assert ops.get_mfma_mode() == 'f32'                       # the default
-    assert ops.set_mfma_mode('f16x2') == 'f32' and ops.get_mfma_mode() == 'f16x2'
+    d = ops.get_mfma_mode()
+    assert d == ops.DEFAULT_MFMA_MODE == 'bf16x6'            # the default: fp32 arithmetic on three exact bf16 planes (tests/test_bf16x6_gpu.py)
+    assert ops.set_mfma_mode('f16x2') == d and ops.get_mfma_mode() == 'f16x2'
     assert ops.set_mfma_mode('f32') == 'f16x2' and ops.get_mfma_mode() == 'f32'
+    assert ops.set_mfma_mode(d) == 'f32'
 
 
 @pytest.mark.parametrize('coef_lo', [True, False])
