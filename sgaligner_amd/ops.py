@@ -1329,13 +1329,13 @@ class FusedContrastiveFn(torch.autograd.Function):
                 buf = [torch.empty((fl,), device=dev, dtype=torch.float32) for _ in range(M)]
                 # 'f16x2': the stash products on split-fp16 MFMA (csrc/stashh.hip) -- transposed fp16 hi / lo planes of every table's unit rows,
                 # once per step; each launch's stash scaled by its largest |coefficient|
-                split_st = F16X2_STASH and dp == 104 and get_mfma_mode() in ('f16x2', 'f16x2p')
+                split_st = F16X2_STASH and dp == 104 and dmax <= 100 and get_mfma_mode() in ('f16x2', 'f16x2p')     # (columns 100, 101 of the planes carry the centring's bookkeeping)
                 if split_st:
                     planes = [torch.empty((int(L.sga_loss_stash_planes_bytes(s.A)),), device=dev, dtype=torch.uint8) for _ in range(M)]
                     for k in range(M):
                         _lib.check(L.sga_loss_stash_planes(_p(zs[k]), s.A, dp, _p(planes[k]), st), 'sga_loss_stash_planes')
                 # 'f16x2': the A x A similarities on fp16 MFMA from fp16 hi + lo rows (same bytes per row; the epilogue is the exact-fp32 code)
-                h16 = F16X2_AA and dp == 104 and get_mfma_mode() in ('f16x2', 'f16x2p')
+                h16 = F16X2_AA and dp == 104 and dmax <= 100 and get_mfma_mode() in ('f16x2', 'f16x2p')      # wider tables (emb_dim 101..104): the fp32 kernel
                 if h16:
                     zh = [torch.empty((2 * s.A + 1, dp), device=dev, dtype=torch.float32) for _ in range(M)]
                     for k in range(M):

@@ -319,3 +319,40 @@ def test_forward_sums_hi_only_products(f16x2):
             assert rel < (1e-6 if tag == 'full' else 3e-6), (tag, rel)
     finally:
         ops.F16X2_SUMS_LO = keep
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16x6'])
+def test_tables_wider_than_100_columns_take_the_fp32_kernels(mode):
+    """emb_dim 101..104 is accepted by the fused loss path, but columns 100, 101 of the split modes' planes carry the row centring's bookkeeping:
+    such tables must run on the fp32 kernels EVERYWHERE -- sweeps, the symmetric A x A similarities, the stash products (round-4 advisor: the
+    A x A planes of 'f16x2' used to drop columns 100..103 silently).  Terms and gradients equal the 'f32' mode's to fp32 summation noise, and
+    columns 100..103 carry gradient."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(40, 40, 4, seed=11, ragged=True, anchors='val')       # enough anchors for the one-pass symmetric walk
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(4)
+    base = [torch.randn(T, 104, device='cuda', generator=g) for _ in range(3)]
+    for b in base:
+        b[:, 100:] *= 3.0                                                  # make the last four columns matter
+    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')
+    from sgaligner_amd.aligner.losses import LossHeadFn      # noqa: F401  (the coefficient hint comes from the loss head in production)
+    res = {}
+    for md in ('f32', mode):
+        old = ops.set_mfma_mode(md)
+        try:
+            tabs = [b.clone().requires_grad_(True) for b in base]
+            w = w0.clone().requires_grad_(True)
+            hint = torch.linspace(0.5, 1.5, 3 + 1 + 6, device='cuda')
+            sums, s = ops.fused_contrastive_terms(tabs, w, dd, coef_hint=hint)
+            (sums * hint).sum().backward()
+            torch.cuda.synchronize()
+            res[md] = (sums.detach().double(), [t.grad.clone() for t in tabs], w.grad.clone())
+        finally:
+            ops.set_mfma_mode(old)
+    a, b = res['f32'], res[mode]
+    assert torch.allclose(a[0], b[0], rtol=1e-6, atol=1e-9)
+    for x, y in zip(a[1], b[1]):
+        assert (x - y).abs().max().item() < 2e-5 * x.abs().max().item()
+        assert x[:, 100:].abs().max().item() > 1e-3 * x.abs().max().item()
+    assert (a[2] - b[2]).abs().max().item() < 1e-4 * a[2].abs().max().item()

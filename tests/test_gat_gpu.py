@@ -167,3 +167,51 @@ def test_complete_graph_fast_path_flags_and_equality():
     assert torch.equal(of, og)
     for a, b in zip(gf, gg):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+
+
+def test_vs_real_pyg():
+    """Closes SURVEY 8(a) row G wherever torch-geometric imports (it is not installable in the build container: the oracle's GATConv is
+    "parity unpinned" there): the REAL torch_geometric.nn.GATConv(in, out, heads) stack the reference builds -- GATConv(3, 128, 2), ELU,
+    GATConv(256, 128, 2): src/aligner/networks/gat.py:36-37,40-48 -- against BOTH the oracle's restatement and the HIP kernels, on the
+    hand-evaluated graph and three random graphs (incomplete, duplicate edges, explicit self loops), forward and every parameter gradient."""
+    pytest.importorskip('torch_geometric')
+    import torch.nn.functional as F
+    from torch_geometric.nn import GATConv
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    import gat_handcase as hc
+    torch.manual_seed(0)
+    cases = [(3, hc.EDGES)]
+    for seed, n in ((1, 9), (2, 33), (3, 128)):
+        e, _ = _graphs(seed, [n], True)
+        cases.append((n, e))
+    for n, edges in cases:
+        x = torch.randn(n, 3, dtype=torch.float64)
+        convs = [GATConv(3, 128, heads=2).double(), GATConv(256, 128, heads=2).double()]
+        with torch.no_grad():
+            for c in convs:
+                c.bias.copy_(0.1 * torch.randn(256, dtype=torch.float64))
+        ei = torch.from_numpy(np.ascontiguousarray(edges.T))
+        ref = convs[1](F.elu(convs[0](x, ei)), ei)                    # MultiGAT.forward: dropout(p = 0) is a no-op
+        cot = torch.randn_like(ref)
+        (ref * cot).sum().backward()
+        lws = [c.lin_src.weight if hasattr(c, 'lin_src') else c.lin.weight for c in convs]
+        ref_g = [(lw.grad, c.att_src.grad, c.att_dst.grad, c.bias.grad) for lw, c in zip(lws, convs)]
+        layers = [dict(lin_w=lw.detach().clone().requires_grad_(True), att_src=c.att_src.detach().clone().requires_grad_(True),
+                       att_dst=c.att_dst.detach().clone().requires_grad_(True), bias=c.bias.detach().clone().requires_grad_(True))
+                  for lw, c in zip(lws, convs)]
+        out_o = O.multi_gat(x, ei, layers)
+        (out_o * cot).sum().backward()
+        assert (out_o - ref).abs().max().item() < 1e-10, n
+        for li in range(2):
+            for k, pg in zip(('lin_w', 'att_src', 'att_dst', 'bias'), ref_g[li]):
+                assert (layers[li][k].grad - pg).abs().max().item() < 1e-9 * max(1.0, pg.abs().max().item()), (n, li, k)
+        gb = ops.GraphBatch(np.asarray([n]), np.asarray([edges.shape[0]]), torch.from_numpy(edges).cuda())
+        dl = [[l[k].detach().float().cuda().requires_grad_(True) for k in ('lin_w', 'att_src', 'att_dst', 'bias')] for l in layers]
+        out_g = ops.multi_gat(gb, x.cuda(), dl[0], dl[1])
+        (out_g * cot.float().cuda()).sum().backward()
+        torch.cuda.synchronize()
+        assert (out_g.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-4, n
+        for li in range(2):
+            for t, pg in zip(dl[li], ref_g[li]):
+                assert (t.grad.cpu().double() - pg).abs().max().item() < 1e-3 * max(1.0, pg.abs().max().item()), (n, li)
