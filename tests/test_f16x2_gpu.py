@@ -336,7 +336,6 @@ def test_tables_wider_than_100_columns_take_the_fp32_kernels(mode):
     for b in base:
         b[:, 100:] *= 3.0                                                  # make the last four columns matter
     w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')
-    from sgaligner_amd.aligner.losses import LossHeadFn      # noqa: F401  (the coefficient hint comes from the loss head in production)
     res = {}
     for md in ('f32', mode):
         old = ops.set_mfma_mode(md)
