@@ -297,6 +297,36 @@ def roofline_objects(events, world):
                       'executed_flops_per_launch': alg * (2.0 if mult == 2.0 else 1.0),
                       'note': 'one entry = the launches of ONE step over all tables (4 x 2 coefficient + 4 x 2 GEMM launches per table '
                               'backward; 4 launches per table forward), HIP events around each table\'s group'})
+    # ---- the HBM-bound kernels SURVEY 8(d) names: fusion (2 x 4 T D M bytes per direction) and the GAT message passing (per layer and head-pair
+    # launch: 256 x 4 B of features in and out per node; the 16 B/edge list only when the batch is not recognised as complete graphs --
+    # then the attention kernels never read it).  `achieved` = algorithmic bytes / mean launch time; one object per kernel, step_ms = all
+    # of its launches in a step.
+    n_steps = max(1, events.get('_steps', 1))
+    for key, what in (('fusion_fwd', 'MultiModalFusion forward (sg_aligner.py:30-35): M x [T, D] in, [T, M D] out'),
+                      ('fusion_bwd', 'MultiModalFusion backward: [T, M D] + M x [T, D] in, M x [T, D] out')):
+        evs = events.get(key, [])
+        if evs:
+            t_, d_, m_ = evs[0][2]
+            avg_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_, _ in evs]))
+            by = (2.0 if key == 'fusion_fwd' else 3.0) * 4.0 * t_ * d_ * m_
+            ach = by / (avg_ms * 1e-3) / 1e9
+            roofs.append({'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+                          'kernel': f'{key}_kernel ({what})', 'launches_timed': len(evs), 'avg_launch_ms': round(avg_ms, 4),
+                          'step_ms': round(avg_ms * len(evs) / n_steps, 4), 'algorithmic_bytes_per_launch': by})
+    for key, mult in (('gat_attn_fwd', 2.0), ('gat_attn_bwd', 3.0)):
+        evs = events.get(key, [])
+        if evs:
+            t_, e_, complete = evs[0][2]
+            avg_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_, _ in evs]))
+            by = mult * 4.0 * t_ * 256 + (0.0 if complete else 16.0 * e_)
+            ach = by / (avg_ms * 1e-3) / 1e9
+            roofs.append({'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+                          'kernel': f'{key}_kernel (GATConv message passing, one launch per layer: {t_} nodes x 2 heads x 128 channels'
+                                    + (', complete graphs: edge list not read' if complete else f', {e_} edges of 16 B') + ')',
+                          'launches_timed': len(evs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms * len(evs) / n_steps, 4),
+                          'algorithmic_bytes_per_launch': by,
+                          'note': 'N x N attention per graph is on-chip work (2 N^2 (2 x 128 + 8) FLOP per graph and head): at 128-node graphs the kernel is bound by '
+                                  'that LDS / VALU work, not by these bytes'})
     roofs.sort(key=lambda r: -r['step_ms'])
     return roofs
 

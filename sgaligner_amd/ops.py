@@ -233,6 +233,21 @@ def _ptr_array(tensors):
     return arr
 
 
+def _ev_start():
+    """HIP-event pair around a launch on torch's current stream when bench.py asks for per-kernel timings (ops.KERNEL_EVENTS is a dict)."""
+    if KERNEL_EVENTS is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    return ev
+
+
+def _ev_stop(ev, key, shape):
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.setdefault(key, []).append(ev + (shape,))
+
+
 class FusionFn(torch.autograd.Function):
     """MultiModalFusion.forward (reference sg_aligner.py:30-35)."""
 
@@ -247,7 +262,9 @@ class FusionFn(torch.autograd.Function):
                 raise RuntimeError('sgaligner_amd.FusionFn: all modality tables must share one shape')
         joint = torch.empty((t, m * d), device=w.device, dtype=torch.float32)
         arr = _ptr_array(embs)
+        ev = _ev_start()
         _lib.check(_lib.lib().sga_fusion_fwd(arr, m, _p(w), _p(joint), t, d, _stream()), 'sga_fusion_fwd')
+        _ev_stop(ev, 'fusion_fwd', (t, d, m))
         ctx.save_for_backward(w, *embs)
         return joint
 
@@ -261,8 +278,10 @@ class FusionFn(torch.autograd.Function):
         gw = torch.empty_like(w)
         nb = _lib.lib().sga_fusion_bwd_workspace_bytes(m)
         ws = torch.empty((nb,), device=w.device, dtype=torch.uint8)
+        ev = _ev_start()
         _lib.check(_lib.lib().sga_fusion_bwd(_ptr_array(embs), m, _p(w), _p(gj), _ptr_array(gembs), _p(gw), t, d,
                                              _p(ws), nb, _stream()), 'sga_fusion_bwd')
+        _ev_stop(ev, 'fusion_bwd', (t, d, m))
         return (gw, *gembs)
 
 
@@ -993,8 +1012,10 @@ def _attn_fwd(h, att_s, att_d, bias, gb, check_status=False):
     if check_status and VALIDATE:
         # a FRESH status word per batch: a sticky shared one re-raised for clean batches whose read-back was enqueued before its reset
         st = torch.zeros((1,), device=h.device, dtype=torch.int32)
+    ev = _ev_start()
     _lib.check(_lib.lib().sga_gat_attn_fwd(_p(h), _p(att_s), _p(att_d), _p(bias), _p(gb.edges), _p(gb.node_off),
                                            _p(gb.edge_off), gb.G, gb.nmax, _p(out), _p(st), _p(getattr(gb, 'complete', None)), _stream()), 'sga_gat_attn_fwd')
+    _ev_stop(ev, 'gat_attn_fwd', (int(h.shape[0]), int(gb.edges.shape[0]), getattr(gb, 'complete', None) is not None))
     if st is not None:            # read back without blocking; raises at the next batch's poll (or DEFERRED_CHECKS.flush())
         DEFERRED_CHECKS.submit_fn(st, _gat_status_verdict)
     return out
@@ -1004,9 +1025,11 @@ def _attn_bwd(h, d_o, att_s, att_d, gb):
     dh = torch.empty_like(h)
     dboth = torch.empty((2,) + tuple(att_s.shape), device=att_s.device, dtype=att_s.dtype)      # adjacent: zeroed in one launch
     das, dad = dboth[0], dboth[1]
+    ev = _ev_start()
     _lib.check(_lib.lib().sga_gat_attn_bwd(_p(h), _p(d_o), _p(att_s), _p(att_d), _p(gb.edges), _p(gb.node_off),
                                            _p(gb.edge_off), gb.G, gb.nmax, _p(dh), _p(das), _p(dad), _p(getattr(gb, 'complete', None)), _stream()),
                'sga_gat_attn_bwd')
+    _ev_stop(ev, 'gat_attn_bwd', (int(h.shape[0]), int(gb.edges.shape[0]), getattr(gb, 'complete', None) is not None))
     return dh, das, dad
 
 

@@ -33,10 +33,12 @@ def _worker(rank, world, port, mods, n_pairs, cuts, out, nobj=14, ragged=True):
     from sgaligner_amd.trainer import AlignerSteps
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    backend = os.environ.get('SGA_TEST_DIST_BACKEND', 'gloo')       # 'nccl' (= RCCL): one GPU per rank, the *_rccl tests below
+    di = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(di)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        dev = torch.device('cuda', 0)
+        dev = torch.device('cuda', di)
         full = to_device(make_batch(n_pairs, nobj, 48, seed=21, ragged=ragged), dev)
         lo, hi = cuts[rank], cuts[rank + 1]
         mine = sdist.shard_data_dict(full, lo, hi)
@@ -125,10 +127,12 @@ def _overlap_worker(rank, world, port, out):
     from sgaligner_amd.trainer import AlignerSteps
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    backend = os.environ.get('SGA_TEST_DIST_BACKEND', 'gloo')       # 'nccl' (= RCCL): one GPU per rank, the *_rccl tests below
+    di = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(di)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        dev = torch.device('cuda', 0)
+        dev = torch.device('cuda', di)
         full = to_device(make_batch(6, 12, 48, seed=33), dev)             # uniform scenes: equal shards -> the asynchronous gathers
         mine = sdist.shard_data_dict(full, 3 * rank, 3 * rank + 3)
         res = {}
@@ -194,8 +198,10 @@ def _acc_worker(rank, world, port, out):
     from sgaligner_amd.synthetic import make_batch
     from sgaligner_amd.trainer import AlignerSteps
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    backend = os.environ.get('SGA_TEST_DIST_BACKEND', 'gloo')       # 'nccl' (= RCCL): one GPU per rank, the *_rccl tests below
+    di = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(di)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         steps = AlignerSteps(['point', 'gat', 'rel'], device='cuda', seed=42)
         tr = EpochBasedTrainer(steps, output_dir=f'/tmp/sga_acc_{port}', max_epoch=1, lr=0.0, grad_acc_steps=2, log_steps=100)
@@ -247,7 +253,7 @@ def _rccl_worker(rank, world, port, mods, ragged_pad, out):
     dist.init_process_group('nccl', rank=0, world_size=1)
     try:
         assert sdist._has_reduce_scatter()
-        dev = torch.device('cuda', 0)
+        dev = torch.device('cuda', di)
         dd = to_device(make_batch(5, 14, 48, seed=23, ragged=True), dev)
         steps = AlignerSteps(mods, device=dev, seed=42)
         steps.zero_grad()
@@ -350,3 +356,37 @@ def test_bench_refuses_a_world_that_is_not_gpus():
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+# ---- the same two-rank checks over RCCL, one GPU per rank: they run on the first box that has two GPUs (the builder's and the driver's test
+# boxes have one: RCCL refuses two ranks on one device, so there the gloo variants above carry the path)
+needs2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL: one rank per device)')
+
+
+@pytest.fixture
+def rccl_backend():
+    os.environ['SGA_TEST_DIST_BACKEND'] = 'nccl'
+    yield
+    os.environ.pop('SGA_TEST_DIST_BACKEND', None)
+
+
+@needs2
+def test_two_ranks_equal_single_process_rccl(rccl_backend):
+    test_two_ranks_equal_single_process(['point', 'gat', 'rel'], 6, [0, 3, 6])
+    test_two_ranks_equal_single_process(['point', 'gat', 'rel'], 5, [0, 4, 5])
+
+
+@needs2
+def test_two_ranks_walk_the_anchor_pairs_symmetrically_rccl(rccl_backend):
+    test_two_ranks_walk_the_anchor_pairs_symmetrically()
+
+
+@needs2
+def test_overlapped_gathers_equal_blocking_and_single_process_rccl(rccl_backend):
+    """asynchronous all_gather_into_tensor from the table hook + reduce_scatter_tensor of the table gradients with TWO real RCCL ranks"""
+    test_overlapped_gathers_equal_blocking_and_single_process()
+
+
+@needs2
+def test_grad_accumulation_two_ranks_equals_single_process_sum_rccl(rccl_backend):
+    test_grad_accumulation_two_ranks_equals_single_process_sum()
