@@ -36,9 +36,9 @@ CONFIGS = {
     'c2': {'ref': 'BASELINE.json configs[1]', 'n_obj': 64, 'n_pts': 512, 'pairs_per_gpu': 512, 'scaling': 'weak'},
     'c3': {'ref': 'BASELINE.json configs[2] (north-star target)', 'n_obj': 128, 'n_pts': 512, 'global_pairs': 4096,
            'scaling': 'strong'},
-    # configs[4] (stress shape; the config names no pair count: 32 pairs per GPU = 16 384 objects, 33.5 M points): 1024-d embeddings,
+    # configs[4] (stress shape; the config names no pair count; SURVEY 8(d): "B sized to memory (e.g. 64/GPU)": 64 pairs per GPU = 32 768 objects, 67 M points): 1024-d embeddings,
     # loss + ranking GEMMs on fp16-input MFMA (ops.set_mfma_mode('f16'), csrc/wide16.hip); the encoder stays exact fp32
-    'c5': {'ref': 'BASELINE.json configs[4] (stress shape)', 'n_obj': 256, 'n_pts': 2048, 'pairs_per_gpu': 32, 'scaling': 'weak',
+    'c5': {'ref': 'BASELINE.json configs[4] (stress shape)', 'n_obj': 256, 'n_pts': 2048, 'pairs_per_gpu': 64, 'scaling': 'weak',
            'emb_dim': 1024, 'mfma_mode': 'f16'},
 }
 PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
