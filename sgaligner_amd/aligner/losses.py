@@ -89,7 +89,8 @@ class OverallLoss(nn.Module):
         src = getattr(output_dict['joint'], '_sga_fusion', None)
         fused = (src is not None and FUSED_JOINT and 2 <= m <= 4 and len(src[1]) == m
                  and all(a is b for a, b in zip(src[1], tabs)) and all(t.shape[1] <= 104 for t in tabs))
-        if not fused and FUSED_JOINT and 2 <= m <= 4 and not OverallLoss._warned_untagged and tabs[0].is_cuda:
+        tag_ok = src is not None and len(src[1]) == m and all(a is b for a, b in zip(src[1], tabs))
+        if not fused and not tag_ok and FUSED_JOINT and 2 <= m <= 4 and not OverallLoss._warned_untagged and tabs[0].is_cuda:
             # the provenance tag is a tensor ATTRIBUTE: any .clone() / .to() / arithmetic on `joint` between the encoder and the loss drops
             # it, and the loss then (correctly, but ~2x slower) treats `joint` as an independent table -- say so once instead of silently
             OverallLoss._warned_untagged = True

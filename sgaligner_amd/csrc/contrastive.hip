@@ -1552,17 +1552,22 @@ __device__ __forceinline__ f32x4 mfma_f16h(u32x4 a, u32x4 b, f32x4 c) {
 // x_i . x_j exactly.  Without it a table of nearly identical rows ('rel') sees every similarity shifted by the same 22-bit rounding residue,
 // 1e-6 in every q against the sums -- 5 x the rerun noise on meta_embedding_rel.weight at configs[2].  The kernel swaps the two columns of its
 // own rows (B operands) as it reads their tails from LDS; the rows it streams from L2 (A operands) are used as stored.
-__global__ __launch_bounds__(256) void aa_colsum_kernel(const float* __restrict__ Z, size_t rows, float* __restrict__ zsum) {
-    const int d = threadIdx.x & 127, part = threadIdx.x >> 7;
+// Column sums in a FIXED order (fp64 partials per block, folded in block order by aa_mean_kernel): the planes -- and with them every A x A
+// similarity of the mode -- are bitwise reproducible from run to run; the atomic float form was not (round-4 advisor).
+__global__ __launch_bounds__(128) void aa_colsum_kernel(const float* __restrict__ Z, size_t rows, double* __restrict__ part) {
+    const int d = threadIdx.x;
+    const size_t per = (rows + gridDim.x - 1) / gridDim.x, r0 = (size_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
     if (d >= 104) return;
-    float sum = 0.f;
-    for (size_t r = (size_t)blockIdx.x * 2 + part; r < rows; r += (size_t)gridDim.x * 2) sum += Z[r * 104 + d];
-    atomicAdd(zsum + d, sum);
+    double sum = 0.0;
+    for (size_t r = r0; r < r1; ++r) sum += (double)Z[r * 104 + d];
+    part[(size_t)blockIdx.x * 104 + d] = sum;
 }
-__global__ void aa_mean_kernel(float* __restrict__ zsum, size_t rows) {       // zsum[0..104) -> mean, zsum[100] = |mean|^2 / 2 (columns 100..103 of Z are zero)
+__global__ void aa_mean_kernel(const double* __restrict__ part, int nblk, float* __restrict__ zsum, size_t rows) {       // -> zsum[0..104): mean, zsum[100] = |mean|^2 / 2 (columns 100..103 of Z are zero)
     __shared__ float sq[128];
     const int d = threadIdx.x;
-    const float m = d < 100 ? zsum[d] / (float)rows : 0.f;
+    double t = 0.0;
+    if (d < 100) for (int b = 0; b < nblk; ++b) t += part[(size_t)b * 104 + d];
+    const float m = d < 100 ? (float)(t / (double)rows) : 0.f;
     sq[d] = m * m;
     __syncthreads();
     for (int o = 64; o > 0; o >>= 1) { if (d < o) sq[d] += sq[d + o]; __syncthreads(); }
@@ -2467,8 +2472,12 @@ extern "C" int sga_loss_aa_planes(const float* Z, size_t rows, float* out, void*
     float* zb = out + rows * 104;                                  // row `rows` of out: the column mean the planes are centred by
     if (hipMemsetAsync(zb, 0, 104 * sizeof(float), s) != hipSuccess) { sga_set_error("sga_loss_aa_planes: memset failed"); return SGA_ERR_HIP; }
     const size_t gcs = rows / 2 < 512 ? (rows + 1) / 2 : 512;
-    hipLaunchKernelGGL(aa_colsum_kernel, dim3((unsigned)(gcs > 0 ? gcs : 1)), dim3(256), 0, s, Z, rows, zb);
-    hipLaunchKernelGGL(aa_mean_kernel, dim3(1), dim3(128), 0, s, zb, rows);
+    (void)gcs;
+    // the per-block partials live at the head of `out` (rows x 104 floats >= nblk x 104 doubles) until aa_planes_kernel overwrites it
+    const int nblk = rows / 2 < 256 ? (int)(rows / 2 > 0 ? rows / 2 : 1) : 256;
+    double* part = reinterpret_cast<double*>(out);
+    hipLaunchKernelGGL(aa_colsum_kernel, dim3(nblk), dim3(128), 0, s, Z, rows, part);
+    hipLaunchKernelGGL(aa_mean_kernel, dim3(1), dim3(128), 0, s, part, nblk, zb, rows);
     const size_t n = rows * 52;
     hipLaunchKernelGGL(aa_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Z, rows, out, static_cast<const float*>(zb));
     SGA_CHECK_LAUNCH("sga_loss_aa_planes");

@@ -739,6 +739,7 @@ extern "C" int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, vo
 extern "C" int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                          double* sums, int a_lo, int a_hi, int s_lo, void* stream) {
     SGA_CHECK_ARG(Zb && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums_f16x2: bad argument");
+    SGA_CHECK_ARG(M >= 2 && M <= 4, "sga_loss_multi_sums_f16x2: M=%d (2, 3 or 4 modality tables)", M);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums_f16x2")) return rc0;
     if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
@@ -757,6 +758,7 @@ extern "C" int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const flo
 extern "C" int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                          const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, int coef_lo, void* stream) {
     SGA_CHECK_ARG(Zb && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad_f16x2: bad argument");
+    SGA_CHECK_ARG(M >= 2 && M <= 4, "sga_loss_multi_grad_f16x2: M=%d (2, 3 or 4 modality tables)", M);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rcz = zero_slots(gamma, M > 0 ? M : 1, s, "sga_loss_multi_grad_f16x2")) return rcz;
     if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;

@@ -289,7 +289,13 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
     // anchor rows per pass so that C + C^T of one block fit the workspace
     auto need = [&](size_t r) { return sizeof(f16) * (r * pad8(Jmax) + (size_t)Jmax * pad8((int)r)) + 256; };
     size_t rows = A;
-    while (rows > 128 && need(rows) > stash_bytes) rows = (rows / 2 + 127) / 128 * 128;
+    // prefer the largest block of which FOUR stash pairs fit (the four sum families then share every launch); only if not even 128 rows do,
+    // fall back to the largest block with one pair (family-by-family launches)
+    while (rows > 128 && 4 * need(rows) > stash_bytes) rows = (rows / 2 + 127) / 128 * 128;
+    if (4 * need(rows) > stash_bytes) {
+        rows = A;
+        while (rows > 128 && need(rows) > stash_bytes) rows = (rows / 2 + 127) / 128 * 128;
+    }
     SGA_CHECK_ARG(need(rows) <= stash_bytes, "sga_loss_neg_grad_f16: workspace of %zu bytes holds fewer than %zu anchor rows for J = %d",
                   stash_bytes, rows, Jmax);
     const SegCols sc = seg_cols(A, J1, J2);

@@ -96,12 +96,13 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
         ev[0].record()
     L = _lib.lib()
     ws, ws_bytes = None, 0
+    global POINTNET_LAST_REDO
+    POINTNET_LAST_REDO = None              # set below only when THIS call leaves a re-run list
     if 0 < T <= POINTNET_SPLIT_MAX_OBJECTS:      # few objects: split every object over a workgroup's 8 waves (needs a partials buffer)
         ws_bytes = int(L.sga_pointnet_fwd_ws_bytes(T, C3))
         ws = torch.empty((ws_bytes,), device=x_tp3.device, dtype=torch.uint8)
     elif T > 0 and want_argmax and get_mfma_mode() in ('f16x2', 'f16'):
         # 'f16x2' training forward: [count | ids] of the objects with a near-tied arg-max -> those again on the exact-fp32 kernel
-        global POINTNET_LAST_REDO
         ws_bytes = 4 * (T + 1)
         ws = POINTNET_LAST_REDO = torch.empty((T + 1,), device=x_tp3.device, dtype=torch.int32)
     rc = L.sga_pointnet_fwd_ws(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
