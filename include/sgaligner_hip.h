@@ -260,6 +260,11 @@ int sga_loss_multi_grad_bf16x6(const void* const* Zb, int M, const float* beta, 
                                const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
 int sga_loss_scatter_tangent(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int A, int J1, int J2, int D,
                              const void* Zb, float* dE, void* stream);
+/* The four stash products of sga_loss_stash_grad_symx (same M1 / M2 / block arguments; a_lo = 0, a_hi .. with j_lo = 0, j_hi = mir = A it is
+ * sga_loss_stash_grad) on the three exact bf16 planes Zb of sga_loss_split3_tables: fp32 coefficients split in registers, six bf16 MFMAs per
+ * product, fp32 accumulation; dZ [2A.., 104] receives the two-part form (columns 0..99 and 101) that sga_loss_scatter_tangent projects. */
+int sga_loss_stash_grad_symx_bf16x6(const float* M1, const float* M2, const void* Zb, int A, int J1, int J2, float* dZ,
+                                    int a_lo, int a_hi, int j_lo, int j_hi, int mir, void* stream);
 
 /* ---- loss_group = b: the same loss on G independent groups of b consecutive pairs ------------------------
  * replaces the reference trainer feeding b pairs per iteration (configs/scan3r/scan3r_ground_truth.yaml:27,

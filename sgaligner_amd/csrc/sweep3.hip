@@ -670,6 +670,135 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The stash products of the anchors x anchors backward on the same three exact bf16 planes: out[own] += sum_oth C[own, oth] Z[oth], C a block
+// of the fp32 coefficient stash the A x A kernel wrote (replaces the four fp32-MFMA GEMMs of sga_loss_stash_grad_symx; the autograd of
+// losses.py:6,50-57,81-94 through S = X1 X2^T).  It IS the gradient phase of sweep3_kernel with the coefficient tile loaded instead of
+// computed: 8 waves x 16 owner rows, the "other" rows' planes as 32-row tiles in LDS (one table per launch: 2 x 22.5 KB), the fp32
+// coefficients of a wave's 16 x 32 tile split into three planes in registers (the A operand), six MFMAs per column tile, the small partial
+// products in their own accumulator.  Because the planes are the sweeps' (centred where the table asks for it, column 101 = 1), the result
+// arrives in the same two parts: dZ[r, 0..100) += sum c (z - zbar), dZ[r, 101] += sum c.
+// One launch = up to four products (P.n), each {stash S [.][ld], transposed?, owner segment / first row / count, other segment / first row /
+// count}: C[own o, oth t] = tn ? S[t ld + o] : S[o ld + t].
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct SProd { const float* S; int ld, tn, own_seg, own0, nown, oth_seg, oth0, noth, blk0, nsplit; };
+struct SArgs { const unsigned char* Zb; float* dZ; int A, nbA, n; SProd p[4]; };
+
+__global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
+    constexpr int NCT = 7, WAVES = 8, OWN = 128;
+    constexpr int KMAX = (S3_NCH + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];      // [2][S3_BLOCK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < a.n && (int)blockIdx.x >= a.p[i].blk0) pi = i;
+    const SProd P = a.p[pi];
+    const int w_in = (int)blockIdx.x - P.blk0;
+    const int n_ob = (P.nown + OWN - 1) / OWN;
+    if (w_in >= n_ob * P.nsplit) return;
+    const int split = w_in / n_ob, ob = w_in - split * n_ob;
+    const int orow = ob * OWN + wave * 16 + l15;                      // this lane's owner row (as the coefficient tile's row), relative to own0
+    const bool ov = orow < P.nown;
+    // others: tiles of 32 rows of the segment, [t_lo, t_hi) cut into nsplit runs
+    const int t_lo = P.oth0 >> 5, t_hi = (P.oth0 + P.noth + 31) >> 5;
+    const int per = (t_hi - t_lo + P.nsplit - 1) / P.nsplit;
+    const int jt0 = t_lo + split * per, jt1 = min(t_hi, jt0 + per);
+    if (jt0 >= jt1) return;
+    const int oblk0 = P.oth_seg ? a.nbA : 0;
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned l16 = threadIdx.x;
+    asm volatile("" : "+v"(l16));
+    l16 = (l16 & 63u) * 16u;
+    auto issue = [&](int blk, unsigned char* buf) {
+        const unsigned long long tb = sreg64(reinterpret_cast<unsigned long long>(a.Zb) + (unsigned long long)blk * S3_BLOCK);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            int c = wave_u + k * WAVES;
+            if ((k + 1) * WAVES > S3_NCH) c = c >= S3_NCH ? c - WAVES : c;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(tb + (unsigned)(c * 1024)) + l16),
+                                             (__attribute__((address_space(3))) void*)(buf + c * 1024), 16, 0, 0);
+        }
+    };
+    // this lane's 8 coefficients of tile jt: owner row orow, others 32 jt + 8 g4 + k (segment rows); zero outside the product's ranges
+    auto load_c = [&](int jt, float (&c)[8]) {
+        const int r0 = 32 * jt + 8 * g4 - P.oth0;                     // stash index of k = 0
+        if (!P.tn && (P.ld & 3) == 0 && (P.oth0 & 3) == 0 && ov && r0 >= 0 && r0 + 8 <= P.noth) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(P.S + (size_t)orow * P.ld + r0);
+            const f32x4 u = q[0], v = q[1];
+            c[0] = u[0]; c[1] = u[1]; c[2] = u[2]; c[3] = u[3]; c[4] = v[0]; c[5] = v[1]; c[6] = v[2]; c[7] = v[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = r0 + k;
+                const bool ok = ov && t >= 0 && t < P.noth;
+                c[k] = ok ? (P.tn ? P.S[(size_t)t * P.ld + orow] : P.S[(size_t)orow * P.ld + t]) : 0.f;
+            }
+        }
+    };
+
+    f32x4 gacc[NCT], gsm[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) { gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; gsm[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
+    const int tr_main = s3_slot(tr_cs >> 1, tr_io) * 16 + (tr_cs & 1) * 8;
+    const int tr_tail = S3_TAIL + tr_io * 16 + (tr_cs & 1) * 8;
+
+    float cn[8];
+    load_c(jt0, cn);
+    issue(oblk0 + jt0, lds3);
+    int it = 0;
+#pragma unroll 1
+    for (int jt = jt0; jt < jt1; ++jt, ++it) {
+        unsigned char* buf = lds3 + (it & 1) * S3_BLOCK;
+        __syncthreads();                                   // tile `it` has landed, the other buffer is free
+        issue(oblk0 + (jt + 1 < jt1 ? jt + 1 : jt), lds3 + ((it + 1) & 1) * S3_BLOCK);
+        float cc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cc[k] = cn[k];
+        if (jt + 1 < jt1) load_c(jt + 1, cn);              // the next tile's coefficients travel under this tile's MFMAs
+        u32x4 ch, cm, cl;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned h_, m_, l_;
+            split3_pair(cc[2 * p], cc[2 * p + 1], h_, m_, l_);
+            ch[p] = h_; cm[p] = m_; cl[p] = l_;
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            u32x4 bp[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned char* ph = ct < 6 ? buf + p * S3_PLANE + tr_main + (ct >> 1) * 2048 + (ct & 1) * 512
+                                                 : buf + tr_tail + (p == 0 ? 0 : (p == 1 ? 512 : 2048));
+                const u32x2 x0 = tr_read16(ph), x1 = tr_read16(ph + 1024);
+                bp[p] = u32x4{x0[0], x0[1], x1[0], x1[1]};
+            }
+            f32x4 sm = gsm[ct];
+            sm = mfma_b(cl, bp[0], sm);
+            sm = mfma_b(ch, bp[2], sm);
+            sm = mfma_b(cm, bp[1], sm);
+            sm = mfma_b(cm, bp[0], sm);
+            sm = mfma_b(ch, bp[1], sm);
+            gsm[ct] = sm;
+            gacc[ct] = mfma_b(ch, bp[0], gacc[ct]);
+        }
+    }
+    // out rows: accumulator layout row = 4 g4 + r of the wave's 16, column 16 ct + l15
+    float* dz = a.dZ + (size_t)(P.own_seg ? a.A : 0) * S3_DP;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int d = ct * 16 + l15;
+        if (d < S3_DREAL || d == S3_DREAL + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ob * OWN + wave * 16 + 4 * g4 + r;
+                if (o < P.nown) atomicAdd(dz + (size_t)(P.own0 + o) * S3_DP + d, gacc[ct][r] + gsm[ct][r]);
+            }
+        }
+    }
+}
+
 int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1, bool grad,
            int a_lo, int a_hi, int own_rows, const char* who) {
     if (M < 2 || M > 3) { sga_set_error("%s: M=%d (the three-plane bf16 sweeps are built for 2 or 3 modality tables)", who, M); return SGA_ERR_ARG; }
@@ -862,5 +991,45 @@ extern "C" int sga_loss_multi_grad_bf16x6(const void* const* Zb, int M, const fl
     if (M == 2) launch_t<2, true>(a, -r, s); else launch_t<3, true>(a, -r, s);
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad_bf16x6");
+    return SGA_OK;
+}
+
+extern "C" int sga_loss_stash_grad_symx_bf16x6(const float* M1, const float* M2, const void* Zb, int A, int J1, int J2, float* dZ,
+                                               int a_lo, int a_hi, int j_lo, int j_hi, int mir, void* stream) {
+    SGA_CHECK_ARG(M1 && Zb && dZ && A >= 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi && j_lo >= 0 && j_lo <= j_hi && j_hi <= A &&
+                  mir >= j_lo && (M2 || mir >= j_hi), "sga_loss_stash_grad_symx_bf16x6: bad argument");
+    const int ns = a_hi - a_lo, c1 = j_hi - j_lo, c2 = mir < j_hi ? j_hi - mir : 0;
+    if (A == 0 || ns == 0 || c1 == 0) return SGA_OK;
+    const TLayout L = make_tlayout(A, J1, J2);
+    SArgs a{};
+    a.Zb = static_cast<const unsigned char*>(Zb); a.dZ = dZ; a.A = A; a.nbA = L.nbA;
+    // d1[a_lo + i] += sum_j M1[j][i] X2[j_lo + j];  d2[j_lo + j] += sum_i M1[j][i] X1[a_lo + i];
+    // d1[mir + j]  += sum_i M2[j][i] X2[a_lo + i];  d2[a_lo + i] += sum_j M2[j][i] X1[mir + j]      (segments: 0 = X1, 1 = X2)
+    int n = 0;
+    a.p[n++] = SProd{M1, ns, 1, 0, a_lo, ns, 1, j_lo, c1, 0, 1};
+    a.p[n++] = SProd{M1, ns, 0, 1, j_lo, c1, 0, a_lo, ns, 0, 1};
+    if (c2 > 0) {
+        a.p[n++] = SProd{M2, ns, 0, 0, mir, c2, 1, a_lo, ns, 0, 1};
+        a.p[n++] = SProd{M2, ns, 1, 1, a_lo, ns, 0, mir, c2, 0, 1};
+    }
+    a.n = n;
+    // work units of ~128 owner rows x ~64 other tiles: enough workgroups to fill the chip several times over whatever the block's shape
+    int nwg = 0;
+    for (int i = 0; i < n; ++i) {
+        SProd& P = a.p[i];
+        const int n_ob = (P.nown + 127) / 128, tiles = ((P.oth0 + P.noth + 31) >> 5) - (P.oth0 >> 5);
+        int nsp = (tiles + 63) / 64;
+        const int want = (4 * sga_num_cus() + n_ob - 1) / n_ob;        // at least ~4 workgroups per CU per product
+        if (nsp < want) nsp = want;
+        if (nsp > tiles) nsp = tiles;
+        if (nsp < 1) nsp = 1;
+        P.nsplit = nsp; P.blk0 = nwg;
+        nwg += n_ob * nsp;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)2 * S3_BLOCK;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(stash3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stash3_kernel, dim3(nwg), dim3(512), lds, s, a);
+    SGA_CHECK_LAUNCH("sga_loss_stash_grad_symx_bf16x6");
     return SGA_OK;
 }

@@ -574,6 +574,7 @@ F16X2P_COVERAGE = ('the f16x2 loss sweeps + the PointNet forward in the same spl
 # 'f16x2': the A x A stash products on split-fp16 MFMA (csrc/stashh.hip).  OFF by default: 7.4 vs 8.4 ms per 2048 x 155 648 block for the exact-fp32
 # GEMMs (tools/bench_aa.py; plus one pass over the stash for its largest |value|) -- at best -0.04 s of a 2.9 s configs[2] step -- while the gate's margin on meta_embedding_rel.bias shrinks from 3.7 to 4.0 x
 # the rerun noise (profiles/r04_v_bench_c3.json).  Kept as a measured experiment with its C-ABI test.
+BF16X6_STASH = _os.environ.get('SGA_BF16X6_STASH', '1') != '0'   # 'bf16x6': the A x A stash products on the sweeps' three exact bf16 planes (off: fp32-MFMA GEMMs)
 F16X2_STASH = _os.environ.get('SGA_F16X2_STASH', '0') == '1'
 F16X2_AA = _os.environ.get('SGA_F16X2_AA', '1') != '0'       # 'f16x2': the symmetric A x A kernel's similarities on split-fp16 MFMA (tools / tests flip it)
 F16X2_COEF_LO = {'1': True, '0': False}.get(_os.environ.get('SGA_F16X2_COEF_LO', ''), None)
@@ -1383,6 +1384,10 @@ class FusedContrastiveFn(torch.autograd.Function):
                             cmx = torch.maximum(m1[k].abs().max(), m2[k][:(jh - mir) * (hi - lo)].abs().max()) if has2 else m1[k].abs().max()
                             _lib.check(L.sga_loss_stash_grad_symx_f16x2(_p(m1[k]), _p(m2[k]) if has2 else None, _p(planes[k]), cmx.data_ptr(), s.A,
                                                                         _p(dz_all[k]), lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx_f16x2')
+                        elif split3 and BF16X6_STASH:
+                            # the four stash products on the sweeps' three exact bf16 planes (csrc/sweep3.hip: stash3_kernel)
+                            _lib.check(L.sga_loss_stash_grad_symx_bf16x6(_p(m1[k]), _p(m2[k]) if has2 else None, _p(zbs[k]), s.A, s.J1, s.J2,
+                                                                         _p(dz_all[k]), lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx_bf16x6')
                         else:
                             _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]) if has2 else None, _p(zcs[k] if split3 else zs[k]), s.A, dp,
                                                                   _p(dz_all[k]), lo, hi, jl, jh, mir, st), 'sga_loss_stash_grad_symx')
@@ -1401,7 +1406,11 @@ class FusedContrastiveFn(torch.autograd.Function):
                     gs_aa += gsc[0]
                     gam_aa += gam2[0]
                     for k in range(M):
-                        _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zcs[k] if split3 else zs[k]), s.A, dp, _p(dz_all[k]), lo, hi, st), 'sga_loss_stash_grad')
+                        if split3 and BF16X6_STASH:
+                            _lib.check(L.sga_loss_stash_grad_symx_bf16x6(_p(m1[k]), None, _p(zbs[k]), s.A, s.J1, s.J2, _p(dz_all[k]), lo, hi, 0, s.A, s.A, st),
+                                       'sga_loss_stash_grad_symx_bf16x6')
+                        else:
+                            _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zcs[k] if split3 else zs[k]), s.A, dp, _p(dz_all[k]), lo, hi, st), 'sga_loss_stash_grad')
                 del m1
             out = _allreduce_sum(out_acc.clone(), reduce)
             extra = [dz_all, gs_aa.clone(), gam_aa.clone(), coef]
@@ -1504,7 +1513,11 @@ class FusedContrastiveFn(torch.autograd.Function):
                 _lib.check(L.sga_loss_stash_grad(_p(m1[M]), _p(zj), A, M * dp, _p(dzj), lo, hi, st), 'sga_loss_stash_grad')
             gs += gsc[0]
             for k in range(M):
-                _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zcs[k] if ctx.split3 else zs[k]), A, dp, _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
+                if ctx.split3 and BF16X6_STASH:
+                    _lib.check(L.sga_loss_stash_grad_symx_bf16x6(_p(m1[k]), None, _p(zbs[k]), A, s.J1, s.J2, _p(dzs[k]), lo, hi, 0, A, A, st),
+                               'sga_loss_stash_grad_symx_bf16x6')
+                else:
+                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zcs[k] if ctx.split3 else zs[k]), A, dp, _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
         if chunks:
             del m1
             if fused:

@@ -277,3 +277,41 @@ def test_nearly_identical_rows_vs_fp64_oracle(bf16x6):
     print('nearly identical rows, (max entry, max column sum) error vs fp64:', err)
     assert err['bf16x6'][0] <= 1.25 * err['f32'][0] + 5e-7, err
     assert err['bf16x6'][1] <= 1.25 * err['f32'][1] + 5e-7, err
+
+
+@pytest.mark.parametrize('sym', [True, False])
+def test_stash_products_on_three_planes_equal_the_fp32_gemms(bf16x6, sym):
+    """The anchors x anchors stash products on the sweeps' planes (stash3_kernel: fp32 coefficients split in registers, six bf16 MFMAs per
+    product) against the four fp32-MFMA GEMMs they replace (ops.BF16X6_STASH = False), one-pass mode, symmetric and ordered walks, with a
+    stash bound that forces several anchor-row blocks and ragged block edges: every table gradient and d fusion weight to fp32 rounding."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(40, 40, 4, seed=12, ragged=True, anchors='val')
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(9)
+    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(3)]
+    base[2] = torch.randn(1, 100, device='cuda', generator=g) + 1e-2 * torch.randn(T, 100, device='cuda', generator=g)   # nearly parallel rows: centred planes
+    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')
+    hint = torch.linspace(0.5, 1.5, 3 + 1 + 6, device='cuda')
+    keep = (ops.BF16X6_STASH, ops.AA_SYMMETRIC, ops.STASH_BYTES)
+    res = {}
+    try:
+        ops.AA_SYMMETRIC = sym
+        s0 = ops.IndexSets.of(dd, 'cuda', T)
+        ops.STASH_BYTES = 3 * 4 * s0.A * 160 * 2                      # ~160-row blocks
+        for flag in (True, False):
+            ops.BF16X6_STASH = flag
+            tabs = [b.clone().requires_grad_(True) for b in base]
+            w = w0.clone().requires_grad_(True)
+            sums, s = ops.fused_contrastive_terms(tabs, w, dd, coef_hint=hint)
+            (sums * hint).sum().backward()
+            torch.cuda.synchronize()
+            res[flag] = (sums.detach().double(), [t.grad.clone() for t in tabs], w.grad.clone())
+    finally:
+        ops.BF16X6_STASH, ops.AA_SYMMETRIC, ops.STASH_BYTES = keep
+    a, b = res[False], res[True]
+    assert torch.allclose(a[0], b[0], rtol=1e-7, atol=0)
+    for k, (x, y) in enumerate(zip(a[1], b[1])):
+        tol = 2e-5 if k < 2 else 1e-3          # (the centred table: the fp32 GEMM form carries the larger error, section 3g of DESIGN.md)
+        assert (x - y).abs().max().item() < tol * x.abs().max().item(), (k, (x - y).abs().max().item(), x.abs().max().item())
+    assert (a[2] - b[2]).abs().max().item() < 1e-4 * a[2].abs().max().item()
