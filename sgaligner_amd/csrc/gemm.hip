@@ -436,7 +436,18 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
     const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
     dim3 grid(gx, gy, splits);
-    if (!a_is_f64 && transA && !transB && use_atomic && a_al && b_al && M % 4 == 0 && N % 4 == 0 && !bias) {
+    // (also unsplit when the output grid fills the chip by itself -- the wide-table stash products of configs[4], [ns x 1024..3072] over K = A:
+    // they fell to the generic kernel at ~9 TFLOP/s, 14 % of that step; the TN kernel always accumulates atomically, so C is zeroed first
+    // unless the caller accumulates)
+    const bool tn_big = !use_atomic && K >= 256 && gx * gy >= ncu && act == 0 && !resid;
+    if (!a_is_f64 && transA && !transB && (use_atomic || tn_big) && a_al && b_al && M % 4 == 0 && N % 4 == 0 && !bias) {
+        if (tn_big && !accumulate) {
+            if (ldc == N) {
+                if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s) != hipSuccess) { sga_set_error("sga_gemm: memset failed"); return SGA_ERR_HIP; }
+            } else {
+                if (hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) { sga_set_error("sga_gemm: memset2d failed"); return SGA_ERR_HIP; }
+            }
+        }
         hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc, M, N, K, kper);
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;

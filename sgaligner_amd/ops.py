@@ -215,7 +215,16 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gemm(gy, weight.t().contiguous(), False, True, t, k, n)   # dX = dY W, as dY (W^T)^T: the prefetching NT kernel
         if ctx.needs_input_grad[1]:
-            gw = gemm(gy, cast_f32(x), True, False, n, k, t)             # dW = dY^T X
+            if k % 4 and t >= 4096:
+                # an input width that is not a multiple of 4 (the 41 relation / 3 pose columns) misses the row-major TN kernel's alignment and
+                # fell to the generic one: 1.9 ms per weight gradient at configs[4]'s 1024-d embeddings (6 of them: 14 % of that step).  Zero
+                # columns up to the next multiple of 4 cost nothing and are cut off again.
+                kp = (k + 3) // 4 * 4
+                xp = torch.zeros((t, kp), device=x.device, dtype=torch.float32)
+                xp[:, :k] = x
+                gw = gemm(gy, xp, True, False, n, kp, t)[:, :k].contiguous()
+            else:
+                gw = gemm(gy, cast_f32(x), True, False, n, k, t)             # dW = dY^T X
         if ctx.needs_input_grad[2]:
             gb = colsum(gy)
         return gx, gw, gb
