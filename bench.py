@@ -340,6 +340,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hits', action='store_true')
     ap.add_argument('--no-attr', action='store_true', help='skip the extra point+gat+rel+attr (M = 4) measurement (N = 1)')
+    ap.add_argument('--no-attr-c3', action='store_true', help='skip the M = 4 measurement at the configs[2] size (N = 1, default config)')
     ap.add_argument('--no-scale-ref', action='store_true', help='skip the extra weak-scaling point (N > 1, --config auto)')
     ap.add_argument('--no-pct', action='store_true', help='skip the extra pct+gat+rel+attr small-batch measurement (N = 1)')
     ap.add_argument('--no-c2', action='store_true', help='skip the extra BASELINE configs[1] measurement (N = 1)')
@@ -628,9 +629,25 @@ def main():
                 finally:
                     ops.set_mfma_mode(mode0)
                 del ref4
+            # ... and at the HEADLINE's size: configs[2] (4096 pairs x 128 objects x 512 pts on this GPU) with the full module list
+            if cname == 'c3' and not args.no_attr_c3:
+                dd2 = None
+                torch.cuda.empty_cache()
+                c3 = CONFIGS['c3']
+                dd3 = make_batch_fast(c3['global_pairs'], c3['n_obj'], c3['n_pts'], seed=43, device=dev)
+                steps4.forward_backward(dd3)
+                torch.cuda.synchronize()
+                ops.KERNEL_EVENTS = {}
+                el43, _, _ = timed(steps4, dd3, 0, 2)
+                ops.KERNEL_EVENTS['_steps'] = 2
+                ev43, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+                extra_attr['at_configs2_size'] = {'workload': f'{c3["ref"]} shape: {c3["global_pairs"]} pairs x {c3["n_obj"]} objects x {c3["n_pts"]} pts, modules {"+".join(mods4)}',
+                                                  'value': round(c3['global_pairs'] * 2 / el43, 2), 'unit': 'pairs/s', 'ms_per_step': round(el43 / 2 * 1e3, 1), 'steps': 2,
+                                                  'warmup': 1, 'roofline': roofline_objects(ev43, world)[:3]}
+                del dd3
             del steps4
         except Exception as e:
-            extra_attr = {'error': f'{type(e).__name__}: {e}'}
+            extra_attr = {'error': f'{type(e).__name__}: {e}'} if extra_attr is None else dict(extra_attr, error_at_configs2_size=f'{type(e).__name__}: {e}')
     dd2 = None
     torch.cuda.empty_cache()
 
