@@ -119,6 +119,12 @@ int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, float tau0,
 /* dZ += d(sums)/dZ weighted by gs8 = dL/d(sums8) (owner-stationary sweeps, atomic accumulate) */
 int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
                       float* dZ, void* stream);
+/* the same two for the anchor shard [a_lo, a_hi) this process owns: anchor-owner sweeps cover the shard only, negative-owner sweeps see
+ * only the shard's anchors -- the outputs of a partition of [0, A) sum to the unsharded ones (one process per GPU all-reduces them) */
+int sga_loss_neg_sums_shard(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, int a_lo, int a_hi,
+                            void* stream);
+int sga_loss_neg_grad_shard(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
+                            float* dZ, int a_lo, int a_hi, void* stream);
 /* anchors x anchors terms for NT tables (modalities..., joint): out = [NT icl sums | M iala | M ialb], M = NT-1 */
 /* [a_lo, a_hi) (here and below): the anchor shard this process owns (0, A on one GPU).  Outputs are that shard's partial
  * contribution; the sum over a partition of [0, A) equals the unsharded result (one process per GPU all-reduces it). */

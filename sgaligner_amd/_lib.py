@@ -71,6 +71,8 @@ SIGNATURES = {
     'sga_loss_scatter': (I, [P, P, P, P, I, I, I, P, P]),
     'sga_loss_neg_sums': (I, [P, I, I, I, I, F, F, P, P]),
     'sga_loss_neg_grad': (I, [P, I, I, I, I, F, F, P, P, P]),
+    'sga_loss_neg_sums_shard': (I, [P, I, I, I, I, F, F, P, I, I, P]),
+    'sga_loss_neg_grad_shard': (I, [P, I, I, I, I, F, F, P, P, I, I, P]),
     'sga_loss_anchor_fwd': (I, [P, P, I, I, P, F, F, F, P, I, I, P]),
     'sga_loss_anchor_bwd': (I, [P, P, I, I, P, F, F, F, P, P, P, I, I, P]),
     'sga_loss_anchor_fwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, I, I, P]),

@@ -37,7 +37,7 @@ class ICLLoss(nn.Module):
         self.device = device
 
     def forward(self, emb, data_dict):
-        sums, s = ops.contrastive_terms([emb], data_dict, alpha=self.alpha)
+        sums, s = ops.contrastive_terms([emb], data_dict, alpha=self.alpha, shard=data_dict.get('_sga_shard'), reduce=data_dict.get('_sga_reduce'))
         return sums[0] / float(s.A * s.A)                         # .mean() over the A x A matrix (:57)
 
 
@@ -121,9 +121,8 @@ class OverallLoss(nn.Module):
                 sums, s = ops.fused_contrastive_terms(tabs, src[0], data_dict, alpha=self.contrastive_loss.alpha,
                                                       shard=data_dict.get('_sga_shard'), reduce=data_dict.get('_sga_reduce'), coef_hint=hint)
             else:          # arbitrary joint table: treat it as an independent (M+1)-th table
-                if data_dict.get('_sga_shard') is not None:
-                    raise RuntimeError('sgaligner_amd: anchor sharding is implemented for the fused joint path only')
-                sums, s = ops.contrastive_terms(tabs + [output_dict['joint']], data_dict, alpha=self.contrastive_loss.alpha)
+                sums, s = ops.contrastive_terms(tabs + [output_dict['joint']], data_dict, alpha=self.contrastive_loss.alpha,
+                                                shard=data_dict.get('_sga_shard'), reduce=data_dict.get('_sga_reduce'))
             nt = m + 1
             if head_fused and sums.is_cuda:
                 # losses.py:114-152 + the two multi-loss layers as one launch (ops.LossHeadFn)

@@ -2044,14 +2044,20 @@ static int total_blocks(const SweepArgs& a) {
 
 extern "C" int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8,
                                  void* stream) {
+    return sga_loss_neg_sums_shard(Z, Dp, A, J1, J2, tau0, tau1, sums8, 0, A, stream);
+}
+
+extern "C" int sga_loss_neg_sums_shard(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8,
+                                       int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && sums8 && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0 && tau0 > 0 && tau1 > 0, "sga_loss_neg_sums: bad argument");
+    SGA_CHECK_ARG(a_lo >= 0 && a_lo <= a_hi && a_hi <= A, "sga_loss_neg_sums: anchor shard [%d,%d) outside [0,%d]", a_lo, a_hi, A);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = zero_slots(sums8, 8, s, "sga_loss_neg_sums")) return rc;
-    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    if (A == 0 || a_hi == a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     SweepArgs a{};
     a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     a.sums = sums8; a.gs = nullptr; a.dZ = nullptr; a.col0 = 0;
-    fill_groups(a, A, J1, J2, false, 0, A);
+    fill_groups(a, A, J1, J2, false, a_lo, a_hi);
     const int nblk = total_blocks(a);
     const int jt = ((J1 > J2 ? J1 : J2) + 127) / 128;
     int gy = (8 * sga_num_cus() + nblk - 1) / nblk;
@@ -2067,13 +2073,19 @@ extern "C" int sga_loss_neg_sums(const float* Z, int Dp, int A, int J1, int J2, 
 
 extern "C" int sga_loss_neg_grad(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1,
                                  const double* gs8, float* dZ, void* stream) {
+    return sga_loss_neg_grad_shard(Z, Dp, A, J1, J2, tau0, tau1, gs8, dZ, 0, A, stream);
+}
+
+extern "C" int sga_loss_neg_grad_shard(const float* Z, int Dp, int A, int J1, int J2, float tau0, float tau1,
+                                       const double* gs8, float* dZ, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && gs8 && dZ && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_neg_grad: bad argument");
+    SGA_CHECK_ARG(a_lo >= 0 && a_lo <= a_hi && a_hi <= A, "sga_loss_neg_grad: anchor shard [%d,%d) outside [0,%d]", a_lo, a_hi, A);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    if (A == 0 || a_hi == a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     SweepArgs a{};
     a.Z = Z; a.Dp = Dp; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     a.sums = nullptr; a.gs = gs8; a.dZ = dZ;
-    fill_groups(a, A, J1, J2, true, 0, A);
+    fill_groups(a, A, J1, J2, true, a_lo, a_hi);
     const int nblk = total_blocks(a);
     int mx = A > J1 ? A : J1;
     if (J2 > mx) mx = J2;

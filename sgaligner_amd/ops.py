@@ -620,10 +620,14 @@ class ContrastiveTermsFn(torch.autograd.Function):
     (reference losses.py:5-15,43-58,68-97).  NT == 1 -> ICL only."""
 
     @staticmethod
-    def forward(ctx, index_sets, alpha, *tables):
+    def forward(ctx, index_sets, alpha, shard, reduce, *tables):
+        """shard = (a_lo, a_hi[, ...]) / reduce: as in FusedContrastiveFn -- this rank evaluates its anchors' share of every global sum and loss
+        term (all-reduced: the returned values are the batch-global ones on every rank) and, in backward, its share of dL/dE for ALL rows."""
         L = _lib.lib()
         nt = len(tables)
         m = nt - 1 if nt > 1 else 0
+        a_lo, a_hi = (0, index_sets.A) if shard is None else (int(shard[0]), int(shard[1]))
+        full = a_lo == 0 and a_hi == index_sets.A
         tables = [_req(t.contiguous(), f'table[{i}]') for i, t in enumerate(tables)]
         dev = tables[0].device
         s = index_sets
@@ -641,6 +645,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
             _lib.check(L.sga_loss_gather(_p(e), T, d, _p(s.idx), s.R, _p(z), dp, _p(nrm), st), 'sga_loss_gather')
             sk = torch.empty((slots * 8,), device=dev, dtype=torch.float64)
             zh = zt = None
+            if dp > 128 and not full:
+                raise RuntimeError('sgaligner_amd: anchor sharding of the general loss path is implemented for tables of at most 128 columns')
             if dp > 128 and f16:
                 # opt-in fp16-input MFMA for wide tables (configs[4]): fp16 copies of the normalised table, once per step
                 ldt = int(L.sga_wide16_ldt(s.A, s.J1, s.J2))
@@ -656,15 +662,18 @@ class ContrastiveTermsFn(torch.autograd.Function):
                     ev[1].record()
                     KERNEL_EVENTS.setdefault('wide16_sums', []).append(ev + ((s.A, s.J1, s.J2, dp),))
             else:
-                _lib.check(L.sga_loss_neg_sums(_p(z), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), st), 'sga_loss_neg_sums')
+                _lib.check(L.sga_loss_neg_sums_shard(_p(z), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), a_lo, a_hi, st), 'sga_loss_neg_sums')
             sums[k].copy_(sk[:8])
             zs.append(z); nrms.append(nrm); dps.append(dp); zhs.append(zh); zts.append(zt)
         out = torch.empty((slots * (nt + 2 * m),), device=dev, dtype=torch.float64)
         zarr = _ptr_array(zs)
         dparr = (_ct.c_int * nt)(*dps)
         # (mode 'f16': the wide tables' anchors x anchors similarities take their fp16 copies as well -- fp16 inputs, fp32 accumulate)
-        _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), 0, s.A, st),
+        sums = _allreduce_sum(sums, reduce)
+        _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi, st),
                    'sga_loss_anchor_fwd')
+        out = _allreduce_sum(out[:nt + 2 * m].contiguous(), reduce)
+        ctx.shard, ctx.reduce = (a_lo, a_hi), reduce
         ctx.s, ctx.alpha, ctx.dps, ctx.nt = s, float(alpha), dps, nt
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.f16 = [zh is not None for zh in zhs]
@@ -689,7 +698,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
         dparr = (_ct.c_int * nt)(*dps)
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for dp in dps]
         gs = torch.zeros((nt, 8), device=dev, dtype=torch.float64)
-        chunks = _anchor_chunks(0, A, A, nt)
+        a_lo, a_hi = ctx.shard
+        chunks = _anchor_chunks(a_lo, a_hi, A, nt)
         if chunks:
             cmax = max(hi - lo for lo, hi in chunks)
             m1 = [torch.empty((A * cmax,), device=dev, dtype=torch.float32) for _ in range(nt)]
@@ -702,6 +712,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
                     # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]
                     _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dps[k], _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
             del m1
+        gs = _allreduce_sum(gs, ctx.reduce)                      # dL/d(global sums) needs every shard's anchors x anchors tiles
         grads = []
         for k in range(nt):
             z, dp, dz = zs[k], dps[k], dzs[k]
@@ -733,7 +744,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
                            'sga_loss_neg_grad_wide')
                 del stash
             else:
-                _lib.check(L.sga_loss_neg_grad(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), st),
+                _lib.check(L.sga_loss_neg_grad_shard(_p(z), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz), a_lo, a_hi, st),
                            'sga_loss_neg_grad')
             if ev is not None:
                 ev[1].record()
@@ -743,12 +754,13 @@ class ContrastiveTermsFn(torch.autograd.Function):
             _lib.check(L.sga_loss_scatter(_p(dz), _p(z), _p(nrms[k]), _p(s.idx), s.R, d, dp, _p(de), st), 'sga_loss_scatter')
             grads.append(de)
             dzs[k] = None
-        return (None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
-def contrastive_terms(tables, data_dict, alpha=ALPHA):
+def contrastive_terms(tables, data_dict, alpha=ALPHA, shard=None, reduce=None):
+    """shard / reduce: the anchor range this rank owns and an in-place SUM all-reduce (one process per GPU); None = everything here."""
     s = IndexSets.of(data_dict, tables[0].device, int(tables[0].shape[0]))
-    return ContrastiveTermsFn.apply(s, alpha, *tables), s
+    return ContrastiveTermsFn.apply(s, alpha, shard, reduce, *tables), s
 
 
 class LossHeadFn(torch.autograd.Function):

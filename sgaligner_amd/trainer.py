@@ -99,7 +99,7 @@ class AlignerSteps:
         M >= 2 (fused joint path): the anchors are SHARDED -- each rank evaluates the loss terms / global sums of its own
         anchors against all negatives (partial scalars all-reduced inside ops.FusedContrastiveFn, so every rank holds the
         global loss value) and its share of dL/dE for all rows, summed over ranks in AllGatherRows.backward.
-        M == 1: every rank evaluates the (small) global loss as a replica and keeps only its own rows' gradient."""
+        M == 1 (ICL of the one table, the general per-table kernels): sharded by anchors the same way (round 5; a replica on every rank before)."""
         world, rank = dist.get_world_size(), dist.get_rank()
         if layout is None:
             layout = sdist.layout_of(data_dict, self.device)                # [world, 4]: rows, |e1i|, |e1j|, |e2j|
@@ -120,8 +120,8 @@ class AlignerSteps:
             joint._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
             gathered['joint'] = joint
         else:
-            gathered = sdist.gather_tables(output_dict, rows, reduce_grad=False)
-        if sharded:
+            gathered = sdist.gather_tables(output_dict, rows, reduce_grad=True)     # every rank holds its anchors' share of dL/dE for all rows
+        if True:
             # (a_lo, a_hi) of this rank + every rank's cut and the rank: with all cuts on 32-row boundaries the anchors x anchors pairs are
             # walked symmetrically ACROSS ranks (ops._sym_jobs: every unordered pair once, the same number on every rank)
             cuts = [sum(anchors[:r]) for r in range(world + 1)]

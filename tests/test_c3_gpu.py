@@ -131,9 +131,9 @@ def test_c3_shard_loss_two_implementations():
     assert torch.allclose(g1f, g1g, rtol=1e-4) and torch.allclose(g2f, g2g, rtol=1e-4)
 
 
-def _replay_sharded(base, w0, cot, dd, cuts):
-    """Deterministic replay of the all-reduces inside ops.FusedContrastiveFn for len(cuts)-1 simulated ranks (see
-    test_modules_gpu.py::test_anchor_sharded_loss_equals_unsharded)."""
+def _replay_sharded(base, w0, cot, dd, cuts, general=False):
+    """Deterministic replay of the all-reduces inside ops.FusedContrastiveFn (general=True: ops.ContrastiveTermsFn, the per-table path; w0
+    unused) for len(cuts)-1 simulated ranks (see test_modules_gpu.py::test_anchor_sharded_loss_equals_unsharded)."""
     from sgaligner_amd import ops
     R = len(cuts) - 1
     M = len(base)
@@ -141,6 +141,10 @@ def _replay_sharded(base, w0, cot, dd, cuts):
     def run(shard, reduce):
         tabs = [b.clone().requires_grad_(True) for b in base]
         w = w0.clone().requires_grad_(True)
+        if general:
+            sums, s = ops.contrastive_terms(tabs, dd, shard=shard, reduce=reduce)
+            (sums * cot).sum().backward()
+            return sums.detach(), [t.grad for t in tabs], torch.zeros_like(w0)
         sums, s = ops.fused_contrastive_terms(tabs, w, dd, shard=shard, reduce=reduce)
         (sums * cot).sum().backward()
         return sums.detach(), [t.grad for t in tabs], w.grad

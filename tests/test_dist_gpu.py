@@ -253,7 +253,7 @@ def _rccl_worker(rank, world, port, mods, ragged_pad, out):
     dist.init_process_group('nccl', rank=0, world_size=1)
     try:
         assert sdist._has_reduce_scatter()
-        dev = torch.device('cuda', di)
+        dev = torch.device('cuda', 0)
         dd = to_device(make_batch(5, 14, 48, seed=23, ragged=True), dev)
         steps = AlignerSteps(mods, device=dev, seed=42)
         steps.zero_grad()
@@ -317,7 +317,7 @@ def test_rccl_collectives_world_of_one(mods):
     summ = r['summary']                                       # bench.py's `collectives` object, from real RCCL calls
     assert summ['backend'] == 'nccl' and summ['ranks_seen'][0]['rank'] == 0
     kinds = set(summ['per_step_this_rank'])
-    assert 'all_gather' in kinds and (('reduce_scatter' in kinds) == (len(mods) > 1)) and (('all_reduce' in kinds) == (len(mods) > 1))
+    assert 'all_gather' in kinds and 'reduce_scatter' in kinds and 'all_reduce' in kinds      # (M = 1 too since round 5: its loss is sharded by anchors as well)
     assert all(t['ms_each'] > 0 for t in summ['timed_alone'])
 
 

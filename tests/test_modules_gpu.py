@@ -343,3 +343,30 @@ def test_backward_retain_graph_twice_like_the_reference_engine(mods):
         if n in g1:
             sc = g1[n].abs().max().item()
             assert (p.grad - g1[n]).abs().max().item() <= 2e-5 * max(1.0, sc), n
+
+
+@pytest.mark.parametrize('nt,emb', [(1, 100), (2, 100), (3, 64), (1, 128)])
+def test_general_loss_path_sharded_by_anchors_equals_unsharded(nt, emb):
+    """The per-table loss kernels (ops.ContrastiveTermsFn: M = 1 -- ICL of one table, what ['point']-only runs use -- and arbitrary joint tables)
+    sharded by anchors: 3 simulated ranks with cuts that are not multiples of any tile, all-reduces replayed deterministically.  Every rank holds
+    the global loss terms; the ranks' gradient shares sum to the unsharded gradients (src/aligner/losses.py:43-58,68-97)."""
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    from test_c3_gpu import _replay_sharded
+    dd = make_batch(9, 30, 4, seed=60 + nt, ragged=True, anchors='val')
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(nt)
+    base = [torch.randn(T, emb if k < nt - 1 or nt == 1 else emb * max(1, nt - 1), device='cuda', generator=g) for k in range(nt)]
+    m = nt - 1 if nt > 1 else 0
+    cot = torch.rand(nt + 2 * m, device='cuda', generator=g) + 0.5
+    tabs = [b.clone().requires_grad_(True) for b in base]
+    sums, s = ops.contrastive_terms(tabs, dd)
+    (sums * cot).sum().backward()
+    A = s.A
+    cuts = [0, A // 3 + 5, 2 * A // 3 - 3, A]
+    _, gs, _, all_sums = _replay_sharded(base, torch.zeros(1, device='cuda'), cot, dd, cuts, general=True)
+    for sr in all_sums:
+        assert torch.allclose(sr, sums.detach(), rtol=1e-5, atol=1e-6)
+    for k in range(nt):
+        sc = tabs[k].grad.abs().max().item()
+        assert (gs[k] - tabs[k].grad).abs().max().item() < 2e-5 * sc, k
