@@ -50,6 +50,19 @@ size_t sga_pointnet_fwd_ws_bytes(int T, int C3);
 int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
                         void* workspace, size_t ws_bytes, int mode, float tie_eps, void* stream);
+/* The exact-fp32 forward (mode 0) that ALSO delivers the side effect of the reference's training forward: its three BatchNorm calls discard
+ * their output but fold the batch statistics of the pre-ReLU conv outputs over all T*P points into running_mean / running_var
+ * (pointnet.py:141-142,154-155,158-159).  The sums are taken inside the forward kernel (no second pass over the activations) and folded in
+ * a fixed order.  bn_sums, 265 + 2 C3 doubles:
+ *   [0, 9)            sum over the points of x0, x1, x2, x0x0, x0x1, x0x2, x1x1, x1x2, x2x2   (z1 = W1 x + b1 is affine in x: the caller
+ *                     forms mean and variance of the 64 channels from these moments)
+ *   [9, 137)          sum z2[c]         [137, 265)          sum z2[c]^2        z2 = W2 relu(z1) + b2
+ *   [265, 265 + C3)   sum u[c]          [265 + C3, + 2 C3)  sum u[c]^2         u = z3 - b3 = W3 relu(z2)
+ * bn_workspace: sga_pointnet_fwd_bn_ws_bytes(T, C3) bytes, caller-owned.  workspace / ws_bytes as in sga_pointnet_fwd_ws (may be NULL). */
+size_t sga_pointnet_fwd_bn_ws_bytes(int T, int C3);
+int sga_pointnet_fwd_bn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
+                        void* workspace, size_t ws_bytes, void* bn_workspace, size_t bn_ws_bytes, double* bn_sums, void* stream);
 /* autograd of the above wrt the six parameters (sparse through the max-pool); gy [T,C3]; C3 == 256. */
 int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy, const float* w1,
                      const float* b1, const float* w2, const float* b2, const float* w3, float* gw1, float* gb1,

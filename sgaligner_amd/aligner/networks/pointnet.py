@@ -38,11 +38,13 @@ class PointNetfeat(BaseNetwork):
             self.bn2 = nn.BatchNorm1d(128)
             self.bn3 = nn.BatchNorm1d(out_size)
         # The reference's discarded BN calls still update running_mean / running_var / num_batches_tracked in train mode
-        # (pointnet.py:141-142,154-155,158-159).  Those buffers never reach any output, and computing them costs a second
-        # pass over every per-point activation (about one more forward), so the side effect is opt-in:
-        # set this attribute (or SGA_POINTNET_BN_STATS=1) when checkpoint buffers must match the reference's.
+        # (pointnet.py:141-142,154-155,158-159).  The buffers never reach any output, but a checkpoint carries them, so the side effect is
+        # reproduced by default: the exact-fp32 forward kernel sums the batch statistics of the three pre-activations on its way
+        # (sga_pointnet_fwd_bn: +64 MFMAs per 32-point tile on 640, no second pass).  In the opt-in arithmetic modes whose forward is another
+        # kernel the statistics come from a separate chunked pass (about one more forward).  SGA_POINTNET_BN_STATS=0 (or this attribute)
+        # switches the side effect off.
         import os
-        self.update_bn_running_stats = os.environ.get('SGA_POINTNET_BN_STATS', '0') == '1'
+        self.update_bn_running_stats = os.environ.get('SGA_POINTNET_BN_STATS', '1') != '0'
         if init_weights:                                     # pointnet.py:116-118
             self.init_weights('constant', 1, target_op='BatchNorm')
             self.init_weights('xavier_normal', 1)
@@ -53,13 +55,49 @@ class PointNetfeat(BaseNetwork):
         xt = x.permute(0, 2, 1)                               # -> [T,P,3]; free when x is the reference's view
         if not xt.is_contiguous():
             xt = xt.contiguous()
+        side = self.training and self.use_batch_norm and self.update_bn_running_stats and xt.shape[0] * xt.shape[1] > 0
+        bn_sums = None
+        if side and ops.pointnet_bn_fusable() and self.out_size in (64, 128, 256):
+            bn_sums = torch.empty((265 + 2 * self.out_size,), device=xt.device, dtype=torch.float64)
         y = ops.pointnet(xt.float() if xt.dtype != torch.float32 else xt, self.conv1.weight, self.conv1.bias,
-                         self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias)
-        if self.training and self.use_batch_norm and self.update_bn_running_stats:
+                         self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias, bn_sums=bn_sums)
+        if bn_sums is not None:
+            self._fold_bn_sums(bn_sums, xt.shape[0] * xt.shape[1])
+        elif side:
             self._update_bn_running_stats(xt)
         if return_meta:
             return y, torch.zeros([1]), torch.zeros([1])       # pointnet.py:138,151 dummies
         return y
+
+    @torch.no_grad()
+    def _fold_bn_sums(self, sums, n):
+        """running_mean / running_var / num_batches_tracked of bn1..3 from the sums the forward kernel took (fp64 throughout):
+        z1 = W1 x + b1 is affine in x, so its channel means / variances follow from the 9 point moments; z2 and z3 - b3 come as per-channel
+        sum and sum of squares.  nn.BatchNorm1d semantics: momentum 0.1 (None: cumulative average), unbiased variance."""
+        c3 = self.out_size
+        m = sums[0:3] / n
+        q = sums[3:9] / n
+        m2 = torch.stack((q[0], q[1], q[2], q[1], q[3], q[4], q[2], q[4], q[5])).view(3, 3)
+        cov = m2 - torch.outer(m, m)
+        w1 = self.conv1.weight.detach().reshape(64, 3).double()
+        mean1 = w1 @ m + self.conv1.bias.detach().double()
+        var1 = ((w1 @ cov) * w1).sum(1)
+        mean2 = sums[9:137] / n
+        var2 = sums[137:265] / n - mean2 * mean2
+        u = sums[265:265 + c3] / n
+        var3 = sums[265 + c3:265 + 2 * c3] / n - u * u
+        mean3 = u + self.conv3.bias.detach().double()
+        unb = n / max(n - 1, 1)
+        for bn, mean, var in ((self.bn1, mean1, var1), (self.bn2, mean2, var2), (self.bn3, mean3, var3)):
+            bn.num_batches_tracked.add_(1)
+            mom = bn.momentum
+            if mom is None:                                   # cumulative moving average (nn.BatchNorm1d(momentum=None))
+                mom_t = 1.0 / bn.num_batches_tracked.double()
+                bn.running_mean.add_(((mean - bn.running_mean.double()) * mom_t).float())
+                bn.running_var.add_(((var.clamp_min(0) * unb - bn.running_var.double()) * mom_t).float())
+            else:
+                bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_((var.clamp_min(0) * unb).float(), alpha=mom)
 
     @torch.no_grad()
     def _update_bn_running_stats(self, xt, chunk_rows=1 << 20):

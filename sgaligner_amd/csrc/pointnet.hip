@@ -22,10 +22,14 @@
 //   * HBM traffic is the points once (12 B/point) + T*C3*(4+4) B out: the kernel is MFMA-bound
 //     (82 304 FLOP/point at C3 = 256).
 #include <stdlib.h>
+#include <type_traits>
 #include "sga_common.h"
 
 namespace {
 
+#ifndef PN_BN_SB
+#define PN_BN_SB 0
+#endif
 constexpr int PN_WAVES = 8;
 constexpr int PN_THREADS = PN_WAVES * 64;
 
@@ -33,7 +37,21 @@ constexpr int PN_THREADS = PN_WAVES * 64;
 // waves share the object's 32-point tiles (tile = wave, wave + 8, ...); each wave leaves its running (max, arg-max) in `part`
 // [T][8][C3] (value, index) and pointnet_combine_kernel folds the 8 partials.  With one wave per object, T = 320 objects keep 40 of
 // the 256 CUs busy for 16 tiles each (0.63 ms); split, every CU works and an object takes 2 tiles per wave.
-template <int C3, bool WITH_ARGMAX, bool SPLIT = false>
+//
+// BN (training forward, the reference's side effect): the three BatchNorm calls of pointnet.py:141-142,154-155,158-159 discard their
+// output but fold the batch statistics of the PRE-ReLU conv outputs over all T*P points into running_mean / running_var.  The sums are
+// taken here, from the registers that hold those values anyway, into per-lane fp64 accumulators (33 + ... doubles) that a wave keeps over
+// all its objects and writes ONCE to bn_part[wave][k][lane]; pointnet_bn_reduce_kernel folds them in a fixed order:
+//   layer 1  z1 = W1 x + b1 is affine in x: only the 9 first / second moments of the points are summed (lane = point, half 0 counts);
+//            mean and variance follow from W1, b1 in fp64 on the host side of the ABI (9 numbers instead of 128 sums);
+//   layer 2  the pre-activations live with lane = point, register = channel -- their per-channel sums are sums over LANES.  Sixteen
+//            MFMAs against identity slices (B[k, j] = [j == channel(k)]; exact: one product by 1, the rest zeros) transpose a 32-channel
+//            block to the layer-3 layout (lane = channel, registers = points), where the sums are in-lane: +64 MFMAs per 32-point tile
+//            on top of 640 (a cross-lane butterfly over 64 registers x 2 moments would be ~640 DPP adds, in-lane accumulators in the
+//            lane = point layout 128 registers);
+//   layer 3  lane = channel already (bias b3 is added after the max: it enters the mean on the host side, not the variance).
+// Replicated tail points (P not a multiple of 32) are masked out.
+template <int C3, bool WITH_ARGMAX, bool SPLIT = false, bool BN = false>
 __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     const float* __restrict__ x,   // [T, P, 3]
     const float* __restrict__ w1,  // [64, 3]
@@ -45,8 +63,21 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     float* __restrict__ y,         // [T, C3]
     int* __restrict__ argmax,      // [T, C3] or nullptr
     int T, int P, float2* __restrict__ part,               // part: SPLIT only, [T][PN_WAVES][C3] (value, index as float bits)
-    const int* __restrict__ only = nullptr) {              // !SPLIT: if given, only the only[0] objects listed in only[1..] run (the 'f16x2' near-tie re-run)
+    const int* __restrict__ only = nullptr,                // !SPLIT: if given, only the only[0] objects listed in only[1..] run (the 'f16x2' near-tie re-run)
+    double* __restrict__ bn_part = nullptr) {              // BN: [gridDim.x * PN_WAVES][PN_BN_SLOTS(C3)][64] per-lane partial sums
     constexpr int NB3 = C3 / 32;
+    constexpr int NBN = BN ? 9 + 2 * 4 + 2 * NB3 : 1;
+    // BN: an object's per-lane fp32 partial sums (24 registers) go to the wave's OWN fp64 slots by (uncontended, no-return) atomic adds when
+    // the object ends; the host zeroes the slots before the launch.  (Slots 0..8, the point moments, are pointnet_xmoments_kernel's.)
+    double* const bn_dst = BN ? bn_part + ((size_t)blockIdx.x * PN_WAVES + (threadIdx.x >> 6)) * NBN * 64 + (threadIdx.x & 63) : nullptr;
+    // (the slot addresses are formed from an OPAQUE copy of the base where they are used: hoisted out of the tile loop they are 2 x 33 registers)
+    auto bn_add = [&](int slot, float v) {
+        if (BN) {
+            double* d = bn_dst;
+            asm volatile("" : "+v"(d));
+            unsafeAtomicAdd(d + slot * 64, (double)v);
+        }
+    };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w2s = lds;             // [4 cb][8 q][64 lane][4]        = 8192 floats
     float* w3s = lds + 8192;      // [NB3 cb][4 kb][4 g][64 lane][4] = C3*128 floats
@@ -77,8 +108,14 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
         int bidx[NB3];
 #pragma unroll
         for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
+        float bacc[BN ? NBN - 9 : 1];                      // BN: this object's per-lane sums (<= 16 tiles x 16 values each), flushed when it ends
+#pragma unroll
+        for (int k = 0; k < (BN ? NBN - 9 : 1); ++k) bacc[k] = 0.f;
 
-        for (int tile = SPLIT ? wave : 0; tile < n_tiles; tile += SPLIT ? PN_WAVES : 1) {
+        // (the tile body in two compile-time forms: a tile that replicates the object's last point masks the copies out of the BN sums;
+        //  a run-time test inside the folds splits the body into 12 conditional regions, which costs hipcc ~100 registers)
+        auto tile_body = [&](int tile, auto tail_c) {
+            constexpr bool tail = BN && decltype(tail_c)::value;
             const int p0 = tile * 32;
             // Opaque per-tile copies of the lane ids: the weight reads below are loop-invariant, and
             // without this LICM hoists ~900 registers of them out of the tile loop (-> scratch spills).
@@ -86,6 +123,20 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
             asm volatile("" : "+v"(lane_o), "+v"(h_o));
             const int pi = min(p0 + pt, P - 1);          // ragged tail: replicate the last point
             const float x0 = xt[pi * 3 + 0], x1 = xt[pi * 3 + 1], x2 = xt[pi * 3 + 2];
+
+            auto bn_fold = [&](f32x16& v, int slot) {          // (v is dead afterwards: the tail tile zeroes its replicated rows in place)
+                if (tail) {
+                    const int lim = P - p0 - 4 * h_o;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = mfma32_row(r, 0) < lim ? v[r] : 0.f;
+                }
+                float sm[4], sq[4];                             // four independent chains each (a 16-deep dependent chain is latency, not issue)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sm[r] = v[r]; sq[r] = v[r] * v[r]; }
+#pragma unroll
+                for (int r = 4; r < 16; ++r) { sm[r & 3] += v[r]; sq[r & 3] = fmaf(v[r], v[r], sq[r & 3]); }
+                bacc[BN ? slot - 9 : 0] += (sm[0] + sm[1]) + (sm[2] + sm[3]); bacc[BN ? slot - 8 : 0] += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+            };
 
             // ---- layer 1 (VALU): channels k = 8q + 4h + r
             float h1[32];
@@ -118,6 +169,18 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], h1[q * 4 + r], acc, 0, 0, 0);
+                }
+                if (BN) {                                   // Z2 block -> (lane = channel, register = point row) through identity slices
+                    f32x16 tr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tr[r] = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            tr = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[g * 4 + r], (lane_o & 31) == 8 * g + 4 * h_o + r ? 1.f : 0.f, tr, 0, 0, 0);
+                    bn_fold(tr, 9 + 2 * cb);
+                    __builtin_amdgcn_sched_barrier(PN_BN_SB);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h2[cb * 16 + r] = fmaxf(acc[r], 0.f);
@@ -152,9 +215,17 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
                     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
                     best[cb] = fmaxf(best[cb], m);
                 }
+                if (BN) { bn_fold(acc, 9 + 8 + 2 * cb); __builtin_amdgcn_sched_barrier(PN_BN_SB); }   // behind the max: the tail tile zeroes rows in place; (barrier: hipcc otherwise interleaves the blocks' folds and spills)
             }
+        };
+        for (int tile = SPLIT ? wave : 0; tile < n_tiles; tile += SPLIT ? PN_WAVES : 1) {
+            if (BN && tile * 32 + 32 > P) tile_body(tile, std::true_type{}); else tile_body(tile, std::false_type{});
         }
 
+        if (BN) {
+#pragma unroll
+            for (int k = 0; k < NBN - 9; ++k) bn_add(9 + k, bacc[k]);
+        }
         // ---- combine the two lane halves (they hold disjoint point rows), bias + ReLU, store
 #pragma unroll
         for (int cb = 0; cb < NB3; ++cb) {
@@ -181,6 +252,42 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
             }
         }
     }
+}
+
+// First / second moments of the points (slots 0..8 of the BN partials: layer 1 is affine in x), same [wave][slot][lane] layout and the same
+// grid as the forward: every lane sums a strided share of the T*P points in fp64 (fp64 products: exact).
+__global__ __launch_bounds__(PN_THREADS) void pointnet_xmoments_kernel(const float* __restrict__ x, size_t n, int C3, double* __restrict__ bn_part) {
+    const int nbn = 9 + 8 + 2 * (C3 / 32);
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * PN_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * PN_THREADS) {
+        const double x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2];
+        a[0] += x0; a[1] += x1; a[2] += x2;
+        a[3] += x0 * x0; a[4] += x0 * x1; a[5] += x0 * x2; a[6] += x1 * x1; a[7] += x1 * x2; a[8] += x2 * x2;
+    }
+    double* dst = bn_part + ((size_t)blockIdx.x * PN_WAVES + (threadIdx.x >> 6)) * nbn * 64 + (threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst[k * 64] = a[k];
+}
+
+// Fold the per-lane partial sums of the BN forward in a fixed order (deterministic).  out (doubles):
+//   [0, 9)            sum x0, x1, x2, x0x0, x0x1, x0x2, x1x1, x1x2, x2x2 over the T*P points
+//   [9, 137)          sum z2[c]          [137, 265)        sum z2[c]^2      (z2 = W2 relu(z1) + b2, bias included)
+//   [265, 265 + C3)   sum (z3 - b3)[c]   [265 + C3, + C3)  sum (z3 - b3)[c]^2
+// One 64-thread block per output.
+__global__ __launch_bounds__(64) void pointnet_bn_reduce_kernel(const double* __restrict__ part, int nwaves, int C3, double* __restrict__ out) {
+    const int o = blockIdx.x, nbn = 9 + 8 + 2 * (C3 / 32);
+    int slot, l0, l1;                                      // which slot and which lanes of a wave's partials feed output o
+    if (o < 9) { slot = o; l0 = 0; l1 = 64; }
+    else if (o < 265) { const int c = (o - 9) & 127, sq = (o - 9) >> 7; slot = 9 + 2 * (c >> 5) + sq; l0 = c & 31; l1 = -1; }
+    else { const int c = (o - 265) % C3, sq = (o - 265) / C3; slot = 17 + 2 * (c >> 5) + sq; l0 = c & 31; l1 = -1; }
+    double acc = 0.0;
+    for (int w = threadIdx.x; w < nwaves; w += 64) {
+        const double* p = part + ((size_t)w * nbn + slot) * 64;
+        if (l1 < 0) acc += p[l0] + p[l0 + 32];
+        else for (int l = l0; l < l1; ++l) acc += p[l];
+    }
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) out[o] = acc;
 }
 
 // fold the PN_WAVES partial (max, arg-max) pairs of the SPLIT forward: larger value wins, equal values -> smaller point index (the
@@ -471,11 +578,29 @@ constexpr float PN_TIE_EPS_DEFAULT = 1.0f / 131072.f;      // 2^-17 of |leader| 
 template <int C3>
 int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                const float* w3, const float* b3, float* y, int* argmax, int T, int P, hipStream_t stream,
-               void* workspace, size_t ws_bytes, int mode, float tie_eps) {
+               void* workspace, size_t ws_bytes, int mode, float tie_eps, double* bn_part = nullptr, double* bn_out = nullptr) {
     const size_t lds_bytes = (size_t)(8192 + C3 * 128) * sizeof(float);
     int grid = (T + PN_WAVES - 1) / PN_WAVES;
     const int ncu = sga_num_cus();
     if (grid > ncu) grid = ncu;
+    if (bn_out) {
+        // the exact-fp32 forward with the batch statistics of the three pre-activations (the reference's BatchNorm side effect)
+        const bool split = workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32;
+        const int g = split ? (T < ncu ? T : ncu) : grid;
+        float2* part = split ? static_cast<float2*>(workspace) : nullptr;
+        if (hipMemsetAsync(bn_part, 0, (size_t)g * PN_WAVES * (9 + 8 + 2 * (C3 / 32)) * 64 * sizeof(double), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd_bn: memset failed"); return SGA_ERR_HIP; }
+        auto go = [&](auto k) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k, dim3(g), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), bn_part);
+        };
+        if (split) { if (argmax) go(pointnet_fwd_kernel<C3, true, true, true>); else go(pointnet_fwd_kernel<C3, false, true, true>); }
+        else { if (argmax) go(pointnet_fwd_kernel<C3, true, false, true>); else go(pointnet_fwd_kernel<C3, false, false, true>); }
+        if (split) hipLaunchKernelGGL(pointnet_combine_kernel, dim3((T * C3 + 255) / 256), dim3(256), 0, stream, part, b3, y, argmax, T, C3, P);
+        hipLaunchKernelGGL(pointnet_xmoments_kernel, dim3(g), dim3(PN_THREADS), 0, stream, x, (size_t)T * P, C3, bn_part);
+        hipLaunchKernelGGL(pointnet_bn_reduce_kernel, dim3(265 + 2 * C3), dim3(64), 0, stream, bn_part, g * PN_WAVES, C3, bn_out);
+        SGA_CHECK_LAUNCH("sga_pointnet_fwd_bn");
+        return SGA_OK;
+    }
     // few objects: one object per workgroup, its tiles dealt to the 8 waves (exact fp32 kernel only; needs the partials workspace)
     if ((mode == 0 || mode == 2) && workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32) {
         float2* part = static_cast<float2*>(workspace);
@@ -483,11 +608,11 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         if (argmax) {
             auto k = pointnet_fwd_kernel<C3, true, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr));
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
         } else {
             auto k = pointnet_fwd_kernel<C3, false, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr));
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
         }
         hipLaunchKernelGGL(pointnet_combine_kernel, dim3((T * C3 + 255) / 256), dim3(256), 0, stream, part, b3, y, argmax, T, C3, P);
         SGA_CHECK_LAUNCH("sga_pointnet_fwd");
@@ -505,7 +630,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         auto k2 = pointnet_fwd_kernel<C3, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL(k2, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr),
-                           static_cast<const int*>(redo));
+                           static_cast<const int*>(redo), static_cast<double*>(nullptr));
     } else if (split_fwd) {                // 'f16x2', inference: values only -- nothing to flip
         auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -533,11 +658,11 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     } else if (argmax) {
         auto k = pointnet_fwd_kernel<C3, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
     } else {
         auto k = pointnet_fwd_kernel<C3, false>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
     }
     SGA_CHECK_LAUNCH("sga_pointnet_fwd");
     return SGA_OK;
@@ -549,7 +674,7 @@ extern "C" size_t sga_pointnet_fwd_ws_bytes(int T, int C3) { return (size_t)(T >
 
 static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                              const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,
-                             int mode, float tie_eps, void* stream) {
+                             int mode, float tie_eps, void* stream, double* bn_part = nullptr, double* bn_out = nullptr) {
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_fwd: need T >= 0 and P >= 1 (got T=%d P=%d)", T, P);
     SGA_CHECK_ARG(mode >= 0 && mode <= 3, "sga_pointnet_fwd: mode %d (0 = exact fp32, 1 = bf16 hi + lo, 2 = fp16 hi + lo with the exact re-run of near-ties, 3 = fp16 hi + lo)", mode);
     // a zero-object shard (T == 0: empty tensors carry null data pointers) is a valid no-op
@@ -557,9 +682,9 @@ static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, c
     if (T == 0) return SGA_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (C3) {
-        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps);
-        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps);
-        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps);
+        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps, bn_part, bn_out);
+        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps, bn_part, bn_out);
+        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps, bn_part, bn_out);
         default:
             sga_set_error("sga_pointnet_fwd: out_size C3=%d unsupported (64, 128 or 256: W3 must fit the 160 KiB LDS)", C3);
             return SGA_ERR_ARG;
@@ -570,6 +695,26 @@ extern "C" int sga_pointnet_fwd_ws(const float* x, const float* w1, const float*
                                    const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
                                    void* workspace, size_t ws_bytes, int mode, float tie_eps, void* stream) {
     return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, mode, tie_eps, stream);
+}
+
+/* The exact-fp32 forward that also delivers the batch statistics the reference's three discarded BatchNorm calls fold into their running
+ * buffers (pointnet.py:141-142,154-155,158-159): bn_sums[265 + 2 C3] doubles (layout: pointnet_bn_reduce_kernel). */
+extern "C" size_t sga_pointnet_fwd_bn_ws_bytes(int T, int C3) {
+    if (T <= 0 || C3 <= 0) return 0;
+    const int ncu = sga_num_cus();
+    const int g = T < ncu ? T : ncu;                       // an upper bound of both launch forms' workgroup counts
+    return (size_t)g * PN_WAVES * (9 + 8 + 2 * (C3 / 32)) * 64 * sizeof(double);
+}
+extern "C" int sga_pointnet_fwd_bn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
+                                   void* workspace, size_t ws_bytes, void* bn_workspace, size_t bn_ws_bytes, double* bn_sums, void* stream) {
+    SGA_CHECK_ARG(bn_sums != nullptr, "sga_pointnet_fwd_bn: bn_sums is null");
+    SGA_CHECK_ARG(T == 0 || (bn_workspace && bn_ws_bytes >= sga_pointnet_fwd_bn_ws_bytes(T, C3)),
+                  "sga_pointnet_fwd_bn: bn_workspace must hold sga_pointnet_fwd_bn_ws_bytes(T, C3) = %zu bytes (got %zu)", sga_pointnet_fwd_bn_ws_bytes(T, C3), bn_ws_bytes);
+    if (T == 0) {
+        if (C3 == 64 || C3 == 128 || C3 == 256) hipMemsetAsync(bn_sums, 0, (size_t)(265 + 2 * C3) * sizeof(double), static_cast<hipStream_t>(stream));
+    }
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, 0, -1.f, stream, static_cast<double*>(bn_workspace), bn_sums);
 }
 
 /* the no-workspace entry: always the exact-fp32 kernel */

@@ -84,8 +84,16 @@ GROUP_LOSS_VALU = _os_mode.environ.get('SGA_GROUP_GRAD_VALU', '0') == '1'      #
 # ------------------------------------------------------------------------------------------ PointNet
 POINTNET_LAST_REDO = None              # 'f16x2': [count | object ids] re-run in exact fp32 by the last training forward (diagnostics: tests, bench)
 POINTNET_SPLIT_MAX_OBJECTS = 1023      # the library uses the split form below 4 x CUs objects; above that a workspace is not allocated
-def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
-    """x_tp3 [T,P,3] (point-major, as in data_dict['tot_obj_pts']).  Returns (y [T,C3], argmax|None)."""
+def pointnet_bn_fusable() -> bool:
+    """True when the PointNet forward of the current arithmetic mode is the exact-fp32 kernel, which can deliver the BatchNorm batch
+    statistics of the reference's training forward from inside the kernel (sga_pointnet_fwd_bn)."""
+    return _POINTNET_MODE[get_mfma_mode()] == 0
+
+
+def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool, bn_sums=None):
+    """x_tp3 [T,P,3] (point-major, as in data_dict['tot_obj_pts']).  Returns (y [T,C3], argmax|None).
+    bn_sums: a float64 tensor of 265 + 2 C3 elements to receive the batch-statistic sums of the three pre-activations (layout:
+    include/sgaligner_hip.h, sga_pointnet_fwd_bn) -- exact-fp32 forward only."""
     T, P, _ = x_tp3.shape
     C3 = w3.shape[0]
     y = torch.empty((T, C3), device=x_tp3.device, dtype=torch.float32)
@@ -105,9 +113,20 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool):
         # 'f16x2' training forward: [count | ids] of the objects with a near-tied arg-max -> those again on the exact-fp32 kernel
         ws_bytes = 4 * (T + 1)
         ws = POINTNET_LAST_REDO = torch.empty((T + 1,), device=x_tp3.device, dtype=torch.int32)
-    rc = L.sga_pointnet_fwd_ws(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
-                               T, P, C3, _p(ws), ws_bytes, _POINTNET_MODE[get_mfma_mode()], float(POINTNET_TIE_EPS), _stream())
-    _lib.check(rc, 'sga_pointnet_fwd')
+    if bn_sums is not None:
+        if not pointnet_bn_fusable():
+            raise RuntimeError(f"sgaligner_amd.pointnet_forward: the fused BatchNorm statistics need the exact-fp32 forward (mode {get_mfma_mode()!r} runs another)")
+        if bn_sums.dtype != torch.float64 or bn_sums.numel() != 265 + 2 * C3 or not bn_sums.is_contiguous() or bn_sums.device != x_tp3.device:
+            raise RuntimeError('sgaligner_amd.pointnet_forward: bn_sums must be a contiguous float64 tensor of 265 + 2 C3 elements on the input device')
+        bws_bytes = int(L.sga_pointnet_fwd_bn_ws_bytes(T, C3))
+        bws = torch.empty((max(bws_bytes, 8),), device=x_tp3.device, dtype=torch.uint8)
+        rc = L.sga_pointnet_fwd_bn(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
+                                   T, P, C3, _p(ws), ws_bytes, _p(bws), bws_bytes, _p(bn_sums), _stream())
+        _lib.check(rc, 'sga_pointnet_fwd_bn')
+    else:
+        rc = L.sga_pointnet_fwd_ws(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
+                                   T, P, C3, _p(ws), ws_bytes, _POINTNET_MODE[get_mfma_mode()], float(POINTNET_TIE_EPS), _stream())
+        _lib.check(rc, 'sga_pointnet_fwd')
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.setdefault('pointnet_fwd_kernel', []).append(ev + ((T, P, w1.shape[0], w2.shape[0], C3, get_mfma_mode() if (ws is not None and ws_bytes == 4 * (T + 1)) else 'f32'),))
@@ -118,13 +137,13 @@ class PointNetFn(torch.autograd.Function):
     """PointNetfeat.forward (reference pointnet.py:120-175) with the sparse max-pool backward."""
 
     @staticmethod
-    def forward(ctx, x_tp3, w1, b1, w2, b2, w3, b3):
+    def forward(ctx, x_tp3, w1, b1, w2, b2, w3, b3, bn_sums=None):
         x = _req(x_tp3.contiguous(), 'tot_obj_pts')
         ws = [_req(w1.reshape(w1.shape[0], -1).contiguous(), 'conv1.weight'), _req(b1.contiguous(), 'conv1.bias'),
               _req(w2.reshape(w2.shape[0], -1).contiguous(), 'conv2.weight'), _req(b2.contiguous(), 'conv2.bias'),
               _req(w3.reshape(w3.shape[0], -1).contiguous(), 'conv3.weight'), _req(b3.contiguous(), 'conv3.bias')]
         need = any(ctx.needs_input_grad[1:])
-        y, am = pointnet_forward(x, *ws, want_argmax=need)
+        y, am = pointnet_forward(x, *ws, want_argmax=need, bn_sums=bn_sums)
         if need:
             ctx.save_for_backward(x, am, y, *ws)
             ctx.wshapes = (tuple(w1.shape), tuple(w2.shape), tuple(w3.shape))
@@ -146,11 +165,11 @@ class PointNetFn(torch.autograd.Function):
                                          _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]), T, P, C3, _stream())
         _lib.check(rc, 'sga_pointnet_bwd')
         s1, s2, s3 = ctx.wshapes
-        return None, g[0].reshape(s1), g[1], g[2].reshape(s2), g[3], g[4].reshape(s3), g[5]
+        return None, g[0].reshape(s1), g[1], g[2].reshape(s2), g[3], g[4].reshape(s3), g[5], None
 
 
-def pointnet(x_tp3, w1, b1, w2, b2, w3, b3):
-    return PointNetFn.apply(x_tp3, w1, b1, w2, b2, w3, b3)
+def pointnet(x_tp3, w1, b1, w2, b2, w3, b3, bn_sums=None):
+    return PointNetFn.apply(x_tp3, w1, b1, w2, b2, w3, b3, bn_sums)
 
 
 # ------------------------------------------------------------------------------------------ GEMM / Linear

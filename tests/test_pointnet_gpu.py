@@ -90,27 +90,82 @@ def test_pointnet_bwd_oracle(T, P):
 
 
 @pytest.mark.parametrize('tag', ['small', 'ragged'])
-def test_pointnet_bn_running_stats_side_effect_opt_in(tag):
+def test_pointnet_bn_running_stats_side_effect(tag):
     """The reference's discarded BatchNorm calls update their running statistics in train mode (pointnet.py:141-142,
-    154-155,158-159); with `update_bn_running_stats` the HIP path reproduces the buffers of the reference run."""
+    154-155,158-159).  The HIP path reproduces the buffers of the reference run BY DEFAULT, from sums taken inside the forward kernel
+    (sga_pointnet_fwd_bn); the separate chunked pass (what the opt-in arithmetic modes use) gives the same; the switch turns it off."""
     from sgaligner_amd.aligner.networks.pointnet import PointNetfeat
     g = load_golden('pointnet_' + tag)
-    net = PointNetfeat(global_feat=True, batch_norm=True, point_size=3, input_transform=False, feature_transform=False, out_size=256).cuda()
-    with torch.no_grad():
-        for conv, w, b in ((net.conv1, 'w1', 'b1'), (net.conv2, 'w2', 'b2'), (net.conv3, 'w3', 'b3')):
-            conv.weight.copy_(_dev(g[w])); conv.bias.copy_(_dev(g[b]))
+
+    def fresh():
+        net = PointNetfeat(global_feat=True, batch_norm=True, point_size=3, input_transform=False, feature_transform=False, out_size=256).cuda()
+        with torch.no_grad():
+            for conv, w, b in ((net.conv1, 'w1', 'b1'), (net.conv2, 'w2', 'b2'), (net.conv3, 'w3', 'b3')):
+                conv.weight.copy_(_dev(g[w])); conv.bias.copy_(_dev(g[b]))
+        return net.train()
+
+    def check(net):
+        for bn, rm, rv in ((net.bn1, 'rm1', 'rv1'), (net.bn2, 'rm2', 'rv2'), (net.bn3, 'rm3', 'rv3')):
+            assert np.abs(bn.running_mean.cpu().numpy() - g[rm]).max() < 1e-5 * max(1.0, np.abs(g[rm]).max()), rm
+            assert np.abs(bn.running_var.cpu().numpy() - g[rv]).max() < 1e-5 * max(1.0, np.abs(g[rv]).max()), rv
+            assert int(bn.num_batches_tracked) == 1
+
     x = _dev(g['x'])                                   # [T,3,P] as the reference passes it
-    net.train()
-    y = net(x)                                          # default: buffers untouched
-    assert float(net.bn1.running_mean.abs().max()) == 0.0 and int(net.bn1.num_batches_tracked) == 0
-    net.update_bn_running_stats = True
+    net = fresh()
+    assert net.update_bn_running_stats                 # the default
     y = net(x)
     torch.cuda.synchronize()
     assert np.abs(y.detach().cpu().numpy() - g['y']).max() < 2e-5
-    for bn, rm, rv in ((net.bn1, 'rm1', 'rv1'), (net.bn2, 'rm2', 'rv2'), (net.bn3, 'rm3', 'rv3')):
-        assert np.abs(bn.running_mean.cpu().numpy() - g[rm]).max() < 1e-5 * max(1.0, np.abs(g[rm]).max()), rm
-        assert np.abs(bn.running_var.cpu().numpy() - g[rv]).max() < 1e-5 * max(1.0, np.abs(g[rv]).max()), rv
-        assert int(bn.num_batches_tracked) == 1
+    check(net)
     net.eval()
     net(x)
     assert int(net.bn1.num_batches_tracked) == 1       # eval: no update
+    # the separate pass
+    net2 = fresh()
+    with torch.no_grad():
+        net2._update_bn_running_stats(x.permute(0, 2, 1).contiguous())
+    check(net2)
+    # switched off: buffers untouched
+    net3 = fresh()
+    net3.update_bn_running_stats = False
+    net3(x)
+    assert float(net3.bn1.running_mean.abs().max()) == 0.0 and int(net3.bn1.num_batches_tracked) == 0
+
+
+@pytest.mark.parametrize('T,P', [(3, 5), (37, 512), (1100, 40), (2500, 64)])
+def test_pointnet_fused_bn_sums_vs_oracle(T, P):
+    """sga_pointnet_fwd_bn in both launch forms (objects split over a workgroup's waves below 4 x CUs objects, one wave per object above),
+    whole and ragged 32-point tiles, with and without arg-max: the forward's outputs are bit-identical to the plain forward's, and
+    the statistics it delivers give the oracle's batch means / unbiased variances (fp64 evaluation of pointnet.py:141-159)."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    from sgaligner_amd.aligner.networks.pointnet import PointNetfeat
+    torch.manual_seed(T * 7 + P)
+    net = PointNetfeat(global_feat=True, batch_norm=True, point_size=3, input_transform=False, feature_transform=False, out_size=256)
+    with torch.no_grad():
+        for c in (net.conv1, net.conv2, net.conv3):
+            c.bias.normal_(0, 0.2)
+    x = torch.randn(T, 3, P) * 0.7 + torch.tensor([1.5, -0.5, 0.25])[None, :, None]     # off-centre points: the moment route must not cancel
+    ws = [net.conv1.weight.detach().reshape(64, 3), net.conv1.bias.detach(), net.conv2.weight.detach().reshape(128, 64), net.conv2.bias.detach(),
+          net.conv3.weight.detach().reshape(256, 128), net.conv3.bias.detach()]
+    ref = O.pointnet_bn_batch_stats(x.double(), *[w.double() for w in ws])
+    net = net.cuda().train()
+    xd = x.cuda()
+    wd = [w.cuda().contiguous() for w in ws]
+    y_plain, am_plain = ops.pointnet_forward(xd.permute(0, 2, 1).contiguous(), *wd, want_argmax=True)
+    for want_am in (True, False):
+        for bn in (net.bn1, net.bn2, net.bn3):
+            bn.reset_running_stats()
+        if want_am:
+            y = net(xd)
+        else:
+            with torch.no_grad():
+                y = net(xd)
+        torch.cuda.synchronize()
+        assert torch.equal(y.detach(), y_plain)
+        for bn, (mean, var) in zip((net.bn1, net.bn2, net.bn3), ref):
+            rm = 0.1 * mean
+            rv = 0.9 + 0.1 * var
+            assert (bn.running_mean.cpu().double() - rm).abs().max() < 2e-6 * max(1.0, rm.abs().max()), (want_am, bn.num_features)
+            assert (bn.running_var.cpu().double() - rv).abs().max() < 2e-6 * max(1.0, rv.abs().max()), (want_am, bn.num_features)
+            assert int(bn.num_batches_tracked) == 1
