@@ -232,7 +232,8 @@ def roofline_objects(events, world):
         d_sum = 100 * M + 100 * M
         alg = (2.0 if grad else 1.0) * (2.0 * d_sum * pairs)
         mfma_flops = 16 * 16 * 32 * 2.0
-        executed = (2.0 * pairs / 512.0 * M * 82 * mfma_flops) if grad else (pairs / 512.0 * M * 40 * mfma_flops)
+        # (M = 4: the backward is TWO launches, each forming all four similarities and the owner gradients of two tables: 2 x (160 + 84) MFMAs)
+        executed = (2.0 * pairs / 512.0 * (M * 82 if M < 4 else 488) * mfma_flops) if grad else (pairs / 512.0 * M * 40 * mfma_flops)
         useful = (3.0 if grad else 1.0) * 2.0 * 100 * M * pairs          # S once + the two gradient GEMMs (backward), sum D = 100 M
         avg_ms = float(np.mean(durs))
         ach = alg / (avg_ms * 1e-3) / 1e12
@@ -246,7 +247,8 @@ def roofline_objects(events, world):
                       'frac_of_bf16_peak_executed': round(executed / (avg_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                       'traffic': pmc_traffic_bytes(f'sweep3_kernel<{M},{"true" if grad else "false"}>', f'ns={ns},A={A},J={J1 + J2}', 'sweep3.hip') if world == 1 else None,
                       'kernel': f'sweep3_kernel<{M},{"true" if grad else "false"}> ({"loss: negatives backward" if grad else "loss: global sums over anchors x negatives (forward)"}, '
-                                f'all {M}+1 tables; fp32 operands as three exact bf16 planes, six bf16 MFMAs per product, fp32 accumulate)',
+                                f'all {M}+1 tables; fp32 operands as three exact bf16 planes, six bf16 MFMAs per product, fp32 accumulate'
+                                + ('; two launches, each all four similarities + the owner gradients of two tables' if (grad and M == 4) else '') + ')',
                       'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                       'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed})
     for key, grad in (('loss_multi_grad', True), ('loss_multi_sums', False)):
@@ -597,7 +599,7 @@ def main():
             extra_attr = {'modules': mods4, 'workload': 'BASELINE.json configs[1] shape (512 pairs x 64 objects x 512 pts)',
                           'value': round(CONFIGS['c2']['pairs_per_gpu'] * n4 / el4, 2), 'unit': 'pairs/s',
                           'ms_per_step': round(el4 / n4 * 1e3, 3), 'steps': n4, 'warmup': 2,
-                          'dtype': 'f32 (M = 4: the loss sweeps run on the fp32 MFMA, sweep16x2_kernel -- the three-plane sweeps hold M <= 3 tables)',
+                          'dtype': dtype_label,
                           'roofline': roofline_objects(ev4, world)}
             if not args.no_split:
                 # the same M = 4 step in the fp32-faithful 'f16x2' mode (sweeph_kernel<4, ...>: four waves per workgroup, one per SIMD), with its

@@ -261,9 +261,11 @@ int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, i
  * sga_loss_multi_grad, in fp32 arithmetic on the bf16 matrix pipe: x = h + m + l (8 + 8 + 8 significand bits, fp32's exponent range: every
  * fp32 value exactly), a product = the six partial products down to 2^-16 relative on v_mfma_f32_16x16x32_bf16 into one fp32 accumulator
  * (the dropped three are <= 2^-23 of the product), i.e. 6/16 of the fp32 MFMA's matrix time at fp32's own accuracy ("fp32 MFMA
- * or split-bf16 x3").  M = 2 or 3 tables, emb_dim <= 100 (columns 100, 101 of the planes carry the row centring's bookkeeping).
- * sga_loss_split3_tables: packed fp32 table Z [R(+32), 104] -> Zb, 32-row blocks of bf16 h / m / l planes in MFMA operand order + two
- * packed K-tail images (sga_loss_split3_bytes bytes; segments X1 | X2 | N1 | N2 each padded to whole blocks; column means summed in a
+ * or split-bf16 x3").  M = 2, 3 or 4 tables, emb_dim <= 100 (columns 100, 101 of the planes carry the row centring's bookkeeping); M = 4's
+ * gradient runs as two launches, each forming all four similarities and the owner gradients of two tables (the accumulators of four
+ * tables do not fit a wave's registers).
+ * sga_loss_split3_tables: packed fp32 table Z [R(+32), 104] -> Zb, 32-row blocks of bf16 h / m / l planes in MFMA operand order + one
+ * packed K-tail image (sga_loss_split3_bytes bytes; segments X1 | X2 | N1 | N2 each padded to whole blocks; column means summed in a
  * fixed order: the planes are bitwise reproducible).  The other arguments and every output: as sga_loss_multi_sums / sga_loss_multi_grad,
  * except that the gradient arrives in TWO parts: dZ[r, 0..100) += sum_j c_rj (z_j - zbar) and dZ[r, 101] += sum_j c_rj (zbar = 0 unless the
  * table's rows are nearly parallel, |mean row|^2 >= 1/4).  Zc (optional) receives the anchor rows as fp32 [2A, 104] = z - zbar with column

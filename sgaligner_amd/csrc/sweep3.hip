@@ -23,11 +23,12 @@
 // sum -- there the centred sweep is MORE accurate than the plain fp32 one (tests/test_fp64_chunked_gpu.py).
 //
 // Data layout.  sga_loss_split3_tables turns a packed fp32 table Z [X1 | X2 | N1 | N2] into 32-row BLOCKS (each segment padded to whole
-// blocks) of 22 528 B: [h plane 6 144 | m plane | l plane | tail image T0 2 048 | tail image T1 2 048]; a plane = [K step q (3)][half jh (2)]
+// blocks) of 20 480 B: [h plane 6 144 | m plane | l plane | tail image 2 048]; a plane = [K step q (3)][half jh (2)]
 // [64 slots][8 bf16], slot(g, i) = 16 g + (i ^ 12 (g & 1)) holds columns 32 q + 8 g .. + 7 of row 8 (i >> 2) + 4 jh + (i & 3) (the XOR
 // swizzle makes both the lane-linear ds_read_b128 of the S product and the ds_read_b64_tr_b16 transpose reads of the gradient GEMM bank-
-// conflict free); a tail image = [jh][64 slots][8 bf16] of columns 96 .. 103 with k groups T0 = (h, h, m, m), T1 = (l, h, l, m): against the
-// owner's (h, m, h, m) and (h, l, m, l) two MFMAs give eight of the nine partial products of the K tail.
+// conflict free); the tail image = [jh][64 slots][8 bf16] of columns 96 .. 103 with k groups (h, h, m, l): against the owner's (h, m, h, h)
+// and (l, 0, m, 0) two MFMAs give the six partial products of the K tail (until round 5: two images, 22 528 B per block -- every 1-KiB
+// LDS-DMA costs the issuing wave ~60 cycles).
 // MFMA bookkeeping as in sweeph.hip: S^T tile with A = other rows from LDS, B = owner rows (registers); half jh of a 32-row tile uses A row
 // i <-> other row 8 (i >> 2) + 4 jh + (i & 3), so a lane's 8 accumulator values are the 8 consecutive other rows 8 g4 .. 8 g4 + 7 = the k
 // slots of the gradient MFMA, whose A operand is therefore the coefficient registers (split into three planes) and whose B operand
@@ -53,10 +54,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int S3_DP = 104;
 constexpr int S3_PLANE = 3 * 2 * 1024;           // 6144 B
-constexpr int S3_TAIL = 3 * S3_PLANE;            // byte offset of the two tail images in a block
-constexpr int S3_BLOCK = S3_TAIL + 2 * 2048;     // 22528 B
-constexpr int S3_NCH = S3_BLOCK / 1024;          // 22 DMA chunks
-constexpr int S3_ROWSLOTS = 3 * 12 + 8;          // 16-byte slots that hold one row: 3 planes x (3 K steps x 4 k groups) + 2 tail images x 4
+constexpr int S3_TAIL = 3 * S3_PLANE;            // byte offset of the tail image in a block
+constexpr int S3_BLOCK = S3_TAIL + 2048;         // 20480 B
+constexpr int S3_NCH = S3_BLOCK / 1024;          // 20 DMA chunks
+constexpr int S3_ROWSLOTS = 3 * 12 + 4;          // 16-byte slots that hold one row: 3 planes x (3 K steps x 4 k groups) + the tail image's 4 k groups
 
 // v0, v1 -> three packed bf16 pairs, v = h + m + l EXACTLY (round to nearest at each step; the residuals are exact in fp32, the last one has
 // at most 8 significant bits).  Residual = v - float(bf16): the bf16 pair is unpacked by a shift / a mask (plain VALU: beside MFMAs they cost
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(128) void split3_stats_kernel(const double* __restr
     if (c == 0) { stat[S3_DP] = centre ? (float)(0.5 * tot) : 0.f; stat[S3_DP + 1] = centre ? 1.f : 0.f; }
 }
 
-// fp32 packed table -> blocked bf16 h / m / l planes + the two tail images of the CENTRED rows (one workgroup per 32-row block)
+// fp32 packed table -> blocked bf16 h / m / l planes + the tail image of the CENTRED rows (one workgroup per 32-row block)
 __global__ __launch_bounds__(256) void split3_tables_kernel(const float* __restrict__ Z, int A, int J1, int J2, unsigned char* __restrict__ Zb,
                                                             const float* __restrict__ stat, float* __restrict__ Zc) {
     __shared__ float tile[32 * S3_DP];
@@ -185,15 +186,14 @@ __global__ __launch_bounds__(256) void split3_tables_kernel(const float* __restr
         split3_pair(tile[row * S3_DP + col], tile[row * S3_DP + col + 1], h, m, l);
         out[e] = h; out[S3_PLANE / 4 + e] = m; out[2 * S3_PLANE / 4 + e] = l;
     }
-    // tail images: dword e = (image, slot of [jh][64], pair p of 4) of columns 96 + 2 p, + 1; k groups T0 = (h, h, m, m), T1 = (l, h, l, m)
-    for (int e = threadIdx.x; e < 2 * 2 * 64 * 4; e += 256) {
-        const int p = e & 3, st = (e >> 2) & 63, jh = (e >> 8) & 1, img = e >> 9;
+    // tail image: dword e = (slot of [jh][64], pair p of 4) of columns 96 + 2 p, + 1; k groups (h, h, m, l)
+    for (int e = threadIdx.x; e < 2 * 64 * 4; e += 256) {
+        const int p = e & 3, st = (e >> 2) & 63, jh = (e >> 8) & 1;
         const int g = st >> 4, i = (st & 15) ^ (12 * (g & 1));
         const int row = 8 * (i >> 2) + 4 * jh + (i & 3), col = 96 + 2 * p;
         unsigned h, m, l;
         split3_pair(tile[row * S3_DP + col], tile[row * S3_DP + col + 1], h, m, l);
-        const unsigned v = img == 0 ? (g < 2 ? h : m) : ((g & 1) == 0 ? l : (g == 1 ? h : m));
-        out[S3_TAIL / 4 + e] = v;
+        out[S3_TAIL / 4 + e] = g < 2 ? h : (g == 2 ? m : l);
     }
 }
 
@@ -206,7 +206,7 @@ __device__ unsigned long long g_s3_dbg[16];
 struct TSeg { int blk0, jt_lo, jt_hi, old0, lo, hi, fam; };   // others: block blk0 + jt holds old rows old0 + 32 jt + w; valid rows in [lo, hi)
 struct TGroup { int own0, nown, own_old0, own_blk0, blk0, nsplit, nseg; TSeg seg[2]; };
 struct TArgs {
-    int M; const unsigned char* Zb[4]; int ngroups; TGroup grp[4];
+    int M; const unsigned char* Zb[4]; int perm[4]; int ngroups; TGroup grp[4];   // perm: kernel table m = the caller's table perm[m] (beta, gs, gamma)
     float k0, k1, it0, it1;
     const float* beta;
     double* sums;                    // SUM out  [(M+1)][8] (+ slots)
@@ -217,7 +217,11 @@ struct TArgs {
 
 // WV: waves per workgroup, each owning 16 owner rows.  8: two waves per SIMD (<= 256 registers), operands requested at the top of a
 // sub-step and covered by the partner wave.  4: one wave per SIMD (<= 512 registers), PIPE: operands requested a group of MFMAs ahead.
-template <int M, bool GRAD, int WV>
+// MG (gradient sweep): the number of tables whose owner gradient THIS launch accumulates -- the first MG of the M tables; the others only
+// contribute their similarities to the joint coefficient.  M = 4 (point + gat + rel + attr) runs as two launches of MG = 2 (the caller's
+// tables {0, 1 | 2, 3} and {2, 3 | 0, 1}): four tables of three planes need 176 operand + 224 accumulator registers, two of them fit.
+// GAM: accumulate Gamma_m = sum dL/dS_J * S_m (one of the two launches only).
+template <int M, bool GRAD, int WV, int MG = M, bool GAM = true>
 __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs a) {
     constexpr int NCT = 7;
     constexpr int WAVES = WV, THREADS = WAVES * 64;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #endif
 
-    // ---- owner rows as the S product's B operand: 3 planes x 3 K = 32 steps + the two tail operands O0 = (h, m, h, m), O1 = (h, l, m, l)
+    // ---- owner rows as the S product's B operand: 3 planes x 3 K = 32 steps + the two tail operands O0 = (h, m, h, h), O1 = (l, 0, m, 0)
     u32x4 opl[M][3][3], otl[M][2];
     float beta[M];
     const bool iv = wrow0 + l15 < own_end;
@@ -268,16 +272,16 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                     const int so = ((q * 2 + ojh) * 64 + s3_slot(g4, oi)) * 16;
                     opl[m][p][q] = iv ? *reinterpret_cast<const u32x4*>(base + p * S3_PLANE + so) : u32x4{0, 0, 0, 0};
                 }
-            // O0: k group g4 -> h, m, h, m = T0 group 2 (g4 & 1);  O1: h, l, m, l = image (g4 & 1), group (g4 & 2)
-            otl[m][0] = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot((g4 & 1) * 2, oi)) * 16) : u32x4{0, 0, 0, 0};
-            otl[m][1] = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (g4 & 1) * 2048 + (ojh * 64 + s3_slot(g4 & 2, oi)) * 16) : u32x4{0, 0, 0, 0};
+            // against the image's k groups (h, h, m, l):  O0 = (h, m, h, h) -> h h + h m + m h + l h;  O1 = (l, 0, m, 0) -> h l + m m
+            otl[m][0] = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot(g4 == 1 ? 2 : 0, oi)) * 16) : u32x4{0, 0, 0, 0};
+            otl[m][1] = (iv && (g4 & 1) == 0) ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot(g4 == 0 ? 3 : 2, oi)) * 16) : u32x4{0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < 2; ++t)                               // columns 100, 101: the owner holds (1, b_i) against the other's (b_j, 1)
                 otl[m][t][2] = (otl[m][t][2] >> 16) | (otl[m][t][2] << 16);
         }
     }
 #pragma unroll
-    for (int m = 0; m < M; ++m) beta[m] = a.beta[m];
+    for (int m = 0; m < M; ++m) beta[m] = a.beta[a.perm[m]];
 
     // Gradient accumulators, TWO per output: gacc takes the h h products, gsm the five small partial products (<= 2^-8 of them).  Why: the
     // 16-bit MFMAs align their 32 products and C to the largest exponent and CHOP what falls ~7 bits below the result's last place --
@@ -285,9 +289,9 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
     // the fp32 MFMA chops too, but toward zero).  Small products added straight onto the large accumulator would give every gradient entry
     // the same one-sided bias, which the column sums over 10^6 rows (the bias gradients of the layers below) would collect coherently; in
     // their own accumulator nothing is chopped, and the two are added once, in fp32, at the end.
-    f32x4 gacc[GRAD ? M : 1][NCT], gsm[GRAD ? M : 1][NCT];
+    f32x4 gacc[GRAD ? MG : 1][NCT], gsm[GRAD ? MG : 1][NCT];
 #pragma unroll
-    for (int m = 0; m < (GRAD ? M : 1); ++m)
+    for (int m = 0; m < (GRAD ? MG : 1); ++m)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) { gacc[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; gsm[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float gam[M];
@@ -335,7 +339,8 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
     const int aoff = s3_slot(g4, l15) * 16;
     const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
     const int tr_main = s3_slot(tr_cs >> 1, tr_io) * 16 + (tr_cs & 1) * 8;       // + p * PLANE + (ct >> 1) * 2048 + rd * 1024 + (ct & 1) * 512
-    const int tr_tail = S3_TAIL + tr_io * 16 + (tr_cs & 1) * 8;                   // h: T0 group 0; m: + 512 (T0 group 2); l: + 2048 (T1 group 0); + rd * 1024
+    const int tr_tail = S3_TAIL + tr_io * 16 + (tr_cs & 1) * 8;                   // h: k group 0; m: + 512 (group 2); l: group 3 (odd: swizzled) = tr_tail_l; + rd * 1024
+    const int tr_tail_l = S3_TAIL + (48 + (tr_io ^ 12)) * 16 + (tr_cs & 1) * 8;
 
 #pragma unroll 1
     for (int sg = 0; sg < 2; ++sg) {
@@ -344,8 +349,9 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
         float c0[M + 1], c1[M + 1];
 #pragma unroll
         for (int m = 0; m <= M; ++m) {
-            c0[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
-            c1[m] = GRAD ? (float)(a.gs[m * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
+            const int mo = m < M ? a.perm[m] : M;
+            c0[m] = GRAD ? (float)(a.gs[mo * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
+            c1[m] = GRAD ? (float)(a.gs[mo * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
         }
         const float k0 = a.k0, k1 = a.k1;
         double dsum[M + 1][2];
@@ -381,36 +387,36 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                             const int pl = pc / 12, q = (pc % 12) >> 2, gq = pc & 3;
                             *reinterpret_cast<u32x4*>(base + pl * S3_PLANE + ((q * 2 + wjh) * 64 + s3_slot(gq, wi)) * 16) = u32x4{0, 0, 0, 0};
                         } else {
-                            const int img = (pc - 36) >> 2, gq = (pc - 36) & 3;
-                            *reinterpret_cast<u32x4*>(base + S3_TAIL + img * 2048 + (wjh * 64 + s3_slot(gq, wi)) * 16) = u32x4{0, 0, 0, 0};
+                            const int gq = pc - 36;
+                            *reinterpret_cast<u32x4*>(base + S3_TAIL + (wjh * 64 + s3_slot(gq, wi)) * 16) = u32x4{0, 0, 0, 0};
                         }
                     }
                     __syncthreads();
                 }
             }
 
-            // ---- S^T tiles: sacc[m][jh][r] = S_m[own = lane & 15, other = 8 g4 + 4 jh + r]; one SUB-STEP = (table, other half): 11 A operands
+            // ---- S^T tiles: sacc[m][jh][r] = S_m[own = lane & 15, other = 8 g4 + 4 jh + r]; one SUB-STEP = (table, other half): 10 A operands
             // from LDS, 20 MFMAs in one accumulator chain, the small partial products first:
             //   tails | l h | m m | m h | h l | h m | h h      (other plane x owner plane).
             // PIPE: the next sub-step's operands are requested once their registers' last readers have issued (tails + l after "l h", m after
             // "m h", h after "h h"): every operand has >= 10 MFMAs to arrive.
             f32x4 sacc[M][2];
             float own[M][2][4];                                // c0 e^{S/tau0} + c1 e^{S/tau1} of the table's own similarities (GRAD)
-            // A operands of a sub-step: two tail images, l, m, h planes x 3 K steps.  PIPE: two register sets; the whole set of sub-step
+            // A operands of a sub-step: the tail image, l, m, h planes x 3 K steps.  PIPE: two register sets; the whole set of sub-step
             // ss + 1 is requested right behind the FIRST MFMA of sub-step ss -- hipcc waits with s_waitcnt lgkmcnt(0) (never a counted wait:
             // the LDS-DMAs in flight make the counter "out of order" in its model) in front of the first MFMA that reads requested data, so
             // that one wait per sub-step must sit where nothing younger than 19 MFMAs is outstanding.
             constexpr int NSET = PIPE ? 2 : 1;
-            u32x4 at[NSET][2], ap[NSET][3][3];                 // ap[.][0]: h, [1]: m, [2]: l
-            auto ld_one = [&](int ss, int idx) {               // idx 0, 1: tail images T1, T0; 2 + 3 p' + q: plane l, m, h (p' = 0, 1, 2) K step q
+            u32x4 at[NSET], ap[NSET][3][3];                    // ap[.][0]: h, [1]: m, [2]: l
+            auto ld_one = [&](int ss, int idx) {               // idx 0: the tail image; 1 + 3 p' + q: plane l, m, h (p' = 0, 1, 2) K step q
                 const int e = ss % NSET;
                 const unsigned char* ar = buf + (ss >> 1) * S3_BLOCK + (ss & 1) * 1024 + aoff;
-                if (idx < 2) at[e][1 - idx] = *reinterpret_cast<const u32x4*>(ar + S3_TAIL + (1 - idx) * 2048);
-                else ap[e][2 - (idx - 2) / 3][(idx - 2) % 3] = *reinterpret_cast<const u32x4*>(ar + (2 - (idx - 2) / 3) * S3_PLANE + ((idx - 2) % 3) * 2048);
+                if (idx < 1) at[e] = *reinterpret_cast<const u32x4*>(ar + S3_TAIL);
+                else ap[e][2 - (idx - 1) / 3][(idx - 1) % 3] = *reinterpret_cast<const u32x4*>(ar + (2 - (idx - 1) / 3) * S3_PLANE + ((idx - 1) % 3) * 2048);
             };
             auto ld_set = [&](int ss) {
 #pragma unroll
-                for (int idx = 0; idx < 11; ++idx) ld_one(ss, idx);
+                for (int idx = 0; idx < 10; ++idx) ld_one(ss, idx);
             };
             if (PIPE) {
                 ld_set(0);
@@ -435,15 +441,15 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                 constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
 #pragma unroll
                 for (int x = 0; x < 20; ++x) {
-                    if (x == 0) acc2[0] = mfma_b(at[e][1], otl[m][1], acc2[0]);
-                    else if (x == 1) acc2[1] = mfma_b(at[e][0], otl[m][0], acc2[1]);
+                    if (x == 0) acc2[0] = mfma_b(at[e], otl[m][1], acc2[0]);
+                    else if (x == 1) acc2[1] = mfma_b(at[e], otl[m][0], acc2[1]);
                     else acc2[x & 1] = mfma_b(ap[e][PA[(x - 2) / 3]][(x - 2) % 3], opl[m][PB[(x - 2) / 3]][(x - 2) % 3], acc2[x & 1]);
                     if (PIPE) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (ss + 1 < 2 * M && x < 11) ld_one(ss + 1, x);
+                        if (ss + 1 < 2 * M && x < 10) ld_one(ss + 1, x);
                         if (ss < NDS && (x % 3) == 1 && (x / 3) < PER) issue_slots(next_buf, ss * PER + (x / 3), ss * PER + (x / 3) + 1);
                         // the previous table's own coefficient part under this table's MFMAs (half jh here): three VALU per gap 11 .. 18
-                        if (OWN_IN_S && m > 0 && x >= 11 && x < 19) {
+                        if (OWN_IN_S && m > 0 && m - 1 < MG && x >= 11 && x < 19) {
                             const int r = (x - 11) >> 1;
                             const float sv = sacc[m - 1][jh][r];
                             if (((x - 11) & 1) == 0) {
@@ -506,14 +512,14 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         const unsigned char* ph = ct < 6 ? pb + p * S3_PLANE + tr_main + (ct >> 1) * 2048 + (ct & 1) * 512
-                                                         : pb + tr_tail + (p == 0 ? 0 : (p == 1 ? 512 : 2048));
+                                                         : pb + (p == 2 ? tr_tail_l : tr_tail + (p == 1 ? 512 : 0));
                         const u32x2 x0 = tr_read16(ph), x1 = tr_read16(ph + 1024);
                         bp[par][p] = u32x4{x0[0], x0[1], x1[0], x1[1]};
                     }
                 };
                 // own coefficient parts not computed under the S phase's MFMAs: the last table's (PIPE), all of them otherwise
 #pragma unroll
-                for (int m = OWN_IN_S ? M - 1 : 0; m < M; ++m)
+                for (int m = OWN_IN_S ? M - 1 : 0; m < MG; ++m)
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                             for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[jh][r], sacc[m][jh][r], gam[m]);
                     }
                 };
-                if (!PIPE) gamma_acc();
+                if (!PIPE && GAM) gamma_acc();
                 S3_T(3)
                 // c_m for this lane's 8 consecutive other rows (k slot j = 4 jh + r), split into three bf16 planes: the A operand
                 u32x4 ch[2], cm[2], cl[2];                     // double-buffered by table parity
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                 };
                 if (!PIPE) {
 #pragma unroll
-                    for (int m = 0; m < M; ++m) {
+                    for (int m = 0; m < MG; ++m) {
                         if (m > 0) planes(m);
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) {
@@ -595,12 +601,12 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                     ld_b(0); ld_b(1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int g4i = 0; g4i < 4 * M; ++g4i) {
+                    for (int g4i = 0; g4i < 4 * MG; ++g4i) {
                         const int m = g4i >> 2, ct0 = (g4i & 3) * 2, n = (g4i & 3) == 3 ? 1 : 2, k0_ = NCT * m + ct0;
-                        if ((g4i & 3) == 0 && m + 1 < M) planes(m + 1);        // source order only: spread under this table's MFMAs below
-                        if (g4i == (M > 1 ? 4 : 0)) gamma_acc();               // ... and Gamma under the second table's (the first carries planes(1))
+                        if ((g4i & 3) == 0 && m + 1 < MG) planes(m + 1);       // source order only: spread under this table's MFMAs below
+                        if (GAM && g4i == (MG > 1 ? 4 : 0)) gamma_acc();       // ... and Gamma under the second table's (the first carries planes(1))
                         const int kn = k0_ + n;                               // the next group's first step
-                        const int nn = kn >= NCT * M ? 0 : ((kn % NCT) == 6 ? 1 : 2);
+                        const int nn = kn >= NCT * MG ? 0 : ((kn % NCT) == 6 ? 1 : 2);
 #pragma unroll
                         for (int j = 0; j < nn; ++j) ld_b(kn + j);
                         if (n == 2) {
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #endif
     if (GRAD) {
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
+        for (int m = 0; m < MG; ++m) {
             float* dz = a.dZ[m];
             // dZ[i, 0..99] += sum_j c_ij z'_j and dZ[i, 101] += rowsum_i = sum_j c_ij (output column 101 of the last column tile): the true
             // gradient is the first + rowsum x zbar, but it is never formed -- sga_loss_scatter_tangent takes the two apart (see there)
@@ -660,11 +666,11 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                 }
             }
         }
-        if (g < 2) {
+        if (GAM && g < 2) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const float v = wave_sum(gam[m]);
-                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + m, (double)v);
+                if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + a.perm[m], (double)v);
             }
         }
     }
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 // The stash products of the anchors x anchors backward on the same three exact bf16 planes: out[own] += sum_oth C[own, oth] Z[oth], C a block
 // of the fp32 coefficient stash the A x A kernel wrote (replaces the four fp32-MFMA GEMMs of sga_loss_stash_grad_symx; the autograd of
 // losses.py:6,50-57,81-94 through S = X1 X2^T).  It IS the gradient phase of sweep3_kernel with the coefficient tile loaded instead of
-// computed: 8 waves x 16 owner rows, the "other" rows' planes as 32-row tiles in LDS (one table per launch: 2 x 22.5 KB), the fp32
+// computed: 8 waves x 16 owner rows, the "other" rows' planes as 32-row tiles in LDS (one table per launch: 2 x 20 KB), the fp32
 // coefficients of a wave's 16 x 32 tile split into three planes in registers (the A operand), six MFMAs per column tile, the small partial
 // products in their own accumulator.  Because the planes are the sweeps' (centred where the table asks for it, column 101 = 1), the result
 // arrives in the same two parts: dZ[r, 0..100) += sum c (z - zbar), dZ[r, 101] += sum c.
@@ -743,6 +749,7 @@ __global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
     const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
     const int tr_main = s3_slot(tr_cs >> 1, tr_io) * 16 + (tr_cs & 1) * 8;
     const int tr_tail = S3_TAIL + tr_io * 16 + (tr_cs & 1) * 8;
+    const int tr_tail_l = S3_TAIL + (48 + (tr_io ^ 12)) * 16 + (tr_cs & 1) * 8;
 
     float cn[8];
     load_c(jt0, cn);
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const unsigned char* ph = ct < 6 ? buf + p * S3_PLANE + tr_main + (ct >> 1) * 2048 + (ct & 1) * 512
-                                                 : buf + tr_tail + (p == 0 ? 0 : (p == 1 ? 512 : 2048));
+                                                 : buf + (p == 2 ? tr_tail_l : tr_tail + (p == 1 ? 512 : 0));
                 const u32x2 x0 = tr_read16(ph), x1 = tr_read16(ph + 1024);
                 bp[p] = u32x4{x0[0], x0[1], x1[0], x1[1]};
             }
@@ -801,13 +808,14 @@ __global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
 
 int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1, bool grad,
            int a_lo, int a_hi, int own_rows, const char* who) {
-    if (M < 2 || M > 3) { sga_set_error("%s: M=%d (the three-plane bf16 sweeps are built for 2 or 3 modality tables)", who, M); return SGA_ERR_ARG; }
+    if (M < 2 || M > 4) { sga_set_error("%s: M=%d (the three-plane bf16 sweeps are built for 2, 3 or 4 modality tables)", who, M); return SGA_ERR_ARG; }
     if (a_lo < 0 || a_hi > A || a_lo > a_hi) { sga_set_error("%s: anchor shard [%d,%d) outside [0,%d]", who, a_lo, a_hi, A); return SGA_ERR_ARG; }
     a.M = M;
     const TLayout L = make_tlayout(A, J1, J2);
     for (int m = 0; m < M; ++m) {
         if (!Zb[m]) { sga_set_error("%s: null table", who); return SGA_ERR_ARG; }
         a.Zb[m] = static_cast<const unsigned char*>(Zb[m]);
+        a.perm[m] = m;
     }
     a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
     const int ns = a_hi - a_lo;
@@ -856,13 +864,14 @@ int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int
 #ifndef S3_WV_GRAD2
 #define S3_WV_GRAD2 4
 #endif
-template <int M, bool GRAD> constexpr int s3_wv() { return GRAD ? (M == 3 ? S3_WV_GRAD3 : S3_WV_GRAD2) : S3_WV_SUMS; }
+// (M = 4: four tables' operands -- 176 registers -- leave no room for a second wave on the SIMD in either sweep)
+template <int M, bool GRAD> constexpr int s3_wv() { return M == 4 ? 4 : GRAD ? (M == 3 ? S3_WV_GRAD3 : S3_WV_GRAD2) : S3_WV_SUMS; }
 
-template <int M, bool GRAD>
+template <int M, bool GRAD, int MG = M, bool GAM = true>
 void launch_t(const TArgs& a, int nwg, hipStream_t s) {
     constexpr int WV = s3_wv<M, GRAD>();
     const size_t lds = (size_t)2 * M * S3_BLOCK;
-    auto k = sweep3_kernel<M, GRAD, WV>;
+    auto k = sweep3_kernel<M, GRAD, WV, MG, GAM>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(nwg), dim3(WV * 64), lds, s, a);
 }
@@ -960,16 +969,16 @@ extern "C" int sga_loss_scatter_tangent(const float* dZ, const float* Z, const f
 extern "C" int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                           double* sums, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Zb && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums_bf16x6: bad argument");
-    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_multi_sums_bf16x6: M=%d (2 or 3 modality tables)", M);
+    SGA_CHECK_ARG(M >= 2 && M <= 4, "sga_loss_multi_sums_bf16x6: M=%d (2, 3 or 4 modality tables)", M);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums_bf16x6")) return rc0;
     if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     TArgs a{};
-    const int own_rows = 16 * (M == 3 ? s3_wv<3, false>() : s3_wv<2, false>());
+    const int own_rows = 16 * (M == 4 ? s3_wv<4, false>() : M == 3 ? s3_wv<3, false>() : s3_wv<2, false>());
     const int r = fill_t(a, Zb, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi, own_rows, "sga_loss_multi_sums_bf16x6");
     if (r > 0) return r;
     a.sums = sums;
-    if (M == 2) launch_t<2, false>(a, -r, s); else launch_t<3, false>(a, -r, s);
+    if (M == 2) launch_t<2, false>(a, -r, s); else if (M == 3) launch_t<3, false>(a, -r, s); else launch_t<4, false>(a, -r, s);
     fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums_bf16x6");
     return SGA_OK;
@@ -978,17 +987,25 @@ extern "C" int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const fl
 extern "C" int sga_loss_multi_grad_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                           const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Zb && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad_bf16x6: bad argument");
-    SGA_CHECK_ARG(M == 2 || M == 3, "sga_loss_multi_grad_bf16x6: M=%d (2 or 3 modality tables)", M);
+    SGA_CHECK_ARG(M >= 2 && M <= 4, "sga_loss_multi_grad_bf16x6: M=%d (2, 3 or 4 modality tables)", M);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rcz = zero_slots(gamma, M, s, "sga_loss_multi_grad_bf16x6")) return rcz;
     if (A == 0 || a_hi <= a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     TArgs a{};
-    const int own_rows = 16 * (M == 3 ? s3_wv<3, true>() : s3_wv<2, true>());
+    const int own_rows = 16 * (M == 4 ? s3_wv<4, true>() : M == 3 ? s3_wv<3, true>() : s3_wv<2, true>());
     const int r = fill_t(a, Zb, M, beta, A, J1, J2, tau0, tau1, true, a_lo, a_hi, own_rows, "sga_loss_multi_grad_bf16x6");
     if (r > 0) return r;
     a.gs = gs; a.gamma = gamma;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad_bf16x6: null dZ"); a.dZ[m] = dZ[m]; }
-    if (M == 2) launch_t<2, true>(a, -r, s); else launch_t<3, true>(a, -r, s);
+    if (M == 2) launch_t<2, true>(a, -r, s);
+    else if (M == 3) launch_t<3, true>(a, -r, s);
+    else {
+        // four tables: two launches, each accumulating the owner gradients of two tables (all four similarities are formed in both)
+        launch_t<4, true, 2, true>(a, -r, s);
+        TArgs b = a;
+        for (int m = 0; m < 4; ++m) { const int o = (m + 2) & 3; b.Zb[m] = a.Zb[o]; b.dZ[m] = a.dZ[o]; b.perm[m] = o; }
+        launch_t<4, true, 2, false>(b, -r, s);
+    }
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad_bf16x6");
     return SGA_OK;

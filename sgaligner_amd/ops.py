@@ -57,7 +57,7 @@ def set_mfma_mode(mode: str) -> str:
     'bf16x6' (THE DEFAULT): the fused 100-d loss sweeps (anchors x negatives: forward sums + gradient) with every fp32 operand split EXACTLY into three
     bf16 terms (8 + 8 + 8 significand bits, fp32's exponent range) and six bf16 MFMAs per product into one fp32 accumulator -- fp32
     arithmetic on the exact operands at 6/16 of the fp32 MFMA's matrix time (csrc/sweep3.hip; SURVEY 7 "fp32 MFMA or split-bf16 x3");
-    everything else exact fp32.  M = 2, 3 tables of emb_dim <= 100; other shapes take the 'f32' kernels.
+    everything else exact fp32.  M = 2, 3, 4 tables of emb_dim <= 100; other shapes take the 'f32' kernels.
     'bf16x3' (opt-in: each fp32 operand as bf16 hi + lo, 16 bits, three bf16 MFMAs per product; ~1e-5 relative error; PointNet forward +
     the fused loss sweeps); 'f16' (opt-in, BASELINE.json configs[4]: loss tables WIDER than 128 columns and the similarity ranking take
     fp16 inputs with fp32 accumulation -- csrc/wide16.hip, 1e-2 tolerance; the PointNet training forward as in 'f16x2'; 100-d tables and
@@ -1315,7 +1315,7 @@ class FusedContrastiveFn(torch.autograd.Function):
             if ev is not None:
                 ev[1].record()
                 KERNEL_EVENTS.setdefault('loss_multi_sums_f16x2', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
-        elif M in (2, 3) and dmax <= 100 and FUSED_ANCHOR_BWD and get_mfma_mode() == 'bf16x6':
+        elif M in (2, 3, 4) and dmax <= 100 and FUSED_ANCHOR_BWD and get_mfma_mode() == 'bf16x6':
             # three exact bf16 planes per table (csrc/sweep3.hip): blocked h / m / l planes of the centred rows, once per step
             split3 = True
             nb = L.sga_loss_split3_bytes(s.A, s.J1, s.J2)
