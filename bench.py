@@ -202,11 +202,27 @@ def roofline_objects(events, world):
         alg = 2.0 * T * P * (3 * C1 + C1 * C2 + C2 * C3)           # three per-point layers
         avg_ms = float(np.mean(durs))
         ach = alg / (avg_ms * 1e-3) / 1e12
-        if pmode == 'f32':
+        with_bn = bool(evs[0][2][6]) if len(evs[0][2]) > 6 else False
+        bn_note = ('; the launch also sums the batch statistics of the reference\'s BatchNorm side effect (pointnet.py:141-159) -- the timed span includes '
+                   'its point-moments and reduce kernels') if with_bn else ''
+        if pmode == 'bf16x6':
+            # three exact bf16 planes: six bf16 MFMAs per product; at C3 = 256 two workgroups share an object and both run layers 1-2
+            executed = 2.0 * T * P * (3 * C1 + (2 if C3 == 256 else 1) * C1 * C2 + C2 * C3) * 6.0
+            roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(PEAK_BF16X6_TFLOPS, 1), 'unit': 'TFLOP/s',
+                          'frac': round(ach / PEAK_BF16X6_TFLOPS, 4),
+                          'peak_is': 'dense bf16 MFMA peak (2500 TFLOP/s) / 6: an fp32 product on three exact bf16 planes is six bf16 MFMAs',
+                          'achieved_over_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4),
+                          'frac_of_bf16_peak_executed': round(executed / (avg_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                          'traffic': pmc_traffic_bytes('pointnet_fwd_p3_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
+                          'kernel': 'pointnet_fwd_p3_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object and channel half; fp32 operands as '
+                                    'three exact bf16 planes, six bf16 MFMAs per product, fp32 accumulate' + bn_note + ')',
+                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
+                          'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed})
+        elif pmode == 'f32':
             roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': round(ach / PEAK_F32_TFLOPS, 4),
                           'traffic': pmc_traffic_bytes('pointnet_fwd_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
-                          'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object)',
+                          'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object' + bn_note + ')',
                           'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                           'algorithmic_flops_per_launch': alg})
         else:

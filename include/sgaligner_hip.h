@@ -46,11 +46,14 @@ size_t sga_pointnet_fwd_ws_bytes(int T, int C3);
  * object in which some channel's two largest layer-3 values lie within tie_eps * (|a| + |b| + max|z| / 8) of each other or a pre-activation
  * within that margin of zero: needs workspace >= 4 (T + 1) bytes and leaves [count | object ids] (int32) there; the listed objects carry
  * the fp32 kernel's own bits (values and arg-maxes), so the max-pool's arg-max routes the backward exactly as in mode 0
- * (pointnet.py:140-161); 3 = mode 2 without the re-run.  tie_eps < 0: the default 2^-17. */
+ * (pointnet.py:140-161); 3 = mode 2 without the re-run; 4 = every fp32 operand as THREE exact bf16 terms (8 + 8 + 8 significand bits, fp32's
+ * exponent range: the value itself), six bf16 MFMAs per product into fp32 accumulators -- fp32 arithmetic on the bf16 matrix pipe, as the
+ * default loss sweeps (sga_loss_multi_*_bf16x6), in both launch forms (identical bits).
+ * tie_eps < 0: the default 2^-17. */
 int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
                         void* workspace, size_t ws_bytes, int mode, float tie_eps, void* stream);
-/* The exact-fp32 forward (mode 0) that ALSO delivers the side effect of the reference's training forward: its three BatchNorm calls discard
+/* The forward in mode 0 (exact fp32) or 4 (three exact bf16 planes) that ALSO delivers the side effect of the reference's training forward: its three BatchNorm calls discard
  * their output but fold the batch statistics of the pre-ReLU conv outputs over all T*P points into running_mean / running_var
  * (pointnet.py:141-142,154-155,158-159).  The sums are taken inside the forward kernel (no second pass over the activations) and folded in
  * a fixed order.  bn_sums, 265 + 2 C3 doubles:
@@ -62,7 +65,7 @@ int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const 
 size_t sga_pointnet_fwd_bn_ws_bytes(int T, int C3);
 int sga_pointnet_fwd_bn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
-                        void* workspace, size_t ws_bytes, void* bn_workspace, size_t bn_ws_bytes, double* bn_sums, void* stream);
+                        void* workspace, size_t ws_bytes, void* bn_workspace, size_t bn_ws_bytes, double* bn_sums, int mode, void* stream);
 /* autograd of the above wrt the six parameters (sparse through the max-pool); gy [T,C3]; C3 == 256. */
 int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy, const float* w1,
                      const float* b1, const float* w2, const float* b2, const float* w3, float* gw1, float* gb1,

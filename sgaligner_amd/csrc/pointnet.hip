@@ -570,9 +570,285 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The forward with every fp32 operand as THREE exact bf16 terms (mode 4; the default arithmetic of the Python layer, 'bf16x6'):
+// x = h + m + l, 8 + 8 + 8 significand bits and fp32's exponent range -- every fp32 value exactly, as in the loss sweeps (sweep3.hip) --
+// a product = the six partial products h h' + (h m' + m h') + (m m' + h l' + l h') on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 is exact in
+// fp32; the three dropped products are <= 2^-23 of the product, below the fp32 accumulation's own rounding): fp32 arithmetic on the
+// reference's fp32 operands (pointnet.py:140-161) at 6 x 32 cycles per 16 k slots where v_mfma_f32_32x32x2_f32 needs 8 x 64.
+// The five small partial products of an accumulation go to their OWN accumulator (the 16-bit MFMAs chop what falls ~7 bits below the
+// result's last place toward minus infinity whatever the sign: tools/micro/mfma_round_probe.hip), added once at the end.
+// Geometry as pointnet_fwd_bf16x3_kernel: one wave per object, the 3 -> 64 -> 128 -> C3 chain of a 32-point tile in registers, layer 2's
+// accumulators are layer 3's A operand.  LDS: W2's three planes (48 KiB) + the three planes of HALF of W3's output channels at C3 = 256
+// (96 KiB; all of them below): a workgroup serves one channel half (blockIdx & 1), two workgroups share an object and both run
+// layers 1-2 -- 2 x 96 + 384 = 576 MFMAs of 32 cycles per 32-point tile against 640 of 64.
+// BN: the batch sums of the reference's BatchNorm side effect as in pointnet_fwd_kernel<.., BN>: layer 3 in-lane; layer 2 (lane = point)
+// through six MFMAs per 32-channel block against a bf16 identity (the three planes of z2 re-delivered with lane = channel: h + m + l
+// adds up to z2 exactly) -- by the workgroup half that matches the object's parity.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pn_split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
+    const float r0 = v0 - __builtin_bit_cast(float, hu << 16), r1 = v1 - __builtin_bit_cast(float, hu & 0xffff0000u);
+    const unsigned mu = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float s0 = r0 - __builtin_bit_cast(float, mu << 16), s1 = r1 - __builtin_bit_cast(float, mu & 0xffff0000u);
+    h = hu; m = mu; l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+__device__ __forceinline__ void pn_split3_8(const float (&v)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned a, b, c;
+        pn_split3_pair(v[2 * p], v[2 * p + 1], a, b, c);
+        h[p] = a; m[p] = b; l[p] = c;
+    }
+}
+
+// SPLIT (few objects) as in pointnet_fwd_kernel: a workgroup (pair) takes one object at a time, its 8 waves share the 32-point tiles and leave
+// partial (max, arg-max) pairs for pointnet_combine_kernel -- per tile the same arithmetic, so both forms give the same bits.
+template <int C3, bool WITH_ARGMAX, bool BN, bool SPLIT = false>
+__global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
+    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ y,
+    int* __restrict__ argmax, int T, int P, double* __restrict__ bn_part, float2* __restrict__ part) {
+    constexpr int HALVES = C3 == 256 ? 2 : 1, CH = C3 / HALVES, NBH = CH / 32, NB3 = C3 / 32;
+    constexpr int NBN = 9 + 8 + 2 * NB3;
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];
+    u32x4* w2p = reinterpret_cast<u32x4*>(ldsu);            // [3 planes][4 cb2][4 ks][64 lane]          3 x 16 KiB
+    u32x4* w3p = w2p + 3 * 16 * 64;                          // [3 planes][NBH cb3][8 ks3][64 lane]       3 x CH / 4 KiB
+    constexpr int W3N = NBH * 8 * 64;
+
+    const int tid = threadIdx.x;
+    const int hf = HALVES == 2 ? ((int)blockIdx.x & 1) : 0;
+    const int slot = HALVES == 2 ? ((int)blockIdx.x >> 1) : (int)blockIdx.x, nslot = HALVES == 2 ? ((int)gridDim.x >> 1) : (int)gridDim.x;
+    for (int d = tid; d < 16 * 64; d += PN_THREADS) {       // W2 as layer-2 A operand: row = out channel, k-slots = in channels 16 ks + 8 h + j
+        const int ln = d & 63, ks = (d >> 6) & 3, cb = d >> 8;
+        const float* src = w2 + (cb * 32 + (ln & 31)) * 64 + 16 * ks + 8 * (ln >> 5);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j];
+        pn_split3_8(v, w2p[d], w2p[1024 + d], w2p[2048 + d]);
+    }
+    for (int d = tid; d < W3N; d += PN_THREADS) {           // W3 (this half's channels) as layer-3 B operand: k-slots follow layer 2's C layout
+        const int ln = d & 63, ks3 = (d >> 6) & 7, cb = d >> 9;
+        const int cb2 = ks3 >> 1, half8 = ks3 & 1, hh = ln >> 5;
+        const float* src = w3 + (size_t)(hf * CH + cb * 32 + (ln & 31)) * 128 + cb2 * 32 + 16 * half8 + 4 * hh;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(j & 3) + 8 * (j >> 2)];
+        pn_split3_8(v, w3p[d], w3p[W3N + d], w3p[2 * W3N + d]);
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, pt = lane & 31;
+    const int n_tiles = (P + 31) >> 5;
+    double* const bn_dst = BN ? bn_part + ((size_t)blockIdx.x * PN_WAVES + wave) * NBN * 64 + lane : nullptr;
+    auto bn_add = [&](int sl, float v) {
+        if (BN) {
+            double* d = bn_dst;
+            asm volatile("" : "+v"(d));
+            unsafeAtomicAdd(d + sl * 64, (double)v);
+        }
+    };
+    // bf16 identity slices for the layer-2 transposition: B[k slot (h, e), j] = [j == channel of the slot], k-slot order of layer 2's C layout
+    u32x4 ident[2];
+    if (BN) {
+#pragma unroll
+        for (int half8 = 0; half8 < 2; ++half8)
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int e0 = 2 * pp, e1 = 2 * pp + 1;
+                const int c0 = (e0 & 3) + 8 * (2 * half8 + (e0 >> 2)) + 4 * h, c1 = (e1 & 3) + 8 * (2 * half8 + (e1 >> 2)) + 4 * h;
+                ident[half8][pp] = (pt == c0 ? 0x3F80u : 0u) | (pt == c1 ? 0x3F800000u : 0u);
+            }
+    }
+
+    for (int t = SPLIT ? slot : slot * PN_WAVES + wave; t < T; t += SPLIT ? nslot : nslot * PN_WAVES) {
+        const float* xt = x + (size_t)t * P * 3;
+        float best[NBH];
+        int bidx[NBH];
+#pragma unroll
+        for (int c = 0; c < NBH; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
+        float bacc[BN ? 8 + 2 * NBH : 1];                  // BN: this object's per-lane sums: layer 2 blocks [0, 8), this half's layer 3 blocks
+#pragma unroll
+        for (int k = 0; k < (BN ? 8 + 2 * NBH : 1); ++k) bacc[k] = 0.f;
+        const bool do_l2_obj = BN && (HALVES == 1 || (__builtin_amdgcn_readfirstlane(t) & 1) == hf);     // (provably uniform: a scalar branch)
+
+        auto tile_body = [&](int tile, auto tail_c, auto l2_c) {
+            constexpr bool tail = BN && decltype(tail_c)::value, DO_L2 = BN && decltype(l2_c)::value;
+            const int p0 = tile * 32;
+            int lane_o = lane, h_o = h;                       // opaque copies: keep the weight reads inside the tile loop
+            asm volatile("" : "+v"(lane_o), "+v"(h_o));
+            const int pi = min(p0 + pt, P - 1);
+            const float x0 = xt[pi * 3 + 0], x1 = xt[pi * 3 + 1], x2 = xt[pi * 3 + 2];
+            auto bn_fold = [&](f32x16& v, int sl) {
+                if (tail) {
+                    const int lim = P - p0 - 4 * h_o;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = mfma32_row(r, 0) < lim ? v[r] : 0.f;
+                }
+                float sm[4], sq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sm[r] = v[r]; sq[r] = v[r] * v[r]; }
+#pragma unroll
+                for (int r = 4; r < 16; ++r) { sm[r & 3] += v[r]; sq[r & 3] = fmaf(v[r], v[r], sq[r & 3]); }
+                bacc[BN ? sl : 0] += (sm[0] + sm[1]) + (sm[2] + sm[3]); bacc[BN ? sl + 1 : 0] += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+            };
+
+            // ---- layer 1 (VALU, fp32): this lane's 32 channels k = 16 ks + 8 h + j, split for the MFMA B operand
+            u32x4 h1p[3][4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 16 * ks + 8 * h_o;
+                float v[8];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int kk = k + 4 * half;
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w1 + kk * 3);
+                    const f32x4 wb = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 4);
+                    const f32x4 wc = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 8);
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + kk);
+                    v[4 * half + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
+                    v[4 * half + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
+                    v[4 * half + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
+                    v[4 * half + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
+                }
+                pn_split3_8(v, h1p[0][ks], h1p[1][ks], h1p[2][ks]);
+            }
+
+            // ---- layer 2: H2^T = W2 H1^T (A = W2 planes from LDS, B = H1 planes); the h h products start at the bias, the small ones at zero
+            u32x4 h2p[3][8];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x16 acc, accs;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * g + 4 * h_o);
+                    acc[g * 4 + 0] = bb[0]; acc[g * 4 + 1] = bb[1]; acc[g * 4 + 2] = bb[2]; acc[g * 4 + 3] = bb[3];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int d = (cb * 4 + ks) * 64 + lane_o;
+                    const u32x4 wh = w2p[d], wm = w2p[1024 + d], wl = w2p[2048 + d];
+                    accs = mfma_bf16(wl, h1p[0][ks], accs);
+                    accs = mfma_bf16(wh, h1p[2][ks], accs);
+                    accs = mfma_bf16(wm, h1p[1][ks], accs);
+                    acc = mfma_bf16(wh, h1p[0][ks], acc);
+                    accs = mfma_bf16(wm, h1p[0][ks], accs);
+                    accs = mfma_bf16(wh, h1p[1][ks], accs);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += accs[r];
+                if (DO_L2) {
+                    // the three planes of z2 itself, re-delivered with lane = channel through the identity (h + m + l adds up to z2 exactly)
+                    f32x16 tr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tr[r] = 0.f;
+                    u32x4 zp[3][2];
+#pragma unroll
+                    for (int half8 = 0; half8 < 2; ++half8) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = acc[half8 * 8 + j];
+                        pn_split3_8(v, zp[0][half8], zp[1][half8], zp[2][half8]);
+                    }
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                        for (int half8 = 0; half8 < 2; ++half8) tr = mfma_bf16(zp[pl][half8], ident[half8], tr);
+                    bn_fold(tr, 2 * cb);
+                    __builtin_amdgcn_sched_barrier(PN_BN_SB);
+                }
+#pragma unroll
+                for (int half8 = 0; half8 < 2; ++half8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[half8 * 8 + j], 0.f);
+                    pn_split3_8(v, h2p[0][cb * 2 + half8], h2p[1][cb * 2 + half8], h2p[2][cb * 2 + half8]);
+                }
+            }
+
+            // ---- layer 3: Z3 = H2 W3^T (A = H2 planes, B = this half's W3 planes), running max over points
+#pragma unroll
+            for (int cb = 0; cb < NBH; ++cb) {
+                f32x16 acc, accs;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accs[r] = 0.f; }
+#pragma unroll
+                for (int ks3 = 0; ks3 < 8; ++ks3) {
+                    const int d = (cb * 8 + ks3) * 64 + lane_o;
+                    const u32x4 wh = w3p[d], wm = w3p[W3N + d], wl = w3p[2 * W3N + d];
+                    accs = mfma_bf16(h2p[2][ks3], wh, accs);
+                    accs = mfma_bf16(h2p[0][ks3], wl, accs);
+                    accs = mfma_bf16(h2p[1][ks3], wm, accs);
+                    acc = mfma_bf16(h2p[0][ks3], wh, acc);
+                    accs = mfma_bf16(h2p[1][ks3], wh, accs);
+                    accs = mfma_bf16(h2p[0][ks3], wm, accs);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += accs[r];
+                if (WITH_ARGMAX) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {        // ascending point order, strict > keeps the first max
+                        const bool gt = acc[r] > best[cb];
+                        best[cb] = gt ? acc[r] : best[cb];
+                        bidx[cb] = gt ? (p0 + mfma32_row(r, h)) : bidx[cb];
+                    }
+                } else {
+                    float m = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                    best[cb] = fmaxf(best[cb], m);
+                }
+                if (BN) { bn_fold(acc, 8 + 2 * cb); __builtin_amdgcn_sched_barrier(PN_BN_SB); }
+            }
+        };
+        for (int tile = SPLIT ? wave : 0; tile < n_tiles; tile += SPLIT ? PN_WAVES : 1) {
+            const bool tl = BN && tile * 32 + 32 > P;
+            if (do_l2_obj) { if (tl) tile_body(tile, std::true_type{}, std::true_type{}); else tile_body(tile, std::false_type{}, std::true_type{}); }
+            else { if (tl) tile_body(tile, std::true_type{}, std::false_type{}); else tile_body(tile, std::false_type{}, std::false_type{}); }
+        }
+
+        if (BN) {
+            if (do_l2_obj) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bn_add(9 + k, bacc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * NBH; ++k) bn_add(17 + 2 * hf * NBH + k, bacc[BN ? 8 + k : 0]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NBH; ++cb) {
+            const float ov = __shfl_xor(best[cb], 32, 64);
+            float v = best[cb];
+            int bi = bidx[cb];
+            if (WITH_ARGMAX) {
+                const int oi = __shfl_xor(bidx[cb], 32, 64);
+                const bool take = (ov > v) || (ov == v && oi < bi);
+                v = take ? ov : v;
+                bi = take ? oi : bi;
+                bi = min(bi, P - 1);
+            } else {
+                v = fmaxf(v, ov);
+            }
+            if (h == 0) {
+                const int c = hf * CH + cb * 32 + pt;
+                if (SPLIT) {
+                    part[((size_t)t * PN_WAVES + wave) * C3 + c] = float2{v, __int_as_float(bi)};
+                } else {
+                    y[(size_t)t * C3 + c] = fmaxf(v + b3[c], 0.f);
+                    if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
+                }
+            }
+        }
+    }
+}
+
 // Forward arithmetic, chosen PER CALL (the library keeps no mode): 0 = exact fp32; 1 = bf16 hi + lo (three bf16 MFMAs per product);
 // 2 = fp16 hi + lo split with every near-tied object re-run on the exact-fp32 kernel (needs the [count | ids] workspace with argmax);
-// 3 = the fp16 split without the re-run.
+// 3 = the fp16 split without the re-run; 4 = three exact bf16 planes, six bf16 MFMAs per product (fp32 arithmetic on the bf16 matrix pipe;
+// both launch forms).
 constexpr float PN_TIE_EPS_DEFAULT = 1.0f / 131072.f;      // 2^-17 of |leader| + |runner-up| (+ 2^-20 of the object's largest |z|): none of the 2.7e8 arg-maxes / masks of a configs[2] batch differs from the fp32 kernel's at 2^-18 already; 9 % of the objects re-run (tools/dbg/f16x2_pointnet_flips.py)
 
 template <int C3>
@@ -583,17 +859,41 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     int grid = (T + PN_WAVES - 1) / PN_WAVES;
     const int ncu = sga_num_cus();
     if (grid > ncu) grid = ncu;
+    const bool split_small = workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32;
+    // mode 4: three exact bf16 planes (pointnet_fwd_p3_kernel); at C3 = 256 a workgroup holds half of W3's channels, two share an object
+    constexpr int P3_HALVES = C3 == 256 ? 2 : 1;
+    const size_t p3_lds = (size_t)(3 * 16 * 64 + 3 * (C3 / P3_HALVES / 32) * 8 * 64) * 16;
+    const int p3_slots_max = P3_HALVES == 2 ? (ncu / 2 > 0 ? ncu / 2 : 1) : ncu;
+    const int p3_want = split_small ? T : grid;              // split form: one object per workgroup (pair) at a time
+    const int p3_grid = P3_HALVES * (p3_want < p3_slots_max ? p3_want : p3_slots_max);
+    auto go_p3 = [&](double* bnp) {
+        float2* part = split_small ? static_cast<float2*>(workspace) : nullptr;
+        auto launch = [&](auto k) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p3_lds);
+            hipLaunchKernelGGL(k, dim3(p3_grid), dim3(PN_THREADS), p3_lds, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, bnp, part);
+        };
+        if (split_small) {
+            if (bnp) { if (argmax) launch(pointnet_fwd_p3_kernel<C3, true, true, true>); else launch(pointnet_fwd_p3_kernel<C3, false, true, true>); }
+            else { if (argmax) launch(pointnet_fwd_p3_kernel<C3, true, false, true>); else launch(pointnet_fwd_p3_kernel<C3, false, false, true>); }
+            hipLaunchKernelGGL(pointnet_combine_kernel, dim3((T * C3 + 255) / 256), dim3(256), 0, stream, part, b3, y, argmax, T, C3, P);
+        } else {
+            if (bnp) { if (argmax) launch(pointnet_fwd_p3_kernel<C3, true, true>); else launch(pointnet_fwd_p3_kernel<C3, false, true>); }
+            else { if (argmax) launch(pointnet_fwd_p3_kernel<C3, true, false>); else launch(pointnet_fwd_p3_kernel<C3, false, false>); }
+        }
+    };
     if (bn_out) {
-        // the exact-fp32 forward with the batch statistics of the three pre-activations (the reference's BatchNorm side effect)
-        const bool split = workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32;
-        const int g = split ? (T < ncu ? T : ncu) : grid;
+        // the forward with the batch statistics of the three pre-activations (the reference's BatchNorm side effect): exact fp32 or mode 4
+        const bool p3 = mode == 4;
+        const bool split = split_small && !p3;
+        const int g = p3 ? p3_grid : split ? (T < ncu ? T : ncu) : grid;
         float2* part = split ? static_cast<float2*>(workspace) : nullptr;
         if (hipMemsetAsync(bn_part, 0, (size_t)g * PN_WAVES * (9 + 8 + 2 * (C3 / 32)) * 64 * sizeof(double), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd_bn: memset failed"); return SGA_ERR_HIP; }
         auto go = [&](auto k) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k, dim3(g), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), bn_part);
         };
-        if (split) { if (argmax) go(pointnet_fwd_kernel<C3, true, true, true>); else go(pointnet_fwd_kernel<C3, false, true, true>); }
+        if (p3) go_p3(bn_part);
+        else if (split) { if (argmax) go(pointnet_fwd_kernel<C3, true, true, true>); else go(pointnet_fwd_kernel<C3, false, true, true>); }
         else { if (argmax) go(pointnet_fwd_kernel<C3, true, false, true>); else go(pointnet_fwd_kernel<C3, false, false, true>); }
         if (split) hipLaunchKernelGGL(pointnet_combine_kernel, dim3((T * C3 + 255) / 256), dim3(256), 0, stream, part, b3, y, argmax, T, C3, P);
         hipLaunchKernelGGL(pointnet_xmoments_kernel, dim3(g), dim3(PN_THREADS), 0, stream, x, (size_t)T * P, C3, bn_part);
@@ -602,7 +902,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         return SGA_OK;
     }
     // few objects: one object per workgroup, its tiles dealt to the 8 waves (exact fp32 kernel only; needs the partials workspace)
-    if ((mode == 0 || mode == 2) && workspace && ws_bytes >= (size_t)T * PN_WAVES * C3 * sizeof(float2) && T < 4 * ncu && P > 32) {
+    if ((mode == 0 || mode == 2) && split_small) {
         float2* part = static_cast<float2*>(workspace);
         const int g2 = T < ncu ? T : ncu;
         if (argmax) {
@@ -620,7 +920,9 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     }
     // ('f16', the configs[4] mode -- fp16 inputs for the loss GEMMs of wide tables -- takes the same fp32-faithful forward: PointNet is 46 % of its step)
     const bool split_fwd = mode == 2;
-    if (split_fwd && argmax) {             // 'f16x2', training: the forward in the fp16 split, objects with a near-tied arg-max re-run in exact fp32
+    if (mode == 4) {
+        go_p3(nullptr);
+    } else if (split_fwd && argmax) {             // 'f16x2', training: the forward in the fp16 split, objects with a near-tied arg-max re-run in exact fp32
         if (!workspace || ws_bytes < (size_t)(T + 1) * sizeof(int)) { sga_set_error("sga_pointnet_fwd: modes 'f16x2' / 'f16' need a workspace of 4 (T + 1) bytes, T = %d (sga_pointnet_fwd_ws)", T); return SGA_ERR_ARG; }
         int* redo = static_cast<int*>(workspace);
         if (hipMemsetAsync(redo, 0, sizeof(int), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd: memset failed"); return SGA_ERR_HIP; }
@@ -676,7 +978,7 @@ static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, c
                              const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,
                              int mode, float tie_eps, void* stream, double* bn_part = nullptr, double* bn_out = nullptr) {
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_fwd: need T >= 0 and P >= 1 (got T=%d P=%d)", T, P);
-    SGA_CHECK_ARG(mode >= 0 && mode <= 3, "sga_pointnet_fwd: mode %d (0 = exact fp32, 1 = bf16 hi + lo, 2 = fp16 hi + lo with the exact re-run of near-ties, 3 = fp16 hi + lo)", mode);
+    SGA_CHECK_ARG(mode >= 0 && mode <= 4, "sga_pointnet_fwd: mode %d (0 = exact fp32, 1 = bf16 hi + lo, 2 = fp16 hi + lo with the exact re-run of near-ties, 3 = fp16 hi + lo, 4 = three exact bf16 planes)", mode);
     // a zero-object shard (T == 0: empty tensors carry null data pointers) is a valid no-op
     SGA_CHECK_ARG((T == 0 || (x && y)) && w1 && b1 && w2 && b2 && w3 && b3, "sga_pointnet_fwd: null pointer");
     if (T == 0) return SGA_OK;
@@ -702,19 +1004,20 @@ extern "C" int sga_pointnet_fwd_ws(const float* x, const float* w1, const float*
 extern "C" size_t sga_pointnet_fwd_bn_ws_bytes(int T, int C3) {
     if (T <= 0 || C3 <= 0) return 0;
     const int ncu = sga_num_cus();
-    const int g = T < ncu ? T : ncu;                       // an upper bound of both launch forms' workgroup counts
+    const int g = 2 * T < ncu ? 2 * T : ncu;              // an upper bound of every launch form's workgroup count
     return (size_t)g * PN_WAVES * (9 + 8 + 2 * (C3 / 32)) * 64 * sizeof(double);
 }
 extern "C" int sga_pointnet_fwd_bn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                                    const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
-                                   void* workspace, size_t ws_bytes, void* bn_workspace, size_t bn_ws_bytes, double* bn_sums, void* stream) {
+                                   void* workspace, size_t ws_bytes, void* bn_workspace, size_t bn_ws_bytes, double* bn_sums, int mode, void* stream) {
     SGA_CHECK_ARG(bn_sums != nullptr, "sga_pointnet_fwd_bn: bn_sums is null");
+    SGA_CHECK_ARG(mode == 0 || mode == 4, "sga_pointnet_fwd_bn: mode %d (0 = exact fp32, 4 = three exact bf16 planes)", mode);
     SGA_CHECK_ARG(T == 0 || (bn_workspace && bn_ws_bytes >= sga_pointnet_fwd_bn_ws_bytes(T, C3)),
                   "sga_pointnet_fwd_bn: bn_workspace must hold sga_pointnet_fwd_bn_ws_bytes(T, C3) = %zu bytes (got %zu)", sga_pointnet_fwd_bn_ws_bytes(T, C3), bn_ws_bytes);
     if (T == 0) {
         if (C3 == 64 || C3 == 128 || C3 == 256) hipMemsetAsync(bn_sums, 0, (size_t)(265 + 2 * C3) * sizeof(double), static_cast<hipStream_t>(stream));
     }
-    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, 0, -1.f, stream, static_cast<double*>(bn_workspace), bn_sums);
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, mode, -1.f, stream, static_cast<double*>(bn_workspace), bn_sums);
 }
 
 /* the no-workspace entry: always the exact-fp32 kernel */

@@ -75,8 +75,9 @@ def get_mfma_mode() -> str:
     return _MODE
 
 
-# PointNet forward arithmetic per mode (sga_pointnet_fwd_ws `mode`): 0 exact fp32, 1 bf16 hi + lo, 2 fp16 hi + lo + exact re-run of near-ties, 3 without
-_POINTNET_MODE = {'f32': 0, 'bf16x6': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 2, 'f16x2p': 3}
+# PointNet forward arithmetic per mode (sga_pointnet_fwd_ws `mode`): 0 exact fp32, 1 bf16 hi + lo, 2 fp16 hi + lo + exact re-run of near-ties, 3 without,
+# 4 three exact bf16 planes (six bf16 MFMAs per product: fp32 arithmetic on the bf16 matrix pipe, like the default loss sweeps)
+_POINTNET_MODE = {'f32': 0, 'bf16x6': 4 if _os_mode.environ.get('SGA_POINTNET_P3', '1') != '0' else 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 2, 'f16x2p': 3}
 POINTNET_TIE_EPS = -1.0                # 'f16x2' forward: < 0 = the library default 2^-17 (tools/dbg/f16x2_pointnet_flips.py sweeps it)
 GROUP_LOSS_VALU = _os_mode.environ.get('SGA_GROUP_GRAD_VALU', '0') == '1'      # loss_group kernels: the VALU forms (cross-checks) instead of MFMA
 
@@ -87,7 +88,7 @@ POINTNET_SPLIT_MAX_OBJECTS = 1023      # the library uses the split form below 4
 def pointnet_bn_fusable() -> bool:
     """True when the PointNet forward of the current arithmetic mode is the exact-fp32 kernel, which can deliver the BatchNorm batch
     statistics of the reference's training forward from inside the kernel (sga_pointnet_fwd_bn)."""
-    return _POINTNET_MODE[get_mfma_mode()] == 0
+    return _POINTNET_MODE[get_mfma_mode()] in (0, 4)
 
 
 def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool, bn_sums=None):
@@ -115,13 +116,13 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool, bn_sums=N
         ws = POINTNET_LAST_REDO = torch.empty((T + 1,), device=x_tp3.device, dtype=torch.int32)
     if bn_sums is not None:
         if not pointnet_bn_fusable():
-            raise RuntimeError(f"sgaligner_amd.pointnet_forward: the fused BatchNorm statistics need the exact-fp32 forward (mode {get_mfma_mode()!r} runs another)")
+            raise RuntimeError(f"sgaligner_amd.pointnet_forward: the fused BatchNorm statistics need the exact-fp32 or the three-plane forward (mode {get_mfma_mode()!r} runs another)")
         if bn_sums.dtype != torch.float64 or bn_sums.numel() != 265 + 2 * C3 or not bn_sums.is_contiguous() or bn_sums.device != x_tp3.device:
             raise RuntimeError('sgaligner_amd.pointnet_forward: bn_sums must be a contiguous float64 tensor of 265 + 2 C3 elements on the input device')
         bws_bytes = int(L.sga_pointnet_fwd_bn_ws_bytes(T, C3))
         bws = torch.empty((max(bws_bytes, 8),), device=x_tp3.device, dtype=torch.uint8)
         rc = L.sga_pointnet_fwd_bn(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
-                                   T, P, C3, _p(ws), ws_bytes, _p(bws), bws_bytes, _p(bn_sums), _stream())
+                                   T, P, C3, _p(ws), ws_bytes, _p(bws), bws_bytes, _p(bn_sums), _POINTNET_MODE[get_mfma_mode()], _stream())
         _lib.check(rc, 'sga_pointnet_fwd_bn')
     else:
         rc = L.sga_pointnet_fwd_ws(_p(x_tp3), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(y), _p(am),
@@ -129,7 +130,9 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool, bn_sums=N
         _lib.check(rc, 'sga_pointnet_fwd')
     if ev is not None:
         ev[1].record()
-        KERNEL_EVENTS.setdefault('pointnet_fwd_kernel', []).append(ev + ((T, P, w1.shape[0], w2.shape[0], C3, get_mfma_mode() if (ws is not None and ws_bytes == 4 * (T + 1)) else 'f32'),))
+        pm = _POINTNET_MODE[get_mfma_mode()]
+        KERNEL_EVENTS.setdefault('pointnet_fwd_kernel', []).append(ev + ((T, P, w1.shape[0], w2.shape[0], C3, 'bf16x6' if pm == 4 else get_mfma_mode() if (ws is not None and ws_bytes == 4 * (T + 1)) else 'f32',
+                                                                          bn_sums is not None),))
     return y, am
 
 
