@@ -49,6 +49,44 @@ def test_pointnet_fwd_oracle(T, P):
     assert agree.float().mean() > 0.999
 
 
+@pytest.mark.parametrize('mode', ['bf16x6', 'f32'])
+@pytest.mark.parametrize('C3,T,P', [(64, 1100, 40), (128, 1100, 40), (128, 30, 70), (256, 1500, 33), (64, 9, 512)])
+def test_pointnet_fwd_out_sizes_and_modes_vs_oracle(mode, C3, T, P):
+    """Every out_size the kernels are built for (64, 128: all of W3's three planes in LDS; 256: channel halves over workgroup pairs), both
+    launch forms, in the default arithmetic (three exact bf16 planes) and on the fp32 MFMA: values within 2e-5 of the fp64 oracle, arg-max
+    parity off rounding ties, and the BatchNorm sums of the fused forward equal to the oracle's batch statistics."""
+    from oracle import sga_oracle as O
+    from sgaligner_amd import ops
+    torch.manual_seed(C3 + T + P)
+    ws = [torch.randn(64, 3) * 0.3, torch.randn(64) * 0.1, torch.randn(128, 64) * 0.15, torch.randn(128) * 0.1,
+          torch.randn(C3, 128) * 0.1, torch.randn(C3) * 0.1]
+    x = torch.randn(T, P, 3) + torch.tensor([0.5, -1.0, 0.25])
+    yo, io = O.pointnet_feat(x.double().permute(0, 2, 1), *[w.double() for w in ws], return_argmax=True)
+    ref = O.pointnet_bn_batch_stats(x.double().permute(0, 2, 1), *[w.double() for w in ws])
+    wd = [w.contiguous().cuda() for w in ws]
+    old = ops.set_mfma_mode(mode)
+    try:
+        y, am = ops.pointnet_forward(x.cuda(), *wd, want_argmax=True)
+        sums = torch.empty(265 + 2 * C3, device='cuda', dtype=torch.float64)
+        y2, am2 = ops.pointnet_forward(x.cuda(), *wd, want_argmax=True, bn_sums=sums)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_mfma_mode(old)
+    assert torch.equal(y, y2) and torch.equal(am, am2)
+    assert (y.cpu().double() - yo).abs().max() < 2e-5
+    agree = (am.cpu().long() == io) | (yo <= 0)
+    assert agree.float().mean() > 0.999
+    n = T * P
+    s = sums.cpu()
+    mean2, var2 = s[9:137] / n, (s[137:265] / n - (s[9:137] / n) ** 2) * n / (n - 1)
+    u = s[265:265 + C3] / n
+    mean3, var3 = u + ws[5].double(), (s[265 + C3:] / n - u * u) * n / (n - 1)
+    for got, want in ((mean2, ref[1][0]), (var2, ref[1][1]), (mean3, ref[2][0]), (var3, ref[2][1])):
+        assert (got - want).abs().max() < 2e-6 * max(1.0, want.abs().max()), (mode, C3)
+    m = s[0:3] / n
+    assert (m - x.double().reshape(-1, 3).mean(0)).abs().max() < 1e-9
+
+
 @pytest.mark.parametrize('tag', ['small', 'ragged'])
 def test_pointnet_bwd_golden(tag):
     from sgaligner_amd import ops
