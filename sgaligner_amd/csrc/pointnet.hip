@@ -31,6 +31,7 @@ namespace {
 #define PN_BN_SB 0
 #endif
 constexpr int PN_WAVES = 8;
+constexpr size_t PN_P3_LG_BYTES = (size_t)(1024 + 8 * 512) * 16;      // the l planes of W2 and W3 (C3 = 256) in operand order: pointnet_p3_lplanes_kernel
 constexpr int PN_THREADS = PN_WAVES * 64;
 
 // SPLIT (few objects: the reference's own batch sizes, single-pair inference): a workgroup takes ONE object at a time and its 8
@@ -604,16 +605,22 @@ __device__ __forceinline__ void pn_split3_8(const float (&v)[8], u32x4& h, u32x4
 
 // SPLIT (few objects) as in pointnet_fwd_kernel: a workgroup (pair) takes one object at a time, its 8 waves share the 32-point tiles and leave
 // partial (max, arg-max) pairs for pointnet_combine_kernel -- per tile the same arithmetic, so both forms give the same bits.
-template <int C3, bool WITH_ARGMAX, bool BN, bool SPLIT = false>
+// LG (C3 = 256, many objects): ONE workgroup serves whole objects -- the h and m planes of W2 and of ALL of W3 fill the 160 KiB of LDS, the
+// l planes (used by one of the six products each) are read per use from a 80-KiB operand-ordered copy in global memory (wlg, written by
+// pointnet_p3_lplanes_kernel; it lives in L2): no second run of layers 1-2, 480 instead of 576 MFMAs per tile.  Same products in the same
+// order per output as the channel-halves form: identical bits.
+template <int C3, bool WITH_ARGMAX, bool BN, bool SPLIT = false, bool LG = false>
 __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ y,
-    int* __restrict__ argmax, int T, int P, double* __restrict__ bn_part, float2* __restrict__ part) {
-    constexpr int HALVES = C3 == 256 ? 2 : 1, CH = C3 / HALVES, NBH = CH / 32, NB3 = C3 / 32;
+    int* __restrict__ argmax, int T, int P, double* __restrict__ bn_part, float2* __restrict__ part, const u32x4* __restrict__ wlg = nullptr) {
+    static_assert(!LG || (C3 == 256 && !SPLIT), "l planes from global memory: the C3 = 256 one-wave-per-object form");
+    constexpr int HALVES = (C3 == 256 && !LG) ? 2 : 1, CH = C3 / HALVES, NBH = CH / 32, NB3 = C3 / 32;
     constexpr int NBN = 9 + 8 + 2 * NB3;
+    constexpr int NPL = LG ? 2 : 3;                          // planes held in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];
-    u32x4* w2p = reinterpret_cast<u32x4*>(ldsu);            // [3 planes][4 cb2][4 ks][64 lane]          3 x 16 KiB
-    u32x4* w3p = w2p + 3 * 16 * 64;                          // [3 planes][NBH cb3][8 ks3][64 lane]       3 x CH / 4 KiB
+    u32x4* w2p = reinterpret_cast<u32x4*>(ldsu);            // [NPL planes][4 cb2][4 ks][64 lane]        NPL x 16 KiB
+    u32x4* w3p = w2p + NPL * 16 * 64;                        // [NPL planes][NBH cb3][8 ks3][64 lane]     NPL x CH / 4 KiB
     constexpr int W3N = NBH * 8 * 64;
 
     const int tid = threadIdx.x;
@@ -625,7 +632,10 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[j];
-        pn_split3_8(v, w2p[d], w2p[1024 + d], w2p[2048 + d]);
+        u32x4 ph, pm, pl;
+        pn_split3_8(v, ph, pm, pl);
+        w2p[d] = ph; w2p[1024 + d] = pm;
+        if (!LG) w2p[2048 + d] = pl;
     }
     for (int d = tid; d < W3N; d += PN_THREADS) {           // W3 (this half's channels) as layer-3 B operand: k-slots follow layer 2's C layout
         const int ln = d & 63, ks3 = (d >> 6) & 7, cb = d >> 9;
@@ -634,7 +644,10 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[(j & 3) + 8 * (j >> 2)];
-        pn_split3_8(v, w3p[d], w3p[W3N + d], w3p[2 * W3N + d]);
+        u32x4 ph, pm, pl;
+        pn_split3_8(v, ph, pm, pl);
+        w3p[d] = ph; w3p[W3N + d] = pm;
+        if (!LG) w3p[2 * W3N + d] = pl;
     }
     __syncthreads();
 
@@ -650,17 +663,18 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
         }
     };
     // bf16 identity slices for the layer-2 transposition: B[k slot (h, e), j] = [j == channel of the slot], k-slot order of layer 2's C layout
-    u32x4 ident[2];
-    if (BN) {
+    auto make_ident = [&](int half8, int hh, int j) {
+        u32x4 r;
 #pragma unroll
-        for (int half8 = 0; half8 < 2; ++half8)
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int e0 = 2 * pp, e1 = 2 * pp + 1;
-                const int c0 = (e0 & 3) + 8 * (2 * half8 + (e0 >> 2)) + 4 * h, c1 = (e1 & 3) + 8 * (2 * half8 + (e1 >> 2)) + 4 * h;
-                ident[half8][pp] = (pt == c0 ? 0x3F80u : 0u) | (pt == c1 ? 0x3F800000u : 0u);
-            }
-    }
+        for (int pp = 0; pp < 4; ++pp) {
+            const int e0 = 2 * pp, e1 = 2 * pp + 1;
+            const int c0 = (e0 & 3) + 8 * (2 * half8 + (e0 >> 2)) + 4 * hh, c1 = (e1 & 3) + 8 * (2 * half8 + (e1 >> 2)) + 4 * hh;
+            r[pp] = (j == c0 ? 0x3F80u : 0u) | (j == c1 ? 0x3F800000u : 0u);
+        }
+        return r;
+    };
+    u32x4 ident[2];                                          // (LG: made where they are used -- 8 registers that kernel does not have)
+    if (BN && !LG) { ident[0] = make_ident(0, h, pt); ident[1] = make_ident(1, h, pt); }
 
     for (int t = SPLIT ? slot : slot * PN_WAVES + wave; t < T; t += SPLIT ? nslot : nslot * PN_WAVES) {
         const float* xt = x + (size_t)t * P * 3;
@@ -668,9 +682,12 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
         int bidx[NBH];
 #pragma unroll
         for (int c = 0; c < NBH; ++c) { best[c] = -INFINITY; bidx[c] = 0; }
-        float bacc[BN ? 8 + 2 * NBH : 1];                  // BN: this object's per-lane sums: layer 2 blocks [0, 8), this half's layer 3 blocks
+        // BN: this object's per-lane sums: layer 2 blocks [0, 8), this half's layer 3 blocks (LG: the eight layer-3 blocks' sums go to their
+        // slots tile by tile instead -- 16 more registers would spill)
+        constexpr int NBACC = BN ? (LG ? 8 : 8 + 2 * NBH) : 1;
+        float bacc[NBACC];
 #pragma unroll
-        for (int k = 0; k < (BN ? 8 + 2 * NBH : 1); ++k) bacc[k] = 0.f;
+        for (int k = 0; k < NBACC; ++k) bacc[k] = 0.f;
         const bool do_l2_obj = BN && (HALVES == 1 || (__builtin_amdgcn_readfirstlane(t) & 1) == hf);     // (provably uniform: a scalar branch)
 
         auto tile_body = [&](int tile, auto tail_c, auto l2_c) {
@@ -691,7 +708,11 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
                 for (int r = 0; r < 4; ++r) { sm[r] = v[r]; sq[r] = v[r] * v[r]; }
 #pragma unroll
                 for (int r = 4; r < 16; ++r) { sm[r & 3] += v[r]; sq[r & 3] = fmaf(v[r], v[r], sq[r & 3]); }
-                bacc[BN ? sl : 0] += (sm[0] + sm[1]) + (sm[2] + sm[3]); bacc[BN ? sl + 1 : 0] += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+                if (LG && sl >= 8) {
+                    bn_add(9 + sl, (sm[0] + sm[1]) + (sm[2] + sm[3])); bn_add(10 + sl, (sq[0] + sq[1]) + (sq[2] + sq[3]));
+                } else {
+                    bacc[BN && sl < NBACC ? sl : 0] += (sm[0] + sm[1]) + (sm[2] + sm[3]); bacc[BN && sl + 1 < NBACC ? sl + 1 : 0] += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+                }
             };
 
             // ---- layer 1 (VALU, fp32): this lane's 32 channels k = 16 ks + 8 h + j, split for the MFMA B operand
@@ -730,7 +751,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int d = (cb * 4 + ks) * 64 + lane_o;
-                    const u32x4 wh = w2p[d], wm = w2p[1024 + d], wl = w2p[2048 + d];
+                    const u32x4 wh = w2p[d], wm = w2p[1024 + d], wl = LG ? wlg[d] : w2p[2048 + d];
                     accs = mfma_bf16(wl, h1p[0][ks], accs);
                     accs = mfma_bf16(wh, h1p[2][ks], accs);
                     accs = mfma_bf16(wm, h1p[1][ks], accs);
@@ -756,7 +777,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                     for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
-                        for (int half8 = 0; half8 < 2; ++half8) tr = mfma_bf16(zp[pl][half8], ident[half8], tr);
+                        for (int half8 = 0; half8 < 2; ++half8) tr = mfma_bf16(zp[pl][half8], LG ? make_ident(half8, h_o, lane_o & 31) : ident[half8], tr);
                     bn_fold(tr, 2 * cb);
                     __builtin_amdgcn_sched_barrier(PN_BN_SB);
                 }
@@ -778,7 +799,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int ks3 = 0; ks3 < 8; ++ks3) {
                     const int d = (cb * 8 + ks3) * 64 + lane_o;
-                    const u32x4 wh = w3p[d], wm = w3p[W3N + d], wl = w3p[2 * W3N + d];
+                    const u32x4 wh = w3p[d], wm = w3p[W3N + d], wl = LG ? wlg[1024 + d] : w3p[2 * W3N + d];
                     accs = mfma_bf16(h2p[2][ks3], wh, accs);
                     accs = mfma_bf16(h2p[0][ks3], wl, accs);
                     accs = mfma_bf16(h2p[1][ks3], wm, accs);
@@ -816,7 +837,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
                 for (int k = 0; k < 8; ++k) bn_add(9 + k, bacc[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 2 * NBH; ++k) bn_add(17 + 2 * hf * NBH + k, bacc[BN ? 8 + k : 0]);
+            for (int k = 0; k < (LG ? 0 : 2 * NBH); ++k) bn_add(17 + 2 * hf * NBH + k, bacc[BN && !LG ? 8 + k : 0]);
         }
 #pragma unroll
         for (int cb = 0; cb < NBH; ++cb) {
@@ -845,6 +866,29 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
     }
 }
 
+// The l planes of W2 and W3 in the MFMA operand order of pointnet_fwd_p3_kernel<.., LG>: out[0, 1024) = W2, out[1024, 1024 + C3 / 32 * 512) = W3.
+template <int C3>
+__global__ __launch_bounds__(256) void pointnet_p3_lplanes_kernel(const float* __restrict__ w2, const float* __restrict__ w3, u32x4* __restrict__ out) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= 1024 + (C3 / 32) * 512) return;
+    float v[8];
+    if (d < 1024) {
+        const int ln = d & 63, ks = (d >> 6) & 3, cb = d >> 8;
+        const float* src = w2 + (cb * 32 + (ln & 31)) * 64 + 16 * ks + 8 * (ln >> 5);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j];
+    } else {
+        const int e = d - 1024, ln = e & 63, ks3 = (e >> 6) & 7, cb = e >> 9;
+        const int cb2 = ks3 >> 1, half8 = ks3 & 1, hh = ln >> 5;
+        const float* src = w3 + (size_t)(cb * 32 + (ln & 31)) * 128 + cb2 * 32 + 16 * half8 + 4 * hh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(j & 3) + 8 * (j >> 2)];
+    }
+    u32x4 ph, pm, pl;
+    pn_split3_8(v, ph, pm, pl);
+    out[d] = pl;
+}
+
 // Forward arithmetic, chosen PER CALL (the library keeps no mode): 0 = exact fp32; 1 = bf16 hi + lo (three bf16 MFMAs per product);
 // 2 = fp16 hi + lo split with every near-tied object re-run on the exact-fp32 kernel (needs the [count | ids] workspace with argmax);
 // 3 = the fp16 split without the re-run; 4 = three exact bf16 planes, six bf16 MFMAs per product (fp32 arithmetic on the bf16 matrix pipe;
@@ -865,12 +909,29 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     const size_t p3_lds = (size_t)(3 * 16 * 64 + 3 * (C3 / P3_HALVES / 32) * 8 * 64) * 16;
     const int p3_slots_max = P3_HALVES == 2 ? (ncu / 2 > 0 ? ncu / 2 : 1) : ncu;
     const int p3_want = split_small ? T : grid;              // split form: one object per workgroup (pair) at a time
-    const int p3_grid = P3_HALVES * (p3_want < p3_slots_max ? p3_want : p3_slots_max);
+    // C3 = 256, many objects, a scratch of PN_P3_LG_BYTES in `workspace`: one workgroup per object, the l planes from global memory (LG)
+    const bool p3_lg = C3 == 256 && !split_small && workspace && ws_bytes >= PN_P3_LG_BYTES && std::getenv("SGA_POINTNET_P3_HALVES") == nullptr;
+    const int p3_grid = p3_lg ? grid : P3_HALVES * (p3_want < p3_slots_max ? p3_want : p3_slots_max);
     auto go_p3 = [&](double* bnp) {
+        if constexpr (C3 == 256) {
+            if (p3_lg) {
+                u32x4* wlg = static_cast<u32x4*>(workspace);
+                hipLaunchKernelGGL(pointnet_p3_lplanes_kernel<C3>, dim3((1024 + 8 * 512 + 255) / 256), dim3(256), 0, stream, w2, w3, wlg);
+                const size_t lg_lds = (size_t)(2 * 16 * 64 + 2 * 8 * 8 * 64) * 16;
+                auto launch = [&](auto k) {
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_lds);
+                    hipLaunchKernelGGL(k, dim3(p3_grid), dim3(PN_THREADS), lg_lds, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, bnp, static_cast<float2*>(nullptr),
+                                       static_cast<const u32x4*>(wlg));
+                };
+                if (bnp) { if (argmax) launch(pointnet_fwd_p3_kernel<C3, true, true, false, true>); else launch(pointnet_fwd_p3_kernel<C3, false, true, false, true>); }
+                else { if (argmax) launch(pointnet_fwd_p3_kernel<C3, true, false, false, true>); else launch(pointnet_fwd_p3_kernel<C3, false, false, false, true>); }
+                return;
+            }
+        }
         float2* part = split_small ? static_cast<float2*>(workspace) : nullptr;
         auto launch = [&](auto k) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p3_lds);
-            hipLaunchKernelGGL(k, dim3(p3_grid), dim3(PN_THREADS), p3_lds, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, bnp, part);
+            hipLaunchKernelGGL(k, dim3(p3_grid), dim3(PN_THREADS), p3_lds, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, bnp, part, static_cast<const u32x4*>(nullptr));
         };
         if (split_small) {
             if (bnp) { if (argmax) launch(pointnet_fwd_p3_kernel<C3, true, true, true>); else launch(pointnet_fwd_p3_kernel<C3, false, true, true>); }

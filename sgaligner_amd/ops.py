@@ -110,6 +110,10 @@ def pointnet_forward(x_tp3, w1, b1, w2, b2, w3, b3, want_argmax: bool, bn_sums=N
     if 0 < T <= POINTNET_SPLIT_MAX_OBJECTS:      # few objects: split every object over a workgroup's 8 waves (needs a partials buffer)
         ws_bytes = int(L.sga_pointnet_fwd_ws_bytes(T, C3))
         ws = torch.empty((ws_bytes,), device=x_tp3.device, dtype=torch.uint8)
+    elif T > 0 and _POINTNET_MODE[get_mfma_mode()] == 4 and C3 == 256:
+        # many objects on three planes: 80 KiB of scratch for the l planes of W2 / W3 in operand order (one workgroup then serves whole objects)
+        ws_bytes = 81920
+        ws = torch.empty((ws_bytes,), device=x_tp3.device, dtype=torch.uint8)
     elif T > 0 and want_argmax and get_mfma_mode() in ('f16x2', 'f16'):
         # 'f16x2' training forward: [count | ids] of the objects with a near-tied arg-max -> those again on the exact-fp32 kernel
         ws_bytes = 4 * (T + 1)
