@@ -839,13 +839,20 @@ int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int
         add(on2, J2, on2, bn2, X1f1, X2f2);
     }
     a.ngroups = g;
-    // uniform ~160-step work units; see sweepb.hip for the XCD argument
+    // uniform work units; see sweepb.hip for the XCD argument
     int nwg = 0;
     for (int i = 0; i < g; ++i) {
         TGroup& G = a.grp[i];
         int steps = 0;
         for (int sg = 0; sg < G.nseg; ++sg) steps += G.seg[sg].jt_hi - G.seg[sg].jt_lo;
-        int nsp = (steps + 159) / 160;
+        // Work units of 160 .. 640 tile steps: the longer a unit, the fewer owner-operand loads and gradient flushes per tile (configs[2]: 2.80 ->
+        // 2.74 s from 160 to 640, flat beyond; SHORTER units, whose tile stream would fit an XCD's L2 whatever the workgroups' phases, only
+        // cost: 2.88 s at 56) -- as long as every CU still gets >= ~12 units of the group.  (SGA_SWEEP3_UNIT overrides, for experiments.)
+        static const int unit_env = [] { const char* e = std::getenv("SGA_SWEEP3_UNIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+        const long n_ob_g = (G.nown + own_rows - 1) / own_rows;
+        const long want = (long)steps * n_ob_g / (12L * sga_num_cus());
+        const int unit_steps = unit_env ? unit_env : want < 160 ? 160 : want > 640 ? 640 : (int)want;
+        int nsp = (steps + unit_steps - 1) / unit_steps;
         if (nsp > steps) nsp = steps;
         if (nsp < 1) nsp = 1;
         G.nsplit = nsp;
