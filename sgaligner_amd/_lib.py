@@ -130,6 +130,10 @@ def lib():
             raise SgaLibraryError(
                 f'HIP library not built: {LIB_PATH} is missing. Run `python -c "import __graft_entry__ as g; g.build()"` '
                 f'(or `python -m sgaligner_amd._build`). sgaligner_amd has no CPU fallback.')
+        # torch first: its bundled HIP runtime must be the one this library binds to.  Loaded the other way round (e.g. build() and then a
+        # training step in one process) the library gets /opt/rocm's libamdhip64 as a SECOND runtime instance, whose memory calls
+        # (hipMemsetAsync on a torch allocation) fail with "no ROCm-capable device is detected" while kernel launches still work.
+        import torch  # noqa: F401
         try:
             l = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover

@@ -30,6 +30,14 @@ namespace {
 #ifndef PN_BN_SB
 #define PN_BN_SB 0
 #endif
+// The BN partial sums: every slot belongs to ONE wave, so the adds need no wider scope than the wavefront -- a device-scope atomic on this
+// multi-XCD part is carried out memory-side (144 GB of HBM writes per configs[2] launch at 16 atomics per tile); wavefront scope lets the
+// XCD's own L2 keep the line.  (PN_BN_ATOMIC_DEVICE builds the device-scope form for comparison.)
+#ifdef PN_BN_ATOMIC_DEVICE
+#define PN_BN_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
+#else
+#define PN_BN_ATOMIC_ADD(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(1))) double*)(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+#endif
 constexpr int PN_WAVES = 8;
 constexpr size_t PN_P3_LG_BYTES = (size_t)(1024 + 8 * 512) * 16;      // the l planes of W2 and W3 (C3 = 256) in operand order: pointnet_p3_lplanes_kernel
 constexpr int PN_THREADS = PN_WAVES * 64;
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
         if (BN) {
             double* d = bn_dst;
             asm volatile("" : "+v"(d));
-            unsafeAtomicAdd(d + slot * 64, (double)v);
+            PN_BN_ATOMIC_ADD(d + slot * 64, (double)v);
         }
     };
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
         if (BN) {
             double* d = bn_dst;
             asm volatile("" : "+v"(d));
-            unsafeAtomicAdd(d + sl * 64, (double)v);
+            PN_BN_ATOMIC_ADD(d + sl * 64, (double)v);
         }
     };
     // bf16 identity slices for the layer-2 transposition: B[k slot (h, e), j] = [j == channel of the slot], k-slot order of layer 2's C layout
@@ -948,7 +956,10 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         const bool split = split_small && !p3;
         const int g = p3 ? p3_grid : split ? (T < ncu ? T : ncu) : grid;
         float2* part = split ? static_cast<float2*>(workspace) : nullptr;
-        if (hipMemsetAsync(bn_part, 0, (size_t)g * PN_WAVES * (9 + 8 + 2 * (C3 / 32)) * 64 * sizeof(double), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd_bn: memset failed"); return SGA_ERR_HIP; }
+        if (hipError_t me = hipMemsetAsync(bn_part, 0, (size_t)g * PN_WAVES * (9 + 8 + 2 * (C3 / 32)) * 64 * sizeof(double), stream); me != hipSuccess) {
+            sga_set_error("sga_pointnet_fwd_bn: memset of %zu bytes at %p failed: %s", (size_t)g * PN_WAVES * (9 + 8 + 2 * (C3 / 32)) * 64 * sizeof(double), (void*)bn_part, hipGetErrorString(me));
+            return SGA_ERR_HIP;
+        }
         auto go = [&](auto k) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k, dim3(g), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), bn_part);
