@@ -77,7 +77,10 @@ def get_mfma_mode() -> str:
 
 # PointNet forward arithmetic per mode (sga_pointnet_fwd_ws `mode`): 0 exact fp32, 1 bf16 hi + lo, 2 fp16 hi + lo + exact re-run of near-ties, 3 without,
 # 4 three exact bf16 planes (six bf16 MFMAs per product: fp32 arithmetic on the bf16 matrix pipe, like the default loss sweeps)
-_POINTNET_MODE = {'f32': 0, 'bf16x6': 4 if _os_mode.environ.get('SGA_POINTNET_P3', '1') != '0' else 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 2, 'f16x2p': 3}
+# ('f16', the wide-table mode of configs[4], takes the three-plane forward too: with the BatchNorm side effect on, the fp16 split + re-run + one more
+#  forward for the sums is slower than the fusable kernel)
+_P3 = 4 if _os_mode.environ.get('SGA_POINTNET_P3', '1') != '0' else 0
+_POINTNET_MODE = {'f32': 0, 'bf16x6': _P3, 'bf16x3': 1, 'f16': _P3 if _P3 else 2, 'f16x2': 2, 'f16x2p': 3}
 POINTNET_TIE_EPS = -1.0                # 'f16x2' forward: < 0 = the library default 2^-17 (tools/dbg/f16x2_pointnet_flips.py sweeps it)
 GROUP_LOSS_VALU = _os_mode.environ.get('SGA_GROUP_GRAD_VALU', '0') == '1'      # loss_group kernels: the VALU forms (cross-checks) instead of MFMA
 
