@@ -54,7 +54,7 @@ def fp64_evidence():
     """What tests/test_fp64_chunked_gpu.py (the chunked fp64 evaluation of OverallLoss at configs[2]) last measured, from the committed
     report: errors against fp64 of the default step (sweeps on three exact bf16 planes), of the same step with fp32-MFMA sweeps, and of the
     opt-in two-plane fp16 mode, side by side."""
-    for name in ('r05_c3_gradient_vs_fp64.json', 'r05_1024_gradient_vs_fp64.json'):
+    for name in ('r05_m_c3_gradient_vs_fp64.json', 'r05_1024_gradient_vs_fp64.json'):
         try:
             r = json.load(open(os.path.join(ROOT, 'profiles', name)))
             e = r['meta_embedding_rel_err_vs_fp64_rel_to_own_max']
