@@ -1,0 +1,109 @@
+"""bench.py's output contract: the LAST stdout line is one compact JSON object the driver can parse (< 4 KB -- round 5's 27 KB line
+came back as `parsed: null`), carrying value / ms_per_step / config / dtype / roofline / cpu_baseline; everything else goes to the
+extras file and stderr.  Built from a fake full record through the same formatter bench.py uses."""
+import io
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def _roof(kernel, frac=0.5, **kw):
+    r = {'bound': 'mfma', 'achieved': 205.5, 'peak': 416.7, 'unit': 'TFLOP/s', 'frac': frac, 'frac_useful': 0.37, 'traffic': 502284177386,
+         'kernel': kernel + ' (' + 'x' * 300 + ')', 'launches_timed': 20, 'avg_launch_ms': 2679.87, 'step_ms': 2679.87,
+         'peak_is': 'dense bf16 MFMA peak (2500 TFLOP/s) / 6: ' + 'y' * 200, 'algorithmic_flops_per_launch': 5.5e14, 'executed_flops_per_launch': 3.6e15}
+    r.update(kw)
+    return r
+
+
+def fake_full(bloat=1):
+    roofs = [_roof(f'kernel_{i}<3,true>', step_ms=100.0 - i) for i in range(12 * bloat)]
+    sweep = [{'b': b, 'threads': t, 'pairs_per_s': 3.0 + 0.1 * i, 'median_ms': 600.0, 'iterations': 5}
+             for i, (b, t) in enumerate([(2, 32), (4, 32), (4, 64), (16, 32), (16, 64), (16, 128)] * bloat)]
+    best = max(sweep, key=lambda p: p['pairs_per_s'])
+    return {
+        'metric': 'subscan-pairs/sec (fwd+bwd) + node-match Hits@1 vs reference', 'value': 907.4, 'unit': 'pairs/s', 'n_gpus': 1, 'steps': 10,
+        'warmup': 3, 'ms_per_step': 4514.2, 'median_ms_per_step': 4510.0, 'value_median': 908.0, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f32 (' + 'z' * 400 + ')', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[2] ' + 'w' * 400, 'name': 'c3', 'global_pairs': 4096, 'pairs_per_gpu': 4096,
+                   'objects_per_scene': 128, 'points_per_object': 512, 'emb_dim': 100, 'modules': ['point', 'gat', 'rel'], 'parallelism': 'dp1',
+                   'loss': 1.5e10, 'peak_hbm_gib': 40.0},
+        'roofline': roofs[0], 'roofline_other': roofs[1:],
+        'extra_exact_f32': {'mode': 'm' * 300, 'value': 579.4, 'ms_per_step': 7070.0, 'roofline': roofs},
+        'default_vs_exact_f32': {'loss_rel_diff': 1e-8, 'max_grad_diff_rel_to_own_max': 2e-4, 'worst_param': 'meta_embedding_rel.weight',
+                                 'note': 'n' * 800, 'fp64_evidence': {'a': 'b' * 500}},
+        'extra_c2': {'workload': 'c' * 200, 'value': 11000.0, 'ms_per_step': 46.0, 'roofline': roofs},
+        'extra_full_module_list': {'value': 9000.0, 'roofline': roofs, 'at_configs2_size': {'value': 494.0, 'roofline': roofs[:3]}},
+        'extra_pct': {'value': 274.0, 'ms_per_step': 14.6, 'note': 'p' * 300},
+        'hits_at_1': {'gpu': 0.42, 'oracle': 0.42, 'anchors': 1016, 'gpu_hits_1to5': [1, 2, 3, 4, 5], 'oracle_hits_1to5': [1, 2, 3, 4, 5],
+                      'max_abs_embedding_err': 3e-7, 'sample': 's' * 200},
+        'cpu_baseline': {'value': best['pairs_per_s'], 'unit': 'pairs/s', 'cores': best['threads'], 'kind': 'port',
+                         'cpu_model': 'AMD EPYC 9575F 64-Core Processor', 'sample': 'oracle fwd+loss+bwd ' + 'q' * 400, 'sweep': sweep},
+        'speedup_vs_cpu_baseline': 230.2,
+        'collectives': {'all_gather': {'calls': 3, 'bytes': 1 << 30, 'ms': 1.0}, 'detail': 'd' * 2000},
+        'weak_scaling_point': {'value': 80000.0, 'ms_per_step': 50.0, 'scaling': 'weak', 'workload': 'w' * 300},
+    }
+
+
+def test_compact_line_is_small_and_complete(tmp_path):
+    for bloat in (1, 8):
+        full = fake_full(bloat)
+        out = io.StringIO()
+        compact = bench.emit(full, out=out, root=str(tmp_path))
+        lines = out.getvalue().splitlines()
+        assert len(lines) == 1
+        assert len(lines[-1]) < 4096
+        got = json.loads(lines[-1])
+        assert got == compact
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                  'data', 'config', 'roofline', 'cpu_baseline', 'hits_at_1'):
+            assert k in got, k
+        assert len(got['config']['workload']) <= 200 and 'model' not in got['config']
+        r = got['roofline']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_useful', 'traffic', 'kernel', 'avg_launch_ms'):
+            assert k in r, k
+        assert len(r['kernel']) <= 120 and r['frac'] == full['roofline']['frac'] and r['traffic'] == full['roofline']['traffic']
+        cb = got['cpu_baseline']
+        assert cb['value'] == full['cpu_baseline']['value'] and cb['cores'] == full['cpu_baseline']['cores'] and cb['kind'] == 'port'
+        assert cb['b'] is not None and cb['threads'] == cb['cores'] and 'sweep' not in cb
+        assert got['hits_at_1']['gpu'] == 0.42 and got['hits_at_1']['anchors'] == 1016
+        assert got['extra_exact_f32']['value'] == 579.4
+        # the full record is beside the script
+        extras = json.load(open(tmp_path / bench.EXTRAS_FILE))
+        assert extras['roofline_other'] == full['roofline_other'] and extras['cpu_baseline']['sweep'] == full['cpu_baseline']['sweep']
+
+
+def test_compact_line_without_optional_parts(tmp_path):
+    full = fake_full()
+    for k in ('cpu_baseline', 'speedup_vs_cpu_baseline', 'hits_at_1', 'extra_exact_f32', 'default_vs_exact_f32', 'extra_c2', 'extra_full_module_list',
+              'extra_pct', 'collectives', 'weak_scaling_point'):
+        full.pop(k)
+    full['roofline'], full['roofline_other'] = None, []
+    out = io.StringIO()
+    bench.emit(full, out=out, root=str(tmp_path))
+    got = json.loads(out.getvalue().splitlines()[-1])
+    assert got['roofline'] is None and got['value'] == 907.4
+
+
+def test_no_fraction_of_peak_above_one_by_construction():
+    """The forward sums of the three-plane sweep derive the joint similarities, so they are priced on what they multiply (sum D = 100 M):
+    SURVEY's 200 M would print 1.01 of the peak at the kernel's measured speed (round 5).  Fake HIP events, real pricing code."""
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    ns, j = 155648, 368640
+    # at the peak the sums sweep cannot be faster than executed / (2500 TFLOP/s): 40 MFMAs per table per 512 pairs
+    pairs = 2.0 * ns * (2 * j)
+    t_min_ms = (pairs / 512.0 * 3 * 40 * 16 * 16 * 32 * 2.0) / 2500e12 * 1e3
+    events = {'loss_multi_sums_bf16x6': [(Ev(0.0), Ev(t_min_ms), (ns, ns, j, j, 3))], '_steps': 1}
+    roofs = bench.roofline_objects(events, world=2)          # world 2: no traffic lookup
+    assert len(roofs) == 1 and roofs[0]['frac'] <= 1.0 + 1e-9, roofs[0]
+    assert roofs[0]['frac_of_bf16_peak_executed'] <= 1.0 + 1e-3
