@@ -47,9 +47,9 @@ PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA p
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) dense peak
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16X6_TFLOPS = PEAK_F16_TFLOPS / 6.0  # an fp32 product on three exact bf16 planes = six bf16 MFMAs: the pipe's ceiling in fp32-product terms
-PMC_TRAFFIC_FILE = 'r05_pmc_traffic.csv'   # written by tools/pmc_traffic.sh on the GPU box, committed under profiles/
+PMC_TRAFFIC_FILE = 'r06_pmc_traffic.csv'   # written by tools/pmc_traffic.sh on the GPU box, committed under profiles/
 HITS_PAIRS = 8                   # fixed val-style subsample for the Hits@K half of the metric
-NOISE_FLOOR = 2e-5               # see extra_f16x2.noise_from
+NOISE_FLOOR = 2e-5               # floor of the rerun-noise unit in default_vs_exact_f32: 5 x the fp32-MFMA step's own table-gradient error against fp64 at configs[2]
 
 COMPACT_LIMIT = 4096             # bytes: the driver keeps only the tail of stdout; the final line must fit and parse (tests/test_bench_line_cpu.py)
 EXTRAS_FILE = 'bench_extras.json'
@@ -155,14 +155,14 @@ def fp64_evidence():
     """What tests/test_fp64_chunked_gpu.py (the chunked fp64 evaluation of OverallLoss at configs[2]) last measured, from the committed
     report: errors against fp64 of the default step (sweeps on three exact bf16 planes), of the same step with fp32-MFMA sweeps, and of the
     opt-in two-plane fp16 mode, side by side."""
-    for name in ('r05_m_c3_gradient_vs_fp64.json', 'r05_1024_gradient_vs_fp64.json'):
+    for name in ('r06_c3_gradient_vs_fp64.json', 'r06_1024_gradient_vs_fp64.json'):
         try:
             r = json.load(open(os.path.join(ROOT, 'profiles', name)))
             e = r['meta_embedding_rel_err_vs_fp64_rel_to_own_max']
             return {'source': f'profiles/{name} (tests/test_fp64_chunked_gpu.py, {r["pairs"]} pairs x 128 objects)',
-                    'table_grad_max_err_vs_fp64_rel_to_max': {m: {k: t[k + '_max_err_rel_to_max'] for k in ('bf16x6', 'f32', 'f16x2') if k + '_max_err_rel_to_max' in t}
+                    'table_grad_max_err_vs_fp64_rel_to_max': {m: {k: t[k + '_max_err_rel_to_max'] for k in ('bf16x6', 'f32') if k + '_max_err_rel_to_max' in t}
                                                               for m, t in r['tables'].items()},
-                    'meta_embedding_rel_err_vs_fp64_rel_to_own_max': {k: e[k] for k in ('bf16x6', 'f32', 'f16x2') if k in e},
+                    'meta_embedding_rel_err_vs_fp64_rel_to_own_max': {k: e[k] for k in ('bf16x6', 'f32') if k in e},
                     'meta_embedding_rel_rerun_diff_rel_to_own_max': r.get('meta_embedding_rel_rerun_diff_rel_to_own_max')}
         except (OSError, KeyError, ValueError):
             continue
@@ -319,22 +319,13 @@ def roofline_objects(events, world):
                                     'three exact bf16 planes, six bf16 MFMAs per product, fp32 accumulate' + bn_note + ')',
                           'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                           'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed})
-        elif pmode == 'f32':
+        else:
             roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': round(ach / PEAK_F32_TFLOPS, 4),
                           'traffic': pmc_traffic_bytes('pointnet_fwd_kernel', f'T={T},P={P}', 'pointnet.hip') if world == 1 else None,
                           'kernel': 'pointnet_fwd_kernel<256,true> (object encoder: 3 per-point layers + max-pool, one wave per object' + bn_note + ')',
                           'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                           'algorithmic_flops_per_launch': alg})
-        else:
-            # modes 'f16x2' / 'f16': the fp16 hi + lo split (3 fp16 MFMAs per product) + the exact-fp32 re-run of the near-tied objects; one
-            # event pair around both launches.  Priced against the fp16 peak on ALGORITHMIC FLOPs (the executed count is ~3.3 x that).
-            roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
-                          'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': None,
-                          'kernel': 'pointnet_fwd_bf16x3_kernel<256,true,F16,TIE> + pointnet_fwd_kernel<256,true> on the near-tied objects (object encoder forward, '
-                                    'fp32-faithful fp16 hi + lo split)',
-                          'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
-                          'algorithmic_flops_per_launch': alg, 'executed_over_algorithmic': '3 fp16 MFMAs per product + ~9-17 % of the objects again in fp32'})
     for key, grad in (('loss_multi_grad_bf16x6', True), ('loss_multi_sums_bf16x6', False)):
         evs = events.get(key, [])
         if not evs:
@@ -465,9 +456,6 @@ def main():
     ap.add_argument('--no-scale-ref', action='store_true', help='skip the extra weak-scaling point (N > 1, --config auto)')
     ap.add_argument('--no-pct', action='store_true', help='skip the extra pct+gat+rel+attr small-batch measurement (N = 1)')
     ap.add_argument('--no-c2', action='store_true', help='skip the extra BASELINE configs[1] measurement (N = 1)')
-    ap.add_argument('--bf16x3', action='store_true', help='also measure the older split-bf16 x3 mode (16-bit split, not fp32-faithful at configs[2])')
-    ap.add_argument('--no-bf16x3', action='store_true', help='(kept for older command lines: the bf16x3 extra is off unless --bf16x3)')
-    ap.add_argument('--no-split', action='store_true', help='skip the extra (opt-in two-plane fp16 MFMA mode) measurements')
     ap.add_argument('--no-exact', action='store_true', help='skip the extra measurement of the same step with fp32-MFMA sweeps (extra_exact_f32)')
     args = ap.parse_args()
 
@@ -509,7 +497,7 @@ def main():
 
     if cfg.get('mfma_mode'):
         ops.set_mfma_mode(cfg['mfma_mode'])
-        args.no_bf16x3 = args.no_split = args.no_c2 = args.no_attr = args.no_exact = True      # the extras belong to the fp32 configurations
+        args.no_c2 = args.no_attr = args.no_exact = True      # the extras belong to the fp32 configurations
     dtype_label = {'f16': 'f16-in/f32-acc (loss + ranking GEMMs on wide tables); f32 encoder',
                    'bf16x6': 'f32 (fp32 operands and fp32 accumulation throughout; the anchors x negatives loss sweeps multiply them as three exact bf16 planes, '
                              'six bf16 MFMAs per product, and so does the PointNet forward -- extra_exact_f32 is the same step with both on the fp32 MFMA)',
@@ -568,15 +556,9 @@ def main():
     #          differences (fp32 atomics: order-dependent sums).  The default (bf16x6: every fp32 operand as three exact bf16 planes, six bf16
     #          MFMAs per product, fp32 accumulate) is fp32 arithmetic on the same operands; tests/test_fp64_chunked_gpu.py holds it to the
     #          fp64 evaluation at this size.
-    #   f16x2  (opt-in): two fp16 planes of 4096 x (22 bits), csrc/sweeph.hip -- narrower than fp32, never the headline; `gate_4x_noise`: every
-    #          parameter's distance from the fp32-MFMA step <= 4 x that step's rerun difference
-    #   f16x2p (opt-in): f16x2 + the PointNet forward in the same split without the re-run of near-ties
-    #   bf16x3 (--bf16x3): the older 16-bit split (two bf16 planes), NOT faithful at this size (kept for comparison).
-    extras_split = {}
     extra_exact = default_vs_exact = None
-    modes = ([] if args.no_split else ['f16x2', 'f16x2p']) + (['bf16x3'] if args.bf16x3 and not args.no_bf16x3 else [])
     want_exact = not args.no_exact and mode0 != 'f32'
-    if modes or want_exact:
+    if want_exact:
         n_x = 2 if cname == 'c3' else max(2, min(args.steps, 10))
         head_grads = {n: p.grad.detach().clone() for n, p in steps.model.named_parameters() if p.grad is not None}
         ops.set_mfma_mode('f32')
@@ -635,59 +617,7 @@ def main():
         finally:
             ops.set_mfma_mode(mode0)
             ops.KERNEL_EVENTS = None
-        del head_grads
-        for mode in modes:
-            ops.set_mfma_mode(mode)
-            try:
-                ops.KERNEL_EVENTS = {}
-                el_x, _, ld_x = timed(steps, dd, 1 if cname == 'c3' else min(2, args.warmup), n_x)
-                ev_x, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-                worst, worst_name, worst_glob, worst_ratio, worst_ratio_name = 0.0, None, 0.0, 0.0, None
-                for n, p in steps.model.named_parameters():
-                    if p.grad is None or n not in ref_grads:
-                        continue
-                    err = float((p.grad - ref_grads[n]).abs().max())
-                    own = err / max(1e-30, float(ref_grads[n].abs().max()))
-                    worst_glob = max(worst_glob, err / max(1e-30, gmax))
-                    ratio = own / max(f32_noise.get(n, 0.0), NOISE_FLOOR)
-                    if own > worst:
-                        worst, worst_name = own, n
-                    if ratio > worst_ratio:
-                        worst_ratio, worst_ratio_name = ratio, n
-                ex = {'mode': f'{mode} (opt-in): ' + (ops.F16X2_COVERAGE if mode == 'f16x2' else ops.F16X2P_COVERAGE if mode == 'f16x2p' else ops.BF16X3_COVERAGE),
-                      'value': round(total_pairs * n_x / el_x, 2), 'unit': 'pairs/s', 'ms_per_step': round(el_x / n_x * 1e3, 3), 'steps': n_x,
-                      'loss_rel_err_vs_f32': abs(float(ld_x['loss'].item()) - float(ld_f['loss'].item())) / max(1e-30, abs(loss_val)),
-                      # gradient error against the fp32-MFMA step on the same batch: relative to the largest gradient entry of the whole model,
-                      # and -- worst case -- relative to the parameter's own largest entry
-                      'max_grad_err_rel_to_global_max': worst_glob, 'max_grad_err_rel_to_own_max': worst, 'worst_param': worst_name,
-                      'f32_rerun_err_rel_to_own_max_same_param': f32_noise.get(worst_name),
-                      'f32_rerun_max_err_rel_to_own_max': max(f32_noise.values()) if f32_noise else None,
-                      'max_err_over_f32_rerun_noise': round(worst_ratio, 3), 'max_err_over_noise_param': worst_ratio_name,
-                      'gate_4x_noise': bool(worst_ratio <= 4.0),
-                      'noise_floor_rel_to_own_max': NOISE_FLOOR, 'noise_from': 'reruns of the fp32-MFMA step on the same batch; floor = 5 x that step\'s own '
-                      'table-gradient error against fp64 at this size'}
-                if mode == 'f16x2':
-                    for key, grad in (('loss_multi_grad_f16x2', True), ('loss_multi_sums_f16x2', False)):
-                        evs = ev_x.get(key, [])
-                        if evs:
-                            ns_, A_, J1_, J2_, M_ = evs[0][2]
-                            ms_ = float(np.mean([a_.elapsed_time(b_) for a_, b_, _ in evs]))
-                            alg_ = (2.0 if grad else 1.0) * (2.0 * 200 * M_ * 2.0 * ns_ * (J1_ + J2_))
-                            if grad:
-                                ex['coef_lo'] = bool(ops._f16x2_coef_lo(ns_, J1_, J2_))
-                            ex['sweep_grad' if grad else 'sweep_sums'] = {
-                                'kernel': f'sweeph_kernel<{M_},{"true" if grad else "false"}> (csrc/sweeph.hip)', 'avg_launch_ms': round(ms_, 3),
-                                'algorithmic_tflops': round(alg_ / (ms_ * 1e-3) / 1e12, 1),
-                                'frac_of_fp16_mfma_peak_algorithmic': round(alg_ / (ms_ * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
-                                'note': 'algorithmic FLOPs as for the fp32 sweeps (SURVEY 8d); the split executes 3 fp16 MFMAs per product'}
-                extras_split[mode] = ex
-            except Exception as e:           # the opt-in measurement must never cost the headline line
-                extras_split[mode] = {'mode': f'{mode} (opt-in)', 'error': f'{type(e).__name__}: {e}'}
-            finally:
-                ops.set_mfma_mode(mode0)
-                ops.KERNEL_EVENTS = None
-        del ref_grads
-    extra = extras_split.get('bf16x3')
+        del head_grads, ref_grads
 
     # ---- extras at N = 1 under --config auto (the headline is configs[2]): BASELINE configs[1] (512 pairs x 64 objects x 512 pts) as
     # its own full measurement with its own roofline object, and the same batch with the reference's full module list
@@ -735,36 +665,6 @@ def main():
                           'ms_per_step': round(el4 / n4 * 1e3, 3), 'steps': n4, 'warmup': 2,
                           'dtype': dtype_label,
                           'roofline': roofline_objects(ev4, world)}
-            if not args.no_split:
-                # the same M = 4 step in the fp32-faithful 'f16x2' mode (sweeph_kernel<4, ...>: four waves per workgroup, one per SIMD), with its
-                # gradient error against the exact-fp32 step and that step's own rerun noise -- as extra_f16x2 does at configs[2]
-                ref4 = {n: p.grad.detach().clone() for n, p in steps4.model.named_parameters() if p.grad is not None}
-                noise4 = {}
-                for _ in range(2):
-                    steps4.forward_backward(dd2)
-                    torch.cuda.synchronize()
-                    for n, p in steps4.model.named_parameters():
-                        if p.grad is not None and n in ref4:
-                            noise4[n] = max(noise4.get(n, 0.0), float((p.grad - ref4[n]).abs().max()) / max(1e-30, float(ref4[n].abs().max())))
-                ops.set_mfma_mode('f16x2')
-                try:
-                    el4h, _, _ = timed(steps4, dd2, 2, n4)
-                    ratio4, name4, own4 = 0.0, None, 0.0
-                    for n, p in steps4.model.named_parameters():
-                        if p.grad is None or n not in ref4:
-                            continue
-                        own = float((p.grad - ref4[n]).abs().max()) / max(1e-30, float(ref4[n].abs().max()))
-                        r = own / max(noise4.get(n, 0.0), NOISE_FLOOR)
-                        own4 = max(own4, own)
-                        if r > ratio4:
-                            ratio4, name4 = r, n
-                    extra_attr['f16x2'] = {'value': round(CONFIGS['c2']['pairs_per_gpu'] * n4 / el4h, 2), 'unit': 'pairs/s',
-                                           'ms_per_step': round(el4h / n4 * 1e3, 3), 'max_grad_err_rel_to_own_max': own4,
-                                           'max_err_over_f32_rerun_noise': round(ratio4, 3), 'max_err_over_noise_param': name4,
-                                           'gate_4x_noise': bool(ratio4 <= 4.0), 'noise_floor_rel_to_own_max': NOISE_FLOOR}
-                finally:
-                    ops.set_mfma_mode(mode0)
-                del ref4
             # ... and at the HEADLINE's size: configs[2] (4096 pairs x 128 objects x 512 pts on this GPU) with the full module list
             if cname == 'c3' and not args.no_attr_c3:
                 dd2 = None
@@ -866,12 +766,6 @@ def main():
         if extra_exact is not None:
             line['extra_exact_f32'] = extra_exact
             line['default_vs_exact_f32'] = default_vs_exact
-        if extras_split.get('f16x2') is not None:
-            line['extra_f16x2'] = extras_split['f16x2']
-        if extras_split.get('f16x2p') is not None:
-            line['extra_f16x2p'] = extras_split['f16x2p']
-        if extra is not None:
-            line['extra_bf16x3'] = extra
         if extra_c2 is not None:
             line['extra_c2'] = extra_c2
         if extra_attr is not None:

@@ -24,8 +24,8 @@ int sga_version(void);                 /* 100 * major + minor */
 const char* sga_last_error(void);
 int sga_device_cus(void);
 /* The library is STATELESS (SURVEY 8(b) "Threading"): no entry point reads or writes a process-global setting.  Which arithmetic a
- * call uses is either in its name (sga_loss_multi_sums = exact fp32 MFMA, _bf16x6 = three exact bf16 planes, _f16x2 = two fp16 planes,
- * _bf16x3 = two bf16 planes, *_f16 = fp16 inputs for wide tables) or an explicit argument (sga_pointnet_fwd_ws: mode).  The policy --
+ * call uses is either in its name (sga_loss_multi_sums = exact fp32 MFMA, _centred = the same over centred tables, _bf16x6 = three exact
+ * bf16 planes, *_f16 = fp16 inputs for wide tables) or an explicit argument (sga_pointnet_fwd_ws: mode).  The policy --
  * which of them a training step calls -- lives in the caller (sgaligner_amd.ops.set_mfma_mode, SGA_MFMA_MODE). */
 
 /* ---- PointNet object encoder ------------------------------------------------------------------------
@@ -41,19 +41,14 @@ int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const flo
  * (max, arg-max) pairs are folded by a second small kernel -- identical results, per-object latency / 8.  workspace may be NULL
  * (then this is sga_pointnet_fwd). */
 size_t sga_pointnet_fwd_ws_bytes(int T, int C3);
-/* mode: the forward's arithmetic.  0 = exact fp32 (sga_pointnet_fwd is this); 1 = every operand as bf16 hi + lo, three bf16 MFMAs per
- * product; 2 = fp16 hi + lo of scaled operands (values within 6e-7 of mode 0) and, with argmax != NULL, an exact-fp32 re-run of every
- * object in which some channel's two largest layer-3 values lie within tie_eps * (|a| + |b| + max|z| / 8) of each other or a pre-activation
- * within that margin of zero: needs workspace >= 4 (T + 1) bytes and leaves [count | object ids] (int32) there; the listed objects carry
- * the fp32 kernel's own bits (values and arg-maxes), so the max-pool's arg-max routes the backward exactly as in mode 0
- * (pointnet.py:140-161); 3 = mode 2 without the re-run; 4 = every fp32 operand as THREE exact bf16 terms (8 + 8 + 8 significand bits, fp32's
- * exponent range: the value itself), six bf16 MFMAs per product into fp32 accumulators -- fp32 arithmetic on the bf16 matrix pipe, as the
- * default loss sweeps (sga_loss_multi_*_bf16x6), in both launch forms (identical bits); with C3 = 256, T >= 4 x CUs (or no partials workspace)
- * and a workspace of >= 81 920 bytes the kernel keeps the l planes of W2 / W3 there and one workgroup serves whole objects (1.15 x faster).
- * tie_eps < 0: the default 2^-17. */
+/* mode: the forward's arithmetic.  0 = exact fp32 on v_mfma_f32_32x32x2_f32 (sga_pointnet_fwd is this); 4 = every fp32 operand as THREE exact
+ * bf16 terms (8 + 8 + 8 significand bits, fp32's exponent range: the value itself), six bf16 MFMAs per product into fp32 accumulators --
+ * fp32 arithmetic on the bf16 matrix pipe, as the default loss sweeps (sga_loss_multi_*_bf16x6), in both launch forms (identical bits);
+ * with C3 = 256, T >= 4 x CUs (or no partials workspace) and a workspace of >= 81 920 bytes the kernel keeps the l planes of W2 / W3 there
+ * and one workgroup serves whole objects (1.15 x faster).  (pointnet.py:140-161) */
 int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
-                        void* workspace, size_t ws_bytes, int mode, float tie_eps, void* stream);
+                        void* workspace, size_t ws_bytes, int mode, void* stream);
 /* The forward in mode 0 (exact fp32) or 4 (three exact bf16 planes) that ALSO delivers the side effect of the reference's training forward: its three BatchNorm calls discard
  * their output but fold the batch statistics of the pre-ReLU conv outputs over all T*P points into running_mean / running_var
  * (pointnet.py:141-142,154-155,158-159).  The sums are taken inside the forward kernel (no second pass over the activations) and folded in
@@ -172,6 +167,22 @@ int sga_loss_multi_sums(const float* const* Z, int M, int D, const float* beta, 
                         double* sums, int a_lo, int a_hi, void* stream);
 int sga_loss_multi_grad(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                         const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
+/* The same two fp32-MFMA sweeps with the gradient delivered in TWO parts (src/aligner/losses.py:43-58 through F.normalize's backward: a
+ * table of nearly parallel rows -- meta_embedding_rel -- has an almost radial gradient, and the tangential part that survives the
+ * normalisation's Jacobian must not be the rounding residue of a large radial sum).  sga_loss_centre_tables: packed table Z [R(+32), 104]
+ * (R = 2A + J1 + J2) -> Zc [R(+32), 104] = (z - zbar | b = zbar.(z - zbar) + |zbar|^2/2 | 1 | 0 | 0), zbar = 0 unless |mean row|^2 >= 1/4
+ * (same rule and same fixed-order column means as sga_loss_split3_tables); stat_ws: sga_loss_centre_bytes() bytes, receives the table's
+ * statistics block.  The _centred sweeps take those tables (emb_dim <= 100): the owner side reads columns 100 / 101 swapped, so the MFMAs
+ * still deliver S_ij = z_i . z_j; dZ[r, 0..100) += sum_j c_rj (z_j - zbar), dZ[r, 101] += sum_j c_rj.  The A x A stash products take Zc as
+ * their B operand (sga_loss_stash_grad*: same two parts); sga_loss_scatter_tangent_stat projects G - rho (z_r - zbar). */
+size_t sga_loss_centre_bytes(void);
+int sga_loss_centre_tables(const float* Z, int A, int J1, int J2, float* Zc, void* stat_ws, void* stream);
+int sga_loss_multi_sums_centred(const float* const* Zc, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                                double* sums, int a_lo, int a_hi, void* stream);
+int sga_loss_multi_grad_centred(const float* const* Zc, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
+                                const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
+int sga_loss_scatter_tangent_stat(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int R, int D,
+                                  const void* stat_ws, float* dE, void* stream);
 /* fused anchors x anchors terms (M in {2,3,4}): same outputs as sga_loss_anchor_fwd/bwd for tables (Z_1..Z_M, joint), with the
  * joint similarities derived in registers; bwd writes M1[m] = dL/dS_m + beta_m dL/dS_J (no joint stash) and gamma[m] += dL/dbeta_m.
  * bwd with out_terms != NULL ([(M+1) + 2M] doubles + slots, like `out` of the fwd call) ALSO returns the forward term values of the
@@ -195,16 +206,6 @@ int sga_loss_anchor_multi_bwd_sym(const float* const* Z, int M, const float* bet
                                   double* gamma, int a_lo, int a_hi, double* out_terms, void* stream);
 int sga_loss_stash_grad_sym(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
                             void* stream);
-/* MFMA mode 'f16x2': sga_loss_anchor_multi_bwd_symx with the similarities S = X1 X2^T on fp16 MFMA from rows held as fp16 hi + lo of 4096 x
- * (22 significand bits, hi.hi + hi.lo + lo.hi, fp32 accumulate: fp32's own error on S; rows centred on their column mean, the mean's share
- * carried by two bookkeeping columns).  Zh[m] = sga_loss_aa_planes(Z[m], rows = 2A, out): out holds rows + 1 rows of 104 floats (the last one
- * receives the column mean), same row pitch as the fp32 table.  losses.py:6,50-57,81-94. */
-int sga_loss_aa_planes(const float* Z, size_t rows, float* out, void* stream);
-int sga_loss_anchor_multi_bwd_symx_h16(const float* const* Zh, int M, const float* beta, int A, const double* sums, float alpha,
-                                       float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
-                                       double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir,
-                                       double* out_terms, void* stream);
-
 /* The same two entry points for ONE RANK of an anchor-sharded job (new design; the reference has no multi-GPU path:
  * src/engine/base_trainer.py:70,146-158 is dead): rows [a_lo, a_hi) meet the columns [j_lo, j_hi) only; tiles at j >= mir also produce the
  * mirrored element (j, i) (stash M2, rows j - mir), tiles left of mir are visited in the ordered way and must lie in the block's own
@@ -215,50 +216,12 @@ int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, const float* be
 int sga_loss_stash_grad_symx(const float* M1, const float* M2, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi,
                              int j_lo, int j_hi, int mir, void* stream);
 
-/* MFMA mode 'f16x2': the four stash products of sga_loss_stash_grad_symx on fp16 MFMA with both operands split into fp16 hi + lo of scaled
- * values (22 significand bits, fp32 accumulate; csrc/stashh.hip).  `planes` = sga_loss_stash_planes(Z = the table's unit rows [X1 | X2 | ...],
- * width 104) -- sga_loss_stash_planes_bytes(A) bytes, built once per step and table; cmax = one uint32 on the device: the float bits of
- * the largest |value| in M1 / M2 (the products scale the stash by it).  dZ [>= 2A, 104] is accumulated into (atomics).  The block's rows,
- * a_lo, j_lo and mir must be multiples of 8 (a ragged last block: use sga_loss_stash_grad_symx).  losses.py:6,50-57,81-94 (autograd). */
-size_t sga_loss_stash_planes_bytes(int A);
-int sga_loss_stash_planes(const float* Z, int A, int Dp, void* planes, void* stream);
-int sga_loss_stash_grad_symx_f16x2(const float* M1, const float* M2, const void* planes, const uint32_t* cmax, int A, float* dZ,
-                                   int a_lo, int a_hi, int j_lo, int j_hi, int mir, void* stream);
 /* ZJ[r, m*104+d] = sqrt(beta_m) Z_m[r,d] for the anchor rows (operand of the anchors x anchors kernels), and its adjoint */
 int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream);
 int sga_loss_fold_joint(const float* const* Z, int M, const float* beta, const float* dZJ, int rows, float* const* dZ,
                         double* gamma2, void* stream);
 /* *poison = NaN if any row norm is below F.normalize's eps (the identity above would not hold): fail loudly */
 int sga_loss_check_norms(const float* nrm, int n, float* poison, void* stream);
-
-/* ---- opt-in split-bf16 x3 form of the two fused sweeps above (sga_set_mfma_mode(1); sweepb.hip) ----------------------
- * sga_loss_split_tables: packed fp32 table Z [R(+32), 104] (sga_loss_gather, Dp = 104) -> Zb, 32-row blocks of four bf16 planes
- * (row-major hi/lo + transposed hi/lo; segments X1 | X2 | N1 | N2 each padded to whole blocks), sga_loss_split_bytes bytes.
- * sga_loss_multi_sums_bf16x3 / _grad_bf16x3: same arguments and outputs as sga_loss_multi_sums / sga_loss_multi_grad with the
- * M tables given as Zb; every similarity / gradient product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi) into fp32. M in {2,3}. */
-size_t sga_loss_split_bytes(int A, int J1, int J2);
-int sga_loss_split_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
-int sga_loss_multi_sums_bf16x3(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                               double* sums, int a_lo, int a_hi, void* stream);
-int sga_loss_multi_grad_bf16x3(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                               const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, void* stream);
-
-/* ---- opt-in, fp32-faithful split-fp16 form of the two fused sweeps (sga_set_mfma_mode(3); sweeph.hip) -------------------------
- * replaces the autograd of losses.py:5-15 on the anchors x negatives products, like sga_loss_multi_sums / sga_loss_multi_grad.
- * sga_loss_split16_tables: packed fp32 table Z [R(+32), 104] -> Zb, 32-row blocks of fp16 hi / lo planes of 4096 z in MFMA operand
- * order + the packed K tail (sga_loss_split16_bytes bytes; segments X1 | X2 | N1 | N2 each padded to whole blocks).
- * sga_loss_multi_sums_f16x2 / _grad_f16x2: same arguments and outputs as sga_loss_multi_sums / sga_loss_multi_grad with the M tables
- * given as Zb; every product is hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16 into fp32 (22 significand bits per operand).
- * coef_lo != 0: the coefficients enter the gradient GEMM as hi + lo as well; 0: rounded to fp16 (11 bits, independent per pair).
- * s_lo != 0: the forward sums use the full three-product similarities; 0: hi.hi only on the 96 main columns (the K tail with the centring's
- * bookkeeping columns stays complete) -- for sums of >= 2^24 terms, where the unbiased 1e-5 error per similarity averages out.
- * M in {2,3,4} (M = 4: four waves per workgroup, one per SIMD). */
-size_t sga_loss_split16_bytes(int A, int J1, int J2);
-int sga_loss_split16_tables(const float* Z, int A, int J1, int J2, void* Zb, void* stream);
-int sga_loss_multi_sums_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                              double* sums, int a_lo, int a_hi, int s_lo, void* stream);
-int sga_loss_multi_grad_f16x2(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                              const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi, int coef_lo, void* stream);
 
 /* ---- the two fused sweeps with every fp32 operand split EXACTLY into three bf16 terms (ops.set_mfma_mode('bf16x6'); sweep3.hip) ------
  * replaces src/aligner/losses.py:5-15 (calculate_prob_dist's anchors x negatives products) and its autograd, like sga_loss_multi_sums /

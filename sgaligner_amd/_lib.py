@@ -32,7 +32,7 @@ SIGNATURES = {
     'sga_loss_neg_grad_f16': (I, [P, P, I, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
     'sga_loss_head_fwd': (I, [P, I, P, P, I, c_double, c_double, c_double, c_double, P, P]),
     'sga_loss_head_bwd': (I, [P, P, I, P, P, I, c_double, c_double, c_double, c_double, P, P, P, P]),
-    'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, I, F, P]),
+    'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, I, P]),
     'sga_pointnet_fwd_bn_ws_bytes': (c_size_t, [I, I]),
     'sga_pointnet_fwd_bn': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, P, c_size_t, P, I, P]),
     'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, P]),
@@ -81,6 +81,11 @@ SIGNATURES = {
     'sga_loss_anchor_bwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, P, P, I, I, P]),
     'sga_loss_multi_sums': (I, [P, I, I, P, I, I, I, F, F, P, I, I, P]),
     'sga_loss_multi_grad': (I, [P, I, I, P, I, I, I, F, F, P, P, P, I, I, P]),
+    'sga_loss_centre_bytes': (c_size_t, []),
+    'sga_loss_centre_tables': (I, [P, I, I, I, P, P, P]),
+    'sga_loss_multi_sums_centred': (I, [P, I, P, I, I, I, F, F, P, I, I, P]),
+    'sga_loss_multi_grad_centred': (I, [P, I, P, I, I, I, F, F, P, P, P, I, I, P]),
+    'sga_loss_scatter_tangent_stat': (I, [P, P, P, P, I, I, P, P, P]),
     'sga_loss_build_joint': (I, [P, I, P, I, P, P]),
     'sga_loss_fold_joint': (I, [P, I, P, P, I, P, P, P]),
     'sga_loss_check_norms': (I, [P, I, P, P]),
@@ -91,20 +96,7 @@ SIGNATURES = {
     'sga_loss_anchor_multi_bwd_sym': (I, [P, I, P, I, P, F, F, F, P, P, P, P, P, I, I, P, P]),
     'sga_loss_stash_grad_sym': (I, [P, P, P, I, I, P, I, I, P]),
     'sga_loss_anchor_multi_bwd_symx': (I, [P, I, P, I, P, F, F, F, P, P, P, P, P, I, I, I, I, I, P, P]),
-    'sga_loss_anchor_multi_bwd_symx_h16': (I, [P, I, P, I, P, F, F, F, P, P, P, P, P, I, I, I, I, I, P, P]),
-    'sga_loss_aa_planes': (I, [P, c_size_t, P, P]),
-    'sga_loss_stash_planes_bytes': (c_size_t, [I]),
-    'sga_loss_stash_planes': (I, [P, I, I, P, P]),
-    'sga_loss_stash_grad_symx_f16x2': (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     'sga_loss_stash_grad_symx': (I, [P, P, P, I, I, P, I, I, I, I, I, P]),
-    'sga_loss_split_bytes': (c_size_t, [I, I, I]),
-    'sga_loss_split_tables': (I, [P, I, I, I, P, P]),
-    'sga_loss_multi_sums_bf16x3': (I, [P, I, P, I, I, I, F, F, P, I, I, P]),
-    'sga_loss_multi_grad_bf16x3': (I, [P, I, P, I, I, I, F, F, P, P, P, I, I, P]),
-    'sga_loss_split16_bytes': (c_size_t, [I, I, I]),
-    'sga_loss_split16_tables': (I, [P, I, I, I, P, P]),
-    'sga_loss_multi_sums_f16x2': (I, [P, I, P, I, I, I, F, F, P, I, I, I, P]),
-    'sga_loss_multi_grad_f16x2': (I, [P, I, P, I, I, I, F, F, P, P, P, I, I, I, P]),
     'sga_loss_split3_bytes': (c_size_t, [I, I, I]),
     'sga_loss_split3_tables': (I, [P, I, I, I, P, P, P]),
     'sga_loss_scatter_tangent': (I, [P, P, P, P, I, I, I, I, P, P, P]),

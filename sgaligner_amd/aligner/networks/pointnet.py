@@ -39,9 +39,8 @@ class PointNetfeat(BaseNetwork):
             self.bn3 = nn.BatchNorm1d(out_size)
         # The reference's discarded BN calls still update running_mean / running_var / num_batches_tracked in train mode
         # (pointnet.py:141-142,154-155,158-159).  The buffers never reach any output, but a checkpoint carries them, so the side effect is
-        # reproduced by default: the exact-fp32 forward kernel sums the batch statistics of the three pre-activations on its way
-        # (sga_pointnet_fwd_bn, no second pass).  In the opt-in arithmetic modes whose forward is another kernel the statistics come from one
-        # extra forward of that kernel.  SGA_POINTNET_BN_STATS=0 (or this attribute) switches the side effect off.
+        # reproduced by default: the forward kernel (either arithmetic) sums the batch statistics of the three pre-activations on its way
+        # (sga_pointnet_fwd_bn, no second pass).  SGA_POINTNET_BN_STATS=0 (or this attribute) switches the side effect off.
         import os
         self.update_bn_running_stats = os.environ.get('SGA_POINTNET_BN_STATS', '1') != '0'
         if init_weights:                                     # pointnet.py:116-118
@@ -61,19 +60,6 @@ class PointNetfeat(BaseNetwork):
         y = ops.pointnet(xt.float() if xt.dtype != torch.float32 else xt, self.conv1.weight, self.conv1.bias,
                          self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias, bn_sums=bn_sums)
         if bn_sums is not None:
-            self._fold_bn_sums(bn_sums, xt.shape[0] * xt.shape[1])
-        elif side and self.out_size in (64, 128, 256):
-            # an arithmetic mode whose forward is another kernel ('bf16x3', 'f16x2', 'f16'): the statistics from one extra forward of the fusable
-            # kernel (values only, no arg-max), in the default arithmetic
-            with torch.no_grad():
-                bn_sums = torch.empty((265 + 2 * self.out_size,), device=xt.device, dtype=torch.float64)
-                old = ops.set_mfma_mode(ops.DEFAULT_MFMA_MODE)
-                try:
-                    ops.pointnet_forward(xt.float() if xt.dtype != torch.float32 else xt, self.conv1.weight.reshape(64, -1), self.conv1.bias,
-                                         self.conv2.weight.reshape(128, -1), self.conv2.bias, self.conv3.weight.reshape(self.out_size, -1), self.conv3.bias,
-                                         want_argmax=False, bn_sums=bn_sums)
-                finally:
-                    ops.set_mfma_mode(old)
             self._fold_bn_sums(bn_sums, xt.shape[0] * xt.shape[1])
         elif side:
             self._update_bn_running_stats(xt)

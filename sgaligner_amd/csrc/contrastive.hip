@@ -420,6 +420,7 @@ struct MultiArgs {
     float* dZ[4];                   // GRAD out, atomic accumulate
     double* gamma;                  // [M]                   GRAD out
     int ktail;                      // K steps of 4 past k = 96 that hold data: ceil((D - 96) / 4), D = 100 -> 1 (columns 100..103 are zero padding)
+    int swap_tail;                  // centred tables (sga_loss_centre_tables: columns 100 = b, 101 = 1): the OWNER reads columns 100 and 101 swapped, so that the K tail adds b_i + b_j
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(S16_THREADS, (S16_WAVES == 4 && M <= 3) ? 2 : 1) vo
 #pragma unroll
         for (int q = 0; q < 6; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 16 * q + 4 * g4) * msk;   // k = 16q + 4g4 + r
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) ownt[m][t] = src[96 + 4 * t + g4] * msk;                                     // k = 96 + 4t + g4
+        for (int t = 0; t < NTL; ++t) ownt[m][t] = src[96 + 4 * t + ((t == 1 && a.swap_tail) ? (g4 ^ 1) : g4)] * msk;      // k = 96 + 4t + g4
         beta[m] = a.beta[m];
     }
     f32x4 gacc[GRAD ? M : 1][NCT];
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void sweep16x2_kernel(MultiArgs a) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) own[m][q] = *reinterpret_cast<const f32x4*>(src + 16 * q + 4 * g4) * msk;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) ownt[m][t] = src[96 + 4 * t + g4] * msk;
+        for (int t = 0; t < 2; ++t) ownt[m][t] = src[96 + 4 * t + ((t == 1 && a.swap_tail) ? (g4 ^ 1) : g4)] * msk;
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) { bm[m] = a.beta[2 * th + m]; bp[m] = a.beta[2 * (1 - th) + m]; }
@@ -1538,61 +1539,6 @@ __global__ void inv_sums_kernel(const double* __restrict__ sums, float* __restri
     if (i < n) inv[i] = (float)(1.0 / (sums[i] + 1e-9));
 }
 
-typedef _Float16 aa_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 aa_f16x2 __attribute__((ext_vector_type(2)));
-typedef float aa_f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma_f16h(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(aa_f16x8, a), __builtin_bit_cast(aa_f16x8, b), c, 0, 0, 0);
-}
-// Rows of width 104 floats (columns 100..103 zero) -> the same 416 bytes as fp16 hi + lo of 4096 x' :
-//   [K step q = 0..2: hi of columns 32 q .. 32 q + 31 (64 B) | lo (64 B)] | hi of columns 96..103 (16 B) | lo (16 B)
-// CENTRED like the sweeps' planes (sweeph.hip): x' = x - xbar (xbar = the column mean of the table's 2A rows), column 100 = b = xbar . x' +
-// |xbar|^2 / 2, column 101 = 1, so that with the OTHER operand's two columns swapped (1, b) the tail adds b_i + b_j and the MFMAs deliver
-// x_i . x_j exactly.  Without it a table of nearly identical rows ('rel') sees every similarity shifted by the same 22-bit rounding residue,
-// 1e-6 in every q against the sums -- 5 x the rerun noise on meta_embedding_rel.weight at configs[2].  The kernel swaps the two columns of its
-// own rows (B operands) as it reads their tails from LDS; the rows it streams from L2 (A operands) are used as stored.
-// Column sums in a FIXED order (fp64 partials per block, folded in block order by aa_mean_kernel): the planes -- and with them every A x A
-// similarity of the mode -- are bitwise reproducible from run to run; the atomic float form was not (round-4 advisor).
-__global__ __launch_bounds__(128) void aa_colsum_kernel(const float* __restrict__ Z, size_t rows, double* __restrict__ part) {
-    const int d = threadIdx.x;
-    const size_t per = (rows + gridDim.x - 1) / gridDim.x, r0 = (size_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
-    if (d >= 104) return;
-    double sum = 0.0;
-    for (size_t r = r0; r < r1; ++r) sum += (double)Z[r * 104 + d];
-    part[(size_t)blockIdx.x * 104 + d] = sum;
-}
-__global__ void aa_mean_kernel(const double* __restrict__ part, int nblk, float* __restrict__ zsum, size_t rows) {       // -> zsum[0..104): mean, zsum[100] = |mean|^2 / 2 (columns 100..103 of Z are zero)
-    __shared__ float sq[128];
-    const int d = threadIdx.x;
-    double t = 0.0;
-    if (d < 100) for (int b = 0; b < nblk; ++b) t += part[(size_t)b * 104 + d];
-    const float m = d < 100 ? (float)(t / (double)rows) : 0.f;
-    sq[d] = m * m;
-    __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) { if (d < o) sq[d] += sq[d + o]; __syncthreads(); }
-    if (d < 104) zsum[d] = d < 100 ? m : (d == 100 ? 0.5f * sq[0] : 0.f);
-}
-__global__ void aa_planes_kernel(const float* __restrict__ Z, size_t rows, float* __restrict__ out, const float* __restrict__ zb) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         // one thread per (row, column pair)
-    if (i >= rows * 52) return;
-    const size_t row = i / 52;
-    const int c = (int)(i - row * 52) * 2;
-    float a, b;
-    if (c < 100) { a = (Z[row * 104 + c] - zb[c]) * 4096.f; b = (Z[row * 104 + c + 1] - zb[c + 1]) * 4096.f; }
-    else if (c == 100) {
-        float dot = zb[100];
-        for (int d = 0; d < 100; ++d) dot = fmaf(zb[d], Z[row * 104 + d] - zb[d], dot);
-        a = dot * 4096.f; b = 4096.f;
-    } else { a = 0.f; b = 0.f; }
-    const aa_f16x2 h = __builtin_convertvector(aa_f32x2{a, b}, aa_f16x2);
-    const aa_f16x2 l = __builtin_convertvector(aa_f32x2{a - (float)h[0], b - (float)h[1]}, aa_f16x2);
-    unsigned* o = reinterpret_cast<unsigned*>(out + row * 104);
-    const int q = c >> 5, k = c & 31;
-    if (c < 96) { o[q * 32 + (k >> 1)] = __builtin_bit_cast(unsigned, h); o[q * 32 + 16 + (k >> 1)] = __builtin_bit_cast(unsigned, l); }
-    else { o[96 + ((c - 96) >> 1)] = __builtin_bit_cast(unsigned, h); o[100 + ((c - 96) >> 1)] = __builtin_bit_cast(unsigned, l); }
-}
-
 // RB = anchor rows staged per workgroup: 32 (two wave pairs, each walking its own J tiles) for M <= 3; 16 for M = 4, where 32 rows of
 // four tables are 106 KiB of LDS = one workgroup per CU (all four waves then share the 16 rows and split the J tiles four ways).
 // TERMS: the same launch also accumulates the forward TERM values (what anchor_multi_kernel<M,false> returns): the epilogue already holds
@@ -1604,14 +1550,9 @@ __global__ void aa_planes_kernel(const float* __restrict__ Z, size_t rows, float
 // owns row j.  The ICL halves of the two elements share every exp2 / g() evaluation and both denominators; the IAL halves are
 // independent.  Half the MFMAs and J-operand loads, ~0.78 of the VALU work per pair.  Tiles inside the block's own
 // column range (the diagonal square) run the ordinary epilogue.
-// H16 ('f16x2', SYM only): the similarities on v_mfma_f32_16x16x32_f16 from rows stored as fp16 hi + lo of 4096 x (aa_planes_kernel: a row
-// keeps its 416 bytes -- [K step q: hi 64 B | lo 64 B] x 3, then the 8-column tail hi 16 B | lo 16 B --, so staging and addressing are
-// unchanged): hi.hi + hi.lo + lo.hi per K step and ONE MFMA for the tail (A slots hi, hi, lo, lo against B slots hi, lo, hi, lo), 10 of 16
-// cycles instead of 26 of 32 per table and orientation; the same 22-bit arithmetic as the loss sweeps (sweeph.hip), fp32's own error on S.
-template <int M, bool TERMS = false, int RB = (M <= 3 ? 32 : 16), bool SYM = false, bool H16 = false>
+template <int M, bool TERMS = false, int RB = (M <= 3 ? 32 : 16), bool SYM = false>
 __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(AnchorMultiArgs a) {
     static_assert(!SYM || TERMS, "symmetric mode: one-pass build");
-    static_assert(!H16 || SYM, "split-fp16 similarities: the symmetric build only");
     constexpr int DP = 104, NT = M + 1, NSUB = RB / 16, TW = 4 / NSUB;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [M][2][RB][DP] own rows
     // The (M+1)*8 sum coefficients and the 3M+1 upstream coefficients are read from global memory at uniform addresses, per element
@@ -1696,54 +1637,6 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
         f32x4 P[M], Q[M];
         // J-side operands of table m + 1 are requested (all 12 quads + tails) before table m's MFMAs start: a whole table of flight time
         // for loads that come straight from L2 (compiler-scheduled two loads ahead: 12.80 ms per symmetric 2048 x 155 648 block; this: 12.39)
-        if constexpr (H16) {
-            struct JH { u32x4 p[7], q[7]; };
-            auto jloadh = [&](int m, JH& o) {
-                const unsigned char* gp = reinterpret_cast<const unsigned char*>(a.Z[m] + (size_t)(A + jrow) * DP) + 16 * g;   // X2[j] for P
-                const unsigned char* gq = reinterpret_cast<const unsigned char*>(a.Z[m] + (size_t)jrow * DP) + 16 * g;         // X1[j] for Q
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {                                // 2 q: hi of K step q, 2 q + 1: lo
-                    o.p[q] = *reinterpret_cast<const u32x4*>(gp + 64 * q);
-                    o.q[q] = *reinterpret_cast<const u32x4*>(gq + 64 * q);
-                }
-                o.p[6] = *reinterpret_cast<const u32x4*>(gp - 16 * g + 384 + 16 * (g >> 1));    // tail as A operand: slots hi, hi, lo, lo
-                o.q[6] = *reinterpret_cast<const u32x4*>(gq - 16 * g + 384 + 16 * (g >> 1));
-            };
-            JH jb[2];
-            jloadh(0, jb[0]);
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                if (m + 1 < M) jloadh(m + 1, jb[(m + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                P[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                Q[m] = P[m];
-                const JH& o = jb[m & 1];
-                const unsigned char* bp = reinterpret_cast<const unsigned char*>(lds + lofs + ((m * 2 + 0) * RB + ih * 16 + l15) * DP) + 16 * g;   // X1[i]
-                const unsigned char* bq = reinterpret_cast<const unsigned char*>(lds + lofs + ((m * 2 + 1) * RB + ih * 16 + l15) * DP) + 16 * g;   // X2[i]
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const u32x4 b1h = *reinterpret_cast<const u32x4*>(bp + 128 * q), b1l = *reinterpret_cast<const u32x4*>(bp + 128 * q + 64);
-                    const u32x4 b2h = *reinterpret_cast<const u32x4*>(bq + 128 * q), b2l = *reinterpret_cast<const u32x4*>(bq + 128 * q + 64);
-                    P[m] = mfma_f16h(o.p[2 * q + 1], b1h, P[m]);
-                    Q[m] = mfma_f16h(o.q[2 * q + 1], b2h, Q[m]);
-                    P[m] = mfma_f16h(o.p[2 * q], b1l, P[m]);
-                    Q[m] = mfma_f16h(o.q[2 * q], b2l, Q[m]);
-                    P[m] = mfma_f16h(o.p[2 * q], b1h, P[m]);
-                    Q[m] = mfma_f16h(o.q[2 * q], b2h, Q[m]);
-                }
-                {                                                            // tail as B operand: slots hi, lo, hi, lo
-                    u32x4 b1t = *reinterpret_cast<const u32x4*>(bp - 16 * g + 384 + 16 * (g & 1));
-                    u32x4 b2t = *reinterpret_cast<const u32x4*>(bq - 16 * g + 384 + 16 * (g & 1));
-                    b1t[2] = __builtin_amdgcn_alignbit(b1t[2], b1t[2], 16);    // own rows are the B operands: columns 100 <-> 101 (the halves of dword 2)
-                    b2t[2] = __builtin_amdgcn_alignbit(b2t[2], b2t[2], 16);
-                    P[m] = mfma_f16h(o.p[6], b1t, P[m]);
-                    Q[m] = mfma_f16h(o.q[6], b2t, Q[m]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { P[m][r] *= 1.f / 16777216.f; Q[m][r] *= 1.f / 16777216.f; }      // operands carry 4096 x
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
         struct JOps { f32x4 p[6], q[6]; float pt[2], qt[2]; };
         auto jload = [&](int m, JOps& o) {
             const float* gp = a.Z[m] + (size_t)(A + jrow) * DP;              // X2[j] for P
@@ -1786,7 +1679,6 @@ __global__ __launch_bounds__(CT_THREADS, 2) void anchor_multi_bwd16_kernel(Ancho
                 Q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qt[t], bq[kk], Q[m], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
         }
         // P[m][r] = S_m[i = lane&15, j = j0 + 4g + r], Q[m][r] = S_m[j, i].  One element (r) at a time, with a
         // scheduling barrier between elements: interleaving the four independent chains keeps ~4x the temporaries
@@ -2249,8 +2141,8 @@ static int plan_multi(MultiArgs& a, int target_steps, int own_rows = 128) {
     return nwg;
 }
 
-extern "C" int sga_loss_multi_sums(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0,
-                                   float tau1, double* sums, int a_lo, int a_hi, void* stream) {
+static int multi_sums_impl(const float* const* Z, int M, int D, bool centred, const float* beta, int A, int J1, int J2, float tau0,
+                           float tau1, double* sums, int a_lo, int a_hi, void* stream) {
     SGA_CHECK_ARG(Z && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(sums, (M + 1) * 8, s, "sga_loss_multi_sums")) return rc0;
@@ -2258,6 +2150,7 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, int D, const fl
     MultiArgs a{};
     int rc = fill_multi(a, Z, M, D, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi);
     if (rc) return rc;
+    a.swap_tail = centred ? 1 : 0;
     a.sums = sums;
     const int nwg = plan_multi(a, 160, S16_OWN);
     if (M == 2) launch_sweep16<2, false>(a, nwg, s);
@@ -2267,10 +2160,21 @@ extern "C" int sga_loss_multi_sums(const float* const* Z, int M, int D, const fl
     SGA_CHECK_LAUNCH("sga_loss_multi_sums");
     return SGA_OK;
 }
+extern "C" int sga_loss_multi_sums(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0,
+                                   float tau1, double* sums, int a_lo, int a_hi, void* stream) {
+    return multi_sums_impl(Z, M, D, false, beta, A, J1, J2, tau0, tau1, sums, a_lo, a_hi, stream);
+}
+// The same sweeps over CENTRED tables Zc (sga_loss_centre_tables: 100 data columns of z - zbar, column 100 = b, 101 = 1): identical
+// similarities (the owner's swapped K tail adds b_i + b_j), gradient delivered in two parts -- dZ[:, 0..99] = sum c (z - zbar),
+// dZ[:, 101] = sum c -- for sga_loss_scatter_tangent_stat.
+extern "C" int sga_loss_multi_sums_centred(const float* const* Zc, int M, const float* beta, int A, int J1, int J2, float tau0,
+                                           float tau1, double* sums, int a_lo, int a_hi, void* stream) {
+    return multi_sums_impl(Zc, M, 102, true, beta, A, J1, J2, tau0, tau1, sums, a_lo, a_hi, stream);
+}
 
-extern "C" int sga_loss_multi_grad(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0,
-                                   float tau1, const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi,
-                                   void* stream) {
+static int multi_grad_impl(const float* const* Z, int M, int D, bool centred, const float* beta, int A, int J1, int J2, float tau0,
+                           float tau1, const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi,
+                           void* stream) {
     SGA_CHECK_ARG(Z && beta && gs && dZ && gamma && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_grad: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rcz = zero_slots(gamma, M > 0 ? M : 1, s, "sga_loss_multi_grad")) return rcz;
@@ -2278,6 +2182,7 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, int D, const fl
     MultiArgs a{};
     int rc = fill_multi(a, Z, M, D, beta, A, J1, J2, tau0, tau1, true, a_lo, a_hi);
     if (rc) return rc;
+    a.swap_tail = centred ? 1 : 0;
     a.gs = gs; a.gamma = gamma;
     for (int m = 0; m < M; ++m) { SGA_CHECK_ARG(dZ[m], "sga_loss_multi_grad: null dZ"); a.dZ[m] = dZ[m]; }
     const int nwg = plan_multi(a, 160, S16_OWN);
@@ -2287,6 +2192,16 @@ extern "C" int sga_loss_multi_grad(const float* const* Z, int M, int D, const fl
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad");
     return SGA_OK;
+}
+extern "C" int sga_loss_multi_grad(const float* const* Z, int M, int D, const float* beta, int A, int J1, int J2, float tau0,
+                                   float tau1, const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi,
+                                   void* stream) {
+    return multi_grad_impl(Z, M, D, false, beta, A, J1, J2, tau0, tau1, gs, dZ, gamma, a_lo, a_hi, stream);
+}
+extern "C" int sga_loss_multi_grad_centred(const float* const* Zc, int M, const float* beta, int A, int J1, int J2, float tau0,
+                                           float tau1, const double* gs, float* const* dZ, double* gamma, int a_lo, int a_hi,
+                                           void* stream) {
+    return multi_grad_impl(Zc, M, 102, true, beta, A, J1, J2, tau0, tau1, gs, dZ, gamma, a_lo, a_hi, stream);
 }
 
 extern "C" int sga_loss_build_joint(const float* const* Z, int M, const float* beta, int rows, float* ZJ, void* stream) {
@@ -2459,47 +2374,19 @@ extern "C" int sga_loss_anchor_multi_bwd(const float* const* Z, int M, const flo
 static int symx_impl(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
                      float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
                      double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir, double* out_terms,
-                     void* stream, bool h16);
+                     void* stream);
 
 extern "C" int sga_loss_anchor_multi_bwd_symx(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
                                               float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
                                               double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir, double* out_terms,
                                               void* stream) {
-    return symx_impl(Z, M, beta, A, sums, alpha, tau_icl, tau_ial, coef, M1, M2, gs, gamma, a_lo, a_hi, j_lo, j_hi, mir, out_terms, stream, false);
-}
-
-/* MFMA mode 'f16x2': the same launch with the similarities on fp16 MFMA -- Zh[m] = sga_loss_aa_planes of table m's rows (same size and row
- * pitch as the fp32 table).  Everything after the similarities (epilogue, stashes, outputs) is the exact-fp32 code. */
-extern "C" int sga_loss_anchor_multi_bwd_symx_h16(const float* const* Zh, int M, const float* beta, int A, const double* sums, float alpha,
-                                                  float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
-                                                  double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir,
-                                                  double* out_terms, void* stream) {
-    return symx_impl(Zh, M, beta, A, sums, alpha, tau_icl, tau_ial, coef, M1, M2, gs, gamma, a_lo, a_hi, j_lo, j_hi, mir, out_terms, stream, true);
-}
-
-extern "C" int sga_loss_aa_planes(const float* Z, size_t rows, float* out, void* stream) {
-    if (rows == 0) return SGA_OK;
-    SGA_CHECK_ARG(Z && out, "sga_loss_aa_planes: null pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    float* zb = out + rows * 104;                                  // row `rows` of out: the column mean the planes are centred by
-    if (hipMemsetAsync(zb, 0, 104 * sizeof(float), s) != hipSuccess) { sga_set_error("sga_loss_aa_planes: memset failed"); return SGA_ERR_HIP; }
-    const size_t gcs = rows / 2 < 512 ? (rows + 1) / 2 : 512;
-    (void)gcs;
-    // the per-block partials live at the head of `out` (rows x 104 floats >= nblk x 104 doubles) until aa_planes_kernel overwrites it
-    const int nblk = rows / 2 < 256 ? (int)(rows / 2 > 0 ? rows / 2 : 1) : 256;
-    double* part = reinterpret_cast<double*>(out);
-    hipLaunchKernelGGL(aa_colsum_kernel, dim3(nblk), dim3(128), 0, s, Z, rows, part);
-    hipLaunchKernelGGL(aa_mean_kernel, dim3(1), dim3(128), 0, s, part, nblk, zb, rows);
-    const size_t n = rows * 52;
-    hipLaunchKernelGGL(aa_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Z, rows, out, static_cast<const float*>(zb));
-    SGA_CHECK_LAUNCH("sga_loss_aa_planes");
-    return SGA_OK;
+    return symx_impl(Z, M, beta, A, sums, alpha, tau_icl, tau_ial, coef, M1, M2, gs, gamma, a_lo, a_hi, j_lo, j_hi, mir, out_terms, stream);
 }
 
 static int symx_impl(const float* const* Z, int M, const float* beta, int A, const double* sums, float alpha,
                      float tau_icl, float tau_ial, const float* coef, float* const* M1, float* const* M2,
                      double* gs, double* gamma, int a_lo, int a_hi, int j_lo, int j_hi, int mir, double* out_terms,
-                     void* stream, bool h16) {
+                     void* stream) {
     SGA_CHECK_ARG(Z && beta && sums && coef && M1 && M2 && gs && gamma && out_terms && A >= 0, "sga_loss_anchor_multi_bwd_symx: bad argument");
     SGA_CHECK_ARG(M >= 2 && M <= 4, "sga_loss_anchor_multi_bwd_symx: M=%d (2, 3 or 4)", M);
     SGA_CHECK_ARG(a_lo % 32 == 0 && (a_hi % 32 == 0 || a_hi == A), "sga_loss_anchor_multi_bwd_symx: block [%d,%d) not on 32-row boundaries", a_lo, a_hi);
@@ -2535,11 +2422,7 @@ static int symx_impl(const float* const* Z, int M, const float* beta, int A, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(nib * nsp), dim3(CT_THREADS), lds, s, a);
     };
-    if (h16) {
-        if (M == 2) go(anchor_multi_bwd16_kernel<2, true, 32, true, true>);
-        else if (M == 3) go(anchor_multi_bwd16_kernel<3, true, 32, true, true>);
-        else go(anchor_multi_bwd16_kernel<4, true, 16, true, true>);
-    } else if (M == 2) go(anchor_multi_bwd16_kernel<2, true, 32, true>);
+    if (M == 2) go(anchor_multi_bwd16_kernel<2, true, 32, true>);
     else if (M == 3) go(anchor_multi_bwd16_kernel<3, true, 32, true>);
     else go(anchor_multi_bwd16_kernel<4, true, 16, true>);
     fold_slots(out_terms, (M + 1) + 2 * M, s);

@@ -439,7 +439,7 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     // (also unsplit when the output grid fills the chip by itself -- the wide-table stash products of configs[4], [ns x 1024..3072] over K = A:
     // they fell to the generic kernel at ~9 TFLOP/s, 14 % of that step; the TN kernel always accumulates atomically, so C is zeroed first
     // unless the caller accumulates)
-    const bool tn_big = !use_atomic && K >= 256 && gx * gy >= ncu && act == 0 && !resid;
+    const bool tn_big = !use_atomic && K >= 256 && gx * gy >= ncu && act == 0 && !resid && !colstats;      // (the TN kernel has no statistics epilogue)
     if (!a_is_f64 && transA && !transB && (use_atomic || tn_big) && a_al && b_al && M % 4 == 0 && N % 4 == 0 && !bias) {
         if (tn_big && !accumulate) {
             if (ldc == N) {

@@ -72,7 +72,6 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     float* __restrict__ y,         // [T, C3]
     int* __restrict__ argmax,      // [T, C3] or nullptr
     int T, int P, float2* __restrict__ part,               // part: SPLIT only, [T][PN_WAVES][C3] (value, index as float bits)
-    const int* __restrict__ only = nullptr,                // !SPLIT: if given, only the only[0] objects listed in only[1..] run (the 'f16x2' near-tie re-run)
     double* __restrict__ bn_part = nullptr) {              // BN: [gridDim.x * PN_WAVES][PN_BN_SLOTS(C3)][64] per-lane partial sums
     constexpr int NB3 = C3 / 32;
     constexpr int NBN = BN ? 9 + 2 * 4 + 2 * NB3 : 1;
@@ -109,9 +108,9 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_kernel(
     const int h = lane >> 5, pt = lane & 31;
     const int n_tiles = (P + 31) >> 5;
 
-    const int n_obj = (!SPLIT && only) ? min(only[0], T) : T;
+    const int n_obj = T;
     for (int it = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * PN_WAVES + wave; it < n_obj; it += SPLIT ? (int)gridDim.x : (int)gridDim.x * PN_WAVES) {
-        const int t = (!SPLIT && only) ? only[1 + it] : it;
+        const int t = it;
         const float* xt = x + (size_t)t * P * 3;
         float best[NB3];
         int bidx[NB3];
@@ -317,266 +316,12 @@ __global__ void pointnet_combine_kernel(const float2* __restrict__ part, const f
     if (argmax) argmax[i] = min(bi, P - 1);
 }
 
-// -------------------------------------------------------------------------------------------------
-// Opt-in split-bf16 x3 form of the forward (sga_set_mfma_mode(1); the default and every headline number stay exact fp32).
-//
-// fp32 MFMA runs at 1/16 of the bf16 rate.  Each fp32 operand is split into two bf16 terms, v = hi + lo with hi = bf16(v),
-// lo = bf16(v - hi) (16 significand bits together), and a product becomes three bf16 MFMAs into the same fp32 accumulator:
-// hi*hi + hi*lo + lo*hi (the dropped lo*lo term is ~2^-18 relative).  Same geometry as pointnet_fwd_kernel -- one wave per
-// object, the 3 -> 64 -> 128 -> C3 chain of a 32-point tile in registers, layer 2's accumulators are layer 3's A operand --
-// on v_mfma_f32_32x32x16_bf16 (K = 16 per instruction, 8 k-slots per lane): layer 3 is 8 K-steps x 3 MFMAs of 32 cycles per
-// 32-channel block instead of 64 fp32 MFMAs of 64 cycles.  Weights are split once per workgroup into hi / lo planes in LDS in
-// per-lane operand order (W2 2 x 16 KiB, W3 2 x 64 KiB: the same 160 KiB as the fp32 layout); activations are split in
-// registers with v_cvt_pk_bf16_f32 (6 VALU per value pair).  Measured error vs the fp32 kernel: DESIGN.md 3d.
-// -------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 8 floats -> packed bf16 hi / lo (4 dwords each; element 2p in the low half of dword p)
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const bf16x2 h = __builtin_convertvector(f32x2{v[2 * p], v[2 * p + 1]}, bf16x2);
-        const unsigned hp = __builtin_bit_cast(unsigned, h);
-        const float b0 = __builtin_bit_cast(float, hp << 16), b1 = __builtin_bit_cast(float, hp & 0xffff0000u);
-        const bf16x2 l = __builtin_convertvector(f32x2{v[2 * p] - b0, v[2 * p + 1] - b1}, bf16x2);
-        hi[p] = hp;
-        lo[p] = __builtin_bit_cast(unsigned, l);
-    }
-}
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// The same kernel in the split of the 'f16x2' loss sweeps (sga_set_mfma_mode(4), 'f16x2p'): operands as fp16 hi + lo -- 22 significand bits,
-// the products' fp32 accumulation rounding dominates -- of SCALED values, so that lo stays a normal fp16 number wherever it matters:
-// weights x 64 (|w| < 1023), activations x 8 (|h| < 8190; they are post-ReLU sums of at most 128 weighted inputs of metre-sized coordinates;
-// an activation beyond that overflows to inf and the object's output is NaN -- loud, never a wrong number).  Absolute representation error
-// <= 2^-25 / scale (4.7e-10 on a weight, 3.7e-9 on an activation) below the normal range.  The accumulators carry 512 x the pre-activation:
-// the bias enters pre-multiplied, the ReLU output is rescaled by an exact power of two on its way into the next split.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr float PN_SW = 64.f, PN_SA = 8.f;
-__device__ __forceinline__ void split8h(const float (&v)[8], float scale, u32x4& hi, u32x4& lo, float& amax) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float a = v[2 * p] * scale, b = v[2 * p + 1] * scale;
-        amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));                 // fp16 range guard (free input modifiers): see PN_F16_MAX
-        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
-        unsigned l;
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp), "v"(a));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp), "v"(b));
-        hi[p] = hp;
-        lo[p] = l;
-    }
-}
-__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-constexpr float PN_F16_MAX = 6.0e4f;          // a scaled operand at or beyond this (fp16 max 65 504) poisons the object's output with NaN
-template <bool F16> __device__ __forceinline__ void split8x(const float (&v)[8], float scale, u32x4& hi, u32x4& lo, float& amax) {
-    if (F16) split8h(v, scale, hi, lo, amax); else split8(v, hi, lo);
-}
-template <bool F16> __device__ __forceinline__ f32x16 mfma_x(u32x4 a, u32x4 b, f32x16 c) { return F16 ? mfma_f16(a, b, c) : mfma_bf16(a, b, c); }
-
-// TIE ('f16x2', training): the arg-max of the max-pool decides where the backward routes an object's gradient, and a different arithmetic
-// flips it wherever the two largest values of a channel lie closer than the arithmetics differ (1 in ~18 000 arg-maxes at the split's
-// ~1e-6; the conv-weight gradients of a 4096-pair step then differ by 100 x their rerun noise).  The kernel therefore also tracks each
-// channel's SECOND largest value (one v_med3 per element) and appends the object to the list `redo` when any channel's two leaders are
-// within tie_eps of each other, or its output's pre-activation is within tie_eps of zero (the backward's y > 0 mask -- the same
-// kind of discontinuity: ~300 flipped masks in a 4096-pair step move the conv3 weight gradient by sqrt(300) terms of a random-sign sum of
-// 1e6, 1e-3..1e-2 of its maximum); launch_fwd then re-runs exactly those objects on the exact-fp32 kernel (`only`), so every arg-max the
-// split could have moved -- and that object's values -- are the fp32 kernel's own bits.
-template <int C3, bool WITH_ARGMAX, bool F16 = false, bool TIE = false>
-__global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
-    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-    const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ y,
-    int* __restrict__ argmax, int T, int P, int* __restrict__ redo = nullptr, float tie_eps = 0.f) {
-    static_assert(!TIE || (WITH_ARGMAX && F16), "near-tie tracking: the training build of the fp16 split");
-    constexpr int NB3 = C3 / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];
-    u32x4* w2hi = reinterpret_cast<u32x4*>(ldsu);            // [4 cb2][4 ks][64 lane]   16 KiB
-    u32x4* w2lo = w2hi + 16 * 64;                            //                            16 KiB
-    u32x4* w3hi = w2lo + 16 * 64;                            // [NB3 cb3][8 ks3][64 lane] C3/4 KiB
-    u32x4* w3lo = w3hi + NB3 * 8 * 64;
-
-    const int tid = threadIdx.x;
-    float wmax = 0.f;
-    // ---- split the weights into bf16 (fp16) hi / lo planes in operand order (once per persistent workgroup)
-    for (int d = tid; d < 16 * 64; d += PN_THREADS) {       // W2 as layer-2 A operand: row = out channel, k-slots = in channels 16 ks + 8 h + j
-        const int ln = d & 63, ks = (d >> 6) & 3, cb = d >> 8;
-        const float* src = w2 + (cb * 32 + (ln & 31)) * 64 + 16 * ks + 8 * (ln >> 5);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[j];
-        split8x<F16>(v, PN_SW, w2hi[d], w2lo[d], wmax);
-    }
-    for (int d = tid; d < NB3 * 8 * 64; d += PN_THREADS) {  // W3 as layer-3 B operand: column = out channel, k-slots follow layer 2's C layout
-        const int ln = d & 63, ks3 = (d >> 6) & 7, cb = d >> 9;
-        const int cb2 = ks3 >> 1, half8 = ks3 & 1, hh = ln >> 5;
-        const float* src = w3 + (cb * 32 + (ln & 31)) * 128 + cb2 * 32 + 16 * half8 + 4 * hh;   // channel (j&3) + 8 (2 half8 + (j>>2)) + 4 h
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[(j & 3) + 8 * (j >> 2)];
-        split8x<F16>(v, PN_SW, w3hi[d], w3lo[d], wmax);
-    }
-    __syncthreads();
-    // fp16 range guard of the weights: every wave scans them itself (41 k floats from L2, once per persistent workgroup) -- the kernel's
-    // dynamic LDS is the CU's whole 160 KiB, so there is no room for a cross-wave flag
-    bool wbad = false;
-    if (F16) {
-        for (int d = tid & 63; d < 128 * 64 + C3 * 128; d += 64) wmax = fmaxf(wmax, fabsf(d < 128 * 64 ? w2[d] : w3[d - 128 * 64]) * PN_SW);
-        wbad = __any(!(wmax < PN_F16_MAX));
-    }
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, pt = lane & 31;
-    const int n_tiles = (P + 31) >> 5;
-
-    for (int t = blockIdx.x * PN_WAVES + wave; t < T; t += gridDim.x * PN_WAVES) {
-        const float* xt = x + (size_t)t * P * 3;
-        float best[NB3], sec[TIE ? NB3 : 1];
-        int bidx[NB3];
-#pragma unroll
-        for (int c = 0; c < NB3; ++c) { best[c] = -INFINITY; bidx[c] = 0; if (TIE) sec[TIE ? c : 0] = -INFINITY; }
-        float amax = 0.f;
-
-        for (int tile = 0; tile < n_tiles; ++tile) {
-            const int p0 = tile * 32;
-            int lane_o = lane, h_o = h;                       // opaque copies: keep the weight reads inside the tile loop
-            asm volatile("" : "+v"(lane_o), "+v"(h_o));
-            const int pi = min(p0 + pt, P - 1);
-            const float x0 = xt[pi * 3 + 0], x1 = xt[pi * 3 + 1], x2 = xt[pi * 3 + 2];
-
-            // ---- layer 1 (VALU, fp32): this lane's 32 channels k = 16 ks + 8 h + j, split for the MFMA B operand
-            u32x4 h1hi[4], h1lo[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int k = 16 * ks + 8 * h_o;
-                float v[8];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int kk = k + 4 * half;
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w1 + kk * 3);
-                    const f32x4 wb = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 4);
-                    const f32x4 wc = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 8);
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + kk);
-                    v[4 * half + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
-                    v[4 * half + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
-                    v[4 * half + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
-                    v[4 * half + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
-                }
-                split8x<F16>(v, PN_SA, h1hi[ks], h1lo[ks], amax);
-            }
-
-            // ---- layer 2: H2^T = W2 H1^T (A = W2 planes from LDS, B = H1 split), accumulators start at the bias
-            u32x4 h2hi[8], h2lo[8];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                f32x16 acc;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * g + 4 * h_o);
-                    const float bs = F16 ? PN_SW * PN_SA : 1.f;
-                    acc[g * 4 + 0] = bb[0] * bs; acc[g * 4 + 1] = bb[1] * bs; acc[g * 4 + 2] = bb[2] * bs; acc[g * 4 + 3] = bb[3] * bs;
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const u32x4 wh = w2hi[(cb * 4 + ks) * 64 + lane_o], wl = w2lo[(cb * 4 + ks) * 64 + lane_o];
-                    acc = mfma_x<F16>(wh, h1hi[ks], acc);
-                    acc = mfma_x<F16>(wh, h1lo[ks], acc);
-                    acc = mfma_x<F16>(wl, h1hi[ks], acc);
-                }
-#pragma unroll
-                for (int half8 = 0; half8 < 2; ++half8) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[half8 * 8 + j], 0.f);
-                    split8x<F16>(v, 1.f / PN_SW, h2hi[cb * 2 + half8], h2lo[cb * 2 + half8], amax);      // F16: 512 h2 -> 8 h2
-                }
-            }
-
-            // ---- layer 3: Z3 = H2 W3^T (A = H2 split, straight from layer 2's accumulators; B = W3 planes), running max over points
-#pragma unroll
-            for (int cb = 0; cb < NB3; ++cb) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int ks3 = 0; ks3 < 8; ++ks3) {
-                    const u32x4 wh = w3hi[(cb * 8 + ks3) * 64 + lane_o], wl = w3lo[(cb * 8 + ks3) * 64 + lane_o];
-                    acc = mfma_x<F16>(h2hi[ks3], wh, acc);
-                    acc = mfma_x<F16>(h2hi[ks3], wl, acc);
-                    acc = mfma_x<F16>(h2lo[ks3], wh, acc);
-                }
-                if (WITH_ARGMAX) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (TIE) {            // second largest so far (sec <= best).  The ragged last tile's replicated rows are no candidates, for
-                            // either place: they are copies of point P - 1, which the strict > below prefers anyway (same value, same arg-max)
-                            if (p0 + 32 > P && p0 + mfma32_row(r, h) >= P) acc[r] = -INFINITY;
-                            sec[TIE ? cb : 0] = __builtin_amdgcn_fmed3f(best[cb], sec[TIE ? cb : 0], acc[r]);
-                        }
-                        const bool gt = acc[r] > best[cb];
-                        best[cb] = gt ? acc[r] : best[cb];
-                        bidx[cb] = gt ? (p0 + mfma32_row(r, h)) : bidx[cb];
-                    }
-                } else {
-                    float m = acc[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                    best[cb] = fmaxf(best[cb], m);
-                }
-            }
-        }
-
-        const bool obad = F16 && (wbad || __any(!(amax < PN_F16_MAX)));       // an operand left the fp16 range: NaN, never a wrong number
-        bool near = false;
-        float zfloor = 0.f;                              // TIE: absolute part of the margin -- the split's error on z follows sum |h2||w3|, about the same for
-        if (TIE) {                                       // every channel of an object, not |z|: a channel whose leaders are small still errs like the large ones
-#pragma unroll
-            for (int cb = 0; cb < NB3; ++cb) zfloor = fmaxf(zfloor, fabsf(best[cb]));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) zfloor = fmaxf(zfloor, __shfl_xor(zfloor, o, 64));
-            zfloor *= 0.125f * tie_eps;
-        }
-#pragma unroll
-        for (int cb = 0; cb < NB3; ++cb) {
-            const float ov = __shfl_xor(best[cb], 32, 64);
-            float v = best[cb];
-            int bi = bidx[cb];
-            if (TIE) {
-                // the channel's two leaders over both lane halves.  Equal leaders count: two distinct points a few 1e-8 apart in one arithmetic
-                // coincide in the other (54 of 2.7e8 arg-maxes at configs[2] while only distinct values were marked)
-                const float os = __shfl_xor(sec[TIE ? cb : 0], 32, 64);
-                const float b1v = fmaxf(v, ov), s1v = fmaxf(fminf(v, ov), fmaxf(sec[TIE ? cb : 0], os));
-                const float gap = b1v - s1v;
-                near = near || (gap <= fmaf(tie_eps, fabsf(b1v) + fabsf(s1v), zfloor));
-                // ... and the ReLU mask of the output (y > 0 gates the channel's whole gradient in the backward): a pre-activation within the
-                // margin of zero could land on the other side in exact fp32
-                const float zs = b1v * (1.f / (PN_SW * PN_SA)), bc = b3[cb * 32 + pt];
-                near = near || (fabsf(zs + bc) <= fmaf(tie_eps, fabsf(zs) + fabsf(bc), zfloor * (1.f / (PN_SW * PN_SA))));
-            }
-            if (WITH_ARGMAX) {
-                const int oi = __shfl_xor(bidx[cb], 32, 64);
-                const bool take = (ov > v) || (ov == v && oi < bi);
-                v = take ? ov : v;
-                bi = take ? oi : bi;
-                bi = min(bi, P - 1);
-            } else {
-                v = fmaxf(v, ov);
-            }
-            if (h == 0) {
-                const int c = cb * 32 + pt;
-                y[(size_t)t * C3 + c] = obad ? __builtin_nanf("") : fmaxf((F16 ? v * (1.f / (PN_SW * PN_SA)) : v) + b3[c], 0.f);
-                if (WITH_ARGMAX) argmax[(size_t)t * C3 + c] = bi;
-            }
-        }
-        if (TIE) {
-            if ((obad || __any(near)) && lane == 0) redo[1 + atomicAdd(redo, 1)] = t;          // redo[0] = count, then the object ids (any order)
-        }
-    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -587,7 +332,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_bf16x3_kernel(
 // reference's fp32 operands (pointnet.py:140-161) at 6 x 32 cycles per 16 k slots where v_mfma_f32_32x32x2_f32 needs 8 x 64.
 // The five small partial products of an accumulation go to their OWN accumulator (the 16-bit MFMAs chop what falls ~7 bits below the
 // result's last place toward minus infinity whatever the sign: tools/micro/mfma_round_probe.hip), added once at the end.
-// Geometry as pointnet_fwd_bf16x3_kernel: one wave per object, the 3 -> 64 -> 128 -> C3 chain of a 32-point tile in registers, layer 2's
+// Geometry: one wave per object, the 3 -> 64 -> 128 -> C3 chain of a 32-point tile in registers, layer 2's
 // accumulators are layer 3's A operand.  LDS: W2's three planes (48 KiB) + the three planes of HALF of W3's output channels at C3 = 256
 // (96 KiB; all of them below): a workgroup serves one channel half (blockIdx & 1), two workgroups share an object and both run
 // layers 1-2 -- 2 x 96 + 384 = 576 MFMAs of 32 cycles per 32-point tile against 640 of 64.
@@ -897,16 +642,12 @@ __global__ __launch_bounds__(256) void pointnet_p3_lplanes_kernel(const float* _
     out[d] = pl;
 }
 
-// Forward arithmetic, chosen PER CALL (the library keeps no mode): 0 = exact fp32; 1 = bf16 hi + lo (three bf16 MFMAs per product);
-// 2 = fp16 hi + lo split with every near-tied object re-run on the exact-fp32 kernel (needs the [count | ids] workspace with argmax);
-// 3 = the fp16 split without the re-run; 4 = three exact bf16 planes, six bf16 MFMAs per product (fp32 arithmetic on the bf16 matrix pipe;
-// both launch forms).
-constexpr float PN_TIE_EPS_DEFAULT = 1.0f / 131072.f;      // 2^-17 of |leader| + |runner-up| (+ 2^-20 of the object's largest |z|): none of the 2.7e8 arg-maxes / masks of a configs[2] batch differs from the fp32 kernel's at 2^-18 already; 9 % of the objects re-run (tools/dbg/f16x2_pointnet_flips.py)
-
+// Forward arithmetic, chosen PER CALL (the library keeps no mode): 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 4 = three exact bf16 planes, six
+// bf16 MFMAs per product (fp32 arithmetic on the bf16 matrix pipe; both launch forms).
 template <int C3>
 int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                const float* w3, const float* b3, float* y, int* argmax, int T, int P, hipStream_t stream,
-               void* workspace, size_t ws_bytes, int mode, float tie_eps, double* bn_part = nullptr, double* bn_out = nullptr) {
+               void* workspace, size_t ws_bytes, int mode, double* bn_part = nullptr, double* bn_out = nullptr) {
     const size_t lds_bytes = (size_t)(8192 + C3 * 128) * sizeof(float);
     int grid = (T + PN_WAVES - 1) / PN_WAVES;
     const int ncu = sga_num_cus();
@@ -918,7 +659,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
     const int p3_slots_max = P3_HALVES == 2 ? (ncu / 2 > 0 ? ncu / 2 : 1) : ncu;
     const int p3_want = split_small ? T : grid;              // split form: one object per workgroup (pair) at a time
     // C3 = 256, many objects, a scratch of PN_P3_LG_BYTES in `workspace`: one workgroup per object, the l planes from global memory (LG)
-    const bool p3_lg = C3 == 256 && !split_small && workspace && ws_bytes >= PN_P3_LG_BYTES && std::getenv("SGA_POINTNET_P3_HALVES") == nullptr;
+    const bool p3_lg = C3 == 256 && !split_small && workspace && ws_bytes >= PN_P3_LG_BYTES;
     const int p3_grid = p3_lg ? grid : P3_HALVES * (p3_want < p3_slots_max ? p3_want : p3_slots_max);
     auto go_p3 = [&](double* bnp) {
         if constexpr (C3 == 256) {
@@ -962,7 +703,7 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         }
         auto go = [&](auto k) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(g), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), bn_part);
+            hipLaunchKernelGGL(k, dim3(g), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, bn_part);
         };
         if (p3) go_p3(bn_part);
         else if (split) { if (argmax) go(pointnet_fwd_kernel<C3, true, true, true>); else go(pointnet_fwd_kernel<C3, false, true, true>); }
@@ -974,69 +715,32 @@ int launch_fwd(const float* x, const float* w1, const float* b1, const float* w2
         return SGA_OK;
     }
     // few objects: one object per workgroup, its tiles dealt to the 8 waves (exact fp32 kernel only; needs the partials workspace)
-    if ((mode == 0 || mode == 2) && split_small) {
+    if (mode == 0 && split_small) {
         float2* part = static_cast<float2*>(workspace);
         const int g2 = T < ncu ? T : ncu;
         if (argmax) {
             auto k = pointnet_fwd_kernel<C3, true, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<double*>(nullptr));
         } else {
             auto k = pointnet_fwd_kernel<C3, false, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
+            hipLaunchKernelGGL(k, dim3(g2), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, part, static_cast<double*>(nullptr));
         }
         hipLaunchKernelGGL(pointnet_combine_kernel, dim3((T * C3 + 255) / 256), dim3(256), 0, stream, part, b3, y, argmax, T, C3, P);
         SGA_CHECK_LAUNCH("sga_pointnet_fwd");
         return SGA_OK;
     }
-    // ('f16', the configs[4] mode -- fp16 inputs for the loss GEMMs of wide tables -- takes the same fp32-faithful forward: PointNet is 46 % of its step)
-    const bool split_fwd = mode == 2;
     if (mode == 4) {
         go_p3(nullptr);
-    } else if (split_fwd && argmax) {             // 'f16x2', training: the forward in the fp16 split, objects with a near-tied arg-max re-run in exact fp32
-        if (!workspace || ws_bytes < (size_t)(T + 1) * sizeof(int)) { sga_set_error("sga_pointnet_fwd: modes 'f16x2' / 'f16' need a workspace of 4 (T + 1) bytes, T = %d (sga_pointnet_fwd_ws)", T); return SGA_ERR_ARG; }
-        int* redo = static_cast<int*>(workspace);
-        if (hipMemsetAsync(redo, 0, sizeof(int), stream) != hipSuccess) { sga_set_error("sga_pointnet_fwd: memset failed"); return SGA_ERR_HIP; }
-        auto k = pointnet_fwd_bf16x3_kernel<C3, true, true, true>;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, redo, tie_eps >= 0.f ? tie_eps : PN_TIE_EPS_DEFAULT);
-        auto k2 = pointnet_fwd_kernel<C3, true>;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k2, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr),
-                           static_cast<const int*>(redo), static_cast<double*>(nullptr));
-    } else if (split_fwd) {                // 'f16x2', inference: values only -- nothing to flip
-        auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
-    } else if (mode == 3) {     // 'f16x2p': the split-fp16 sweeps AND this forward in the same split, arg-maxes as the split finds them
-        if (argmax) {
-            auto k = pointnet_fwd_bf16x3_kernel<C3, true, true>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
-        } else {
-            auto k = pointnet_fwd_bf16x3_kernel<C3, false, true>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
-        }
-    } else if (mode == 1) {
-        if (argmax) {
-            auto k = pointnet_fwd_bf16x3_kernel<C3, true>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
-        } else {
-            auto k = pointnet_fwd_bf16x3_kernel<C3, false>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<int*>(nullptr), 0.f);
-        }
     } else if (argmax) {
         auto k = pointnet_fwd_kernel<C3, true>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<double*>(nullptr));
     } else {
         auto k = pointnet_fwd_kernel<C3, false>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<const int*>(nullptr), static_cast<double*>(nullptr));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN_THREADS), lds_bytes, stream, x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, static_cast<float2*>(nullptr), static_cast<double*>(nullptr));
     }
     SGA_CHECK_LAUNCH("sga_pointnet_fwd");
     return SGA_OK;
@@ -1048,17 +752,17 @@ extern "C" size_t sga_pointnet_fwd_ws_bytes(int T, int C3) { return (size_t)(T >
 
 static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                              const float* b3, float* y, int32_t* argmax, int T, int P, int C3, void* workspace, size_t ws_bytes,
-                             int mode, float tie_eps, void* stream, double* bn_part = nullptr, double* bn_out = nullptr) {
+                             int mode, void* stream, double* bn_part = nullptr, double* bn_out = nullptr) {
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_fwd: need T >= 0 and P >= 1 (got T=%d P=%d)", T, P);
-    SGA_CHECK_ARG(mode >= 0 && mode <= 4, "sga_pointnet_fwd: mode %d (0 = exact fp32, 1 = bf16 hi + lo, 2 = fp16 hi + lo with the exact re-run of near-ties, 3 = fp16 hi + lo, 4 = three exact bf16 planes)", mode);
+    SGA_CHECK_ARG(mode == 0 || mode == 4, "sga_pointnet_fwd: mode %d (0 = exact fp32, 4 = three exact bf16 planes)", mode);
     // a zero-object shard (T == 0: empty tensors carry null data pointers) is a valid no-op
     SGA_CHECK_ARG((T == 0 || (x && y)) && w1 && b1 && w2 && b2 && w3 && b3, "sga_pointnet_fwd: null pointer");
     if (T == 0) return SGA_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (C3) {
-        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps, bn_part, bn_out);
-        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps, bn_part, bn_out);
-        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, tie_eps, bn_part, bn_out);
+        case 256: return launch_fwd<256>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, bn_part, bn_out);
+        case 128: return launch_fwd<128>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, bn_part, bn_out);
+        case 64: return launch_fwd<64>(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, s, workspace, ws_bytes, mode, bn_part, bn_out);
         default:
             sga_set_error("sga_pointnet_fwd: out_size C3=%d unsupported (64, 128 or 256: W3 must fit the 160 KiB LDS)", C3);
             return SGA_ERR_ARG;
@@ -1067,8 +771,8 @@ static int pointnet_fwd_impl(const float* x, const float* w1, const float* b1, c
 
 extern "C" int sga_pointnet_fwd_ws(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                                    const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
-                                   void* workspace, size_t ws_bytes, int mode, float tie_eps, void* stream) {
-    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, mode, tie_eps, stream);
+                                   void* workspace, size_t ws_bytes, int mode, void* stream) {
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, mode, stream);
 }
 
 /* The exact-fp32 forward that also delivers the batch statistics the reference's three discarded BatchNorm calls fold into their running
@@ -1089,14 +793,14 @@ extern "C" int sga_pointnet_fwd_bn(const float* x, const float* w1, const float*
     if (T == 0) {
         if (C3 == 64 || C3 == 128 || C3 == 256) hipMemsetAsync(bn_sums, 0, (size_t)(265 + 2 * C3) * sizeof(double), static_cast<hipStream_t>(stream));
     }
-    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, mode, -1.f, stream, static_cast<double*>(bn_workspace), bn_sums);
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, workspace, ws_bytes, mode, stream, static_cast<double*>(bn_workspace), bn_sums);
 }
 
 /* the no-workspace entry: always the exact-fp32 kernel */
 extern "C" int sga_pointnet_fwd(const float* x, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* w3, const float* b3, float* y,
                                 int32_t* argmax, int T, int P, int C3, void* stream) {
-    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, nullptr, 0, 0, -1.f, stream);
+    return pointnet_fwd_impl(x, w1, b1, w2, b2, w3, b3, y, argmax, T, P, C3, nullptr, 0, 0, stream);
 }
 
 // =================================================================================================

@@ -1,13 +1,13 @@
 // The anchors x negatives loss sweeps with every fp32 operand split EXACTLY into three bf16 terms (ops.set_mfma_mode('bf16x6'); SURVEY 7:
 // "parity configs use fp32 MFMA or split-bf16 x3").  Same mathematics and the same two-owner-sweep structure as sweep16_kernel
-// (contrastive.hip, exact-fp32 MFMA) and sweeph.hip (two fp16 planes):
+// (contrastive.hip, exact-fp32 MFMA):
 //     pass 1 (sums)   s_fam,temp[table] = sum exp(S / tau)                 S = X_own . X_other^T per modality table,
 //     backward (grad) dZ[own] += C . Z[other],  C = dL/dS_m + beta_m dL/dS_J    S_J = sum_m beta_m S_m (joint table derived)
 // (reference src/aligner/losses.py:5-15 and its autograd).
 //
 // Arithmetic.  x = h + m + l with h = bf16(x), m = bf16(x - h), l = x - h - m: 8 + 8 + 8 significand bits (round to nearest at every step,
 // so |m| <= 2^-8 |x|, |l| <= 2^-16 |x|), and bf16 has fp32's exponent range -- the three terms represent EVERY fp32 value exactly, no
-// pre-scale, no range condition (the fp16 planes of sweeph.hip hold 22 bits of 4096 x).  A product x y is the six partial products
+// pre-scale, no range condition.  A product x y is the six partial products
 //     h h' + (h m' + m h') + (m m' + h l' + l h')
 // on v_mfma_f32_16x16x32_bf16 into ONE fp32 accumulator (a bf16 x bf16 product is exact in fp32); the three dropped ones (m l', l m', l l')
 // are <= 2^-23 |x y| in the worst case, 2^-27 typically -- below the rounding of the fp32 accumulation that both this kernel and the
@@ -16,7 +16,7 @@
 // The coefficient C = dL/dS (A operand of the gradient GEMM) is an fp32 value computed in fp32 exactly as in sweep16_kernel and is split the
 // same way inside the loop: v_cvt_pk_bf16_f32 + two v_dot2c_f32_bf16 (residual = x - h, exact) per plane and pair, 7 VALU per pair.
 //
-// Rows are CENTRED like sweeph.hip's planes (z' = z - zbar, bookkeeping columns 100: b = zbar . z' + |zbar|^2 / 2, 101: 1; the owner holds
+// Rows are CENTRED (z' = z - zbar, bookkeeping columns 100: b = zbar . z' + |zbar|^2 / 2, 101: 1; the owner holds
 // (1, b_i) so that the K tail adds b_i + b_j: the MFMAs deliver S_ij = z_i . z_j; the gradient GEMM's column 101 is rowsum_i = sum_j c_ij
 // and dZ_i = sum_j c_ij z'_j + rowsum_i zbar).  With exact operands this is not needed for correctness; it keeps the accumulators of a
 // table of nearly identical rows (meta_embedding_rel) small, so that its tangential gradient is not the rounding residue of a large radial
@@ -29,15 +29,14 @@
 // conflict free); the tail image = [jh][64 slots][8 bf16] of columns 96 .. 103 with k groups (h, h, m, l): against the owner's (h, m, h, h)
 // and (l, 0, m, 0) two MFMAs give the six partial products of the K tail (until round 5: two images, 22 528 B per block -- every 1-KiB
 // LDS-DMA costs the issuing wave ~60 cycles).
-// MFMA bookkeeping as in sweeph.hip: S^T tile with A = other rows from LDS, B = owner rows (registers); half jh of a 32-row tile uses A row
+// MFMA bookkeeping: S^T tile with A = other rows from LDS, B = owner rows (registers); half jh of a 32-row tile uses A row
 // i <-> other row 8 (i >> 2) + 4 jh + (i & 3), so a lane's 8 accumulator values are the 8 consecutive other rows 8 g4 .. 8 g4 + 7 = the k
 // slots of the gradient MFMA, whose A operand is therefore the coefficient registers (split into three planes) and whose B operand
 // comes from transpose reads of the same planes.
 //
 // Geometry.  Per 16 owner rows a wave holds 44 operand + 28 gradient-accumulator + 8 S registers PER TABLE; with three tables (240) plus the
 // operands in flight that is more than the 256 registers of a two-wave SIMD, so the M = 3 gradient sweep runs ONE wave per SIMD (4 waves x
-// 16 owner rows, <= 512 registers) with every LDS operand requested a group of MFMAs ahead inside the matrix stream (sched_barrier-pinned,
-// as sweeph.hip's OH = 2 build); M = 2 and the forward sums (no accumulators) run 8 waves, two per SIMD.
+// 16 owner rows, <= 512 registers) with every LDS operand requested a group of MFMAs ahead inside the matrix stream (sched_barrier-pinned); M = 2 and the forward sums (no accumulators) run 8 waves, two per SIMD.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -108,7 +107,7 @@ __host__ __device__ inline TLayout make_tlayout(int A, int J1, int J2) { return 
 constexpr int S3_STAT_BYTES = 2048;
 constexpr int S3_DREAL = 100;                    // data columns; 100, 101 are the bookkeeping columns (emb_dim <= 100 in this mode)
 
-// column sums in a FIXED order (deterministic, unlike the atomic form of sweeph.hip): block b sums its row range into part[b][c], one
+// column sums in a FIXED order (deterministic): block b sums its row range into part[b][c], one
 // workgroup folds the partials in index order.
 constexpr int S3_CS_BLOCKS = 256;
 __global__ __launch_bounds__(128) void split3_colsum_kernel(const float* __restrict__ Z, int R, double* __restrict__ part) {
@@ -197,6 +196,32 @@ __global__ __launch_bounds__(256) void split3_tables_kernel(const float* __restr
     }
 }
 
+
+// fp32 form of the same centring, for the fp32-MFMA sweeps (contrastive.hip: sga_loss_multi_sums_centred / _grad_centred): row r of Zc =
+// (z - zbar [100] | b = zbar . (z - zbar) + |zbar|^2 / 2 | 1 | 0 | 0).  The owner side of those kernels reads columns 100 and 101 swapped,
+// so that its K tail adds b_i + b_j and S_ij = z_i . z_j; the gradient GEMM's output column 101 is then rho_i = sum_j c_ij and columns
+// 0..99 hold sum_j c_ij (z_j - zbar): the two-part gradient sga_loss_scatter_tangent projects.  One wave per row.
+__global__ __launch_bounds__(256) void centre_tables_kernel(const float* __restrict__ Z, int R, const float* __restrict__ stat, float* __restrict__ Zc) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
+        const float* z = Z + (size_t)r * S3_DP;
+        float* o = Zc + (size_t)r * S3_DP;
+        double acc = 0.0;
+        float v[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int d = lane + 64 * t;
+            const float zb = d < S3_DREAL ? stat[d] : 0.f;
+            v[t] = d < S3_DREAL ? z[d] - zb : 0.f;
+            acc += (double)zb * (double)v[t];
+        }
+        acc = wave_sum_d(acc);
+        o[lane] = v[0];
+        const int d1 = lane + 64;
+        if (d1 < S3_DP) o[d1] = d1 < S3_DREAL ? v[1] : (d1 == S3_DREAL ? (float)(acc + (double)stat[S3_DP]) : (d1 == S3_DREAL + 1 ? 1.f : 0.f));
+    }
+}
+
 #ifdef S3_DBG_TIMING
 __device__ unsigned long long g_s3_dbg[16];
 #define S3_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; }
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < a.ngroups && (int)blockIdx.x >= a.grp[i].blk0) g = i;
     const TGroup& grp = a.grp[g];
-    // XCD-aware work order (as sweeph / sweep16): the group's (split major, owner block minor) work list in 8 contiguous per-XCD chunks
+    // XCD-aware work order (as sweep16_kernel, contrastive.hip): the group's (split major, owner block minor) work list in 8 contiguous per-XCD chunks
     const int wg_in_grp = (int)blockIdx.x - grp.blk0;
     const int nsplit = grp.nsplit, n_ob = (grp.nown + OWN - 1) / OWN, n_units = n_ob * nsplit;
     const int unit = (wg_in_grp & 7) * ((n_units + 7) >> 3) + (wg_in_grp >> 3);
@@ -839,7 +864,7 @@ int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int
         add(on2, J2, on2, bn2, X1f1, X2f2);
     }
     a.ngroups = g;
-    // uniform work units; see sweepb.hip for the XCD argument
+    // uniform work units; see sweep16_kernel (contrastive.hip) for the XCD argument
     int nwg = 0;
     for (int i = 0; i < g; ++i) {
         TGroup& G = a.grp[i];
@@ -919,6 +944,28 @@ extern "C" int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, voi
     return SGA_OK;
 }
 
+extern "C" size_t sga_loss_centre_bytes(void) { return S3_STAT_BYTES + (size_t)S3_CS_BLOCKS * S3_DP * sizeof(double); }
+
+extern "C" int sga_loss_centre_tables(const float* Z, int A, int J1, int J2, float* Zc, void* stat_ws, void* stream) {
+    SGA_CHECK_ARG(A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_centre_tables: bad sizes");
+    const int R = 2 * A + J1 + J2;
+    SGA_CHECK_ARG(stat_ws, "sga_loss_centre_tables: null statistics workspace");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(stat_ws, 0, S3_STAT_BYTES, s) != hipSuccess) { sga_set_error("sga_loss_centre_tables: memset failed"); return SGA_ERR_HIP; }
+    if (R == 0) return SGA_OK;
+    SGA_CHECK_ARG(Z && Zc, "sga_loss_centre_tables: null pointer");
+    float* stat = static_cast<float*>(stat_ws);
+    double* part = reinterpret_cast<double*>(static_cast<unsigned char*>(stat_ws) + S3_STAT_BYTES);
+    const int ncs = R < 64 * S3_CS_BLOCKS ? (R + 63) / 64 : S3_CS_BLOCKS;
+    hipLaunchKernelGGL(split3_colsum_kernel, dim3(ncs), dim3(128), 0, s, Z, R, part);
+    hipLaunchKernelGGL(split3_stats_kernel, dim3(1), dim3(128), 0, s, part, ncs, R, stat);
+    int grid = (R + 3) / 4;
+    if (grid > 8 * sga_num_cus()) grid = 8 * sga_num_cus();
+    hipLaunchKernelGGL(centre_tables_kernel, dim3(grid), dim3(256), 0, s, Z, R, stat, Zc);
+    SGA_CHECK_LAUNCH("sga_loss_centre_tables");
+    return SGA_OK;
+}
+
 // dE[idx[r], :] += J_normalize^T dZ[r, :] for a gradient that arrives in two parts: G = dZ[r, 0..D) = sum_j c_rj (z_j - zbar) and
 // rho = dZ[r, 101] = sum_j c_rj (the true gradient of the unit row z_r is G + rho zbar).  The normalisation's Jacobian projects the
 // component along z_r out: P_r (G + rho zbar) = P_r (G - rho (z_r - zbar)) because P_r z_r = 0 -- and THAT is what is evaluated.  For a table
@@ -958,6 +1005,15 @@ __global__ void scatter_tangent_kernel(const float* __restrict__ dZ, const float
     }
 }
 
+static int scatter_tangent_impl(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int R, int D, const float* stat, float* dE,
+                                hipStream_t s) {
+    int grid = (R + 3) / 4;
+    if (grid > 8 * sga_num_cus()) grid = 8 * sga_num_cus();
+    hipLaunchKernelGGL(scatter_tangent_kernel, dim3(grid), dim3(256), 0, s, dZ, Z, nrm, idx, R, D, stat, dE);
+    SGA_CHECK_LAUNCH("sga_loss_scatter_tangent");
+    return SGA_OK;
+}
+
 extern "C" int sga_loss_scatter_tangent(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int A, int J1, int J2, int D,
                                         const void* Zb, float* dE, void* stream) {
     SGA_CHECK_ARG(D >= 1 && D <= S3_DREAL && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_scatter_tangent: bad argument (emb_dim <= 100)");
@@ -966,11 +1022,16 @@ extern "C" int sga_loss_scatter_tangent(const float* dZ, const float* Z, const f
     SGA_CHECK_ARG(dZ && Z && nrm && idx && dE && Zb, "sga_loss_scatter_tangent: null pointer");
     const TLayout L = make_tlayout(A, J1, J2);
     const float* stat = reinterpret_cast<const float*>(static_cast<const unsigned char*>(Zb) + (size_t)(2 * L.nbA + L.nb1 + L.nb2 + 1) * S3_BLOCK);
-    int grid = (R + 3) / 4;
-    if (grid > 8 * sga_num_cus()) grid = 8 * sga_num_cus();
-    hipLaunchKernelGGL(scatter_tangent_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), dZ, Z, nrm, idx, R, D, stat, dE);
-    SGA_CHECK_LAUNCH("sga_loss_scatter_tangent");
-    return SGA_OK;
+    return scatter_tangent_impl(dZ, Z, nrm, idx, R, D, stat, dE, static_cast<hipStream_t>(stream));
+}
+
+// the same with the table's statistics block given directly (the workspace of sga_loss_centre_tables)
+extern "C" int sga_loss_scatter_tangent_stat(const float* dZ, const float* Z, const float* nrm, const int32_t* idx, int R, int D,
+                                             const void* stat_ws, float* dE, void* stream) {
+    SGA_CHECK_ARG(D >= 1 && D <= S3_DREAL && R >= 0, "sga_loss_scatter_tangent_stat: bad argument (emb_dim <= 100)");
+    if (R == 0) return SGA_OK;
+    SGA_CHECK_ARG(dZ && Z && nrm && idx && dE && stat_ws, "sga_loss_scatter_tangent_stat: null pointer");
+    return scatter_tangent_impl(dZ, Z, nrm, idx, R, D, static_cast<const float*>(stat_ws), dE, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,

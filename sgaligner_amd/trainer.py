@@ -11,9 +11,23 @@ import torch.distributed as dist
 
 from . import dist as sdist
 from . import ops
+from .aligner import losses
 from .aligner.losses import CustomMultiLossLayer, OverallLoss
 from .aligner.sg_aligner import MultiModalEncoder
 from .utils import alignment
+
+
+class _ScaleGrad(torch.autograd.Function):
+    """Identity whose backward multiplies the gradient by a constant (the replica fallback of AlignerSteps._global_loss)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = float(k)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.k, None
 
 
 class AlignerSteps:
@@ -99,35 +113,50 @@ class AlignerSteps:
         M >= 2 (fused joint path): the anchors are SHARDED -- each rank evaluates the loss terms / global sums of its own
         anchors against all negatives (partial scalars all-reduced inside ops.FusedContrastiveFn, so every rank holds the
         global loss value) and its share of dL/dE for all rows, summed over ranks in AllGatherRows.backward.
-        M == 1 (ICL of the one table, the general per-table kernels): sharded by anchors the same way (round 5; a replica on every rank before)."""
+        M == 1 (ICL of the one table of <= 128 columns, the general per-table kernels): sharded by anchors the same way.
+        Anything else (wide tables, FUSED_JOINT off): a replica of the whole loss on every rank."""
         world, rank = dist.get_world_size(), dist.get_rank()
         if layout is None:
             layout = sdist.layout_of(data_dict, self.device)                # [world, 4]: rows, |e1i|, |e1j|, |e2j|
         rows = [int(v) for v in layout[:, 0]]
         anchors = [int(v) for v in layout[:, 1]]
-        sharded = len(self.modules) > 1
+        mods = list(self.modules)
+        widths = [int(output_dict[m].shape[1]) for m in mods]
+        fused = len(mods) in (2, 3, 4) and max(widths) <= 104 and losses.FUSED_JOINT
         idx, A, J1, J2 = sdist.gather_index_sets_device(data_dict, layout, self.device)
         gdd = {'_sga_index_sets': ops.IndexSets.from_device(idx, A, J1, J2)}   # our own dict, never the caller's
-        if sharded:
+        if early is not None:                                                # launched from inside the encoder, table by table
+            tabs = early.tables(mods)
+        else:
+            tabs = sdist.gather_tables({m: output_dict[m] for m in mods}, rows, reduce_grad=True)
+        if not fused and not (len(mods) == 1 and widths[0] <= 128):
+            # REPLICA fallback (tables the anchor-sharded kernels do not take: wider than 104 columns under a fused joint -- BASELINE
+            # configs[4], emb_dim 1024 -- or a single table wider than 128; or FUSED_JOINT switched off): every rank evaluates the whole loss on
+            # the gathered tables.  The table gradients are still summed over ranks by AllGatherRows.backward and the fusion weight's by the
+            # parameter all-reduce, and every rank now holds the FULL gradient, not a share: both enter through a 1 / world factor.
+            k = 1.0 / world
+            gathered = {m: _ScaleGrad.apply(tabs[m], k) for m in mods}
+            if len(mods) > 1:
+                fusion = self.model.fusion
+                joint = ops.fusion(_ScaleGrad.apply(fusion.weight, k), [gathered[m] for m in mods])     # sg_aligner.py:30-35 on the gathered rows
+                joint._sga_fusion = (fusion.weight, tuple(gathered[m] for m in mods))
+                gathered['joint'] = joint
+            return self.loss_func(gathered, gdd)
+        gathered = dict(tabs)
+        if fused:
             # only the M modality tables travel: the fused loss derives every joint similarity from them (S_J = sum beta_m
             # S_m with the replicated fusion weight), so the 100*M-wide joint table is neither gathered nor reduced --
             # half of the bytes of both collectives.  The placeholder only carries the provenance tag OverallLoss checks.
-            if early is not None:                                            # launched from inside the encoder, table by table
-                gathered = early.tables(self.modules)
-            else:
-                gathered = sdist.gather_tables({m: output_dict[m] for m in self.modules}, rows, reduce_grad=True)
             joint = torch.empty((0,), device=self.device)
-            joint._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in self.modules))
+            joint._sga_fusion = (self.model.fusion.weight, tuple(gathered[m] for m in mods))
             gathered['joint'] = joint
-        else:
-            gathered = sdist.gather_tables(output_dict, rows, reduce_grad=True)     # every rank holds its anchors' share of dL/dE for all rows
-        if True:
-            # (a_lo, a_hi) of this rank + every rank's cut and the rank: with all cuts on 32-row boundaries the anchors x anchors pairs are
-            # walked symmetrically ACROSS ranks (ops._sym_jobs: every unordered pair once, the same number on every rank)
-            cuts = [sum(anchors[:r]) for r in range(world + 1)]
-            gdd['_sga_shard'] = (cuts[rank], cuts[rank + 1], cuts, rank)
-            def _reduce(t):                                                   # fp64 partial sums / loss terms / dL/d(sums)
-                sdist._log('all_reduce', t, t)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            gdd['_sga_reduce'] = _reduce
+        # (a_lo, a_hi) of this rank + every rank's cut and the rank: with all cuts on 32-row boundaries the anchors x anchors pairs are
+        # walked symmetrically ACROSS ranks (ops._sym_jobs: every unordered pair once, the same number on every rank)
+        cuts = [sum(anchors[:r]) for r in range(world + 1)]
+        gdd['_sga_shard'] = (cuts[rank], cuts[rank + 1], cuts, rank)
+
+        def _reduce(t):                                                   # fp64 partial sums / loss terms / dL/d(sums)
+            sdist._log('all_reduce', t, t)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        gdd['_sga_reduce'] = _reduce
         return self.loss_func(gathered, gdd)

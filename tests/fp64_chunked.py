@@ -29,9 +29,18 @@ def _q(d, sa, sb):
     return 1.0 / (1.0 + 1.0 / (a + 1e-9) + 1.0 / (b + 1e-9) + 1e-9)
 
 
-def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None):
+def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None, timings=None):
     """tables: list of M fp32/fp64 [T, D] tensors (module order), fusion_weight [M, 1], lv_ial / lv_icl [M].
-    Returns dict(loss, icl_uni, icl_multi, ial) as python floats and, if want_grad, dE (list of M [T, D] fp64), dw [M, 1], dlv_ial, dlv_icl."""
+    Returns dict(loss, icl_uni, icl_multi, ial) as python floats and, if want_grad, dE (list of M [T, D] fp64), dw [M, 1], dlv_ial, dlv_icl.
+    timings: an optional dict that receives the wall seconds of the four phases (synchronised)."""
+    import time
+
+    def _tick(name, t0):
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings[name] = timings.get(name, 0.0) + time.time() - t0
+        return time.time()
+    t_ph = time.time()
     dev = device or tables[0].device
     M = len(tables)
     assert M > 1
@@ -62,6 +71,7 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
                     for ti, tau in enumerate(temps):
                         sums[t, ti, f] += torch.exp(S / tau).sum()      # (two passes per temperature; kept literal: this is the checker)
     s_leaf = sums.clone().requires_grad_(want_grad)
+    t_ph = _tick('1_global_sums', t_ph)
 
     # (2) anchors x anchors terms, one anchor-row chunk at a time
     Xl = [[P[t][0].clone().requires_grad_(want_grad), P[t][1].clone().requires_grad_(want_grad)] for t in range(nt)]
@@ -94,6 +104,7 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
             contrib = zoom * (torch.exp(-l1.detach()) * ca).sum() + (torch.exp(-l2.detach()) * ci[:M]).sum() + ci[M]
             contrib.backward()
         del q, S12, S21, qa, qb, qm_a, qm_b, chunk_icl, chunk_ial, ci, ca
+    t_ph = _tick('2_anchors_x_anchors', t_ph)
     ial = (torch.exp(-l1) * acc['ial'] + l1).sum() * zoom
     icl_uni = (torch.exp(-l2) * acc['icl'][:M] + l2).sum()
     icl_multi = acc['icl'][M]
@@ -115,10 +126,12 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
                     dP[t][xi][lo:lo + rows] += C @ N
                     dP[t][ni] += C.t() @ X[lo:lo + rows]
                     del S, C
+    t_ph = _tick('3_gradient_through_sums', t_ph)
     # (4) gathers, normalisation, fusion; the log_vars see the term values
     tot = sum((parts[t][k] * dP[t][k]).sum() for t in range(nt) for k in range(4))
     head = (torch.exp(-l1) * acc['ial'] + l1).sum() * zoom + (torch.exp(-l2) * acc['icl'][:M] + l2).sum()
     (tot + head).backward()
+    t_ph = _tick('4_gathers', t_ph)
     out.update(dE=[e.grad for e in E], dw=w.grad, dlv_ial=l1.grad, dlv_icl=l2.grad,
                dZ=[[d for d in dP[t]] for t in range(nt)])
     return out

@@ -314,3 +314,50 @@ def test_stash_products_on_three_planes_equal_the_fp32_gemms(bf16x6, sym):
         tol = 2e-5 if k < 2 else 1e-3          # (the centred table: the fp32 GEMM form carries the larger error, section 3g of DESIGN.md)
         assert (x - y).abs().max().item() < tol * x.abs().max().item(), (k, (x - y).abs().max().item(), x.abs().max().item())
     assert (a[2] - b[2]).abs().max().item() < 1e-4 * a[2].abs().max().item()
+
+
+def test_mode_switch_roundtrip():
+    from sgaligner_amd import ops
+    d = ops.get_mfma_mode()
+    assert d == ops.DEFAULT_MFMA_MODE == 'bf16x6'            # the default: fp32 arithmetic on three exact bf16 planes
+    assert ops.MFMA_MODES == ('f32', 'bf16x6', 'f16')
+    assert ops.set_mfma_mode('f32') == d and ops.get_mfma_mode() == 'f32'
+    assert ops.set_mfma_mode('f16') == 'f32' and ops.get_mfma_mode() == 'f16'
+    assert ops.set_mfma_mode(d) == 'f16'
+    with pytest.raises(ValueError):
+        ops.set_mfma_mode('f16x2')                           # the two-plane modes of rounds 2-5 are gone
+
+
+def test_tables_wider_than_100_columns_take_the_fp32_kernels():
+    """emb_dim 101..104 is accepted by the fused loss path, but columns 100, 101 of the three-plane blocks (and of the 'f32' mode's centred
+    tables) carry the row centring's bookkeeping: such tables must run on the plain fp32 kernels EVERYWHERE -- sweeps, the stash products.
+    Terms and gradients of the default mode equal the 'f32' mode's to fp32 summation noise, and columns 100..103 carry gradient."""
+    mode = 'bf16x6'
+    from sgaligner_amd import ops
+    from sgaligner_amd.synthetic import make_batch
+    dd = make_batch(40, 40, 4, seed=11, ragged=True, anchors='val')       # enough anchors for the one-pass symmetric walk
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(4)
+    base = [torch.randn(T, 104, device='cuda', generator=g) for _ in range(3)]
+    for b in base:
+        b[:, 100:] *= 3.0                                                  # make the last four columns matter
+    w0 = torch.tensor([[0.3], [1.1], [-0.4]], device='cuda')
+    res = {}
+    for md in ('f32', mode):
+        old = ops.set_mfma_mode(md)
+        try:
+            tabs = [b.clone().requires_grad_(True) for b in base]
+            w = w0.clone().requires_grad_(True)
+            hint = torch.linspace(0.5, 1.5, 3 + 1 + 6, device='cuda')
+            sums, s = ops.fused_contrastive_terms(tabs, w, dd, coef_hint=hint)
+            (sums * hint).sum().backward()
+            torch.cuda.synchronize()
+            res[md] = (sums.detach().double(), [t.grad.clone() for t in tabs], w.grad.clone())
+        finally:
+            ops.set_mfma_mode(old)
+    a, b = res['f32'], res[mode]
+    assert torch.allclose(a[0], b[0], rtol=1e-6, atol=1e-9)
+    for x, y in zip(a[1], b[1]):
+        assert (x - y).abs().max().item() < 2e-5 * x.abs().max().item()
+        assert x[:, 100:].abs().max().item() > 1e-3 * x.abs().max().item()
+    assert (a[2] - b[2]).abs().max().item() < 1e-4 * a[2].abs().max().item()

@@ -20,7 +20,6 @@ def test_headline_kernels_do_not_spill():
                             '25anchor_multi_bwd16_kernelILi3ELb1ELi32ELb1E', '25anchor_multi_bwd16_kernelILi3ELb1ELi32ELb0E',
                             '25anchor_multi_bwd16_kernelILi4ELb1ELi16ELb0E', '19anchor_multi_kernelILi3ELb0E'],
         'pointnet.hip': ['19pointnet_fwd_kernelILi256ELb1ELb0E', '25pointnet_bwd_fused_kernel'],
-        'sweepb.hip': ['13sweepb_kernelILi3ELb1E', '13sweepb_kernelILi3ELb0E'],          # opt-in bf16x3 sweeps (39 spills until round 3)
         # the DEFAULT sweeps (three exact bf16 planes): gradient (one wave per SIMD), sums (two), the stash products
         'sweep3.hip': ['13sweep3_kernelILi3ELb1ELi4E', '13sweep3_kernelILi3ELb0ELi8E', '13sweep3_kernelILi2ELb1ELi4E', '13sweep3_kernelILi2ELb0ELi8E',
                        '13stash3_kernel'],

@@ -194,101 +194,6 @@ def test_symmetric_kernel_walk_at_the_c_abi(A, rows, M):
         assert (x - y).abs().max().item() <= 5e-6 * y.abs().max().item(), ((x - y).abs().max().item(), y.abs().max().item())
 
 
-@pytest.mark.parametrize('A,rows,M', [(2100, 512, 3), (1000, 96, 2), (1500, 480, 4)])
-def test_split_fp16_stash_products_equal_the_fp32_ones(A, rows, M):
-    """MFMA mode 'f16x2', csrc/stashh.hip: the four stash products of every block of a symmetric walk on fp16 MFMA -- both operands as fp16
-    hi + lo of scaled values, the stash scaled by its largest |coefficient|, rows of X centred with exact fp32 row sums of the stash --
-    against sga_loss_stash_grad_symx (exact fp32) on the same stashes: 2e-6 of the gradient's maximum (fp32 accumulation order differs too);
-    a ragged last block is refused (its caller takes the fp32 form)."""
-    from sgaligner_amd import _lib
-    from sgaligner_amd.ops import _p, _ptr_array, _stream
-    L = _lib.lib(); st = _stream(); dev = 'cuda'
-    g = torch.Generator(device=dev).manual_seed(A + M)
-    zs = []
-    for m in range(M):
-        z = torch.zeros(2 * A + 32, 104, device=dev)
-        z[:2 * A, :100] = torch.nn.functional.normalize(torch.randn(2 * A, 100, device=dev, generator=g), dim=1)
-        zs.append(z)
-    nt, n_terms, slots = M + 1, M + 1 + 2 * M, 1 + L.sga_loss_slots()
-    sums = torch.rand(nt, 8, device=dev, dtype=torch.float64, generator=g) * 1e3 + 1e3
-    beta = torch.softmax(torch.randn(M, device=dev, generator=g), 0)
-    coef = (torch.rand(3 * M + 1, device=dev, generator=g) + 0.5) * 1e-2
-    zarr = _ptr_array(zs)
-    planes = [torch.empty(int(L.sga_loss_stash_planes_bytes(A)), device=dev, dtype=torch.uint8) for _ in range(M)]
-    for k in range(M):
-        _lib.check(L.sga_loss_stash_planes(_p(zs[k]), A, 104, _p(planes[k]), st), 'planes')
-    dz = [[torch.zeros(2 * A + 32, 104, device=dev) for _ in range(M)] for _ in range(2)]
-    gsc = torch.empty(slots + 1, nt, 8, device=dev, dtype=torch.float64)
-    gam2 = torch.empty(slots, M, device=dev, dtype=torch.float64)
-    out = torch.empty(slots * n_terms, device=dev, dtype=torch.float64)
-    cmax = torch.zeros(M, device=dev, dtype=torch.int32)
-    ragged = 0
-    for lo in range(0, A, rows):
-        hi = min(lo + rows, A); ns = hi - lo
-        m1 = [torch.full(((A - lo) * ns,), float('nan'), device=dev) for _ in range(M)]
-        m2 = [torch.full((max(1, (A - hi) * ns),), float('nan'), device=dev) for _ in range(M)]
-        _lib.check(L.sga_loss_anchor_multi_bwd_sym(zarr, M, _p(beta), A, _p(sums), 0.5, 0.1, 1.0, _p(coef), _ptr_array(m1), _ptr_array(m2),
-                                                   _p(gsc), _p(gam2), lo, hi, _p(out), st), 'sym')
-        torch.cuda.synchronize()
-        for k in range(M):
-            own = max(float(m1[k].abs().max()), float(m2[k].abs().max()) if hi < A else 0.0)
-            cmax[k] = torch.tensor([own], dtype=torch.float32).view(torch.int32)[0]
-            _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]), _p(zs[k]), A, 104, _p(dz[0][k]), lo, hi, lo, A, hi, st), 'fp32')
-            rc = L.sga_loss_stash_grad_symx_f16x2(_p(m1[k]), _p(m2[k]), _p(planes[k]), cmax[k:].data_ptr(), A, _p(dz[1][k]), lo, hi, lo, A, hi, st)
-            if ns % 8:
-                assert rc != 0 and b'8-row' in L.sga_last_error()
-                ragged += 1
-                _lib.check(L.sga_loss_stash_grad_symx(_p(m1[k]), _p(m2[k]), _p(zs[k]), A, 104, _p(dz[1][k]), lo, hi, lo, A, hi, st), 'fp32')
-            else:
-                _lib.check(rc, 'f16x2')
-    torch.cuda.synchronize()
-    assert ragged == (M if (A % rows) % 8 else 0)
-    for a, b in zip(dz[1], dz[0]):
-        assert torch.isfinite(a).all()
-        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), ((a - b).abs().max().item(), b.abs().max().item())
-
-
-@pytest.mark.parametrize('A,rows,M', [(2100, 512, 3), (1000, 96, 2), (700, 160, 4)])
-def test_split_fp16_similarities_walk_equals_the_fp32_walk(A, rows, M):
-    """MFMA mode 'f16x2', anchor_multi_bwd16_kernel<..., H16>: the A x A similarities on fp16 MFMA from rows held as fp16 hi + lo of 4096 x
-    (sga_loss_aa_planes: same bytes per row) -- a whole symmetric walk against the exact-fp32 kernel: terms to 1e-7, dL/d(sums), dL/dbeta and
-    the stashed coefficients to 5e-6 of their maximum (S carries fp32's own 1e-7; tau = 0.1 amplifies it tenfold); ragged last block, A not a
-    multiple of 16."""
-    from sgaligner_amd import _lib
-    from sgaligner_amd.ops import _p, _ptr_array, _stream
-    L = _lib.lib(); st = _stream(); dev = 'cuda'
-    g = torch.Generator(device=dev).manual_seed(A * 3 + M)
-    zs, zh = [], []
-    for m in range(M):
-        z = torch.zeros(2 * A + 32, 104, device=dev)
-        z[:2 * A, :100] = torch.nn.functional.normalize(torch.randn(2 * A, 100, device=dev, generator=g) + (3.0 if m == 1 else 0.0), dim=1)
-        zs.append(z)
-        h = torch.empty(2 * A + 1, 104, device=dev)
-        _lib.check(L.sga_loss_aa_planes(_p(z), 2 * A, _p(h), st), 'planes')
-        zh.append(h)
-    nt, n_terms, slots = M + 1, M + 1 + 2 * M, 1 + L.sga_loss_slots()
-    sums = torch.rand(nt, 8, device=dev, dtype=torch.float64, generator=g) * 1e3 + 1e3
-    beta = torch.softmax(torch.randn(M, device=dev, generator=g), 0)
-    coef = (torch.rand(3 * M + 1, device=dev, generator=g) + 0.5) * 1e-2
-    gsc = torch.empty(slots + 1, nt, 8, device=dev, dtype=torch.float64)
-    gam2 = torch.empty(slots, M, device=dev, dtype=torch.float64)
-    out = torch.empty(slots * n_terms, device=dev, dtype=torch.float64)
-    for lo in range(0, A, rows):
-        hi = min(lo + rows, A); ns = hi - lo
-        res = []
-        for fn, tabs in ((L.sga_loss_anchor_multi_bwd_symx, zs), (L.sga_loss_anchor_multi_bwd_symx_h16, zh)):
-            m1 = [torch.full(((A - lo) * ns,), float('nan'), device=dev) for _ in range(M)]
-            m2 = [torch.full((max(1, (A - hi) * ns),), float('nan'), device=dev) for _ in range(M)]
-            _lib.check(fn(_ptr_array(tabs), M, _p(beta), A, _p(sums), 0.5, 0.1, 1.0, _p(coef), _ptr_array(m1), _ptr_array(m2),
-                          _p(gsc), _p(gam2), lo, hi, lo, A, hi, _p(out), st), 'sym')
-            torch.cuda.synchronize()
-            res.append([out[:n_terms].clone(), gsc[0].clone(), gam2[0].clone()] + m1 + ([m[:(A - hi) * ns] for m in m2] if hi < A else []))
-        for i, (x, y) in enumerate(zip(res[1], res[0])):
-            assert torch.isfinite(x).all()
-            tol = 1e-7 if i == 0 else 5e-6
-            assert (x - y).abs().max().item() <= tol * y.abs().max().item(), (lo, i, (x - y).abs().max().item(), y.abs().max().item())
-
-
 def test_symmetric_entry_refuses_blocks_off_the_32_row_grid():
     from sgaligner_amd import _lib
     from sgaligner_amd.ops import _p, _ptr_array, _stream

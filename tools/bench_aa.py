@@ -61,47 +61,3 @@ if M <= 4 and NS % 32 == 0:
             ts.append(e[0].elapsed_time(e[1])); tgs.append(e[1].elapsed_time(e[2]))
     pairs = float(NS) * A * 2 - float(NS) * NS
     print(f'symmetric block: kernel {np.median(ts):.3f} ms = {np.median(ts) * 1e6 / pairs:.4f} ns per ordered pair; stash GEMMs {np.median(tgs):.3f} ms')
-    # the same block with the stash products on split-fp16 MFMA ('f16x2': csrc/stashh.hip)
-    if NS % 8 == 0:
-        planes = [torch.empty(int(L.sga_loss_stash_planes_bytes(A)), device=dev, dtype=torch.uint8) for _ in range(M)]
-        for k in range(M):
-            _lib.check(L.sga_loss_stash_planes(_p(zs[k]), A, 104, _p(planes[k]), st), 'planes')
-        dref = [torch.zeros_like(d) for d in dz]
-        dh = [torch.zeros_like(d) for d in dz]
-        cmax = torch.stack([torch.maximum(a_.abs().max(), b_.abs().max()) for a_, b_ in zip(m1s, m2s)]).view(torch.int32)
-        th = []
-        for r in range(reps + 1):
-            for d in dh: d.zero_()
-            e[0].record()
-            for k in range(M):
-                _lib.check(L.sga_loss_stash_grad_symx_f16x2(_p(m1s[k]), _p(m2s[k]), _p(planes[k]), cmax[k:].data_ptr(), A, _p(dh[k]), 0, NS, 0, A, NS, st), 'sgh')
-            e[1].record(); torch.cuda.synchronize()
-            if r: th.append(e[0].elapsed_time(e[1]))
-        for k in range(M):
-            _lib.check(L.sga_loss_stash_grad_symx(_p(m1s[k]), _p(m2s[k]), _p(zs[k]), A, 104, _p(dref[k]), 0, NS, 0, A, NS, st), 'sgs')
-        torch.cuda.synchronize()
-        err = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(dh, dref))
-        byts = 4.0 * M * (float(A) * NS + float(A - NS) * NS) * 2
-        print(f'   stash products on split-fp16 MFMA: {np.median(th):.3f} ms ({byts / np.median(th) / 1e9:.2f} TB/s of stash reads); max |d - d_fp32| / max |d_fp32| = {err:.2e}; '
-              f'largest |coefficient| per table {[float(c) for c in cmax.view(torch.float32)]}')
-    # the same block with the similarities on split-fp16 MFMA ('f16x2': anchor_multi_bwd16_kernel<..., H16>)
-    zh = [torch.empty(2 * A + 1, 104, device=dev) for z in zs]
-    for k in range(M):
-        _lib.check(L.sga_loss_aa_planes(_p(zs[k]), 2 * A, _p(zh[k]), st), 'aa planes')
-    m1h = [torch.empty_like(x) for x in m1s]; m2h = [torch.empty_like(x) for x in m2s]
-    outh = torch.empty_like(out)
-    tsh = []
-    for r in range(reps + 1):
-        e[0].record()
-        _lib.check(L.sga_loss_anchor_multi_bwd_symx_h16(_ptr_array(zh), M, _p(beta), A, _p(sums), 0.5, 0.1, 1.0, _p(coef), _ptr_array(m1h), _ptr_array(m2h), _p(gsc), _p(gam2),
-                                                        0, NS, 0, A, NS, _p(outh), st), 'sym h16')
-        e[1].record(); torch.cuda.synchronize()
-        if r: tsh.append(e[0].elapsed_time(e[1]))
-    _lib.check(L.sga_loss_anchor_multi_bwd_sym(zarr, M, _p(beta), A, _p(sums), 0.5, 0.1, 1.0, _p(coef), _ptr_array(m1s), _ptr_array(m2s), _p(gsc), _p(gam2),
-                                               0, NS, _p(out), st), 'sym')
-    torch.cuda.synchronize()
-    n_t = nt + 2 * M
-    errc = max(float((a_ - b_).abs().max() / b_.abs().max()) for a_, b_ in zip(m1h + m2h, m1s + m2s))
-    errt = float(((outh[:n_t] - out[:n_t]).abs() / out[:n_t].abs()).max())
-    print(f'   similarities on split-fp16 MFMA: kernel {np.median(tsh):.3f} ms = {np.median(tsh) * 1e6 / pairs:.4f} ns per ordered pair; '
-          f'max |dL/dS - fp32| / max = {errc:.2e}, terms rel {errt:.2e}')

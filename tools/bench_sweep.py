@@ -19,7 +19,7 @@ for _ in range(reps + 2):
     sums, s = ops.fused_contrastive_terms(tabs, w, dd)
     sums.sum().backward()
 torch.cuda.synchronize()
-sfx = {'f16x2': '_f16x2', 'bf16x6': '_bf16x6'}.get(ops.get_mfma_mode(), '')
+sfx = {'bf16x6': '_bf16x6', 'f16': '_bf16x6'}.get(ops.get_mfma_mode(), '')
 ev = ops.KERNEL_EVENTS['loss_multi_grad' + sfx][2:]
 ms = [a.elapsed_time(b) for a, b, _ in ev]
 ns, A, J1, J2, M = ev[0][2]
@@ -30,7 +30,7 @@ print(f'sums {np.median(msf):.3f} ms | sweep grad: median {np.median(ms):.3f} ms
 # accuracy of the opt-in mode against the exact-fp32 sweeps on the same inputs (run with SGA_BENCH_SWEEP_COMPARE=1)
 if os.environ.get('SGA_BENCH_SWEEP_COMPARE'):
     res = {}
-    other = os.environ.get('SGA_BENCH_SWEEP_COMPARE') if os.environ.get('SGA_BENCH_SWEEP_COMPARE') in ('bf16x3', 'f16x2', 'bf16x6') else 'bf16x3'
+    other = 'bf16x6'
     for mode in ('f32', other):
         ops.set_mfma_mode(mode)
         for t in tabs:

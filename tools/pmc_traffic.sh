@@ -16,7 +16,7 @@ if [ ! -f "$out" ]; then
   echo "kernel;workload_key;source_sha16;counter;avg_kib_per_launch;launches" >> $out
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, (true|false)|pointnet_fwd(_p3)?_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct --no-split $EXTRA < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-include-regex 'sweep.*_kernel<3, (true|false)|pointnet_fwd(_p3)?_kernel' --output-format csv -d gpurun_out/pmc_t_${cfg}_$c -- python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct $EXTRA < /dev/null > gpurun_out/pmc_t_${cfg}_$c.log 2>&1
   python - $c $cfg >> $out <<'PY'
 import csv, glob, sys, collections, hashlib
 c, cfg = sys.argv[1], sys.argv[2]

@@ -16,9 +16,9 @@ bash tools/pmc_traffic.sh c2 gpurun_out/${tag}_pmc_traffic.csv --no-exact > gpur
 cp gpurun_out/${tag}_pmc_traffic.csv profiles/r05_pmc_traffic.csv
 rm -rf gpurun_out/pmc_t_*
 timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_flags.json 2> gpurun_out/${tag}_bench_driver_flags.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_c3_stats -- python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct --no-exact --no-split < /dev/null > gpurun_out/${tag}_c3_bench_under_rocprof.json 2> gpurun_out/${tag}_c3_stats.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_c3_stats -- python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct --no-exact < /dev/null > gpurun_out/${tag}_c3_bench_under_rocprof.json 2> gpurun_out/${tag}_c3_stats.err
 python tools/prof_summary.py gpurun_out/${tag}_c3_stats gpurun_out/${tag}_c3_default_only_kernel_stats.csv > /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_c2_stats -- python bench.py --config c2 --steps 10 --warmup 3 --no-cpu-baseline --no-hits --no-pct --no-exact --no-split < /dev/null > gpurun_out/${tag}_c2_bench_under_rocprof.json 2> gpurun_out/${tag}_c2_stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_c2_stats -- python bench.py --config c2 --steps 10 --warmup 3 --no-cpu-baseline --no-hits --no-pct --no-exact < /dev/null > gpurun_out/${tag}_c2_bench_under_rocprof.json 2> gpurun_out/${tag}_c2_stats.err
 python tools/prof_summary.py gpurun_out/${tag}_c2_stats gpurun_out/${tag}_c2_kernel_stats.csv > /dev/null
 rm -rf gpurun_out/${tag}_c3_stats gpurun_out/${tag}_c2_stats
 SGA_PMC_CONFIG=c2 bash tools/pmc_kernel.sh 'sweep3_kernel<3|pointnet_fwd_p3_kernel' ${tag}_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" > gpurun_out/${tag}_sq_counters.txt 2>&1
