@@ -118,7 +118,12 @@ def split_line(full):
         c['default_vs_exact_f32'] = {k: d.get(k) for k in ('loss_rel_diff', 'max_grad_diff_rel_to_own_max', 'worst_param')}
     if full.get('collectives') is not None:
         col = full['collectives']
-        c['collectives'] = col if len(json.dumps(col)) <= 600 else {'see': EXTRAS_FILE}
+        # the self-certifying part (who took part, what a step moved per kind) stays on the line; per-call timings go to the extras
+        c['collectives'] = {'backend': col.get('backend'), 'world_size': col.get('world_size'),
+                            'ranks_seen': [{'rank': x.get('rank'), 'device': x.get('device')} for x in (col.get('ranks_seen') or [])][:16],
+                            'bytes_per_step_this_rank': {k: col.get(k + '_bytes') for k in ('all_gather', 'reduce_scatter', 'all_reduce')},
+                            'ms_alone_per_step': round(sum(t.get('ms_each', 0.0) * t.get('calls_in_timed_steps', 0) for t in col.get('timed_alone', []))
+                                                       / max(1, full.get('steps', 1)), 3)}
     w = full.get('weak_scaling_point')
     if w:
         c['weak_scaling_point'] = {k: w.get(k) for k in ('value', 'ms_per_step', 'scaling') if k in w} if 'error' not in w else {'error': _clip(w['error'], 80)}

@@ -232,7 +232,7 @@ struct TSeg { int blk0, jt_lo, jt_hi, old0, lo, hi, fam; };   // others: block b
 struct TGroup { int own0, nown, own_old0, own_blk0, blk0, nsplit, nseg; TSeg seg[2]; };
 struct TArgs {
     int M; const unsigned char* Zb[4]; int perm[4]; int ngroups; TGroup grp[4];   // perm: kernel table m = the caller's table perm[m] (beta, gs, gamma)
-    float k0, k1, it0, it1;
+    float k0, k1, it0, it1, ka;      // ka = k0 / k1 (the owner rows carry k1)
     const float* beta;
     double* sums;                    // SUM out  [(M+1)][8] (+ slots)
     const double* gs;                // GRAD in  [(M+1)][8]
@@ -297,9 +297,29 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                     const int so = ((q * 2 + ojh) * 64 + s3_slot(g4, oi)) * 16;
                     opl[m][p][q] = iv ? *reinterpret_cast<const u32x4*>(base + p * S3_PLANE + so) : u32x4{0, 0, 0, 0};
                 }
+            // The owner rows carry the factor k1 = log2(e) / tau1 (as sweep16_kernel's): the MFMAs then deliver the exp2 argument of the tau1 terms
+            // directly and the tau0 argument is one multiply away -- one VALU less per similarity and temperature in the tile loop.  Done here, once
+            // per work unit: x = h + m + l (exact), y = fl(k1 x), y split into three planes again.
+            u32x4 th = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot(0, oi)) * 16) : u32x4{0, 0, 0, 0};
+            u32x4 tm = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot(2, oi)) * 16) : u32x4{0, 0, 0, 0};
+            u32x4 tl = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot(3, oi)) * 16) : u32x4{0, 0, 0, 0};
+            const float ksc = a.k1;
+            auto rescale = [&](u32x4& ph, u32x4& pm, u32x4& pl) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float x0 = (__builtin_bit_cast(float, ph[d] << 16) + __builtin_bit_cast(float, pm[d] << 16)) + __builtin_bit_cast(float, pl[d] << 16);
+                    const float x1 = (__builtin_bit_cast(float, ph[d] & 0xffff0000u) + __builtin_bit_cast(float, pm[d] & 0xffff0000u)) + __builtin_bit_cast(float, pl[d] & 0xffff0000u);
+                    unsigned nh, nm, nl;
+                    split3_pair(x0 * ksc, x1 * ksc, nh, nm, nl);
+                    ph[d] = nh; pm[d] = nm; pl[d] = nl;
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rescale(opl[m][0][q], opl[m][1][q], opl[m][2][q]);
+            rescale(th, tm, tl);
             // against the image's k groups (h, h, m, l):  O0 = (h, m, h, h) -> h h + h m + m h + l h;  O1 = (l, 0, m, 0) -> h l + m m
-            otl[m][0] = iv ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot(g4 == 1 ? 2 : 0, oi)) * 16) : u32x4{0, 0, 0, 0};
-            otl[m][1] = (iv && (g4 & 1) == 0) ? *reinterpret_cast<const u32x4*>(base + S3_TAIL + (ojh * 64 + s3_slot(g4 == 0 ? 3 : 2, oi)) * 16) : u32x4{0, 0, 0, 0};
+            otl[m][0] = g4 == 1 ? tm : th;
+            otl[m][1] = g4 == 0 ? tl : (g4 == 2 ? tm : u32x4{0, 0, 0, 0});
 #pragma unroll
             for (int t = 0; t < 2; ++t)                               // columns 100, 101: the owner holds (1, b_i) against the other's (b_j, 1)
                 otl[m][t][2] = (otl[m][t][2] >> 16) | (otl[m][t][2] << 16);
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             c0[m] = GRAD ? (float)(a.gs[mo * 8 + seg.fam * 2 + 0] * (double)a.it0) : 0.f;
             c1[m] = GRAD ? (float)(a.gs[mo * 8 + seg.fam * 2 + 1] * (double)a.it1) : 0.f;
         }
-        const float k0 = a.k0, k1 = a.k1;
+        const float ka = a.ka;                             // the owner rows carry k1: a similarity `sv` arrives as the tau1 exp2 argument, sv * ka is the tau0 one
         double dsum[M + 1][2];
 #pragma unroll
         for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
@@ -478,10 +498,10 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                             const int r = (x - 11) >> 1;
                             const float sv = sacc[m - 1][jh][r];
                             if (((x - 11) & 1) == 0) {
-                                ownt[0] = fexp2(sv * k0);
-                                ownt[1] = sv * k1;
+                                ownt[0] = fexp2(sv * ka);
+                                ownt[1] = fexp2(sv);
                             } else {
-                                own[m - 1][jh][r] = fmaf(c0[m - 1], ownt[0], c1[m - 1] * fexp2(ownt[1]));
+                                own[m - 1][jh][r] = fmaf(c0[m - 1], ownt[0], c1[m - 1] * ownt[1]);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -512,11 +532,11 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                             for (int m = 0; m < M; ++m) {
                                 const float sv = sacc[m][jh][r];
                                 sj = fmaf(beta[m], sv, sj);
-                                p0[m] = MASKED ? fmaf(okf, fexp2(sv * k0), p0[m]) : p0[m] + fexp2(sv * k0);
-                                p1[m] = MASKED ? fmaf(okf, fexp2(sv * k1), p1[m]) : p1[m] + fexp2(sv * k1);
+                                p0[m] = MASKED ? fmaf(okf, fexp2(sv * ka), p0[m]) : p0[m] + fexp2(sv * ka);
+                                p1[m] = MASKED ? fmaf(okf, fexp2(sv), p1[m]) : p1[m] + fexp2(sv);
                             }
-                            p0[M] = MASKED ? fmaf(okf, fexp2(sj * k0), p0[M]) : p0[M] + fexp2(sj * k0);
-                            p1[M] = MASKED ? fmaf(okf, fexp2(sj * k1), p1[M]) : p1[M] + fexp2(sj * k1);
+                            p0[M] = MASKED ? fmaf(okf, fexp2(sj * ka), p0[M]) : p0[M] + fexp2(sj * ka);
+                            p1[M] = MASKED ? fmaf(okf, fexp2(sj), p1[M]) : p1[M] + fexp2(sj);
                         }
                 };
                 if (j0 >= seg.lo && j0 + 32 <= seg.hi && own0 + OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #ifdef S3_DBG_NOEPI
                             own[m][jh][r] = sv;
 #else
-                            own[m][jh][r] = fmaf(c0[m], fexp2(sv * k0), c1[m] * fexp2(sv * k1));
+                            own[m][jh][r] = fmaf(c0[m], fexp2(sv * ka), c1[m] * fexp2(sv));
 #endif
                         }
                 // joint coefficient dL/dS_J for this lane's 8 pairs (plain VALU: beside MFMAs a v_pk_*_f32 costs 3 x a v_fma, tools/micro/valu_issue.hip)
@@ -568,7 +588,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #ifdef S3_DBG_NOEPI
                         cj[jh][r] = sj;
 #else
-                        cj[jh][r] = c0[M] * fexp2(sj * k0) + c1[M] * fexp2(sj * k1);
+                        cj[jh][r] = c0[M] * fexp2(sj * ka) + c1[M] * fexp2(sj);
 #endif
                     }
                 auto gamma_acc = [&]() {                        // Gamma_m = sum dL/dS_J * S_m (used from the anchor-owner sweeps only: each pair once;
@@ -694,7 +714,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
         if (GAM && g < 2) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const float v = wave_sum(gam[m]);
+                const float v = wave_sum(gam[m]) / a.k1;             // Gamma was accumulated on the pre-scaled similarities
                 if (lane == 0 && v != 0.f) atomicAdd(a.gamma + M * (1 + my_slot()) + a.perm[m], (double)v);
             }
         }
@@ -842,7 +862,7 @@ int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int
         a.Zb[m] = static_cast<const unsigned char*>(Zb[m]);
         a.perm[m] = m;
     }
-    a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1;
+    a.beta = beta; a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1; a.ka = a.k0 / a.k1;
     const int ns = a_hi - a_lo;
     const int bx1 = 0, bx2 = L.nbA, bn1 = 2 * L.nbA, bn2 = 2 * L.nbA + L.nb1;
     const int ox1 = 0, ox2 = A, on1 = 2 * A, on2 = 2 * A + J1;

@@ -44,7 +44,10 @@ def fake_full(bloat=1):
         'cpu_baseline': {'value': best['pairs_per_s'], 'unit': 'pairs/s', 'cores': best['threads'], 'kind': 'port',
                          'cpu_model': 'AMD EPYC 9575F 64-Core Processor', 'sample': 'oracle fwd+loss+bwd ' + 'q' * 400, 'sweep': sweep},
         'speedup_vs_cpu_baseline': 230.2,
-        'collectives': {'all_gather': {'calls': 3, 'bytes': 1 << 30, 'ms': 1.0}, 'detail': 'd' * 2000},
+        'collectives': {'backend': 'nccl', 'world_size': 8, 'ranks_seen': [{'rank': r, 'device': f'cuda:{r}', 'name': 'AMD Instinct MI355X'} for r in range(8)],
+                        'per_step_this_rank': {'all_gather': {'calls_per_step': 3.0}}, 'all_gather_bytes': 1 << 30, 'reduce_scatter_bytes': 1 << 30,
+                        'all_reduce_bytes': 4096, 'timed_alone': [{'kind': 'all_gather', 'ms_each': 1.5, 'calls_in_timed_steps': 30, 'shape': [1, 2] * 50}] * 12 * bloat,
+                        'timing': 't' * 300},
         'weak_scaling_point': {'value': 80000.0, 'ms_per_step': 50.0, 'scaling': 'weak', 'workload': 'w' * 300},
     }
 
@@ -72,6 +75,7 @@ def test_compact_line_is_small_and_complete(tmp_path):
         assert cb['b'] is not None and cb['threads'] == cb['cores'] and 'sweep' not in cb
         assert got['hits_at_1']['gpu'] == 0.42 and got['hits_at_1']['anchors'] == 1016
         assert got['extra_exact_f32']['value'] == 579.4
+        assert got['collectives']['world_size'] == 8 and sorted(x['rank'] for x in got['collectives']['ranks_seen']) == list(range(8))
         # the full record is beside the script
         extras = json.load(open(tmp_path / bench.EXTRAS_FILE))
         assert extras['roofline_other'] == full['roofline_other'] and extras['cpu_baseline']['sweep'] == full['cpu_baseline']['sweep']

@@ -42,7 +42,7 @@ def _worker(rank, world, port, mods, n_pairs, cuts, out, nobj=14, ragged=True, e
         full = to_device(make_batch(n_pairs, nobj, 48, seed=21, ragged=ragged), dev)
         lo, hi = cuts[rank], cuts[rank + 1]
         mine = sdist.shard_data_dict(full, lo, hi)
-        from sgaligner_amd import ops as ops_mod
+        from sgaligner_amd import loss_ops as ops_mod          # (where FusedContrastiveFn looks _sym_jobs up)
         orig_jobs, ops_mod._sym_calls = ops_mod._sym_jobs, []
         ops_mod._sym_jobs = lambda c, r, nt: (ops_mod._sym_calls.append((len(c) - 1, r)), orig_jobs(c, r, nt))[1]
         steps = AlignerSteps(mods, device=dev, seed=42, emb_dim=emb_dim)

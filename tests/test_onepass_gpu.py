@@ -225,8 +225,9 @@ def test_symmetric_walk_sharded_over_ranks_equals_unsharded(R, M, stash):
     lv1, lv2 = 0.3 * torch.randn(M, device='cuda', generator=g), 0.3 * torch.randn(M, device='cuda', generator=g)
     hint = ops.LossHeadFn.coef_hint(lv1, lv2, 32 * pairs, 0.1, 0.5, 0.1)
     keep, calls = ops.STASH_BYTES, []
-    orig = ops._sym_jobs
-    ops._sym_jobs = lambda cuts, rank, nt: (calls.append((len(cuts) - 1, rank)), orig(cuts, rank, nt))[1]
+    from sgaligner_amd import loss_ops          # (where FusedContrastiveFn looks _sym_jobs up)
+    orig = loss_ops._sym_jobs
+    loss_ops._sym_jobs = lambda cuts, rank, nt: (calls.append((len(cuts) - 1, rank)), orig(cuts, rank, nt))[1]
     if stash is not None:
         ops.STASH_BYTES = stash
     try:
@@ -268,4 +269,4 @@ def test_symmetric_walk_sharded_over_ranks_equals_unsharded(R, M, stash):
         assert (totw - ref_w).abs().max().item() < 2e-4 * max(1e-3, ref_w.abs().max().item())
     finally:
         ops.STASH_BYTES = keep
-        ops._sym_jobs = orig
+        loss_ops._sym_jobs = orig
