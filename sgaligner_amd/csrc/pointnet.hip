@@ -337,8 +337,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // (96 KiB; all of them below): a workgroup serves one channel half (blockIdx & 1), two workgroups share an object and both run
 // layers 1-2 -- 2 x 96 + 384 = 576 MFMAs of 32 cycles per 32-point tile against 640 of 64.
 // BN: the batch sums of the reference's BatchNorm side effect as in pointnet_fwd_kernel<.., BN>: layer 3 in-lane; layer 2 (lane = point)
-// through six MFMAs per 32-channel block against a bf16 identity (the three planes of z2 re-delivered with lane = channel: h + m + l
-// adds up to z2 exactly) -- by the workgroup half that matches the object's parity.
+// through four MFMAs per 32-channel block against a bf16 identity (two planes of z2 re-delivered with lane = channel: 16 significant bits,
+// statistics only) -- by the workgroup half that matches the object's parity.
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pn_split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
@@ -353,6 +353,18 @@ __device__ __forceinline__ void pn_split3_8(const float (&v)[8], u32x4& h, u32x4
         unsigned a, b, c;
         pn_split3_pair(v[2 * p], v[2 * p + 1], a, b, c);
         h[p] = a; m[p] = b; l[p] = c;
+    }
+}
+
+// two planes (16 significant bits, round to nearest at both steps: |v - h - m| <= 2^-17 |v|, unbiased) -- enough for the STATISTICS-only
+// transposition of z2 (batch sums over >= 10^4 points; the values layer 3 consumes keep all three planes)
+__device__ __forceinline__ void pn_split2_8(const float (&v)[8], u32x4& h, u32x4& m) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2 * p], v[2 * p + 1]}, bf16x2));
+        const float r0 = v[2 * p] - __builtin_bit_cast(float, hu << 16), r1 = v[2 * p + 1] - __builtin_bit_cast(float, hu & 0xffff0000u);
+        h[p] = hu;
+        m[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
     }
 }
 
@@ -515,20 +527,20 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] += accs[r];
                 if (DO_L2) {
-                    // the three planes of z2 itself, re-delivered with lane = channel through the identity (h + m + l adds up to z2 exactly)
+                    // two planes of z2 itself (16 bits: statistics only), re-delivered with lane = channel through the identity
                     f32x16 tr;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) tr[r] = 0.f;
-                    u32x4 zp[3][2];
+                    u32x4 zp[2][2];
 #pragma unroll
                     for (int half8 = 0; half8 < 2; ++half8) {
                         float v[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = acc[half8 * 8 + j];
-                        pn_split3_8(v, zp[0][half8], zp[1][half8], zp[2][half8]);
+                        pn_split2_8(v, zp[0][half8], zp[1][half8]);
                     }
 #pragma unroll
-                    for (int pl = 2; pl >= 0; --pl)
+                    for (int pl = 1; pl >= 0; --pl)
 #pragma unroll
                         for (int half8 = 0; half8 < 2; ++half8) tr = mfma_bf16(zp[pl][half8], LG ? make_ident(half8, h_o, lane_o & 31) : ident[half8], tr);
                     bn_fold(tr, 2 * cb);

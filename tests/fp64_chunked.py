@@ -29,10 +29,11 @@ def _q(d, sa, sb):
     return 1.0 / (1.0 + 1.0 / (a + 1e-9) + 1.0 / (b + 1e-9) + 1e-9)
 
 
-def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None, timings=None):
+def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None, timings=None, compile_chunks=False):
     """tables: list of M fp32/fp64 [T, D] tensors (module order), fusion_weight [M, 1], lv_ial / lv_icl [M].
     Returns dict(loss, icl_uni, icl_multi, ial) as python floats and, if want_grad, dE (list of M [T, D] fp64), dw [M, 1], dlv_ial, dlv_icl.
-    timings: an optional dict that receives the wall seconds of the four phases (synchronised)."""
+    timings: an optional dict that receives the wall seconds of the four phases (synchronised).
+    compile_chunks: run the anchors x anchors chunk function (aa_chunk below: plain torch ops) through torch.compile -- the same operations, fused."""
     import time
 
     def _tick(name, t0):
@@ -77,16 +78,19 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
     Xl = [[P[t][0].clone().requires_grad_(want_grad), P[t][1].clone().requires_grad_(want_grad)] for t in range(nt)]
     acc = {'icl': torch.zeros(nt, dtype=torch.float64, device=dev), 'ial': torch.zeros(M, dtype=torch.float64, device=dev)}
     n_el = float(A) * float(A)
-    for lo in range(0, A, rows_aa):
-        hi = min(A, lo + rows_aa)
+    w_ial = (zoom * torch.exp(-l1.detach())).clone()
+    w_icl = torch.cat([torch.exp(-l2.detach()), torch.ones(1, dtype=torch.float64, device=dev)])
+
+    def aa_chunk(x1c, x2c, x1, x2, s_l):
+        """The terms of one anchor-row chunk: (ICL per table [nt], IAL per modality [M], their weighted sum).  Plain torch ops, literal
+        formulas; `compile_chunks` hands exactly this function to torch.compile (same ops, fused -- ~300 full-size fp64 passes otherwise)."""
         q = {}
         for t in range(nt):
-            X1, X2 = Xl[t]
-            S12 = X1[lo:hi] @ X2.t()                          # e1i[i] . e2i[j]
-            S21 = X2[lo:hi] @ X1.t()                          # e2i[i] . e1i[j]  (qb is indexed [i, j] un-transposed)
+            S12 = x1c[t] @ x2[t].t()                          # e1i[i] . e2i[j]
+            S21 = x2c[t] @ x1[t].t()                          # e2i[i] . e1i[j]  (qb is indexed [i, j] un-transposed)
             for ti, tau in enumerate(temps):
-                qa = _q(torch.exp(S12 / tau), s_leaf[t, ti, 0], s_leaf[t, ti, 1])
-                qb = _q(torch.exp(S21 / tau), s_leaf[t, ti, 2], s_leaf[t, ti, 3])
+                qa = _q(torch.exp(S12 / tau), s_l[t, ti, 0], s_l[t, ti, 1])
+                qb = _q(torch.exp(S21 / tau), s_l[t, ti, 2], s_l[t, ti, 3])
                 q[(t, ti)] = (qa, qb)
         chunk_icl = [-(torch.log(ALPHA * q[(t, 0)][0] + (1 - ALPHA) * q[(t, 0)][1])).sum() / n_el for t in range(nt)]
         qm_a, qm_b = q[(M, 1)]
@@ -97,13 +101,29 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
             lb = (torch.exp(qo_b) * (qo_b - qm_b.log())).sum()
             chunk_ial.append(IAL_ZOOM * (ALPHA * la + (1 - ALPHA) * lb))
         ci, ca = torch.stack(chunk_icl), torch.stack(chunk_ial)
+        # d loss / d (terms) is constant: loss = zoom sum_m e^{-l1_m} IAL_m + sum_m e^{-l2_m} ICL_m + ICL_joint (+ the log_vars themselves)
+        return ci, ca, (w_ial * ca).sum() + (w_icl * ci).sum()
+    chunk_fn = aa_chunk
+    if compile_chunks:
+        try:
+            chunk_fn = torch.compile(aa_chunk, dynamic=False)
+        except Exception:                                      # no inductor backend here: the eager function is the same mathematics
+            chunk_fn = aa_chunk
+    for lo in range(0, A, rows_aa):
+        hi = min(A, lo + rows_aa)
+        args = ([Xl[t][0][lo:hi] for t in range(nt)], [Xl[t][1][lo:hi] for t in range(nt)], [Xl[t][0] for t in range(nt)], [Xl[t][1] for t in range(nt)], s_leaf)
+        try:
+            ci, ca, contrib = chunk_fn(*args)
+        except Exception:
+            if chunk_fn is aa_chunk:
+                raise
+            chunk_fn = aa_chunk                                # compilation failed at run time: fall back to eager for the rest
+            ci, ca, contrib = chunk_fn(*args)
         acc['icl'] += ci.detach()
         acc['ial'] += ca.detach()
         if want_grad:
-            # d loss / d (terms) is constant: loss = zoom sum_m e^{-l1_m} IAL_m + sum_m e^{-l2_m} ICL_m + ICL_joint (+ the log_vars themselves)
-            contrib = zoom * (torch.exp(-l1.detach()) * ca).sum() + (torch.exp(-l2.detach()) * ci[:M]).sum() + ci[M]
             contrib.backward()
-        del q, S12, S21, qa, qb, qm_a, qm_b, chunk_icl, chunk_ial, ci, ca
+        del ci, ca, contrib, args
     t_ph = _tick('2_anchors_x_anchors', t_ph)
     ial = (torch.exp(-l1) * acc['ial'] + l1).sum() * zoom
     icl_uni = (torch.exp(-l2) * acc['icl'][:M] + l2).sum()
