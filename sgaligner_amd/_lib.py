@@ -101,7 +101,7 @@ SIGNATURES = {
     'sga_loss_split3_tables': (I, [P, I, I, I, P, P, P]),
     'sga_loss_scatter_tangent': (I, [P, P, P, P, I, I, I, I, P, P, P]),
     'sga_loss_stash_grad_symx_bf16x6': (I, [P, P, P, I, I, I, P, I, I, I, I, I, P]),
-    'sga_loss_multi_sums_bf16x6': (I, [P, I, P, I, I, I, F, F, P, I, I, P]),
+    'sga_loss_multi_sums_bf16x6': (I, [P, I, P, I, I, I, F, F, P, I, I, I, P]),
     'sga_loss_multi_grad_bf16x6': (I, [P, I, P, I, I, I, F, F, P, P, P, I, I, P]),
     'sga_group_loss_fwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, I, P]),
     'sga_group_loss_bwd': (I, [P, I, P, I, I, P, I, P, c_int64, F, F, F, P, P, P, P, P, I, P]),

@@ -246,12 +246,19 @@ struct TArgs {
 // contribute their similarities to the joint coefficient.  M = 4 (point + gat + rel + attr) runs as two launches of MG = 2 (the caller's
 // tables {0, 1 | 2, 3} and {2, 3 | 0, 1}): four tables of three planes need 176 operand + 224 accumulator registers, two of them fit.
 // GAM: accumulate Gamma_m = sum dL/dS_J * S_m (one of the two launches only).
-template <int M, bool GRAD, int WV, int MG = M, bool GAM = true>
+// LITE (forward sums only): the similarities from the h and m planes alone -- products h h + h m + m h + m m (+ the exact K tail), 14 instead of
+// 20 MFMAs per sub-step, and the l planes are neither copied to LDS (14 of a block's 20 chunks) nor read.  Each similarity then carries an
+// UNBIASED rounding of ~2^-17 (round to nearest at both splits), i.e. exp(S / tau0) a relative 1e-4 per pair with a 1e-8 bias: over the >= 2^24
+// terms the caller requires for this form (ops.BF16X6_SUMS_LITE_MIN_TERMS) a global sum moves by < 1e-7 relative -- below the fp32 rounding
+// of its own accumulation.  The gradient sweep always multiplies all six products.
+template <int M, bool GRAD, int WV, int MG = M, bool GAM = true, bool LITE = false>
 __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs a) {
+    static_assert(!LITE || !GRAD, "LITE: the forward sums only");
     constexpr int NCT = 7;
     constexpr int WAVES = WV, THREADS = WAVES * 64;
     constexpr int OWN = WV * 16;                                     // owner rows per workgroup
-    constexpr int KMAX = (S3_NCH + WAVES - 1) / WAVES;              // DMA chunk slots per table and wave
+    constexpr int NCH = LITE ? S3_NCH - S3_PLANE / 1024 : S3_NCH;   // DMA chunks of a block that are copied (LITE: not the l plane's six)
+    constexpr int KMAX = (NCH + WAVES - 1) / WAVES;                 // DMA chunk slots per table and wave
     constexpr int BUF = M * S3_BLOCK;
     constexpr bool PIPE = WV == 4;
 #ifndef S3_OWN_IN_S
@@ -371,7 +378,8 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             const int m = f / KMAX, k = f % KMAX;
             const int rot = (wave_u + m) & (WAVES - 1);
             int c = rot + k * WAVES;
-            if ((k + 1) * WAVES > S3_NCH) c = c >= S3_NCH ? c - WAVES : c;          // only the last k can fall off the block (scalar select)
+            if ((k + 1) * WAVES > NCH) c = c >= NCH ? c - WAVES : c;                // only the last k can fall off the block (scalar select)
+            if (LITE) c = c >= 2 * (S3_PLANE / 1024) ? c + S3_PLANE / 1024 : c;     // chunks 0..11 = h, m planes; 12..13 -> the tail image (18, 19)
             // scalar base + 32-bit lane offset (the saddr form: no 64-bit VALU address per copy)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(tb[m] + (unsigned)(c * 1024)) + l16),
                                              (__attribute__((address_space(3))) void*)(buf + m * S3_BLOCK + c * 1024), 16, 0, 0);
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             };
             auto ld_set = [&](int ss) {
 #pragma unroll
-                for (int idx = 0; idx < 10; ++idx) ld_one(ss, idx);
+                for (int idx = 0; idx < 10; ++idx) if (!(LITE && idx >= 1 && idx <= 3)) ld_one(ss, idx);        // idx 1..3: the l plane
             };
             if (PIPE) {
                 ld_set(0);
@@ -486,6 +494,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                 constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
 #pragma unroll
                 for (int x = 0; x < 20; ++x) {
+                    if (LITE && x >= 2 && (PA[(x - 2) / 3] == 2 || PB[(x - 2) / 3] == 2)) continue;             // no product with an l plane
                     if (x == 0) acc2[0] = mfma_b(at[e], otl[m][1], acc2[0]);
                     else if (x == 1) acc2[1] = mfma_b(at[e], otl[m][0], acc2[1]);
                     else acc2[x & 1] = mfma_b(ap[e][PA[(x - 2) / 3]][(x - 2) % 3], opl[m][PB[(x - 2) / 3]][(x - 2) % 3], acc2[x & 1]);
@@ -919,11 +928,11 @@ int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int
 // (M = 4: four tables' operands -- 176 registers -- leave no room for a second wave on the SIMD in either sweep)
 template <int M, bool GRAD> constexpr int s3_wv() { return M == 4 ? 4 : GRAD ? (M == 3 ? S3_WV_GRAD3 : S3_WV_GRAD2) : S3_WV_SUMS; }
 
-template <int M, bool GRAD, int MG = M, bool GAM = true>
+template <int M, bool GRAD, int MG = M, bool GAM = true, bool LITE = false>
 void launch_t(const TArgs& a, int nwg, hipStream_t s) {
     constexpr int WV = s3_wv<M, GRAD>();
     const size_t lds = (size_t)2 * M * S3_BLOCK;
-    auto k = sweep3_kernel<M, GRAD, WV, MG, GAM>;
+    auto k = sweep3_kernel<M, GRAD, WV, MG, GAM, LITE>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(nwg), dim3(WV * 64), lds, s, a);
 }
@@ -1055,7 +1064,7 @@ extern "C" int sga_loss_scatter_tangent_stat(const float* dZ, const float* Z, co
 }
 
 extern "C" int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
-                                          double* sums, int a_lo, int a_hi, void* stream) {
+                                          double* sums, int a_lo, int a_hi, int lite, void* stream) {
     SGA_CHECK_ARG(Zb && beta && sums && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_multi_sums_bf16x6: bad argument");
     SGA_CHECK_ARG(M >= 2 && M <= 4, "sga_loss_multi_sums_bf16x6: M=%d (2, 3 or 4 modality tables)", M);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1066,7 +1075,11 @@ extern "C" int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const fl
     const int r = fill_t(a, Zb, M, beta, A, J1, J2, tau0, tau1, false, a_lo, a_hi, own_rows, "sga_loss_multi_sums_bf16x6");
     if (r > 0) return r;
     a.sums = sums;
-    if (M == 2) launch_t<2, false>(a, -r, s); else if (M == 3) launch_t<3, false>(a, -r, s); else launch_t<4, false>(a, -r, s);
+    if (lite) {           // h and m planes only (see sweep3_kernel, LITE): the caller vouches for >= 2^24 terms per global sum
+        if (M == 2) launch_t<2, false, 2, true, true>(a, -r, s); else if (M == 3) launch_t<3, false, 3, true, true>(a, -r, s); else launch_t<4, false, 4, true, true>(a, -r, s);
+    } else {
+        if (M == 2) launch_t<2, false>(a, -r, s); else if (M == 3) launch_t<3, false>(a, -r, s); else launch_t<4, false>(a, -r, s);
+    }
     fold_slots(sums, (M + 1) * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_sums_bf16x6");
     return SGA_OK;

@@ -430,6 +430,14 @@ def group_data_dicts(data_dict, b):
     return out
 
 
+def _sums_lite(ns, J1, J2):
+    """Forward sums of the three-plane sweeps from the h and m planes only (csrc/sweep3.hip, LITE)?  ops.BF16X6_SUMS_LITE = True / False forces it;
+    None (default): only when the smallest of the four global sums of this rank's shard has at least BF16X6_SUMS_LITE_MIN_TERMS terms."""
+    if _o.BF16X6_SUMS_LITE is not None:
+        return bool(_o.BF16X6_SUMS_LITE)
+    return ns * min(J1, J2) >= _o.BF16X6_SUMS_LITE_MIN_TERMS
+
+
 def _allreduce_sum(t, group_reduce):
     """Sum a device tensor over the ranks that shard the anchors (identity on one GPU)."""
     if group_reduce is not None:
@@ -495,11 +503,12 @@ class FusedContrastiveFn(torch.autograd.Function):
             if _o.KERNEL_EVENTS is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
+            lite = _sums_lite(a_hi - a_lo, s.J1, s.J2)
             _lib.check(L.sga_loss_multi_sums_bf16x6(_ptr_array(zbs), M, _p(beta), s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sums),
-                                                    a_lo, a_hi, st), 'sga_loss_multi_sums_bf16x6')
+                                                    a_lo, a_hi, 1 if lite else 0, st), 'sga_loss_multi_sums_bf16x6')
             if ev is not None:
                 ev[1].record()
-                _o.KERNEL_EVENTS.setdefault('loss_multi_sums_bf16x6', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M),))
+                _o.KERNEL_EVENTS.setdefault('loss_multi_sums_bf16x6', []).append(ev + ((a_hi - a_lo, s.A, s.J1, s.J2, M, bool(lite)),))
         elif M in (2, 3, 4) and dmax <= 100 and _o.FUSED_ANCHOR_BWD and _o.CENTRED_F32:
             # fp32-MFMA sweeps over the centred fp32 tables (z - zbar | b | 1): the gradient in the same two parts as the three-plane sweeps
             centred32 = True

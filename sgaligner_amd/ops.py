@@ -435,6 +435,11 @@ def _stash_bytes():
 
 # ---- run-time switches of the kernels whose autograd nodes live in pointnet_ops / loss_ops / gat_ops / rank_ops (read there as ops.<FLAG>)
 POINTNET_SPLIT_MAX_OBJECTS = 1023      # the library uses the split form below 4 x CUs objects; above that a workspace is not allocated
+# 'bf16x6' forward sums: all six partial products (False), or the h and m planes only (True: 14 of 20 MFMAs, no l-plane traffic; every similarity
+# with an unbiased 2^-17 rounding).  None (default) = lite only when the smallest of the four global sums has >= BF16X6_SUMS_LITE_MIN_TERMS terms:
+# the roundings average out (relative 1e-4 per term / sqrt(terms), bias 1e-8) far below the fp32 rounding of the sums' own accumulation.
+BF16X6_SUMS_LITE = {'1': True, '0': False}.get(_os.environ.get('SGA_BF16X6_SUMS_LITE', ''), None)
+BF16X6_SUMS_LITE_MIN_TERMS = 1 << 24
 BF16X6_STASH = _os.environ.get('SGA_BF16X6_STASH', '1') != '0'   # 'bf16x6': the A x A stash products on the sweeps' three exact bf16 planes (off: fp32-MFMA GEMMs)
 GAT_COMPLETE_FAST_PATH = _os.environ.get('SGA_GAT_COMPLETE', '1') != '0'     # complete graphs (what the reference's preprocessing writes) skip the edge list in the attention kernels
 SIMRANK_F16 = False      # opt-in: fp16-input MFMA similarity (BASELINE.json configs[4]); the default is exact fp32 MFMA

@@ -29,11 +29,10 @@ def _q(d, sa, sb):
     return 1.0 / (1.0 + 1.0 / (a + 1e-9) + 1.0 / (b + 1e-9) + 1e-9)
 
 
-def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None, timings=None, compile_chunks=False):
+def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None, timings=None):
     """tables: list of M fp32/fp64 [T, D] tensors (module order), fusion_weight [M, 1], lv_ial / lv_icl [M].
     Returns dict(loss, icl_uni, icl_multi, ial) as python floats and, if want_grad, dE (list of M [T, D] fp64), dw [M, 1], dlv_ial, dlv_icl.
-    timings: an optional dict that receives the wall seconds of the four phases (synchronised).
-    compile_chunks: run the anchors x anchors chunk function (aa_chunk below: plain torch ops) through torch.compile -- the same operations, fused."""
+    timings: an optional dict that receives the wall seconds of the four phases (synchronised)."""
     import time
 
     def _tick(name, t0):
@@ -82,8 +81,8 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
     w_icl = torch.cat([torch.exp(-l2.detach()), torch.ones(1, dtype=torch.float64, device=dev)])
 
     def aa_chunk(x1c, x2c, x1, x2, s_l):
-        """The terms of one anchor-row chunk: (ICL per table [nt], IAL per modality [M], their weighted sum).  Plain torch ops, literal
-        formulas; `compile_chunks` hands exactly this function to torch.compile (same ops, fused -- ~300 full-size fp64 passes otherwise)."""
+        """The terms of one anchor-row chunk: (ICL per table [nt], IAL per modality [M], their weighted sum).  Plain torch ops, literal formulas
+        (through torch.compile the same function measured 3 x SLOWER at 1024 pairs -- fp64 codegen + recompiles -- and is not used)."""
         q = {}
         for t in range(nt):
             S12 = x1c[t] @ x2[t].t()                          # e1i[i] . e2i[j]
@@ -103,22 +102,10 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
         ci, ca = torch.stack(chunk_icl), torch.stack(chunk_ial)
         # d loss / d (terms) is constant: loss = zoom sum_m e^{-l1_m} IAL_m + sum_m e^{-l2_m} ICL_m + ICL_joint (+ the log_vars themselves)
         return ci, ca, (w_ial * ca).sum() + (w_icl * ci).sum()
-    chunk_fn = aa_chunk
-    if compile_chunks:
-        try:
-            chunk_fn = torch.compile(aa_chunk, dynamic=False)
-        except Exception:                                      # no inductor backend here: the eager function is the same mathematics
-            chunk_fn = aa_chunk
     for lo in range(0, A, rows_aa):
         hi = min(A, lo + rows_aa)
         args = ([Xl[t][0][lo:hi] for t in range(nt)], [Xl[t][1][lo:hi] for t in range(nt)], [Xl[t][0] for t in range(nt)], [Xl[t][1] for t in range(nt)], s_leaf)
-        try:
-            ci, ca, contrib = chunk_fn(*args)
-        except Exception:
-            if chunk_fn is aa_chunk:
-                raise
-            chunk_fn = aa_chunk                                # compilation failed at run time: fall back to eager for the rest
-            ci, ca, contrib = chunk_fn(*args)
+        ci, ca, contrib = aa_chunk(*args)
         acc['icl'] += ci.detach()
         acc['ial'] += ca.detach()
         if want_grad:

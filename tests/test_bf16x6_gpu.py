@@ -361,3 +361,41 @@ def test_tables_wider_than_100_columns_take_the_fp32_kernels():
         assert (x - y).abs().max().item() < 2e-5 * x.abs().max().item()
         assert x[:, 100:].abs().max().item() > 1e-3 * x.abs().max().item()
     assert (a[2] - b[2]).abs().max().item() < 1e-4 * a[2].abs().max().item()
+
+
+def test_lite_forward_sums_move_the_global_sums_by_less_than_1e6_and_are_used_only_for_large_batches():
+    """ops.BF16X6_SUMS_LITE (csrc/sweep3.hip, LITE): the forward sums from the h and m planes only -- every similarity with an unbiased 2^-17
+    rounding, which averages out over the terms of a global sum.  At 64 pairs x 64 objects (1e7 terms per sum) every loss term moves by < 1e-6
+    relative and the gradients (which always multiply all six products) by < 1e-5 of their maximum; the DEFAULT policy takes the lite form only
+    when the smallest global sum has >= 2^24 terms (reference arithmetic: src/aligner/losses.py:5-15)."""
+    from sgaligner_amd import loss_ops, ops
+    from sgaligner_amd.synthetic import make_batch
+    assert ops.BF16X6_SUMS_LITE is None and ops.BF16X6_SUMS_LITE_MIN_TERMS == 1 << 24
+    assert not loss_ops._sums_lite(2432, 4000, 4100) and loss_ops._sums_lite(9728, 46080, 46080) and loss_ops._sums_lite(19456, 368640, 368640)
+    dd = make_batch(64, 64, 4, seed=31, ragged=True)
+    T = int(dd['tot_obj_count'].sum())
+    g = torch.Generator(device='cuda').manual_seed(8)
+    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(3)]
+    base[2] = base[2] * 0.05 + torch.randn(1, 100, device='cuda', generator=g)            # a table of nearly parallel rows (centred planes)
+    w0 = torch.tensor([[0.4], [1.0], [-0.3]], device='cuda')
+    hint = torch.linspace(0.5, 1.5, 3 + 1 + 6, device='cuda')
+    res = {}
+    keep = ops.BF16X6_SUMS_LITE
+    try:
+        for lite in (False, True):
+            ops.BF16X6_SUMS_LITE = lite
+            tabs = [b.clone().requires_grad_(True) for b in base]
+            w = w0.clone().requires_grad_(True)
+            sums, s = ops.fused_contrastive_terms(tabs, w, dd, coef_hint=hint)
+            (sums * hint).sum().backward()
+            torch.cuda.synchronize()
+            res[lite] = (sums.detach().double(), [t.grad.clone() for t in tabs], w.grad.clone())
+    finally:
+        ops.BF16X6_SUMS_LITE = keep
+    a, b = res[False], res[True]
+    rel = ((a[0] - b[0]).abs() / a[0].abs().clamp_min(1e-300)).max().item()
+    assert rel < 1e-6, rel
+    assert not torch.equal(a[0], b[0])                                                        # (the lite kernel really ran)
+    for x, y in zip(a[1], b[1]):
+        assert (x - y).abs().max().item() < 1e-5 * x.abs().max().item()
+    assert (a[2] - b[2]).abs().max().item() < 1e-5 * a[2].abs().max().item()
