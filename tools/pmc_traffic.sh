@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the two dominant kernels: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over
 # `python bench.py --config <c2|c3> --steps 2 --warmup 1` (counters only, no trace domains).
-# usage: tools/pmc_traffic.sh <c2|c3> <out.csv>   (rows are APPENDED; bench.py reads profiles/r05_pmc_traffic.csv)
+# usage: tools/pmc_traffic.sh <c2|c3> <out.csv>   (rows are APPENDED; bench.py reads profiles/r06_pmc_traffic.csv)
 # row: kernel;workload_key;sha16(kernel source);counter;avg KiB per dispatch;launches  -- bench.py uses a row only when the
 # workload key matches what it runs and the source file is unchanged since the pass.
 set -u
@@ -33,7 +33,7 @@ for f in glob.glob(f'gpurun_out/pmc_t_{cfg}_{c}/**/*counter_collection.csv', rec
         else:
             import re
             mm = re.search(r'(\w+_kernel)<3, (true|false)', name)
-            src = 'sweep3.hip' if mm.group(1) == 'sweep3_kernel' else 'sweeph.hip' if mm.group(1) == 'sweeph_kernel' else 'contrastive.hip'
+            src = 'sweep3.hip' if mm.group(1) == 'sweep3_kernel' else 'contrastive.hip'
             k = (mm.group(1) + '<3,' + mm.group(2) + '>', keys[1], sha(src))
         acc[k] += float(r['Counter_Value']); n[k] += 1
 for k in sorted(acc):

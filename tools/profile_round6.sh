@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 final measurements in one GPU-box call:  tools/profile_round5_final.sh <tag>
-#   1. HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, counters only) at configs[2] and configs[1] -> profiles/r05_pmc_traffic.csv ON THE BOX, so that
+# Round-6 measurements in one GPU-box call:  tools/profile_round6.sh <tag>
+#   1. HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, counters only) at configs[2] and configs[1] -> profiles/r06_pmc_traffic.csv ON THE BOX, so that
 #      the bench line of step 2 carries `traffic`; the file comes back as gpurun_out/<tag>_pmc_traffic.csv
-#   2. the default bench line with the driver's flags
+#   2. the default bench line with the driver's flags (the compact line on stdout + bench_extras.json)
 #   3. rocprofv3 kernel-trace stats at configs[2] (default arithmetic only) and configs[1]
 #   4. SQ counters (MFMA busy, instruction mix, LDS) of the two sweeps and the PointNet forward at configs[1]
 set -u
@@ -13,9 +13,10 @@ mkdir -p gpurun_out
 rm -f gpurun_out/${tag}_pmc_traffic.csv
 bash tools/pmc_traffic.sh c3 gpurun_out/${tag}_pmc_traffic.csv --no-exact > gpurun_out/${tag}_pmc_c3.log 2>&1
 bash tools/pmc_traffic.sh c2 gpurun_out/${tag}_pmc_traffic.csv --no-exact > gpurun_out/${tag}_pmc_c2.log 2>&1
-cp gpurun_out/${tag}_pmc_traffic.csv profiles/r05_pmc_traffic.csv
+cp gpurun_out/${tag}_pmc_traffic.csv profiles/r06_pmc_traffic.csv
 rm -rf gpurun_out/pmc_t_*
 timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_flags.json 2> gpurun_out/${tag}_bench_driver_flags.err
+cp bench_extras.json gpurun_out/${tag}_bench_extras.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_c3_stats -- python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline --no-hits --no-attr --no-c2 --no-pct --no-exact < /dev/null > gpurun_out/${tag}_c3_bench_under_rocprof.json 2> gpurun_out/${tag}_c3_stats.err
 python tools/prof_summary.py gpurun_out/${tag}_c3_stats gpurun_out/${tag}_c3_default_only_kernel_stats.csv > /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_c2_stats -- python bench.py --config c2 --steps 10 --warmup 3 --no-cpu-baseline --no-hits --no-pct --no-exact < /dev/null > gpurun_out/${tag}_c2_bench_under_rocprof.json 2> gpurun_out/${tag}_c2_stats.err
