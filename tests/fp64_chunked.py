@@ -14,7 +14,7 @@ and MultiModalFusion (sg_aligner.py:30-35) for the joint table.  tests/test_fp64
 
 Structure: (1) the global sums of every table / temperature / family by chunked matmul + exp (no graph); (2) the anchors x anchors terms one
 anchor-row chunk at a time under autograd, with the normalised anchor rows and the 16 sums per table as leaves (each chunk's graph is freed by
-its own backward); (3) the gradient that arrives through the sums, dX += (g/t) exp(X N^T / t) N and dN += (g/t) exp(.)^T X, chunked, no graph;
+its own backward) -- or, closed_form=True, the same terms with hand-derived gradients, pinned on the autograd form; (3) the gradient that arrives through the sums, dX += (g/t) exp(X N^T / t) N and dN += (g/t) exp(.)^T X, chunked, no graph;
 (4) normalisation, fusion and the row gathers by one small autograd graph."""
 import numpy as np
 import torch
@@ -29,10 +29,12 @@ def _q(d, sa, sb):
     return 1.0 / (1.0 + 1.0 / (a + 1e-9) + 1.0 / (b + 1e-9) + 1e-9)
 
 
-def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None, timings=None):
+def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1, rows=1024, rows_aa=128, want_grad=True, device=None, timings=None, closed_form=False):
     """tables: list of M fp32/fp64 [T, D] tensors (module order), fusion_weight [M, 1], lv_ial / lv_icl [M].
     Returns dict(loss, icl_uni, icl_multi, ial) as python floats and, if want_grad, dE (list of M [T, D] fp64), dw [M, 1], dlv_ial, dlv_icl.
-    timings: an optional dict that receives the wall seconds of the four phases (synchronised)."""
+    timings: an optional dict that receives the wall seconds of the four phases (synchronised).
+    closed_form: the anchors x anchors chunks with hand-derived gradients (aa_chunk_closed) instead of autograd over the literal formulas (aa_chunk):
+    the same numbers to fp64 rounding, ~6 x fewer full-size passes -- what the headline-size test uses; the pin test runs both."""
     import time
 
     def _tick(name, t0):
@@ -102,8 +104,91 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
         ci, ca = torch.stack(chunk_icl), torch.stack(chunk_ial)
         # d loss / d (terms) is constant: loss = zoom sum_m e^{-l1_m} IAL_m + sum_m e^{-l2_m} ICL_m + ICL_joint (+ the log_vars themselves)
         return ci, ca, (w_ial * ca).sum() + (w_icl * ci).sum()
+    EPS = 1e-9
+    gX = [[torch.zeros_like(P[t][0]), torch.zeros_like(P[t][1])] for t in range(nt)] if (closed_form and want_grad) else None
+    gS = torch.zeros(nt, 2, 4, dtype=torch.float64, device=dev) if (closed_form and want_grad) else None
+    s_val = sums.tolist()
+    wial_l, wicl_l = w_ial.tolist(), w_icl.tolist()
+
+    def q_parts(S, tau, sa, sb):
+        """q = _q(exp(S / tau), sa, sb) with what its derivatives need, in place where possible: returns (d, ru2, rv2, q, ia, ib) with
+        u = d ia + eps, v = d ib + eps (ia = 1 / (sa + eps), ...), ru2 = 1 / u^2, rv2 = 1 / v^2, q = 1 / (1 + eps + 1/u + 1/v)."""
+        ia, ib = 1.0 / (sa + EPS), 1.0 / (sb + EPS)
+        d = S.mul(1.0 / tau).exp_()
+        ru = d.mul(ia).add_(EPS).reciprocal_()
+        rv = d.mul(ib).add_(EPS).reciprocal_()
+        q = (ru + rv).add_(1.0 + EPS).reciprocal_()
+        return d, ru.square_(), rv.square_(), q, ia, ib
+
+    def q_backward(G, parts, tau, t, ti, side):
+        """G = d contrib / d q (consumed).  Returns d contrib / d S and adds d contrib / d (the two sums) to gS:
+        dq/dd = q^2 (ia / u^2 + ib / v^2), dq/dsa = -q^2 d ia^2 / u^2, dq/dsb = -q^2 d ib^2 / v^2, dd/dS = d / tau."""
+        d, ru2, rv2, q, ia, ib = parts
+        T = G.mul_(q).mul_(q).mul_(d)                              # G q^2 d
+        gS[t, ti, 2 * side] -= (ia * ia) * torch.dot(T.reshape(-1), ru2.reshape(-1))
+        gS[t, ti, 2 * side + 1] -= (ib * ib) * torch.dot(T.reshape(-1), rv2.reshape(-1))
+        base = ru2.mul_(ia).add_(rv2, alpha=ib)
+        return T.mul_(base).mul_(1.0 / tau)
+
+    def aa_chunk_closed(lo, hi):
+        """The same chunk terms as aa_chunk with HAND-DERIVED gradients (no autograd graph: ~6 x fewer full-size fp64 passes); pinned on aa_chunk
+        by tests/test_fp64_chunked_gpu.py::test_chunked_fp64_equals_oracle, which runs both."""
+        ci = torch.zeros(nt, dtype=torch.float64, device=dev)
+        ca = torch.zeros(M, dtype=torch.float64, device=dev)
+        Ss = [(P[t][0][lo:hi] @ P[t][1].t(), P[t][1][lo:hi] @ P[t][0].t()) for t in range(nt)]      # (S12, S21)
+        dS = [[None, None] for _ in range(nt)]
+
+        def add_dS(t, side, g):
+            dS[t][side] = g if dS[t][side] is None else dS[t][side].add_(g)
+        # ---- ICL (tau 0.1), table by table
+        for t in range(nt):
+            pa = q_parts(Ss[t][0], temps[0], s_val[t][0][0], s_val[t][0][1])
+            pb = q_parts(Ss[t][1], temps[0], s_val[t][0][2], s_val[t][0][3])
+            wsum = pa[3].mul(ALPHA).add_(pb[3], alpha=1.0 - ALPHA)
+            ci[t] = -torch.log(wsum).sum() / n_el
+            if want_grad:
+                gw = wsum.reciprocal_().mul_(-wicl_l[t] / n_el)                  # d contrib / d (a qa + (1 - a) qb)
+                add_dS(t, 0, q_backward(gw.mul(ALPHA), pa, temps[0], t, 0, 0))
+                add_dS(t, 1, q_backward(gw.mul_(1.0 - ALPHA), pb, temps[0], t, 0, 1))
+            del pa, pb, wsum
+        # ---- IAL (tau 1): qm from the joint table, qo from each modality table
+        for side in (0, 1):
+            wt = ALPHA if side == 0 else 1.0 - ALPHA
+            pm = q_parts(Ss[M][side], temps[1], s_val[M][1][2 * side], s_val[M][1][2 * side + 1])
+            lqm = pm[3].log()
+            rqm = pm[3].reciprocal() if want_grad else None
+            Gm = torch.zeros_like(lqm) if want_grad else None
+            for m in range(M):
+                po = q_parts(Ss[m][side], temps[1], s_val[m][1][2 * side], s_val[m][1][2 * side + 1])
+                e = po[3].exp()
+                diff = po[3] - lqm
+                ca[m] += IAL_ZOOM * wt * torch.dot(e.reshape(-1), diff.reshape(-1))
+                if want_grad:
+                    k = wial_l[m] * IAL_ZOOM * wt
+                    Gm.sub_(e * rqm, alpha=k)                                     # d/dqm of e^{qo} (qo - log qm) = -e^{qo} / qm
+                    Go = diff.add_(1.0).mul_(e).mul_(k)                           # d/dqo = e^{qo} (qo - log qm + 1)
+                    add_dS(m, side, q_backward(Go, po, temps[1], m, 1, side))
+                del po, e, diff
+            if want_grad:
+                add_dS(M, side, q_backward(Gm, pm, temps[1], M, 1, side))
+            del pm, lqm, rqm, Gm
+        if want_grad:
+            for t in range(nt):
+                g12, g21 = dS[t]
+                gX[t][0][lo:hi] += g12 @ P[t][1]
+                gX[t][1] += g12.t() @ P[t][0][lo:hi]
+                gX[t][1][lo:hi] += g21 @ P[t][0]
+                gX[t][0] += g21.t() @ P[t][1][lo:hi]
+        return ci, ca
+
     for lo in range(0, A, rows_aa):
         hi = min(A, lo + rows_aa)
+        if closed_form:
+            with torch.no_grad():
+                ci, ca = aa_chunk_closed(lo, hi)
+            acc['icl'] += ci
+            acc['ial'] += ca
+            continue
         args = ([Xl[t][0][lo:hi] for t in range(nt)], [Xl[t][1][lo:hi] for t in range(nt)], [Xl[t][0] for t in range(nt)], [Xl[t][1] for t in range(nt)], s_leaf)
         ci, ca, contrib = aa_chunk(*args)
         acc['icl'] += ci.detach()
@@ -121,8 +206,9 @@ def overall_loss_fp64(tables, fusion_weight, lv_ial, lv_icl, data_dict, zoom=0.1
         return out
 
     # (3) the gradient through the global sums
-    gs = s_leaf.grad                                           # [nt, 2, 4]
-    dP = [[Xl[t][0].grad.clone(), Xl[t][1].grad.clone(), torch.zeros_like(P[t][2]), torch.zeros_like(P[t][3])] for t in range(nt)]
+    gs = gS if closed_form else s_leaf.grad                    # [nt, 2, 4]
+    dP = [[(gX[t][0] if closed_form else Xl[t][0].grad.clone()), (gX[t][1] if closed_form else Xl[t][1].grad.clone()),
+           torch.zeros_like(P[t][2]), torch.zeros_like(P[t][3])] for t in range(nt)]
     with torch.no_grad():
         for t in range(nt):
             for f, (xi, ni) in enumerate(fam):

@@ -35,8 +35,10 @@ def test_chunked_fp64_equals_oracle(B, N, seed):
     out_o['joint'] = O.fusion([eo[k] for k in mods], wo)
     ref = O.overall_loss(out_o, dd, mods, lo1, lo2)
     ref['loss'].backward()
-    for rows, rows_aa in ((1024, 128), (7, 5)):            # chunk sizes that do / do not divide the anchor count
-        r = overall_loss_fp64([b.cuda() for b in base], w0, lv1, lv2, dd, rows=rows, rows_aa=rows_aa)
+    # chunk sizes that do / do not divide the anchor count; the anchors x anchors part under autograd (literal formulas) and with the hand-derived
+    # gradients the headline-size test below uses
+    for rows, rows_aa, closed in ((1024, 128, False), (7, 5, False), (1024, 128, True), (7, 5, True)):
+        r = overall_loss_fp64([b.cuda() for b in base], w0, lv1, lv2, dd, rows=rows, rows_aa=rows_aa, closed_form=closed)
         assert abs(r['loss'] - ref['loss'].item()) < 1e-10 * abs(ref['loss'].item())
         assert abs(r['ial'] - ref['ial_loss'].item()) < 1e-10 * abs(ref['ial_loss'].item())
         assert abs(r['icl_uni'] - ref['icl_loss_unimodal'].item()) < 1e-10 * abs(ref['icl_loss_unimodal'].item())
@@ -108,7 +110,7 @@ def test_headline_loss_gradient_vs_fp64(pairs):
         ops.set_mfma_mode(old)
     ref32 = res['f32']
     truth = overall_loss_fp64(ref32['tables'], steps.model.fusion.weight, steps.multi_loss_layer_ial.log_vars, steps.multi_loss_layer_icl.log_vars, dd,
-                              rows=4096 if pairs >= 4096 else 1024, timings=(timings := {}))
+                              rows=4096 if pairs >= 4096 else 1024, timings=(timings := {}), closed_form=True, rows_aa=512 if pairs >= 4096 else 256)
     for i in range(len(mods)):
         assert torch.equal(res['bf16x6']['tables'][i], ref32['tables'][i])        # the encoder is the same arithmetic in both steps
     gen = torch.Generator().manual_seed(7)
