@@ -62,10 +62,12 @@ size_t sga_pointnet_fwd_bn_ws_bytes(int T, int C3);
 int sga_pointnet_fwd_bn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* w3, const float* b3, float* y, int32_t* argmax, int T, int P, int C3,
                         void* workspace, size_t ws_bytes, void* bn_workspace, size_t bn_ws_bytes, double* bn_sums, int mode, void* stream);
-/* autograd of the above wrt the six parameters (sparse through the max-pool); gy [T,C3]; C3 == 256. */
+/* autograd of the above wrt the six parameters (sparse through the max-pool: pointnet.py:140-161 through the arg-max points); gy [T,C3]; C3 == 256.
+ * mode: the arithmetic of the three winner-row GEMMs (Z2 recomputation, dH1 = dZ2 W2, gW2 += dZ2^T H1) -- 0 = fp32 MFMA, 4 = three exact bf16
+ * planes, six bf16 MFMAs per product into fp32 accumulators (as sga_pointnet_fwd_ws mode 4).  Everything else is fp32 VALU in both. */
 int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy, const float* w1,
                      const float* b1, const float* w2, const float* b2, const float* w3, float* gw1, float* gb1,
-                     float* gw2, float* gb2, float* gw3, float* gb3, int T, int P, int C3, void* stream);
+                     float* gw2, float* gb2, float* gw3, float* gb3, int T, int P, int C3, int mode, void* stream);
 
 /* ---- dense layers -----------------------------------------------------------------------------------
  * C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]);  transX = 0: X stored [rows][K]..., see gemm.hip.

@@ -35,7 +35,7 @@ SIGNATURES = {
     'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, I, P]),
     'sga_pointnet_fwd_bn_ws_bytes': (c_size_t, [I, I]),
     'sga_pointnet_fwd_bn': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, P, c_size_t, P, I, P]),
-    'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, P]),
+    'sga_pointnet_bwd': (I, [P] * 15 + [I, I, I, I, P]),
     'sga_gat_complete_flags': (I, [P, P, P, I, P, P]),
     'sga_gat_attn_fwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
     'sga_gat_attn_bwd': (I, [P, P, P, P, P, P, P, I, I, P, P, P, P, P]),

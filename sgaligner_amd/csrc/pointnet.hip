@@ -842,6 +842,7 @@ namespace {
 // odd ones 4-7 -- so the gW3 partials stay private to (wave, lane) across objects.
 // -------------------------------------------------------------------------------------------------
 constexpr int TRS = 36;            // transpose tile row stride (floats): 16-byte aligned rows, conflict-free column reads
+constexpr int W3S = 68;            // row stride (floats) of the three-plane backward's W3 rows in LDS (64 channels + 4: 16-byte aligned, rows off each other's banks)
 
 __global__ __launch_bounds__(256) void pointnet_bwd_fused_kernel(
     const float* __restrict__ x, const int* __restrict__ argmax, const float* __restrict__ y,
@@ -1054,13 +1055,341 @@ __global__ __launch_bounds__(256) void pointnet_bwd_fused_kernel(
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// The same fused backward with the three GEMMs of a winner-row tile on three exact bf16 planes (mode 4, the default arithmetic; six bf16
+// MFMAs per product as in the forward): 288 v_mfma_f32_32x32x16_bf16 of 32 cycles per tile instead of 384 v_mfma_f32_32x32x2_f32 of 64.
+//   Z2^T = W2 H1^T      A = W2 planes, operand order (LDS, as the forward's layer 2)   B = H1 planes (lane = row)        D: lane = row, regs = ch2
+//   dH1  = dZ2 W2       A = dZ2 planes: the D registers of Z2 ARE the A k-slots        B = W2 planes in that k-slot order D: lane = k1,  regs = rows
+//   gW2 += dZ2^T H1     A = planes of dZ2^T (transposed through the wave's LDS tile)   B = planes of H1 (lane = k1)     D: lane = k1,  regs = ch2
+// Z2 is recomputed with the forward kernel's products in the forward kernel's order: the ReLU masks of the backward are the forward's own bits.
+// The five small partial products of every accumulation go to their own accumulator (the 16-bit MFMAs chop toward minus infinity what falls
+// below the result's last place: tools/micro/mfma_round_probe.hip); gW2's products of a tile start from zero and are added to the running
+// fp32 sums on the VALU (round to nearest), so that nothing small is ever added onto a large MFMA accumulator across the million objects
+// of a batch.  Everything else -- H1, the ReLU masks, gW3 / gb3, dZ1 and gW1 / gb1 -- is the fp32 VALU code of the kernel above.
+// Work split: the operand planes cost registers the fp32 kernel spends on accumulators, so a wave owns a winner-row tile AND one half of the
+// 128 layer-2 channels (64 running gW2 sums + 32 gW3 sums per lane instead of 128 + 64): workgroup kinds (tiles 0-3 | 4-7) x (ch2 0-63 | 64-127).
+// dH1 = dZ2 W2 is linear in dZ2, so each half's partial dH1 goes through the ReLU mask and into gW1 / gb1 on its own.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pointnet_bwd_p3_kernel(
+    const float* __restrict__ x, const int* __restrict__ argmax, const float* __restrict__ y,
+    const float* __restrict__ gy, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+    float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
+    float* __restrict__ gw3, float* __restrict__ gb3, int T, int P) {
+    constexpr int C3 = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsb[];
+    u32x4* w2a = reinterpret_cast<u32x4*>(ldsb);            // [3 planes][2 ci][4 ks][64 lane]         A operand of Z2^T = W2 H1^T (this half's channels)  24 KiB
+    u32x4* w2b = w2a + 3 * 512;                              // [3 planes][2 ci][2 half8][2 kt][64 lane] B operand of dH1 = dZ2 W2                            24 KiB
+    float* trs = reinterpret_cast<float*>(w2b + 3 * 512);    // [4 waves][32][TRS] transpose tiles; reused as the gW2 combine buffer at the end
+    float* w3s = trs + 4 * 32 * TRS;                         // [128 rows c of this tile group][64 ch2 of this half + 4 pad]: loop invariant          34 KiB
+    float* w1s = w3s + 128 * W3S;
+    float* b1s = w1s + 192;
+    float* b2s = b1s + 64;
+    const int tid = threadIdx.x;
+    const int kind = (int)blockIdx.x & 3, tg = kind & 1, chh = kind >> 1;        // tile group, ch2 half
+    for (int d = tid; d < 128 * 16; d += 256) {
+        const int row = d >> 4, q = d & 15;
+        *reinterpret_cast<f32x4*>(w3s + row * W3S + 4 * q) = *reinterpret_cast<const f32x4*>(w3 + (size_t)(tg * 128 + row) * 128 + chh * 64 + 4 * q);
+    }
+    for (int d = tid; d < 384; d += 256) w1s[d] = d < 192 ? w1[d] : (d < 256 ? b1[d - 192] : b2[d - 256]);
+    for (int d = tid; d < 512; d += 256) {
+        const int ln = d & 63;
+        {   // A operand: row = out channel cb * 32 + (ln & 31), k-slots = in channels 16 ks + 8 (ln >> 5) + j
+            const int ks = (d >> 6) & 3, cb = 2 * chh + (d >> 8);
+            const float* src = w2 + (cb * 32 + (ln & 31)) * 64 + 16 * ks + 8 * (ln >> 5);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[j];
+            u32x4 ph, pm, pl;
+            pn_split3_8(v, ph, pm, pl);
+            w2a[d] = ph; w2a[512 + d] = pm; w2a[1024 + d] = pl;
+        }
+        {   // B operand: column = k1 = kt * 32 + (ln & 31), k-slot (hh, j) = ch2 = cb * 32 + 16 half8 + 4 hh + (j & 3) + 8 (j >> 2): the D layout of Z2
+            const int kt = (d >> 6) & 1, half8 = (d >> 7) & 1, cb = 2 * chh + (d >> 8), hh = ln >> 5;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w2[(cb * 32 + 16 * half8 + 4 * hh + (j & 3) + 8 * (j >> 2)) * 64 + kt * 32 + (ln & 31)];
+            u32x4 ph, pm, pl;
+            pn_split3_8(v, ph, pm, pl);
+            w2b[d] = ph; w2b[512 + d] = pm; w2b[1024 + d] = pl;
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave0 = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int wave = tg * 4 + wave0;                         // this wave's winner-row tile, fixed for the whole kernel
+    float* tr = trs + wave0 * 32 * TRS;
+    float gw3a[32];                 // [ci][r] : gW3[wave*32 + l31][(2 chh + ci)*32 + mfma32_row(r, h)]
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gw3a[i] = 0.f;
+    f32x16 gw2a[4];                 // [ci][kt] : gW2[(2 chh + ci)*32 + row(r,h)][kt*32 + l31], running fp32 sums (VALU adds of each tile's fresh products)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gw2a[i][r] = 0.f;
+    float gb3a = 0.f, gb2a[2] = {0.f, 0.f};
+    float gw1a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb1a[2] = {0.f, 0.f};
+
+    const int obj0 = (int)blockIdx.x >> 2, ostep = ((int)gridDim.x + 3) >> 2;
+    const int n_iter = obj0 < T ? (T - obj0 + ostep - 1) / ostep : 0;
+    float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, ng = 0.f;
+    if (n_iter > 0) {
+        const size_t ri = (size_t)obj0 * C3 + wave * 32 + l31;
+        const int p0 = min(max(argmax[ri], 0), P - 1);
+        const float* xp = x + ((size_t)obj0 * P + p0) * 3;
+        nx0 = xp[0]; nx1 = xp[1]; nx2 = xp[2];
+        ng = y[ri] > 0.f ? gy[ri] : 0.f;
+    }
+    for (int it = 0; it < n_iter; ++it) {
+        int lane_o = lane, h_o = h;
+        asm volatile("" : "+v"(lane_o), "+v"(h_o));          // keep weight reads inside the loop (see fwd)
+        const int l31_o = lane_o & 31;
+        const float x0 = nx0, x1 = nx1, x2 = nx2, g = ng;
+        const int tn = obj0 + min(it + 1, n_iter - 1) * ostep;
+        const size_t rin = (size_t)tn * C3 + wave * 32 + l31_o;
+        const int pn_raw = argmax[rin];
+        const float yn = y[rin], gyn = gy[rin];
+        if (h == 0 && chh == 0) gb3a += g;
+
+        // ---- H1, lane = row: this lane's 32 channels k = 16 ks + 8 h + j, split for the MFMA B operand (as the forward's layer 1)
+        u32x4 h1p[3][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 16 * ks + 8 * h_o;
+            float v[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kk = k + 4 * half;
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w1s + kk * 3);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w1s + kk * 3 + 4);
+                const f32x4 wc = *reinterpret_cast<const f32x4*>(w1s + kk * 3 + 8);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + kk);
+                v[4 * half + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
+                v[4 * half + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
+                v[4 * half + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
+                v[4 * half + 3] = fmaxf(fmaf(wc[3], x2, fmaf(wc[2], x1, fmaf(wc[1], x0, bb[3]))), 0.f);
+            }
+            pn_split3_8(v, h1p[0][ks], h1p[1][ks], h1p[2][ks]);
+        }
+        // ---- H1, lane = k1 / regs = rows, from two K = 2 fp32 MFMAs per 32 channels (as the kernel above), and its planes as B operand of gW2
+        // (the fp32 values are not kept: the ReLU mask of dZ1 at the end is read off the h plane -- bf16(v) != 0 exactly when v > 0 for v >= 0)
+        u32x4 h1cp[3][2][2];                                 // [plane][kt][half8]: k-slot (h, j) = row mfma32_row(half8 * 8 + j, h)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int k1 = kt * 32 + l31_o;
+            const float bA = w1s[k1 * 3 + h_o];
+            const float bB = h_o ? b1s[k1] : w1s[k1 * 3 + 2];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? x1 : x0, bA, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h_o ? 1.f : x2, bB, acc, 0, 0, 0);
+#pragma unroll
+            for (int half8 = 0; half8 < 2; ++half8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[half8 * 8 + j], 0.f);
+                pn_split3_8(v, h1cp[0][kt][half8], h1cp[1][kt][half8], h1cp[2][kt][half8]);
+            }
+        }
+        {   // the next tile's point: its index arrived during the H1 section
+            const int pn = min(max(pn_raw, 0), P - 1);
+            const float* xpn = x + ((size_t)tn * P + pn) * 3;
+            nx0 = xpn[0]; nx1 = xpn[1]; nx2 = xpn[2];
+            ng = yn > 0.f ? gyn : 0.f;
+        }
+
+        f32x16 dh1[2], dh1s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dh1[kt][r] = 0.f; dh1s[kt][r] = 0.f; }
+        // Z2[row = lane][ch2 = cb*32 + mfma32_row(r, h)] of BOTH channel blocks: the h h products start at the bias, the small ones at zero; products
+        // and their order per accumulator as in the forward kernel's layer 2 (the same bits), the two blocks' chains interleaved so that two
+        // consecutive MFMAs never share an accumulator
+        f32x16 z2a[2], z2s[2];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + (2 * chh + ci) * 32 + 8 * gq + 4 * h_o);
+                z2a[ci][gq * 4 + 0] = bb[0]; z2a[ci][gq * 4 + 1] = bb[1]; z2a[ci][gq * 4 + 2] = bb[2]; z2a[ci][gq * 4 + 3] = bb[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z2s[ci][r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 wh[2], wm[2], wl[2];
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int d = (ci * 4 + ks) * 64 + lane_o;
+                wh[ci] = w2a[d]; wm[ci] = w2a[512 + d]; wl[ci] = w2a[1024 + d];
+            }
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) z2s[ci] = mfma_bf16(wl[ci], h1p[0][ks], z2s[ci]);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) z2s[ci] = mfma_bf16(wh[ci], h1p[2][ks], z2s[ci]);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) z2s[ci] = mfma_bf16(wm[ci], h1p[1][ks], z2s[ci]);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) z2a[ci] = mfma_bf16(wh[ci], h1p[0][ks], z2a[ci]);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) z2s[ci] = mfma_bf16(wm[ci], h1p[0][ks], z2s[ci]);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) z2s[ci] = mfma_bf16(wh[ci], h1p[1][ks], z2s[ci]);
+        }
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            const f32x16 acc = z2a[ci], accs = z2s[ci];
+            // dZ2 = g * W3[c][ch2] * (Z2 > 0); gW3 partials; the tile goes to LDS for the transpose
+            float dz[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 w3v = *reinterpret_cast<const f32x4*>(w3s + (wave0 * 32 + l31_o) * W3S + ci * 32 + 8 * gq + 4 * h_o);
+                f32x4 dzv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = acc[gq * 4 + r] + accs[gq * 4 + r];
+                    gw3a[ci * 16 + gq * 4 + r] = fmaf(g, fmaxf(z, 0.f), gw3a[ci * 16 + gq * 4 + r]);
+                    dzv[r] = (z > 0.f ? g : 0.f) * w3v[r];
+                    dz[gq * 4 + r] = dzv[r];
+                }
+                *reinterpret_cast<f32x4*>(tr + l31_o * TRS + 8 * gq + 4 * h_o) = dzv;       // tr[row][ch2 local]
+            }
+            // dH1[row][k1] += sum_ch2 dZ2[row][ch2] W2[ch2][k1]: the D registers of Z2 are the A operand's k-slots (two K = 16 steps)
+#pragma unroll
+            for (int half8 = 0; half8 < 2; ++half8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = dz[half8 * 8 + j];
+                u32x4 ah, am, al;
+                pn_split3_8(v, ah, am, al);
+                // (the two k1 halves alternate: two consecutive MFMAs never share an accumulator -- an LDS read or a VALU instruction between two
+                //  dependent MFMAs breaks their back-to-back forwarding, +43 cycles each, and a wave alone on its SIMD has nobody to hide it)
+                u32x4 wh[2], wm[2], wl[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int d = ((ci * 2 + half8) * 2 + kt) * 64 + lane_o;
+                    wh[kt] = w2b[d]; wm[kt] = w2b[512 + d]; wl[kt] = w2b[1024 + d];
+                }
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) dh1s[kt] = mfma_bf16(al, wh[kt], dh1s[kt]);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) dh1s[kt] = mfma_bf16(ah, wl[kt], dh1s[kt]);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) dh1s[kt] = mfma_bf16(am, wm[kt], dh1s[kt]);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) dh1[kt] = mfma_bf16(ah, wh[kt], dh1[kt]);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) dh1s[kt] = mfma_bf16(am, wh[kt], dh1s[kt]);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) dh1s[kt] = mfma_bf16(ah, wm[kt], dh1s[kt]);
+            }
+            // lane = ch2, regs = rows: gb2 and gW2 += dZ2^T H1   (wave-private tile: the waitcnt of the reads orders them after this wave's
+            // own writes; no barrier)
+            float colsum = 0.f;
+            float dzt[16];
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                dzt[s_] = tr[mfma32_row(s_, h_o) * TRS + l31_o];
+                colsum += dzt[s_];
+            }
+            gb2a[ci] += colsum;
+            u32x4 tp[3][2];
+#pragma unroll
+            for (int half8 = 0; half8 < 2; ++half8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = dzt[half8 * 8 + j];
+                pn_split3_8(v, tp[0][half8], tp[1][half8], tp[2][half8]);
+            }
+            {
+                f32x16 ga[2], gs_[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ga[kt][r] = 0.f; gs_[kt][r] = 0.f; }
+#pragma unroll
+                for (int half8 = 0; half8 < 2; ++half8) {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) gs_[kt] = mfma_bf16(tp[2][half8], h1cp[0][kt][half8], gs_[kt]);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) gs_[kt] = mfma_bf16(tp[0][half8], h1cp[2][kt][half8], gs_[kt]);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) gs_[kt] = mfma_bf16(tp[1][half8], h1cp[1][kt][half8], gs_[kt]);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) ga[kt] = mfma_bf16(tp[0][half8], h1cp[0][kt][half8], ga[kt]);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) gs_[kt] = mfma_bf16(tp[1][half8], h1cp[0][kt][half8], gs_[kt]);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) gs_[kt] = mfma_bf16(tp[0][half8], h1cp[1][kt][half8], gs_[kt]);
+                }
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gw2a[ci * 2 + kt][r] += ga[kt][r] + gs_[kt][r];
+            }
+        }
+        // ---- dZ1 = (this half's part of dH1) * (H1 > 0) in the lane = k1 layout; gW1 / gb1 (x of row(s,h) by lane shuffle)
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const int src = mfma32_row(s_, h);
+            const float sx0 = __shfl(x0, src, 64), sx1 = __shfl(x1, src, 64), sx2 = __shfl(x2, src, 64);
+            const unsigned m0 = h1cp[0][0][s_ >> 3][(s_ & 7) >> 1], m1 = h1cp[0][1][s_ >> 3][(s_ & 7) >> 1];       // pair (j, j + 1) of k-slot j = s_ & 7
+            const bool on0 = ((s_ & 1) ? (m0 >> 16) : (m0 & 0xffffu)) != 0, on1 = ((s_ & 1) ? (m1 >> 16) : (m1 & 0xffffu)) != 0;
+            const float dz0 = on0 ? dh1[0][s_] + dh1s[0][s_] : 0.f;
+            const float dz1 = on1 ? dh1[1][s_] + dh1s[1][s_] : 0.f;
+            gw1a[0][0] = fmaf(dz0, sx0, gw1a[0][0]); gw1a[0][1] = fmaf(dz0, sx1, gw1a[0][1]); gw1a[0][2] = fmaf(dz0, sx2, gw1a[0][2]);
+            gw1a[1][0] = fmaf(dz1, sx0, gw1a[1][0]); gw1a[1][1] = fmaf(dz1, sx1, gw1a[1][1]); gw1a[1][2] = fmaf(dz1, sx2, gw1a[1][2]);
+            gb1a[0] += dz0;
+            gb1a[1] += dz1;
+        }
+    }
+
+    // ---- flush the per-workgroup partials (gw3a's index r is the D register: ch2 = cb*32 + mfma32_row(r, h))
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        atomicAdd(gw3 + (size_t)(wave * 32 + l31) * 128 + (2 * chh + (i >> 4)) * 32 + mfma32_row(i & 15, h), gw3a[i]);
+    if (h == 0 && chh == 0) atomicAdd(gb3 + wave * 32 + l31, gb3a);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int k1 = kt * 32 + l31;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = gw1a[kt][d] + __shfl_xor(gw1a[kt][d], 32, 64);
+            if (h == 0) atomicAdd(gw1 + k1 * 3 + d, v);
+        }
+        const float vb = gb1a[kt] + __shfl_xor(gb1a[kt], 32, 64);
+        if (h == 0) atomicAdd(gb1 + k1, vb);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const float v = gb2a[ci] + __shfl_xor(gb2a[ci], 32, 64);
+        if (h == 0) atomicAdd(gb2 + (2 * chh + ci) * 32 + l31, v);
+    }
+    // gW2 (this half's 64 rows): combine the 4 waves in LDS (the transpose tiles are dead now), then one global atomic per element
+    __syncthreads();
+    for (int d = tid; d < 4096; d += 256) trs[d] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            atomicAdd(trs + ((i >> 1) * 32 + mfma32_row(r, h)) * 64 + (i & 1) * 32 + l31, gw2a[i][r]);
+    __syncthreads();
+    for (int d = tid; d < 4096; d += 256) atomicAdd(gw2 + chh * 4096 + d, trs[d]);
+}
+
 }  // namespace
 
 extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const float* y, const float* gy,
                                 const float* w1, const float* b1, const float* w2, const float* b2,
                                 const float* w3, float* gw1, float* gb1, float* gw2, float* gb2, float* gw3,
-                                float* gb3, int T, int P, int C3, void* stream) {
+                                float* gb3, int T, int P, int C3, int mode, void* stream) {
     SGA_CHECK_ARG(C3 == 256, "sga_pointnet_bwd: out_size C3=%d unsupported (256 only)", C3);
+    SGA_CHECK_ARG(mode == 0 || mode == 4, "sga_pointnet_bwd: mode %d (0 = exact fp32 MFMA, 4 = three exact bf16 planes)", mode);
     SGA_CHECK_ARG(T >= 0 && P >= 1, "sga_pointnet_bwd: bad sizes");
     SGA_CHECK_ARG((T == 0 || (x && argmax && y && gy)) && w1 && b1 && w2 && b2 && w3 && gw1 && gb1 && gw2 && gb2 && gw3 && gb3,
                   "sga_pointnet_bwd: null pointer");
@@ -1076,9 +1405,14 @@ extern "C" int sga_pointnet_bwd(const float* x, const int32_t* argmax, const flo
         hipMemsetAsync(gb3, 0, 256 * sizeof(float), s);
     }
     if (T == 0) return SGA_OK;
-    {
+    const int g2 = 2 * T < sga_num_cus() ? 2 * T : (sga_num_cus() & ~1);      // workgroups come in (tiles 0-3, tiles 4-7) pairs
+    if (mode == 4) {
+        const int g4 = 4 * T < sga_num_cus() ? 4 * T : (sga_num_cus() & ~3);  // ... here in quadruples: (tile group) x (half of the layer-2 channels)
+        const size_t lds_b = (size_t)2 * 3 * 512 * 16 + (4 * 32 * TRS + 128 * W3S + 384) * sizeof(float);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_bwd_p3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        hipLaunchKernelGGL(pointnet_bwd_p3_kernel, dim3(g4), dim3(256), lds_b, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
+    } else {
         const size_t lds_f = (3 * 8192 + 384) * sizeof(float);
-        int g2 = 2 * T < sga_num_cus() ? 2 * T : (sga_num_cus() & ~1);      // workgroups come in (tiles 0-3, tiles 4-7) pairs
         hipFuncSetAttribute(reinterpret_cast<const void*>(pointnet_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
         hipLaunchKernelGGL(pointnet_bwd_fused_kernel, dim3(g2), dim3(256), lds_f, s, x, argmax, y, gy, w1, b1, w2, b2, w3, gw1, gb1, gw2, gb2, gw3, gb3, T, P);
     }

@@ -410,6 +410,11 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
         double dsum[M + 1][2];
 #pragma unroll
         for (int m = 0; m <= M; ++m) { dsum[m][0] = 0.0; dsum[m][1] = 0.0; }
+        // LITE: a lane's fp32 partial sums run over FOUR tiles (32 terms) before they go to the fp64 sums -- 2 (M + 1) conversions and fp64 adds
+        // (half-rate VALU) per four tiles instead of per tile; the extra fp32 roundings are unbiased and ~3e-7 of a partial each
+        float pl0[LITE ? M + 1 : 1], pl1[LITE ? M + 1 : 1];
+#pragma unroll
+        for (int m = 0; m < (LITE ? M + 1 : 1); ++m) { pl0[m] = 0.f; pl1[m] = 0.f; }
 
         __syncthreads();
         if (seg.jt_lo + split < seg.jt_hi) issue(seg.blk0 + seg.jt_lo + split, lds3);
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             if (!GRAD) {
                 float p0[M + 1], p1[M + 1];
 #pragma unroll
-                for (int m = 0; m <= M; ++m) { p0[m] = 0.f; p1[m] = 0.f; }
+                for (int m = 0; m <= M; ++m) { p0[m] = LITE ? pl0[LITE ? m : 0] : 0.f; p1[m] = LITE ? pl1[LITE ? m : 0] : 0.f; }
                 // forward sums: exp2(0) = 1 of a padded / foreign row would count, so edge tiles are masked; interior tiles add unmasked
                 auto sums_tile = [&](auto masked_c) {
                     constexpr bool MASKED = decltype(masked_c)::value;
@@ -549,8 +554,15 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                         }
                 };
                 if (j0 >= seg.lo && j0 + 32 <= seg.hi && own0 + OWN <= own_end) sums_tile(std::false_type{}); else sums_tile(std::true_type{});   // uniform
+                if (!LITE || (it & 3) == 3) {
 #pragma unroll
-                for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
+                    for (int m = 0; m <= M; ++m) { dsum[m][0] += (double)p0[m]; dsum[m][1] += (double)p1[m]; }
+#pragma unroll
+                    for (int m = 0; m < (LITE ? M + 1 : 1); ++m) { pl0[m] = 0.f; pl1[m] = 0.f; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < (LITE ? M + 1 : 1); ++m) { pl0[m] = p0[m]; pl1[m] = p1[m]; }
+                }
             } else {
                 // Gradient GEMM B operands (8 consecutive other rows 8 g4 .. + 7 of column 16 ct + c) by LDS transpose reads of the row planes,
                 // one STEP = (table, column tile): 6 transpose reads, 6 MFMAs: five small partial products into gsm, h h into gacc
@@ -692,6 +704,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             for (int m = 0; m <= M; ++m)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
+                    if (LITE) dsum[m][tt] += (double)(tt ? pl1[LITE ? m : 0] : pl0[LITE ? m : 0]);         // what the last (< 4) tiles left
                     const double v = wave_sum_d(dsum[m][tt]);
                     if (lane == 0 && v != 0.0) atomicAdd(a.sums + (M + 1) * 8 * (1 + my_slot()) + m * 8 + seg.fam * 2 + tt, v);
                 }

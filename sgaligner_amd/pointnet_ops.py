@@ -92,7 +92,7 @@ class PointNetFn(torch.autograd.Function):
             g.append(flat[o:o + t.numel()].view(t.shape))
             o += t.numel()
         rc = _lib.lib().sga_pointnet_bwd(_p(x), _p(am), _p(y), _p(gy), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3),
-                                         _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]), T, P, C3, _stream())
+                                         _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]), T, P, C3, _POINTNET_MODE[get_mfma_mode()], _stream())
         _lib.check(rc, 'sga_pointnet_bwd')
         s1, s2, s3 = ctx.wshapes
         return None, g[0].reshape(s1), g[1], g[2].reshape(s2), g[3], g[4].reshape(s3), g[5], None
