@@ -349,15 +349,15 @@ def roofline_objects(events, world):
         alg = (2.0 if grad else 1.0) * (2.0 * d_sum * pairs)
         mfma_flops = 16 * 16 * 32 * 2.0
         # (M = 4: the backward is TWO launches, each forming all four similarities and the owner gradients of two tables: 2 x (160 + 84) MFMAs)
-        executed = (2.0 * pairs / 512.0 * (M * 82 if M < 4 else 488) * mfma_flops) if grad else (pairs / 512.0 * M * (28 if lite else 40) * mfma_flops)
-        # the ceiling in fp32-product terms: six bf16 MFMAs per product; the lite forward sums execute 14/20 of them (4.2 per product)
-        peak = PEAK_F16_TFLOPS / (6.0 * (14.0 / 20.0 if lite else 1.0))
+        executed = (2.0 * pairs / 512.0 * (M * 82 if M < 4 else 488) * mfma_flops) if grad else (pairs / 512.0 * M * (22 if lite else 40) * mfma_flops)
+        # the ceiling in fp32-product terms: six bf16 MFMAs per product; the lite forward sums execute 11/20 of them (3.3 per product)
+        peak = PEAK_F16_TFLOPS / (6.0 * (11.0 / 20.0 if lite else 1.0))
         useful = (3.0 if grad else 1.0) * 2.0 * 100 * M * pairs          # S once + the two gradient GEMMs (backward), sum D = 100 M
         avg_ms = float(np.mean(durs))
         ach = alg / (avg_ms * 1e-3) / 1e12
         roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                       'frac': round(ach / peak, 4),
-                      'peak_is': ('dense bf16 MFMA peak (2500 TFLOP/s) / 4.2: the forward sums multiply the h and m planes only (14 of the 20 MFMAs of a six-product sub-step)' if lite else
+                      'peak_is': ('dense bf16 MFMA peak (2500 TFLOP/s) / 3.3: the forward sums multiply the h and m planes only (h h + h m + m h + the K tail: 11 of the 20 MFMAs of a six-product sub-step)' if lite else
                                   'dense bf16 MFMA peak (2500 TFLOP/s) / 6: an fp32 product on three exact bf16 planes is six bf16 MFMAs'),
                       'frac_useful': round(useful / (avg_ms * 1e-3) / 1e12 / peak, 4),
                       'frac_useful_is': 'S once + two gradient GEMMs over the M modality tables (sum D = 100 M; the joint table is derived), same peak',

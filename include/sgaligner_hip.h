@@ -244,8 +244,8 @@ int sga_loss_check_norms(const float* nrm, int n, float* poison, void* stream);
  * costs a table of nearly parallel rows 3e-4 of its gradient when the radial part is formed in fp32 first. */
 size_t sga_loss_split3_bytes(int A, int J1, int J2);
 int sga_loss_split3_tables(const float* Z, int A, int J1, int J2, void* Zb, float* Zc, void* stream);
-/* lite != 0 (forward sums only): similarities from the h and m planes alone (products h h + h m + m h + m m, exact K tail; 14 instead of 20 MFMAs
- * and no l-plane traffic) -- every similarity with an unbiased ~2^-17 rounding; for global sums of >= 2^24 terms each (the caller's call) they move by
+/* lite != 0 (forward sums only): similarities from the h and m planes alone (products h h + h m + m h, exact K tail; 11 instead of 20 MFMAs
+ * and no l-plane traffic) -- every similarity with an unbiased ~2^-16 rounding; for global sums of >= 2^24 terms each (the caller's call) they move by
  * < 1e-7 relative.  lite == 0: all six products. */
 int sga_loss_multi_sums_bf16x6(const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1,
                                double* sums, int a_lo, int a_hi, int lite, void* stream);

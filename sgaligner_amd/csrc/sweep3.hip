@@ -246,9 +246,9 @@ struct TArgs {
 // contribute their similarities to the joint coefficient.  M = 4 (point + gat + rel + attr) runs as two launches of MG = 2 (the caller's
 // tables {0, 1 | 2, 3} and {2, 3 | 0, 1}): four tables of three planes need 176 operand + 224 accumulator registers, two of them fit.
 // GAM: accumulate Gamma_m = sum dL/dS_J * S_m (one of the two launches only).
-// LITE (forward sums only): the similarities from the h and m planes alone -- products h h + h m + m h + m m (+ the exact K tail), 14 instead of
+// LITE (forward sums only): the similarities from the h and m planes alone -- products h h + h m + m h (+ the exact K tail), 11 instead of
 // 20 MFMAs per sub-step, and the l planes are neither copied to LDS (14 of a block's 20 chunks) nor read.  Each similarity then carries an
-// UNBIASED rounding of ~2^-17 (round to nearest at both splits), i.e. exp(S / tau0) a relative 1e-4 per pair with a 1e-8 bias: over the >= 2^24
+// UNBIASED rounding of ~2^-16 (round to nearest at both splits; the dropped m m product is of that size too), i.e. exp(S / tau0) a relative 1e-4 per pair with a 1e-8 bias: over the >= 2^24
 // terms the caller requires for this form (ops.BF16X6_SUMS_LITE_MIN_TERMS) a global sum moves by < 1e-7 relative -- below the fp32 rounding
 // of its own accumulation.  The gradient sweep always multiplies all six products.
 template <int M, bool GRAD, int WV, int MG = M, bool GAM = true, bool LITE = false>
@@ -499,7 +499,9 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                 constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
 #pragma unroll
                 for (int x = 0; x < 20; ++x) {
-                    if (LITE && x >= 2 && (PA[(x - 2) / 3] == 2 || PB[(x - 2) / 3] == 2)) continue;             // no product with an l plane
+                    // LITE: h h + h m + m h only (no product with an l plane, no m m); the K tail (which carries the centring's b_i + b_j, the same
+                    // for every pair of an owner row) keeps both MFMAs
+                    if (LITE && x >= 2 && (PA[(x - 2) / 3] == 2 || PB[(x - 2) / 3] == 2 || (PA[(x - 2) / 3] == 1 && PB[(x - 2) / 3] == 1))) continue;
                     if (x == 0) acc2[0] = mfma_b(at[e], otl[m][1], acc2[0]);
                     else if (x == 1) acc2[1] = mfma_b(at[e], otl[m][0], acc2[1]);
                     else acc2[x & 1] = mfma_b(ap[e][PA[(x - 2) / 3]][(x - 2) % 3], opl[m][PB[(x - 2) / 3]][(x - 2) % 3], acc2[x & 1]);
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 // The stash products of the anchors x anchors backward on the same three exact bf16 planes: out[own] += sum_oth C[own, oth] Z[oth], C a block
 // of the fp32 coefficient stash the A x A kernel wrote (replaces the four fp32-MFMA GEMMs of sga_loss_stash_grad_symx; the autograd of
 // losses.py:6,50-57,81-94 through S = X1 X2^T).  It IS the gradient phase of sweep3_kernel with the coefficient tile loaded instead of
-// computed: 8 waves x 16 owner rows, the "other" rows' planes as 32-row tiles in LDS (one table per launch: 2 x 20 KB), the fp32
+// computed: 4 waves x 32 owner rows, the "other" rows' planes as 32-row tiles in LDS (one table per launch: 2 x 20 KB), the fp32
 // coefficients of a wave's 16 x 32 tile split into three planes in registers (the A operand), six MFMAs per column tile, the small partial
 // products in their own accumulator.  Because the planes are the sweeps' (centred where the table asks for it, column 101 = 1), the result
 // arrives in the same two parts: dZ[r, 0..100) += sum c (z - zbar), dZ[r, 101] += sum c.
@@ -757,8 +759,11 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 struct SProd { const float* S; int ld, tn, own_seg, own0, nown, oth_seg, oth0, noth, blk0, nsplit; };
 struct SArgs { const unsigned char* Zb; float* dZ; int A, nbA, n; SProd p[4]; };
 
-__global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
-    constexpr int NCT = 7, WAVES = 8, OWN = 128;
+__global__ __launch_bounds__(256, 2) void stash3_kernel(SArgs a) {
+    // 4 waves x 32 owner rows: a wave applies every B operand it reads from LDS (the other rows' planes, transposed) to TWO 16-row coefficient
+    // sets.  With 16 rows per wave and 16 waves per CU the transpose reads alone were 344 KB per CU and tile round -- 2 700 cycles of the LDS's
+    // 128 B per cycle, as long as the round's MFMAs (round 6: the kernel ran at 2.6 TB/s of stash reads with neither HBM nor the matrix pipe full).
+    constexpr int NCT = 7, WAVES = 4, RW = 2, OWN = WAVES * RW * 16;
     constexpr int KMAX = (S3_NCH + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];      // [2][S3_BLOCK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
@@ -770,8 +775,7 @@ __global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
     const int n_ob = (P.nown + OWN - 1) / OWN;
     if (w_in >= n_ob * P.nsplit) return;
     const int split = w_in / n_ob, ob = w_in - split * n_ob;
-    const int orow = ob * OWN + wave * 16 + l15;                      // this lane's owner row (as the coefficient tile's row), relative to own0
-    const bool ov = orow < P.nown;
+    const int orow0 = ob * OWN + wave * (RW * 16) + l15;              // this lane's owner rows orow0, orow0 + 16 (as the coefficient tile's rows), relative to own0
     // others: tiles of 32 rows of the segment, [t_lo, t_hi) cut into nsplit runs
     const int t_lo = P.oth0 >> 5, t_hi = (P.oth0 + P.noth + 31) >> 5;
     const int per = (t_hi - t_lo + P.nsplit - 1) / P.nsplit;
@@ -793,8 +797,10 @@ __global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
                                              (__attribute__((address_space(3))) void*)(buf + c * 1024), 16, 0, 0);
         }
     };
-    // this lane's 8 coefficients of tile jt: owner row orow, others 32 jt + 8 g4 + k (segment rows); zero outside the product's ranges
-    auto load_c = [&](int jt, float (&c)[8]) {
+    // this lane's 8 coefficients of tile jt for its row set rs: owner row orow0 + 16 rs, others 32 jt + 8 g4 + k (segment rows); zero outside the product's ranges
+    auto load_c = [&](int jt, int rs, float (&c)[8]) {
+        const int orow = orow0 + 16 * rs;
+        const bool ov = orow < P.nown;
         const int r0 = 32 * jt + 8 * g4 - P.oth0;                     // stash index of k = 0
         if (!P.tn && (P.ld & 3) == 0 && (P.oth0 & 3) == 0 && ov && r0 >= 0 && r0 + 8 <= P.noth) {
             const f32x4* q = reinterpret_cast<const f32x4*>(P.S + (size_t)orow * P.ld + r0);
@@ -810,33 +816,43 @@ __global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
         }
     };
 
-    f32x4 gacc[NCT], gsm[NCT];
+    f32x4 gacc[RW][NCT], gsm[RW][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) { gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; gsm[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int rs = 0; rs < RW; ++rs)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { gacc[rs][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; gsm[rs][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int tr_io = 4 * g4 + (l15 >> 2), tr_cs = l15 & 3;
     const int tr_main = s3_slot(tr_cs >> 1, tr_io) * 16 + (tr_cs & 1) * 8;
     const int tr_tail = S3_TAIL + tr_io * 16 + (tr_cs & 1) * 8;
     const int tr_tail_l = S3_TAIL + (48 + (tr_io ^ 12)) * 16 + (tr_cs & 1) * 8;
 
-    float cn[8];
-    load_c(jt0, cn);
+    // The coefficient tiles come straight from HBM (the stash is read once per product and never again): TWO tiles in flight per wave -- a tile's
+    // values are split into their planes first thing in its step and the load of the tile after next goes into the same registers, while the
+    // next tile's load (issued one step earlier) is still travelling.
+    float c0[RW][8], c1[RW][8];
+#pragma unroll
+    for (int rs = 0; rs < RW; ++rs) {
+        load_c(jt0, rs, c0[rs]);
+        if (jt0 + 1 < jt1) load_c(jt0 + 1, rs, c1[rs]);
+    }
     issue(oblk0 + jt0, lds3);
     int it = 0;
-#pragma unroll 1
-    for (int jt = jt0; jt < jt1; ++jt, ++it) {
+    auto step = [&](int jt, float (&cc)[RW][8]) {
         unsigned char* buf = lds3 + (it & 1) * S3_BLOCK;
         __syncthreads();                                   // tile `it` has landed, the other buffer is free
         issue(oblk0 + (jt + 1 < jt1 ? jt + 1 : jt), lds3 + ((it + 1) & 1) * S3_BLOCK);
-        float cc[8];
+        u32x4 ch[RW], cm[RW], cl[RW];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cc[k] = cn[k];
-        if (jt + 1 < jt1) load_c(jt + 1, cn);              // the next tile's coefficients travel under this tile's MFMAs
-        u32x4 ch, cm, cl;
+        for (int rs = 0; rs < RW; ++rs)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            unsigned h_, m_, l_;
-            split3_pair(cc[2 * p], cc[2 * p + 1], h_, m_, l_);
-            ch[p] = h_; cm[p] = m_; cl[p] = l_;
+            for (int p = 0; p < 4; ++p) {
+                unsigned h_, m_, l_;
+                split3_pair(cc[rs][2 * p], cc[rs][2 * p + 1], h_, m_, l_);
+                ch[rs][p] = h_; cm[rs][p] = m_; cl[rs][p] = l_;
+            }
+        if (jt + 2 < jt1) {                                // into the registers just consumed
+#pragma unroll
+            for (int rs = 0; rs < RW; ++rs) load_c(jt + 2, rs, cc[rs]);
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -848,29 +864,42 @@ __global__ __launch_bounds__(512, 2) void stash3_kernel(SArgs a) {
                 const u32x2 x0 = tr_read16(ph), x1 = tr_read16(ph + 1024);
                 bp[p] = u32x4{x0[0], x0[1], x1[0], x1[1]};
             }
-            f32x4 sm = gsm[ct];
-            sm = mfma_b(cl, bp[0], sm);
-            sm = mfma_b(ch, bp[2], sm);
-            sm = mfma_b(cm, bp[1], sm);
-            sm = mfma_b(cm, bp[0], sm);
-            sm = mfma_b(ch, bp[1], sm);
-            gsm[ct] = sm;
-            gacc[ct] = mfma_b(ch, bp[0], gacc[ct]);
+            // (coefficient plane x row plane) l h | h l | m m | m h | h m into gsm, h h into gacc; the two row sets alternate
+#pragma unroll
+            for (int rs = 0; rs < RW; ++rs) gsm[rs][ct] = mfma_b(cl[rs], bp[0], gsm[rs][ct]);
+#pragma unroll
+            for (int rs = 0; rs < RW; ++rs) gsm[rs][ct] = mfma_b(ch[rs], bp[2], gsm[rs][ct]);
+#pragma unroll
+            for (int rs = 0; rs < RW; ++rs) gsm[rs][ct] = mfma_b(cm[rs], bp[1], gsm[rs][ct]);
+#pragma unroll
+            for (int rs = 0; rs < RW; ++rs) gsm[rs][ct] = mfma_b(cm[rs], bp[0], gsm[rs][ct]);
+#pragma unroll
+            for (int rs = 0; rs < RW; ++rs) gsm[rs][ct] = mfma_b(ch[rs], bp[1], gsm[rs][ct]);
+#pragma unroll
+            for (int rs = 0; rs < RW; ++rs) gacc[rs][ct] = mfma_b(ch[rs], bp[0], gacc[rs][ct]);
         }
+        ++it;
+    };
+#pragma unroll 1
+    for (int jt = jt0; jt < jt1; jt += 2) {
+        step(jt, c0);
+        if (jt + 1 < jt1) step(jt + 1, c1);
     }
-    // out rows: accumulator layout row = 4 g4 + r of the wave's 16, column 16 ct + l15
+    // out rows: accumulator layout row = 4 g4 + r of the row set's 16, column 16 ct + l15
     float* dz = a.dZ + (size_t)(P.own_seg ? a.A : 0) * S3_DP;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const int d = ct * 16 + l15;
-        if (d < S3_DREAL || d == S3_DREAL + 1) {
+    for (int rs = 0; rs < RW; ++rs)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = ob * OWN + wave * 16 + 4 * g4 + r;
-                if (o < P.nown) atomicAdd(dz + (size_t)(P.own0 + o) * S3_DP + d, gacc[ct][r] + gsm[ct][r]);
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int d = ct * 16 + l15;
+            if (d < S3_DREAL || d == S3_DREAL + 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ob * OWN + wave * (RW * 16) + 16 * rs + 4 * g4 + r;
+                    if (o < P.nown) atomicAdd(dz + (size_t)(P.own0 + o) * S3_DP + d, gacc[rs][ct][r] + gsm[rs][ct][r]);
+                }
             }
         }
-    }
 }
 
 int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int J1, int J2, float tau0, float tau1, bool grad,
@@ -1160,7 +1189,7 @@ extern "C" int sga_loss_stash_grad_symx_bf16x6(const float* M1, const float* M2,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = (size_t)2 * S3_BLOCK;
     hipFuncSetAttribute(reinterpret_cast<const void*>(stash3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stash3_kernel, dim3(nwg), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(stash3_kernel, dim3(nwg), dim3(256), lds, s, a);
     SGA_CHECK_LAUNCH("sga_loss_stash_grad_symx_bf16x6");
     return SGA_OK;
 }

@@ -435,8 +435,8 @@ def _stash_bytes():
 
 # ---- run-time switches of the kernels whose autograd nodes live in pointnet_ops / loss_ops / gat_ops / rank_ops (read there as ops.<FLAG>)
 POINTNET_SPLIT_MAX_OBJECTS = 1023      # the library uses the split form below 4 x CUs objects; above that a workspace is not allocated
-# 'bf16x6' forward sums: all six partial products (False), or the h and m planes only (True: 14 of 20 MFMAs, no l-plane traffic; every similarity
-# with an unbiased 2^-17 rounding).  None (default) = lite only when the smallest of the four global sums has >= BF16X6_SUMS_LITE_MIN_TERMS terms:
+# 'bf16x6' forward sums: all six partial products (False), or the h and m planes only (True: h h + h m + m h, 11 of 20 MFMAs, no l-plane traffic; every similarity
+# with an unbiased 2^-16 rounding).  None (default) = lite only when the smallest of the four global sums has >= BF16X6_SUMS_LITE_MIN_TERMS terms:
 # the roundings average out (relative 1e-4 per term / sqrt(terms), bias 1e-8) far below the fp32 rounding of the sums' own accumulation.
 BF16X6_SUMS_LITE = {'1': True, '0': False}.get(_os.environ.get('SGA_BF16X6_SUMS_LITE', ''), None)
 BF16X6_SUMS_LITE_MIN_TERMS = 1 << 24
