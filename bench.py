@@ -256,6 +256,14 @@ def hits_at_k(steps, n_obj, n_pts, dev):
             'sample': f'{HITS_PAIRS} val-style pairs x {n_obj} obj x {n_pts} pts, random-init weights (seed 42), same inputs/weights both sides'}
 
 
+def _finite(loss_dict, what):
+    """A measured step whose loss is not finite is not a measurement (round 6: an M = 4 kernel variant returned NaN sums and the line still carried its rate)."""
+    v = float(loss_dict['loss'].item())
+    if not np.isfinite(v):
+        raise FloatingPointError(f'{what}: loss = {v}')
+    return v
+
+
 def _sha16(path):
     try:
         return hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]
@@ -555,7 +563,7 @@ def main():
     events = ops.KERNEL_EVENTS
     ops.KERNEL_EVENTS = None
     coll_events, sdist.COLLECTIVE_EVENTS = sdist.COLLECTIVE_EVENTS, None
-    loss_val = float(loss_dict['loss'].item())
+    loss_val = _finite(loss_dict, 'headline step')
     peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
     roofs = roofline_objects(events, world)
 
@@ -643,7 +651,8 @@ def main():
             torch.cuda.synchronize()
             ops.KERNEL_EVENTS = {}
             n2 = max(5, min(args.steps, 20))
-            el2, med2, _ = timed(steps, dd2, 0, n2)
+            el2, med2, ld2 = timed(steps, dd2, 0, n2)
+            _finite(ld2, 'extra_c2')
             ops.KERNEL_EVENTS['_steps'] = n2
             ev2, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
             extra_c2 = {'workload': f'{c2["ref"]}: {c2["pairs_per_gpu"]} pairs x {c2["n_obj"]} objects x {c2["n_pts"]} pts, modules '
@@ -666,7 +675,8 @@ def main():
                 steps4.forward_backward(dd2)
             torch.cuda.synchronize()
             ops.KERNEL_EVENTS = {}
-            el4, _, _ = timed(steps4, dd2, 0, n4)
+            el4, _, ld4 = timed(steps4, dd2, 0, n4)
+            _finite(ld4, 'extra_full_module_list')
             ops.KERNEL_EVENTS['_steps'] = n4
             ev4, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
             extra_attr = {'modules': mods4, 'workload': 'BASELINE.json configs[1] shape (512 pairs x 64 objects x 512 pts)',
@@ -683,7 +693,8 @@ def main():
                 steps4.forward_backward(dd3)
                 torch.cuda.synchronize()
                 ops.KERNEL_EVENTS = {}
-                el43, _, _ = timed(steps4, dd3, 0, 2)
+                el43, _, ld43 = timed(steps4, dd3, 0, 2)
+                _finite(ld43, 'extra_full_module_list.at_configs2_size')
                 ops.KERNEL_EVENTS['_steps'] = 2
                 ev43, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
                 extra_attr['at_configs2_size'] = {'workload': f'{c3["ref"]} shape: {c3["global_pairs"]} pairs x {c3["n_obj"]} objects x {c3["n_pts"]} pts, modules {"+".join(mods4)}',

@@ -500,14 +500,16 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #pragma unroll
                 for (int x = 0; x < 20; ++x) {
                     // LITE: h h + h m + m h only (no product with an l plane, no m m); the K tail (which carries the centring's b_i + b_j, the same
-                    // for every pair of an owner row) keeps both MFMAs
-                    if (LITE && x >= 2 && (PA[(x - 2) / 3] == 2 || PB[(x - 2) / 3] == 2 || (PA[(x - 2) / 3] == 1 && PB[(x - 2) / 3] == 1))) continue;
-                    if (x == 0) acc2[0] = mfma_b(at[e], otl[m][1], acc2[0]);
+                    // for every pair of an owner row) keeps both MFMAs.  (Only the MFMA is skipped: the PIPE form's operand requests and copies below
+                    // hang on the same loop index.)
+                    const bool skip = LITE && x >= 2 && (PA[(x - 2) / 3] == 2 || PB[(x - 2) / 3] == 2 || (PA[(x - 2) / 3] == 1 && PB[(x - 2) / 3] == 1));
+                    if (skip) {}
+                    else if (x == 0) acc2[0] = mfma_b(at[e], otl[m][1], acc2[0]);
                     else if (x == 1) acc2[1] = mfma_b(at[e], otl[m][0], acc2[1]);
                     else acc2[x & 1] = mfma_b(ap[e][PA[(x - 2) / 3]][(x - 2) % 3], opl[m][PB[(x - 2) / 3]][(x - 2) % 3], acc2[x & 1]);
                     if (PIPE) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (ss + 1 < 2 * M && x < 10) ld_one(ss + 1, x);
+                        if (ss + 1 < 2 * M && x < 10 && !(LITE && x >= 1 && x <= 3)) ld_one(ss + 1, x);       // (LITE: not the l plane)
                         if (ss < NDS && (x % 3) == 1 && (x / 3) < PER) issue_slots(next_buf, ss * PER + (x / 3), ss * PER + (x / 3) + 1);
                         // the previous table's own coefficient part under this table's MFMAs (half jh here): three VALU per gap 11 .. 18
                         if (OWN_IN_S && m > 0 && m - 1 < MG && x >= 11 && x < 19) {

@@ -363,11 +363,13 @@ def test_tables_wider_than_100_columns_take_the_fp32_kernels():
     assert (a[2] - b[2]).abs().max().item() < 1e-4 * a[2].abs().max().item()
 
 
-def test_lite_forward_sums_move_the_global_sums_by_less_than_1e6_and_are_used_only_for_large_batches():
+@pytest.mark.parametrize('M', [3, 2, 4])
+def test_lite_forward_sums_move_the_global_sums_by_less_than_1e6_and_are_used_only_for_large_batches(M):
     """ops.BF16X6_SUMS_LITE (csrc/sweep3.hip, LITE): the forward sums from the h and m planes only -- every similarity with an unbiased 2^-17
     rounding, which averages out over the terms of a global sum.  At 64 pairs x 64 objects (1e7 terms per sum) every loss term moves by < 1e-6
     relative and the gradients (which always multiply all six products) by < 1e-5 of their maximum; the DEFAULT policy takes the lite form only
-    when the smallest global sum has >= 2^24 terms (reference arithmetic: src/aligner/losses.py:5-15)."""
+    when the smallest global sum has >= 2^24 terms (reference arithmetic: src/aligner/losses.py:5-15).  M = 4 runs the one-wave-per-SIMD form of the
+    kernel, whose operand requests ride on the MFMA loop (a skipped product must not skip its neighbour's request: round-6 fuzz finding)."""
     from sgaligner_amd import loss_ops, ops
     from sgaligner_amd.synthetic import make_batch
     assert ops.BF16X6_SUMS_LITE is None and ops.BF16X6_SUMS_LITE_MIN_TERMS == 1 << 24
@@ -375,10 +377,10 @@ def test_lite_forward_sums_move_the_global_sums_by_less_than_1e6_and_are_used_on
     dd = make_batch(64, 64, 4, seed=31, ragged=True)
     T = int(dd['tot_obj_count'].sum())
     g = torch.Generator(device='cuda').manual_seed(8)
-    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(3)]
-    base[2] = base[2] * 0.05 + torch.randn(1, 100, device='cuda', generator=g)            # a table of nearly parallel rows (centred planes)
-    w0 = torch.tensor([[0.4], [1.0], [-0.3]], device='cuda')
-    hint = torch.linspace(0.5, 1.5, 3 + 1 + 6, device='cuda')
+    base = [torch.randn(T, 100, device='cuda', generator=g) for _ in range(M)]
+    base[M - 1] = base[M - 1] * 0.05 + torch.randn(1, 100, device='cuda', generator=g)    # a table of nearly parallel rows (centred planes)
+    w0 = torch.tensor([[0.4], [1.0], [-0.3], [0.7]], device='cuda')[:M].contiguous()
+    hint = torch.linspace(0.5, 1.5, M + 1 + 2 * M, device='cuda')
     res = {}
     keep = ops.BF16X6_SUMS_LITE
     try:
