@@ -98,6 +98,15 @@ __device__ __forceinline__ unsigned long long sreg64(unsigned long long v) {    
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
+// scheduling directives of one column-tile group of the gradient phase: per MFMA one transpose read (the first NR MFMAs) and two VALU
+template <int X, int END, int NR, bool VALU_ALL> __device__ __forceinline__ void sgb_seq() {
+    if constexpr (X < END) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (X < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (VALU_ALL || X < 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        sgb_seq<X + 1, END, NR, VALU_ALL>();
+    }
+}
 __host__ __device__ constexpr int s3_slot(int g, int i) { return 16 * g + (i ^ (12 * (g & 1))); }
 
 struct TLayout { int nbA, nb1, nb2; };
@@ -251,9 +260,14 @@ struct TArgs {
 // UNBIASED rounding of ~2^-16 (round to nearest at both splits; the dropped m m product is of that size too), i.e. exp(S / tau0) a relative 1e-4 per pair with a 1e-8 bias: over the >= 2^24
 // terms the caller requires for this form (ops.BF16X6_SUMS_LITE_MIN_TERMS) a global sum moves by < 1e-7 relative -- below the fp32 rounding
 // of its own accumulation.  The gradient sweep always multiplies all six products.
-template <int M, bool GRAD, int WV, int MG = M, bool GAM = true, bool LITE = false>
+// FOLD (gradient sweep, one wave per SIMD): ONE set of small-product accumulators shared by all tables -- a column tile's five small products
+// start from zero in every tile and are added to the tile's gacc by a plain fp32 v_add (round to nearest: unbiased, unlike the MFMA's chop)
+// two column-tile groups later, under other MFMAs.  28 registers instead of 28 MG: four tables' owner gradients fit ONE launch (M = 4: every
+// similarity formed once, 328 instead of 2 x 244 MFMAs per 16 x 32 pairs), at 28 VALU per table and tile.
+template <int M, bool GRAD, int WV, int MG = M, bool GAM = true, bool LITE = false, bool FOLD = false>
 __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs a) {
     static_assert(!LITE || !GRAD, "LITE: the forward sums only");
+    static_assert(!FOLD || (GRAD && WV == 4), "FOLD: the one-wave-per-SIMD gradient sweep only");
     constexpr int NCT = 7;
     constexpr int WAVES = WV, THREADS = WAVES * 64;
     constexpr int OWN = WV * 16;                                     // owner rows per workgroup
@@ -341,11 +355,16 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
     // the fp32 MFMA chops too, but toward zero).  Small products added straight onto the large accumulator would give every gradient entry
     // the same one-sided bias, which the column sums over 10^6 rows (the bias gradients of the layers below) would collect coherently; in
     // their own accumulator nothing is chopped, and the two are added once, in fp32, at the end.
-    f32x4 gacc[GRAD ? MG : 1][NCT], gsm[GRAD ? MG : 1][NCT];
+    constexpr int NSM = GRAD ? (FOLD ? 1 : MG) : 1;                  // sets of small-product accumulators
+    f32x4 gacc[GRAD ? MG : 1][NCT], gsm[NSM][NCT];
 #pragma unroll
     for (int m = 0; m < (GRAD ? MG : 1); ++m)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) { gacc[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; gsm[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int ct = 0; ct < NCT; ++ct) gacc[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < NSM; ++m)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) gsm[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float gam[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) gam[m] = 0.f;
@@ -625,7 +644,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                             for (int r = 0; r < 4; ++r) gam[m] = fmaf(cj[jh][r], sacc[m][jh][r], gam[m]);
                     }
                 };
-                if (!PIPE && GAM) gamma_acc();
+                if ((!PIPE || FOLD) && GAM) gamma_acc();        // (FOLD: here, so that the similarities' registers are free in the gradient phase)
                 S3_T(3)
                 // c_m for this lane's 8 consecutive other rows (k slot j = 4 jh + r), split into three bf16 planes: the A operand
                 u32x4 ch[2], cm[2], cl[2];                     // double-buffered by table parity
@@ -649,7 +668,16 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                     const int e = m & 1;
                     const u32x4 ca = i == 0 ? cl[e] : (i == 1 || i == 4) ? ch[e] : cm[e];
                     const int pb_ = i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 1 : i == 3 ? 0 : 1;
-                    gsm[GRAD ? m : 0][ct] = mfma_b(ca, bp[par][pb_], gsm[GRAD ? m : 0][ct]);
+                    const int sm = (GRAD && !FOLD) ? m : 0;
+                    gsm[sm][ct] = mfma_b(ca, bp[par][pb_], (FOLD && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : gsm[sm][ct]);
+                };
+                // FOLD: the small products of column-tile group `gq` (of the table it belongs to) onto their gacc, element-wise v_add
+                auto fold_group = [&](int gq) {
+                    const int m = gq >> 2, ct0 = (gq & 3) * 2, n = (gq & 3) == 3 ? 1 : 2;
+#pragma unroll
+                    for (int j = 0; j < n; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gacc[GRAD ? m : 0][ct0 + j][r] += gsm[0][ct0 + j][r];
                 };
                 if (!PIPE) {
 #pragma unroll
@@ -674,7 +702,8 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                     for (int g4i = 0; g4i < 4 * MG; ++g4i) {
                         const int m = g4i >> 2, ct0 = (g4i & 3) * 2, n = (g4i & 3) == 3 ? 1 : 2, k0_ = NCT * m + ct0;
                         if ((g4i & 3) == 0 && m + 1 < MG) planes(m + 1);       // source order only: spread under this table's MFMAs below
-                        if (GAM && g4i == (MG > 1 ? 4 : 0)) gamma_acc();       // ... and Gamma under the second table's (the first carries planes(1))
+                        if (GAM && !FOLD && g4i == (MG > 1 ? 4 : 0)) gamma_acc();   // ... and Gamma under the second table's (the first carries planes(1))
+                        if (FOLD && g4i >= 2) fold_group(g4i - 2);             // (its MFMAs finished a group ago)
                         const int kn = k0_ + n;                               // the next group's first step
                         const int nn = kn >= NCT * MG ? 0 : ((kn % NCT) == 6 ? 1 : 2);
 #pragma unroll
@@ -691,14 +720,22 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                             for (int i = 1; i < 5; ++i) step_small(m, ct0, k0_ % BD, i);
                         }
                         // directives: per MFMA one transpose read (while there are any) and two VALU
+                        if (FOLD) {
+                            // (the same directives by template recursion: in the MG = 4 instantiation hipcc leaves the loop below rolled -- a run-time
+                            //  loop around nothing -- and the directives with it)
+                            if (n == 2) { if (nn == 2) sgb_seq<0, 12, 12, true>(); else if (nn == 1) sgb_seq<0, 12, 6, true>(); else sgb_seq<0, 12, 0, true>(); }
+                            else { if (nn == 2) sgb_seq<0, 6, 12, false>(); else if (nn == 1) sgb_seq<0, 6, 6, false>(); else sgb_seq<0, 6, 0, false>(); }
+                        } else {
 #pragma unroll
                         for (int x = 0; x < 6 * n; ++x) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             if (x < 6 * nn) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                             if (n == 2 || x < 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                         }
+                        }
                         if ((g4i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (FOLD) { fold_group(4 * MG - 2); fold_group(4 * MG - 1); }
                 }
                 S3_T(4)
             }
@@ -724,7 +761,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             // dZ[i, 0..99] += sum_j c_ij z'_j and dZ[i, 101] += rowsum_i = sum_j c_ij (output column 101 of the last column tile): the true
             // gradient is the first + rowsum x zbar, but it is never formed -- sga_loss_scatter_tangent takes the two apart (see there)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) gacc[GRAD ? m : 0][ct] += gsm[GRAD ? m : 0][ct];
+            for (int ct = 0; ct < NCT; ++ct) if (!FOLD) gacc[GRAD ? m : 0][ct] += gsm[(GRAD && !FOLD) ? m : 0][ct];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int d = ct * 16 + l15;
@@ -972,11 +1009,11 @@ int fill_t(TArgs& a, const void* const* Zb, int M, const float* beta, int A, int
 // (M = 4: four tables' operands -- 176 registers -- leave no room for a second wave on the SIMD in either sweep)
 template <int M, bool GRAD> constexpr int s3_wv() { return M == 4 ? 4 : GRAD ? (M == 3 ? S3_WV_GRAD3 : S3_WV_GRAD2) : S3_WV_SUMS; }
 
-template <int M, bool GRAD, int MG = M, bool GAM = true, bool LITE = false>
+template <int M, bool GRAD, int MG = M, bool GAM = true, bool LITE = false, bool FOLD = false>
 void launch_t(const TArgs& a, int nwg, hipStream_t s) {
     constexpr int WV = s3_wv<M, GRAD>();
     const size_t lds = (size_t)2 * M * S3_BLOCK;
-    auto k = sweep3_kernel<M, GRAD, WV, MG, GAM, LITE>;
+    auto k = sweep3_kernel<M, GRAD, WV, MG, GAM, LITE, FOLD>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(nwg), dim3(WV * 64), lds, s, a);
 }
@@ -1145,11 +1182,16 @@ extern "C" int sga_loss_multi_grad_bf16x6(const void* const* Zb, int M, const fl
     if (M == 2) launch_t<2, true>(a, -r, s);
     else if (M == 3) launch_t<3, true>(a, -r, s);
     else {
+#ifdef S3_M4_TWO_LAUNCHES
         // four tables: two launches, each accumulating the owner gradients of two tables (all four similarities are formed in both)
         launch_t<4, true, 2, true>(a, -r, s);
         TArgs b = a;
         for (int m = 0; m < 4; ++m) { const int o = (m + 2) & 3; b.Zb[m] = a.Zb[o]; b.dZ[m] = a.dZ[o]; b.perm[m] = o; }
         launch_t<4, true, 2, false>(b, -r, s);
+#else
+        // four tables in ONE launch: every similarity formed once, the small-product accumulators shared between the tables (FOLD)
+        launch_t<4, true, 4, true, false, true>(a, -r, s);
+#endif
     }
     fold_slots(gamma, M, s);
     SGA_CHECK_LAUNCH("sga_loss_multi_grad_bf16x6");
