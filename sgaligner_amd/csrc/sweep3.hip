@@ -279,6 +279,16 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #define S3_OWN_IN_S 1
 #endif
     constexpr bool OWN_IN_S = GRAD && PIPE && S3_OWN_IN_S;          // the own coefficient part of table m - 1 under table m's S-phase MFMAs
+#ifndef S3_SPREAD
+#define S3_SPREAD 1
+#endif
+    // SPREAD (gradient sweep, one wave per SIMD): v_exp_f32 is a quarter-rate instruction -- measured here: the 64 of a tile cost ~15 cycles each
+    // (the kernel without them: -13 %) -- and only ONE of them fits under a 16-cycle MFMA.  So: the S sub-steps run in HALF-major order
+    // (ss -> other half jh = ss / M, table m = ss % M); sub-step ss carries the own coefficient part of sub-step ss - 1 with one transcendental
+    // per MFMA gap (never in a copy's gap); the joint coefficient of half 0 (complete after M sub-steps) rides in the copy-free gaps of the last
+    // two sub-steps; the own part of the LAST sub-step runs under the first table's gradient MFMAs.  Left between the phases: the joint
+    // coefficient of half 1 and the first table's split.
+    constexpr bool SPREAD = OWN_IN_S && S3_SPREAD && !FOLD;      // (FOLD, M = 4: the register file is full)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];      // [2][M][S3_BLOCK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
@@ -479,6 +489,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             // "m h", h after "h h"): every operand has >= 10 MFMAs to arrive.
             f32x4 sacc[M][2];
             float own[M][2][4];                                // c0 e^{S/tau0} + c1 e^{S/tau1} of the table's own similarities (GRAD)
+            float cj[2][4];                                    // joint coefficient dL/dS_J of this lane's 8 pairs (GRAD)
             // A operands of a sub-step: the tail image, l, m, h planes x 3 K steps.  PIPE: two register sets; the whole set of sub-step
             // ss + 1 is requested right behind the FIRST MFMA of sub-step ss -- hipcc waits with s_waitcnt lgkmcnt(0) (never a counted wait:
             // the LDS-DMAs in flight make the counter "out of order" in its model) in front of the first MFMA that reads requested data, so
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
             u32x4 at[NSET], ap[NSET][3][3];                    // ap[.][0]: h, [1]: m, [2]: l
             auto ld_one = [&](int ss, int idx) {               // idx 0: the tail image; 1 + 3 p' + q: plane l, m, h (p' = 0, 1, 2) K step q
                 const int e = ss % NSET;
-                const unsigned char* ar = buf + (ss >> 1) * S3_BLOCK + (ss & 1) * 1024 + aoff;
+                const unsigned char* ar = buf + (SPREAD ? ss % M : ss >> 1) * S3_BLOCK + (SPREAD ? ss / M : ss & 1) * 1024 + aoff;
                 if (idx < 1) at[e] = *reinterpret_cast<const u32x4*>(ar + S3_TAIL);
                 else ap[e][2 - (idx - 1) / 3][(idx - 1) % 3] = *reinterpret_cast<const u32x4*>(ar + (2 - (idx - 1) / 3) * S3_PLANE + ((idx - 1) % 3) * 2048);
             };
@@ -500,6 +511,71 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                 __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0) HERE, not behind the requests of set 1 (see above)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (SPREAD) {
+                constexpr int NDS = 2 * M - 2, PER = (M * KMAX + NDS - 1) / NDS;
+                constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
+                f32x4 accp[2][2];                              // a sub-step's two chains; added up in the NEXT sub-step's first gaps (behind the MFMAs' latency)
+                float ot0 = 0.f, ot1 = 0.f, sjt = 0.f, ce0 = 0.f, ce1 = 0.f;
+                auto own_step = [&](int mm, int hh, int r, int k) {
+                    const float sv = sacc[mm][hh][r];
+                    if (k == 0) ot0 = fexp2(sv * ka);
+                    else if (k == 1) ot1 = fexp2(sv);
+                    else own[mm][hh][r] = fmaf(c0[mm], ot0, c1[mm] * ot1);
+                };
+                auto cj_step = [&](int hh, int r, int k) {
+                    if (k == 0) {
+                        sjt = 0.f;
+#pragma unroll
+                        for (int mm = 0; mm < M; ++mm) sjt = fmaf(beta[mm], sacc[mm][hh][r], sjt);
+                    } else if (k == 1) ce0 = fexp2(sjt * ka);
+                    else if (k == 2) ce1 = fexp2(sjt);
+                    else cj[hh][r] = c0[M] * ce0 + c1[M] * ce1;
+                };
+#pragma unroll
+                for (int ss = 0; ss < 2 * M; ++ss) {
+                    const int m = ss % M, jh = ss / M, e = ss % NSET, pa = ss & 1;
+                    const int pm = ss > 0 ? (ss - 1) % M : 0, pjh = ss > 0 ? (ss - 1) / M : 0;
+                    accp[pa][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accp[pa][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int x = 0; x < 20; ++x) {
+                        if (x == 0) accp[pa][0] = mfma_b(at[e], otl[m][1], accp[pa][0]);
+                        else if (x == 1) accp[pa][1] = mfma_b(at[e], otl[m][0], accp[pa][1]);
+                        else accp[pa][x & 1] = mfma_b(ap[e][PA[(x - 2) / 3]][(x - 2) % 3], opl[m][PB[(x - 2) / 3]][(x - 2) % 3], accp[pa][x & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ss + 1 < 2 * M && x < 10) ld_one(ss + 1, x);
+                        if (ss < NDS && (x % 3) == 1 && (x / 3) < PER) issue_slots(next_buf, ss * PER + (x / 3), ss * PER + (x / 3) + 1);
+                        if (ss > 0) {
+                            // the previous sub-step's similarities, then its own coefficient part: gaps 3 .. 18 but the copies' (1, 4, 7, 10, 13)
+                            if (x == 0) { sacc[pm][pjh][0] = accp[pa ^ 1][0][0] + accp[pa ^ 1][1][0]; sacc[pm][pjh][1] = accp[pa ^ 1][0][1] + accp[pa ^ 1][1][1]; }
+                            if (x == 2) { sacc[pm][pjh][2] = accp[pa ^ 1][0][2] + accp[pa ^ 1][1][2]; sacc[pm][pjh][3] = accp[pa ^ 1][0][3] + accp[pa ^ 1][1][3]; }
+                            if (pm < MG) {
+                                constexpr int G0[4] = {3, 8, 12, 16}, G1[4] = {5, 9, 14, 17}, G2[4] = {6, 11, 15, 18};
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    if (x == G0[r]) own_step(pm, pjh, r, 0);
+                                    if (x == G1[r]) own_step(pm, pjh, r, 1);
+                                    if (x == G2[r]) own_step(pm, pjh, r, 2);
+                                }
+                            }
+                        }
+                        if (ss >= NDS) {
+                            // the joint coefficient of half 0 in the gaps the copies leave free in the last two sub-steps: slot q = 0 .. 11
+                            //   q:  0      1      2      3          4      5      6          7      8      9          10     11
+                            //       r0k0   r0k1   r0k2   r0k3 r1k0  r1k1   r1k2   r1k3 r2k0  r2k1   r2k2   r2k3 r3k0  r3k1   r3k2       (r3k3 behind the loop)
+                            const int q = (x == 19 ? 5 : (x % 3) == 1 && x <= 13 ? x / 3 : -1);
+                            if (q >= 0) {
+                                const int qq = (ss - NDS) * 6 + q, r = qq / 3, k = qq % 3;
+                                if (k == 0) { if (r > 0) cj_step(0, r - 1, 3); cj_step(0, r, 0); }
+                                else cj_step(0, r, k);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[M - 1][1][r] = accp[(2 * M - 1) & 1][0][r] + accp[(2 * M - 1) & 1][1][r];
+                cj_step(0, 3, 3);
+            } else {
 #pragma unroll
             for (int ss = 0; ss < 2 * M; ++ss) {
                 const int m = ss >> 1, jh = ss & 1, e = ss % NSET;
@@ -548,6 +624,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sacc[m][jh][r] = acc2[0][r] + acc2[1][r];       // (element-wise: a vector add becomes v_pk_add_f32, 3 x the price beside MFMAs)
+            }
             }
 
             S3_T(2)
@@ -607,8 +684,15 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
                     }
                 };
                 // own coefficient parts not computed under the S phase's MFMAs: the last table's (PIPE), all of them otherwise
+                auto own_last = [&]() {                         // SPREAD: the last sub-step's own part (table M - 1, half 1) -- under the first table's gradient MFMAs
 #pragma unroll
-                for (int m = OWN_IN_S ? M - 1 : 0; m < MG; ++m)
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = sacc[M - 1][1][r];
+                        own[M - 1][1][r] = fmaf(c0[M - 1], fexp2(sv * ka), c1[M - 1] * fexp2(sv));
+                    }
+                };
+#pragma unroll
+                for (int m = SPREAD ? M : OWN_IN_S ? M - 1 : 0; m < MG; ++m)
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
@@ -621,9 +705,8 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #endif
                         }
                 // joint coefficient dL/dS_J for this lane's 8 pairs (plain VALU: beside MFMAs a v_pk_*_f32 costs 3 x a v_fma, tools/micro/valu_issue.hip)
-                float cj[2][4];
 #pragma unroll
-                for (int jh = 0; jh < 2; ++jh)
+                for (int jh = SPREAD ? 1 : 0; jh < 2; ++jh)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float sj = 0.f;
@@ -701,6 +784,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 #pragma unroll
                     for (int g4i = 0; g4i < 4 * MG; ++g4i) {
                         const int m = g4i >> 2, ct0 = (g4i & 3) * 2, n = (g4i & 3) == 3 ? 1 : 2, k0_ = NCT * m + ct0;
+                        if (SPREAD && g4i == 0 && M - 1 < MG && M > 1) own_last();
                         if ((g4i & 3) == 0 && m + 1 < MG) planes(m + 1);       // source order only: spread under this table's MFMAs below
                         if (GAM && !FOLD && g4i == (MG > 1 ? 4 : 0)) gamma_acc();   // ... and Gamma under the second table's (the first carries planes(1))
                         if (FOLD && g4i >= 2) fold_group(g4i - 2);             // (its MFMAs finished a group ago)
