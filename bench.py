@@ -356,8 +356,8 @@ def roofline_objects(events, world):
         d_sum = (100 * M + 100 * M) if grad else 100 * M
         alg = (2.0 if grad else 1.0) * (2.0 * d_sum * pairs)
         mfma_flops = 16 * 16 * 32 * 2.0
-        # (M = 4: the backward is TWO launches, each forming all four similarities and the owner gradients of two tables: 2 x (160 + 84) MFMAs)
-        executed = (2.0 * pairs / 512.0 * (M * 82 if M < 4 else 488) * mfma_flops) if grad else (pairs / 512.0 * M * (22 if lite else 40) * mfma_flops)
+        # (M = 4 as well since round 6: ONE launch, the small-product accumulators shared by the tables -- sweep3_kernel's FOLD form)
+        executed = (2.0 * pairs / 512.0 * M * 82 * mfma_flops) if grad else (pairs / 512.0 * M * (22 if lite else 40) * mfma_flops)
         # the ceiling in fp32-product terms: six bf16 MFMAs per product; the lite forward sums execute 11/20 of them (3.3 per product)
         peak = PEAK_F16_TFLOPS / (6.0 * (11.0 / 20.0 if lite else 1.0))
         useful = (3.0 if grad else 1.0) * 2.0 * 100 * M * pairs          # S once + the two gradient GEMMs (backward), sum D = 100 M
@@ -375,7 +375,7 @@ def roofline_objects(events, world):
                       'traffic': pmc_traffic_bytes(f'sweep3_kernel<{M},{"true" if grad else "false"}>', f'ns={ns},A={A},J={J1 + J2}', 'sweep3.hip') if world == 1 else None,
                       'kernel': f'sweep3_kernel<{M},{"true" if grad else "false"}> ({"loss: negatives backward" if grad else "loss: global sums over anchors x negatives (forward)"}, '
                                 f'all {M}+1 tables; ' + ('h and m planes (16 bits, unbiased) of the fp32 operands, fp32 accumulate' if lite else 'fp32 operands as three exact bf16 planes, six bf16 MFMAs per product, fp32 accumulate')
-                                + ('; two launches, each all four similarities + the owner gradients of two tables' if (grad and M == 4) else '') + ')',
+                                + ('; one launch, small-product accumulators shared by the four tables' if (grad and M == 4) else '') + ')',
                       'launches_timed': len(durs), 'avg_launch_ms': round(avg_ms, 4), 'step_ms': round(avg_ms, 4),
                       'algorithmic_flops_per_launch': alg, 'executed_flops_per_launch': executed})
     for key, grad in (('loss_multi_grad', True), ('loss_multi_sums', False)):

@@ -880,7 +880,7 @@ __global__ __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) void sweep3_kernel(TArgs 
 // count}: C[own o, oth t] = tn ? S[t ld + o] : S[o ld + t].
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct SProd { const float* S; int ld, tn, own_seg, own0, nown, oth_seg, oth0, noth, blk0, nsplit; };
-struct SArgs { const unsigned char* Zb; float* dZ; int A, nbA, n; SProd p[4]; };
+struct SArgs { const unsigned char* Zb; float* dZ; const float* zero; int A, nbA, n; SProd p[4]; };   // zero: a readable word that holds 0.f
 
 __global__ __launch_bounds__(256, 2) void stash3_kernel(SArgs a) {
     // 4 waves x 32 owner rows: a wave applies every B operand it reads from LDS (the other rows' planes, transposed) to TWO 16-row coefficient
@@ -893,7 +893,13 @@ __global__ __launch_bounds__(256, 2) void stash3_kernel(SArgs a) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < a.n && (int)blockIdx.x >= a.p[i].blk0) pi = i;
-    const SProd P = a.p[pi];
+    // A REFERENCE into the kernel arguments: a copy of the struct by value keeps every field in SGPRs over the whole kernel (11 spilled SGPRs
+    // with the two row sets' branches); the fields the tile loop reads (load_c) are copied once -- a scalar load inside the loop would share
+    // lgkmcnt with the LDS reads.
+    const SProd& P = a.p[pi];
+    const float* const PS = P.S;
+    const float* const zero_word = a.zero;
+    const int Pld = P.ld, Ptn = P.tn, Pnown = P.nown, Poth0 = P.oth0, Pnoth = P.noth;
     const int w_in = (int)blockIdx.x - P.blk0;
     const int n_ob = (P.nown + OWN - 1) / OWN;
     if (w_in >= n_ob * P.nsplit) return;
@@ -923,18 +929,24 @@ __global__ __launch_bounds__(256, 2) void stash3_kernel(SArgs a) {
     // this lane's 8 coefficients of tile jt for its row set rs: owner row orow0 + 16 rs, others 32 jt + 8 g4 + k (segment rows); zero outside the product's ranges
     auto load_c = [&](int jt, int rs, float (&c)[8]) {
         const int orow = orow0 + 16 * rs;
-        const bool ov = orow < P.nown;
-        const int r0 = 32 * jt + 8 * g4 - P.oth0;                     // stash index of k = 0
-        if (!P.tn && (P.ld & 3) == 0 && (P.oth0 & 3) == 0 && ov && r0 >= 0 && r0 + 8 <= P.noth) {
-            const f32x4* q = reinterpret_cast<const f32x4*>(P.S + (size_t)orow * P.ld + r0);
+        const bool ov = orow < Pnown;
+        const int r0 = 32 * jt + 8 * g4 - Poth0;                     // stash index of k = 0
+        if (!Ptn && (Pld & 3) == 0 && (Poth0 & 3) == 0 && ov && r0 >= 0 && r0 + 8 <= Pnoth) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(PS + (size_t)orow * Pld + r0);
             const f32x4 u = q[0], v = q[1];
             c[0] = u[0]; c[1] = u[1]; c[2] = u[2]; c[3] = u[3]; c[4] = v[0]; c[5] = v[1]; c[6] = v[2]; c[7] = v[3];
         } else {
+            // (no exec-masked loads and no masks kept until the values arrive -- eight of them per call cost this kernel its scalar registers:
+            //  an element outside the product's ranges is read from a word that holds zero, the tables' slack block)
+            const float* base = PS + (Ptn ? (size_t)orow : (size_t)orow * Pld);
+            const int stride = Ptn ? Pld : 1;
+            const unsigned lim = ov ? (unsigned)Pnoth : 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int t = r0 + k;
-                const bool ok = ov && t >= 0 && t < P.noth;
-                c[k] = ok ? (P.tn ? P.S[(size_t)t * P.ld + orow] : P.S[(size_t)orow * P.ld + t]) : 0.f;
+                const bool ok = (unsigned)t < lim;                    // one compare per element: 0 <= t < noth and the row is valid
+                const float* q = ok ? base + (size_t)t * stride : zero_word;
+                c[k] = *q;
             }
         }
     };
@@ -1291,6 +1303,7 @@ extern "C" int sga_loss_stash_grad_symx_bf16x6(const float* M1, const float* M2,
     const TLayout L = make_tlayout(A, J1, J2);
     SArgs a{};
     a.Zb = static_cast<const unsigned char*>(Zb); a.dZ = dZ; a.A = A; a.nbA = L.nbA;
+    a.zero = reinterpret_cast<const float*>(a.Zb + (size_t)(2 * L.nbA + L.nb1 + L.nb2) * S3_BLOCK);      // the slack block (zeroed by sga_loss_split3_tables)
     // d1[a_lo + i] += sum_j M1[j][i] X2[j_lo + j];  d2[j_lo + j] += sum_i M1[j][i] X1[a_lo + i];
     // d1[mir + j]  += sum_i M2[j][i] X2[a_lo + i];  d2[a_lo + i] += sum_j M2[j][i] X1[mir + j]      (segments: 0 = X1, 1 = X2)
     int n = 0;
