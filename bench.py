@@ -185,7 +185,8 @@ def cpu_baseline(n_obj, n_pts, seconds_budget=45.0, emb_dim=100):
     ncpu = os.cpu_count() or 1
     params = O.init_params(MODULES, seed=42, emb_dim=emb_dim)
     # (all hardware threads is NOT in the sweep: on the 2 x 64-core EPYC 9575F GPU host 256 threads run these small per-graph ops at 0.023 pairs/s,
-    # 300 x slower than 32 threads -- 171 s per b = 4 step, measured once in round 5 -- and a torch op cannot be interrupted)
+    # 300 x slower than 32 threads -- 171 s per b = 4 step, measured once in round 5 -- and a torch op cannot be interrupted; 96 and 128 threads at
+    # b = 16: 1.97 and 1.78 pairs/s against 4.05 at 32, profiles/r06_cpu_threads.txt)
     points = [(2, min(32, ncpu)), (4, min(32, ncpu)), (4, min(64, ncpu)), (16, min(32, ncpu)), (16, min(64, ncpu)), (2, min(16, ncpu))]
     seen, sweep, best = set(), [], None
     t_all = time.time()

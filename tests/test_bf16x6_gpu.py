@@ -147,16 +147,17 @@ def test_sweeps_vs_fp32_sweeps_and_anchor_shards(bf16x6, M, emb):
     assert (gw - wb).abs().max().item() < 2e-4 * max(1e-3, wb.abs().max().item())
 
 
-def _overall_vs_fp64(pairs, nobj, seed, modes=('f32', 'bf16x6')):
+def _overall_vs_fp64(pairs, nobj, seed, modes=('f32', 'bf16x6'), mods=('point', 'gat', 'rel')):
     """The product OverallLoss on fused tables in both modes and the fp64 oracle: errors of every gradient against the oracle."""
     from oracle import sga_oracle as O
     from sgaligner_amd import ops
     from test_fullsize_gpu import _loss_setup, _run_overall
-    mods = ['point', 'gat', 'rel']
+    mods = list(mods)
+    M = len(mods)
     dd, T, base = _loss_setup(pairs, nobj, mods, seed=seed)
-    w0 = torch.tensor([[0.7], [1.2], [0.9]], device='cuda')
-    lv1 = torch.tensor([0.1, -0.2, 0.05], device='cuda')
-    lv2 = torch.tensor([-0.1, 0.15, 0.0], device='cuda')
+    w0 = torch.tensor([[0.7], [1.2], [0.9], [1.05]], device='cuda')[:M].contiguous()
+    lv1 = torch.tensor([0.1, -0.2, 0.05, 0.12], device='cuda')[:M].contiguous()
+    lv2 = torch.tensor([-0.1, 0.15, 0.0, -0.07], device='cuda')[:M].contiguous()
     eo = {k: base[i].cpu().double().requires_grad_(True) for i, k in enumerate(mods)}
     wo = w0.cpu().double().requires_grad_(True)
     lo1, lo2 = lv1.cpu().double().requires_grad_(True), lv2.cpu().double().requires_grad_(True)
@@ -190,6 +191,19 @@ def test_error_vs_fp64_oracle_no_larger_than_the_fp32_mfma_paths(pairs, nobj, se
     exact-fp32 MFMA path's own error + 5e-7 relative (two different fp32 summation orders differ by that much among themselves), and
     within the fp32 tests' tolerances (1e-4 loss, 1e-3 gradients)."""
     errs = _overall_vs_fp64(pairs, nobj, seed)
+    a, b = errs['f32'], errs['bf16x6']
+    for k in a:
+        assert b[k] <= 1.25 * a[k] + 5e-7, (k, a[k], b[k])
+        assert b[k] < (1e-4 if k == 'loss' else 1e-3), (k, b[k])
+
+
+@pytest.mark.parametrize('pairs,nobj,seed', [(64, 64, 31), (16, 40, 6)])
+def test_four_tables_one_launch_error_vs_fp64_oracle(pairs, nobj, seed):
+    """M = 4 (point + gat + rel + attr, the module list of every yaml the reference ships): the gradient sweep forms all four tables' owner
+    gradients in ONE launch with a shared set of small-product accumulators that is folded into the large ones by fp32 adds every tile
+    (sweep3_kernel's FOLD form).  Against the fp64 oracle its errors -- entries AND column sums of every table gradient, where a one-sided
+    fold would show -- stay those of fp32 arithmetic: at most 1.25 x the fp32-MFMA paired-wave kernels' own error + 5e-7."""
+    errs = _overall_vs_fp64(pairs, nobj, seed, mods=('point', 'gat', 'rel', 'attr'))
     a, b = errs['f32'], errs['bf16x6']
     for k in a:
         assert b[k] <= 1.25 * a[k] + 5e-7, (k, a[k], b[k])
