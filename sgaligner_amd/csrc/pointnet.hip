@@ -460,6 +460,15 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
             const int p0 = tile * 32;
             int lane_o = lane, h_o = h;                       // opaque copies: keep the weight reads inside the tile loop
             asm volatile("" : "+v"(lane_o), "+v"(h_o));
+            // Global operands as UNIFORM base + 32-bit lane offset (the saddr form of global_load: the base moves on the scalar unit): with 64-bit
+            // per-lane addresses the 128 loads of a tile cost ~570 VALU of address arithmetic (a quarter of the tile's VALU instructions).
+            const unsigned loff = (unsigned)lane_o * 16u, hoff = (unsigned)h_o;
+            auto gl4 = [&](const void* base, unsigned byte_const, unsigned lane_bytes) {
+                return *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(base) + byte_const + lane_bytes);
+            };
+            auto glu = [&](const void* base, unsigned byte_const, unsigned lane_bytes) {
+                return *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(base) + byte_const + lane_bytes);
+            };
             const int pi = min(p0 + pt, P - 1);
             const float x0 = xt[pi * 3 + 0], x1 = xt[pi * 3 + 1], x2 = xt[pi * 3 + 2];
             auto bn_fold = [&](f32x16& v, int sl) {
@@ -489,10 +498,12 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int kk = k + 4 * half;
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w1 + kk * 3);
-                    const f32x4 wb = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 4);
-                    const f32x4 wc = *reinterpret_cast<const f32x4*>(w1 + kk * 3 + 8);
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + kk);
+                    const unsigned kc = 16 * ks + 4 * half;      // kk = kc + 8 h
+                    const f32x4 wa = gl4(w1, kc * 12, hoff * 96);
+                    const f32x4 wb = gl4(w1, kc * 12 + 16, hoff * 96);
+                    const f32x4 wc = gl4(w1, kc * 12 + 32, hoff * 96);
+                    const f32x4 bb = gl4(b1, kc * 4, hoff * 32);
+                    (void)kk;
                     v[4 * half + 0] = fmaxf(fmaf(wa[2], x2, fmaf(wa[1], x1, fmaf(wa[0], x0, bb[0]))), 0.f);
                     v[4 * half + 1] = fmaxf(fmaf(wb[1], x2, fmaf(wb[0], x1, fmaf(wa[3], x0, bb[1]))), 0.f);
                     v[4 * half + 2] = fmaxf(fmaf(wc[0], x2, fmaf(wb[3], x1, fmaf(wb[2], x0, bb[2]))), 0.f);
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
                 f32x16 acc, accs;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + cb * 32 + 8 * g + 4 * h_o);
+                    const f32x4 bb = gl4(b2, (cb * 32 + 8 * g) * 4, hoff * 16);
                     acc[g * 4 + 0] = bb[0]; acc[g * 4 + 1] = bb[1]; acc[g * 4 + 2] = bb[2]; acc[g * 4 + 3] = bb[3];
                 }
 #pragma unroll
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int d = (cb * 4 + ks) * 64 + lane_o;
-                    const u32x4 wh = w2p[d], wm = w2p[1024 + d], wl = LG ? wlg[d] : w2p[2048 + d];
+                    const u32x4 wh = w2p[d], wm = w2p[1024 + d], wl = LG ? glu(wlg, (cb * 4 + ks) * 1024, loff) : w2p[2048 + d];
                     accs = mfma_bf16(wl, h1p[0][ks], accs);
                     accs = mfma_bf16(wh, h1p[2][ks], accs);
                     accs = mfma_bf16(wm, h1p[1][ks], accs);
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int ks3 = 0; ks3 < 8; ++ks3) {
                     const int d = (cb * 8 + ks3) * 64 + lane_o;
-                    const u32x4 wh = w3p[d], wm = w3p[W3N + d], wl = LG ? wlg[1024 + d] : w3p[2 * W3N + d];
+                    const u32x4 wh = w3p[d], wm = w3p[W3N + d], wl = LG ? glu(wlg, (16 + cb * 8 + ks3) * 1024, loff) : w3p[2 * W3N + d];
                     accs = mfma_bf16(h2p[2][ks3], wh, accs);
                     accs = mfma_bf16(h2p[0][ks3], wl, accs);
                     accs = mfma_bf16(h2p[1][ks3], wm, accs);
