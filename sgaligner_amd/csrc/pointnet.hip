@@ -463,11 +463,14 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
             // Global operands as UNIFORM base + 32-bit lane offset (the saddr form of global_load: the base moves on the scalar unit): with 64-bit
             // per-lane addresses the 128 loads of a tile cost ~570 VALU of address arithmetic (a quarter of the tile's VALU instructions).
             const unsigned loff = (unsigned)lane_o * 16u, hoff = (unsigned)h_o;
+            const u32x4* wlg_t = wlg;                          // (opaque per tile: the ~80 scalar bases are made where they are used, not kept in SGPRs over the loop)
+            asm volatile("" : "+s"(wlg_t));
             auto gl4 = [&](const void* base, unsigned byte_const, unsigned lane_bytes) {
                 return *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(base) + byte_const + lane_bytes);
             };
-            auto glu = [&](const void* base, unsigned byte_const, unsigned lane_bytes) {
-                return *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(base) + byte_const + lane_bytes);
+            auto glu = [&](const void* base, unsigned byte_const, unsigned lane_bytes) {       // (explicitly GLOBAL: behind the opaque base the compiler would emit flat loads)
+                typedef const __attribute__((address_space(1))) unsigned char* gptr;
+                return *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>((gptr)base + byte_const + lane_bytes);
             };
             const int pi = min(p0 + pt, P - 1);
             const float x0 = xt[pi * 3 + 0], x1 = xt[pi * 3 + 1], x2 = xt[pi * 3 + 2];
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int d = (cb * 4 + ks) * 64 + lane_o;
-                    const u32x4 wh = w2p[d], wm = w2p[1024 + d], wl = LG ? glu(wlg, (cb * 4 + ks) * 1024, loff) : w2p[2048 + d];
+                    const u32x4 wh = w2p[d], wm = w2p[1024 + d], wl = LG ? glu(wlg_t, (cb * 4 + ks) * 1024, loff) : w2p[2048 + d];
                     accs = mfma_bf16(wl, h1p[0][ks], accs);
                     accs = mfma_bf16(wh, h1p[2][ks], accs);
                     accs = mfma_bf16(wm, h1p[1][ks], accs);
@@ -567,6 +570,15 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
             }
 
             // ---- layer 3: Z3 = H2 W3^T (A = H2 planes, B = this half's W3 planes), running max over points
+            // LG: the l-plane fragments come from L2 (~600 cycles): requested PN_LPF steps ahead (a ring of PN_LPF + 1 fragments), not one
+#ifndef PN_LPF
+#define PN_LPF 3
+#endif
+            u32x4 wlq[PN_LPF + 1];
+            if (LG) {
+#pragma unroll
+                for (int i = 0; i < PN_LPF; ++i) wlq[i] = glu(wlg_t, (16 + i) * 1024, loff);
+            }
 #pragma unroll
             for (int cb = 0; cb < NBH; ++cb) {
                 f32x16 acc, accs;
@@ -575,7 +587,9 @@ __global__ __launch_bounds__(PN_THREADS) void pointnet_fwd_p3_kernel(
 #pragma unroll
                 for (int ks3 = 0; ks3 < 8; ++ks3) {
                     const int d = (cb * 8 + ks3) * 64 + lane_o;
-                    const u32x4 wh = w3p[d], wm = w3p[W3N + d], wl = LG ? glu(wlg, (16 + cb * 8 + ks3) * 1024, loff) : w3p[2 * W3N + d];
+                    const int li = cb * 8 + ks3;
+                    if (LG && li + PN_LPF < NBH * 8) wlq[(li + PN_LPF) % (PN_LPF + 1)] = glu(wlg_t, (16 + li + PN_LPF) * 1024, loff);
+                    const u32x4 wh = w3p[d], wm = w3p[W3N + d], wl = LG ? wlq[li % (PN_LPF + 1)] : w3p[2 * W3N + d];
                     accs = mfma_bf16(h2p[2][ks3], wh, accs);
                     accs = mfma_bf16(h2p[0][ks3], wl, accs);
                     accs = mfma_bf16(h2p[1][ks3], wm, accs);

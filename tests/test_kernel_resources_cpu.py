@@ -19,7 +19,9 @@ def test_headline_kernels_do_not_spill():
                             '16sweep16x2_kernelILb1E', '16sweep16x2_kernelILb0E',
                             '25anchor_multi_bwd16_kernelILi3ELb1ELi32ELb1E', '25anchor_multi_bwd16_kernelILi3ELb1ELi32ELb0E',
                             '25anchor_multi_bwd16_kernelILi4ELb1ELi16ELb0E', '19anchor_multi_kernelILi3ELb0E'],
-        'pointnet.hip': ['19pointnet_fwd_kernelILi256ELb1ELb0E', '25pointnet_bwd_fused_kernel'],
+        # (the three-plane forward of the training step -- arg-max, BN sums, whole objects per workgroup -- and the three-plane backward: the defaults)
+        'pointnet.hip': ['19pointnet_fwd_kernelILi256ELb1ELb0E', '25pointnet_bwd_fused_kernel',
+                         '22pointnet_fwd_p3_kernelILi256ELb1ELb1ELb0ELb1E', '22pointnet_bwd_p3_kernel'],
         # the DEFAULT sweeps (three exact bf16 planes): gradient (one wave per SIMD), sums (two), the stash products
         # (M = 4: all four tables' owner gradients in one launch, the small-product accumulators shared -- 495 of 512 registers)
         'sweep3.hip': ['13sweep3_kernelILi3ELb1ELi4E', '13sweep3_kernelILi3ELb0ELi8E', '13sweep3_kernelILi2ELb1ELi4E', '13sweep3_kernelILi2ELb0ELi8E',
