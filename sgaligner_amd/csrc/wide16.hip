@@ -5,25 +5,29 @@
 //   sga_loss_neg_sums      -> sga_loss_neg_sums_f16       the 4x2 global sums  sum_ij exp(S_ij / tau)              (losses.py:6-11)
 //   sga_loss_neg_grad_wide -> sga_loss_neg_grad_f16       dL/dZ through the anchors x negatives similarities       (autograd of :6-11)
 // with S = Z Z^T and both gradient GEMMs on v_mfma_f32_32x32x16_f16.  One tiled NT-GEMM core (out[m][n] = sum_k A[m][k] B[n][k],
-// both operands fp16 with k contiguous, 128 x 128 tile per workgroup, K chunks of 64 through LDS, next chunk prefetched into registers
-// under the MFMAs) carries three epilogues:
+// both operands fp16 with k contiguous, 256 x 256 tile per workgroup of 8 waves, K chunks of 64 double-buffered in LDS by LDS-DMA -- see
+// wide16_body) carries three epilogues:
 //   SUMS  exp2 of the S tile, masked, reduced to the fp64 per-wave slots;
 //   COEF  c_ij = (g0/tau0 exp(S/tau0) + g1/tau1 exp(S/tau1)) / alpha  written as fp16 (alpha = the coefficient's bound, so |c/alpha| <= 1:
 //         inside fp16's range whatever the loss scale; values below 6e-8 of the bound flush to zero);
 //   GEMM  out += alpha * acc  (fp32 atomics; split over K for occupancy).
 // Operand layouts (sga_wide16_prepare): Zh [R][Dp] = fp16 copy of the packed normalised table (S operand), ZhT [Dp][ldt] = its
 // transpose with every segment (X1 | X2 | N1 | N2) starting at a multiple of 8 columns (the gradient GEMMs' B operand: k = packed row).
-// The coefficient tile leaves the S kernel with lanes along its B operand, so it is produced twice, once per orientation
-// (anchor-major C for dZ[anchors] = C Z[neg], negative-major C^T for dZ[neg] = C^T Z[anchors]) -- S costs 1/16 of its fp32 time here,
-// recomputing it is cheaper than a transposing store.
+// The gradient GEMMs need the coefficient tile in both orientations (anchor-major C for dZ[anchors] = C Z[neg], negative-major C^T for
+// dZ[neg] = C^T Z[anchors]); ONE S pass writes both: in the 32 x 32 accumulator layout a lane's registers 4 t .. 4 t + 3 are four consecutive
+// rows, i.e. one 8-byte store into C^T (until round 6 S was formed twice, once per orientation).
 #include "loss_math.h"
 
 namespace {
 
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int W_THREADS = 256, W_T = 128, W_KC = 64, W_LS = W_KC + 8;     // LDS row stride in halfs (144 B: conflict-free ds_read_b128)
+constexpr int W_THREADS = 512, W_T = 256, W_KC = 64;
+constexpr int W_OP = W_T * W_KC * 2;        // bytes of one operand's K chunk in LDS: 256 rows x 128 B (32 KiB)
+constexpr int W_STAGE = 2 * W_OP;           // A rows | B rows
+constexpr int W_LDS = 2 * W_STAGE;          // two stages: 128 KiB, one workgroup (8 waves, two per SIMD) per CU
 constexpr int W_SUMS = 0, W_COEF = 1, W_GEMM = 2;
 
 struct W16Args {
@@ -33,21 +37,19 @@ struct W16Args {
     float k0, k1, it0, it1;                 // log2(e)/tau, 1/tau
     const double* gs; int fam;              // dL/d(sums) [8] (COEF / GEMM: the block's coefficient scale), sum family 0..3
     double* sums;                           // SUMS out (slots)
-    f16* cout; long ldc;                    // COEF out [M][ldc]
+    f16* cout; long ldc;                    // COEF out  C [M][ldc]; columns N .. ldc - 1 are written as zeros (the GEMMs read whole 8-half groups)
+    f16* cout2; long ldc2;                  // COEF out  C^T [N][ldc2] (ldc2 = M padded to 8), same zero padding
     float* out; long ldo;                   // GEMM out [M][ldo], atomically accumulated
 };
 
-// 8 halfs of row `row` starting at column k: zero past the matrix (row >= rows or k >= K), tail elements of a partial group zeroed
-__device__ __forceinline__ f16x8 load8(const f16* __restrict__ base, long ld, int row, int rows, int k, int K) {
-    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < rows && k < K) {
-        v = *reinterpret_cast<const f16x8*>(base + (size_t)row * ld + k);
-        if (k + 8 > K) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (k + e >= K) v[e] = (f16)0.f;
-        }
-    }
-    return v;
+// 16 readable zero bytes: the source of every 8-half group that lies past the K range
+__device__ __attribute__((aligned(16))) const unsigned g_w16_zero[4] = {0u, 0u, 0u, 0u};
+
+// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr + 16 lane] (lds_addr wave-uniform, through M0).  Inline asm
+// on purpose: hipcc does not count these loads, so IT never drains them (beside the builtin it waits vmcnt(0) in front of the next LDS
+// read, i.e. for the chunk that was requested a moment ago); the one wait per K chunk is written out below.
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
 }
 
 // the coefficient bound of a sum family: |g0|/tau0 * 2^k0 + |g1|/tau1 * 2^k1  (S <= 1 for normalised rows; +2 % for fp16 rounding of S)
@@ -56,111 +58,148 @@ __device__ __forceinline__ float coef_bound(const double* gs, int fam, float k0,
     return fmaxf(1.02f * (c0 * fexp2(k0) + c1 * fexp2(k1)), 1e-30f);
 }
 
+// The tile core: out[m][n] = sum_k A[m][k] B[n][k] on a 256 x 256 tile, 8 waves as 2 (m) x 4 (n), a wave owns 128 x 64 = 4 x 2 accumulator
+// tiles of v_mfma_f32_32x32x16_f16 (128 registers; 6 ds_read_b128 per 8 MFMAs).  K in chunks of 64: both operands' 256 rows x 128 B go
+// global -> LDS by LDS-DMA (no staging registers, no ds_write pass), double-buffered: the chunk after this one is requested right behind
+// the barrier that frees its buffer and lands under this chunk's 32 MFMAs per wave; one wait + one barrier per chunk.
+// LDS image of an operand chunk: row r at 128 r, its eight 16-byte k groups XOR-swizzled, group g at slot g ^ ((r >> 1) & 7): the 16 lanes
+// ds_read_b128 serves per cycle (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a 32-row operand tile, one k group) then hit 16 different
+// 16-byte slots of the 256-byte bank row.  The DMA writes lane-linearly, so the swizzle is in the SOURCE address: lane l of copy i
+// (rows 8 i .. 8 i + 7) fetches row 8 i + (l >> 3), group (l & 7) ^ swizzle(row).
+// Edges: rows past M / N re-read the last row (their results are masked in the epilogues); 8-half groups that START past the K range read
+// the zero block; a group that straddles K (GEMM mode: K = a packed row count) reads the operands' zero padding up to the next multiple of 8.
 template <int MODE>
 __device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
-    __shared__ __attribute__((aligned(16))) f16 As[W_T * W_LS];
-    __shared__ __attribute__((aligned(16))) f16 Bs[W_T * W_LS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 2, wn = wave & 3;
     const int m0 = blockIdx.y * W_T, n0 = blockIdx.x * W_T;
     if (m0 >= a.M || n0 >= a.N) return;                      // (batched launches: the grid is the largest family's)
     const int kb = bz * a.kper, ke = min(a.K, kb + a.kper);
     if (kb >= ke) return;
 
-    f32x16 acc[4];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // staging: 128 rows x 8 groups of 8 halfs per operand = 1024 groups = 4 per thread; thread -> (row = e >> 3, group = e & 7)
-    f16x8 pa[4], pb[4];
-    auto gload = [&](int k) {
+    // staging: copy i = 8 wave + q of a chunk's 64 (0..31: A rows 8 i .., 32..63: B rows); waves 0..3 carry A, 4..7 carry B
+    const f16* rp[8];
+    int kg[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * W_THREADS, r = e >> 3, g = e & 7;
-            pa[q] = load8(a.A, a.lda, m0 + r, a.M, k + g * 8, ke);
-            pb[q] = load8(a.B, a.ldb, n0 + r, a.N, k + g * 8, ke);
-        }
-    };
-    auto lstore = [&]() {
+    for (int q = 0; q < 8; ++q) {
+        const int i = wave * 8 + q, ii = i & 31, row = 8 * ii + (lane >> 3);
+        const int g = (lane & 7) ^ ((row >> 1) & 7);
+        kg[q] = 8 * g;
+        if (i < 32) rp[q] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + 8 * g;
+        else rp[q] = a.B + (size_t)min(n0 + row, a.N - 1) * a.ldb + 8 * g;
+    }
+    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)lds16) + (unsigned)wave * 8192u;
+    const f16* zero = reinterpret_cast<const f16*>(g_w16_zero);
+    auto stage = [&](int buf, int k) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * W_THREADS, r = e >> 3, g = e & 7;
-            *reinterpret_cast<f16x8*>(As + r * W_LS + g * 8) = pa[q];
-            *reinterpret_cast<f16x8*>(Bs + r * W_LS + g * 8) = pb[q];
-        }
+        for (int q = 0; q < 8; ++q) glds16(k + kg[q] < ke ? rp[q] + k : zero, lbase + (unsigned)(buf * W_STAGE + q * 1024));
     };
-    gload(kb);
-    for (int k = kb; k < ke; k += W_KC) {
-        __syncthreads();                        // previous chunk's reads done
-        lstore();
-        __syncthreads();
-        if (k + W_KC < ke) gload(k + W_KC);     // next chunk in flight under the MFMAs
-        const f16* ap = As + (wave * 32 + l31) * W_LS + h * 8;
-        const f16* bp = Bs + l31 * W_LS + h * 8;
+    const int swz = (l31 >> 1) & 7;
+    stage(0, kb);
+    int it = 0;
+    for (int k = kb; k < ke; k += W_KC, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of chunk `it` have landed ...
+        __syncthreads();                                     // ... everybody's have, and everybody has read chunk it - 1: its buffer is free
+        if (k + W_KC < ke) stage((it + 1) & 1, k + W_KC);
+        const unsigned char* sa = lds16 + (it & 1) * W_STAGE + (wm * 128 + l31) * 128;
+        const unsigned char* sb = lds16 + (it & 1) * W_STAGE + W_OP + (wn * 64 + l31) * 128;
 #pragma unroll
         for (int kk = 0; kk < W_KC / 16; ++kk) {
-            const f16x8 av = *reinterpret_cast<const f16x8*>(ap + kk * 16);
+            const int co = ((2 * kk + h) ^ swz) << 4;
+            f16x8 av[4], bv[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f16x8 bv = *reinterpret_cast<const f16x8*>(bp + t * 32 * W_LS + kk * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t], 0, 0, 0);
-            }
+            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f16x8*>(sa + i * 4096 + co);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const f16x8*>(sb + j * 4096 + co);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     }
 
-    // epilogue: element (r, t) of this lane <-> A row m = m0 + wave*32 + mfma32_row(r, h), B row n = n0 + t*32 + l31
+    // epilogue: element (i, j, r) of this lane <-> A row m = m0 + 128 wm + 32 i + mfma32_row(r, h), B row n = n0 + 64 wn + 32 j + l31
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64 + l31;
     if (MODE == W_SUMS) {
         float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 + mfma32_row(r, h), n = n0 + t * 32 + l31;
-                const float ok = (m < a.M && n < a.N) ? 1.f : 0.f;
-                p0 = fmaf(ok, fexp2(acc[t][r] * a.k0), p0);
-                p1 = fmaf(ok, fexp2(acc[t][r] * a.k1), p1);
-            }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + mfma32_row(r, h), n = nw + j * 32;
+                    const float ok = (m < a.M && n < a.N) ? 1.f : 0.f;
+                    p0 = fmaf(ok, fexp2(acc[i][j][r] * a.k0), p0);
+                    p1 = fmaf(ok, fexp2(acc[i][j][r] * a.k1), p1);
+                }
         const double v0 = wave_sum_d((double)p0), v1 = wave_sum_d((double)p1);
         if (lane == 0) {
-            const int slot = (int)(((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) % SGA_SLOTS);
+            const int slot = (int)(((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) % SGA_SLOTS);
             atomicAdd(a.sums + 8 * (1 + slot) + a.fam * 2 + 0, v0);
             atomicAdd(a.sums + 8 * (1 + slot) + a.fam * 2 + 1, v1);
         }
     } else if (MODE == W_COEF) {
+        // Both orientations from the one S tile: C [m][n] (lanes along n: 64-byte runs of 2-byte stores) and C^T [n][m] -- a lane's four
+        // registers r = 4 t .. 4 t + 3 are four CONSECUTIVE rows m, i.e. one 8-byte store into row n of C^T.
         const float inv = 1.f / coef_bound(a.gs, a.fam, a.k0, a.k1, a.it0, a.it1);
         const float c0 = (float)(a.gs[a.fam * 2 + 0] * (double)a.it0) * inv, c1 = (float)(a.gs[a.fam * 2 + 1] * (double)a.it1) * inv;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = n0 + t * 32 + l31;
+        for (int j = 0; j < 2; ++j) {
+            const int n = nw + j * 32;
+            const float keep = n < a.N ? 1.f : 0.f;             // a row's padding up to ldc: zeros
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 + mfma32_row(r, h);
-                if (m < a.M && n < a.N) a.cout[(size_t)m * a.ldc + n] = (f16)(c0 * fexp2(acc[t][r] * a.k0) + c1 * fexp2(acc[t][r] * a.k1));
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int mq = mw + i * 32 + 8 * t + 4 * h;  // = mfma32_row(4 t, h): rows mq .. mq + 3
+                    f16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[i][j][4 * t + e];
+                        v[e] = (f16)((mq + e < a.M ? keep : 0.f) * (c0 * fexp2(x * a.k0) + c1 * fexp2(x * a.k1)));
+                    }
+                    if (n < a.ldc) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (mq + e < a.M) a.cout[(size_t)(mq + e) * a.ldc + n] = v[e];
+                    }
+                    if (n < a.N && mq < a.ldc2) *reinterpret_cast<f16x4*>(a.cout2 + (size_t)n * a.ldc2 + mq) = v;
+                }
         }
     } else {
         const float alpha = coef_bound(a.gs, a.fam, a.k0, a.k1, a.it0, a.it1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = n0 + t * 32 + l31;
+        for (int j = 0; j < 2; ++j) {
+            const int n = nw + j * 32;
+            if (n >= a.N) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 + mfma32_row(r, h);
-                if (m < a.M && n < a.N) atomicAdd(a.out + (size_t)m * a.ldo + n, alpha * acc[t][r]);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + mfma32_row(r, h);
+                    if (m < a.M) atomicAdd(a.out + (size_t)m * a.ldo + n, alpha * acc[i][j][r]);
+                }
         }
     }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(W_THREADS, 2) void wide16_kernel(W16Args a) { wide16_body<MODE>(a, blockIdx.z); }
+__global__ __launch_bounds__(W_THREADS, 1) void wide16_kernel(W16Args a) { wide16_body<MODE>(a, blockIdx.z); }
 
 // The four sum families of a table in ONE launch (blockIdx.z = family * zper + K split): 16 launches of ~85 us per table and backward at
 // configs[4] -- grids of a few hundred tiles each -- become 4.
 struct W16Batch { W16Args a[4]; int n, zper; };
 template <int MODE>
-__global__ __launch_bounds__(W_THREADS, 2) void wide16_batch_kernel(W16Batch b) {
+__global__ __launch_bounds__(W_THREADS, 1) void wide16_batch_kernel(W16Batch b) {
     const int q = blockIdx.z / b.zper;
     if (q >= b.n) return;
     wide16_body<MODE>(b.a[q], blockIdx.z - q * b.zper);
@@ -204,7 +243,8 @@ inline SegCols seg_cols(int A, int J1, int J2) {
 
 template <int MODE>
 void launch(const W16Args& a, int ksplit, hipStream_t s) {
-    hipLaunchKernelGGL(wide16_kernel<MODE>, dim3((a.N + W_T - 1) / W_T, (a.M + W_T - 1) / W_T, ksplit), dim3(W_THREADS), 0, s, a);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wide16_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    hipLaunchKernelGGL(wide16_kernel<MODE>, dim3((a.N + W_T - 1) / W_T, (a.M + W_T - 1) / W_T, ksplit), dim3(W_THREADS), W_LDS, s, a);
 }
 template <int MODE>
 void launch_batch(W16Batch& b, const int* ksplit, hipStream_t s) {
@@ -213,7 +253,8 @@ void launch_batch(W16Batch& b, const int* ksplit, hipStream_t s) {
         gx = max(gx, (b.a[q].N + W_T - 1) / W_T); gy = max(gy, (b.a[q].M + W_T - 1) / W_T); kz = max(kz, ksplit[q]);
     }
     b.zper = kz;
-    hipLaunchKernelGGL(wide16_batch_kernel<MODE>, dim3(gx, gy, kz * b.n), dim3(W_THREADS), 0, s, b);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wide16_batch_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    hipLaunchKernelGGL(wide16_batch_kernel<MODE>, dim3(gx, gy, kz * b.n), dim3(W_THREADS), W_LDS, s, b);
 }
 
 }  // namespace
@@ -304,10 +345,12 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
     Blk b[4];
     four_blocks(b, A, J1, J2);
     const int ncu = sga_num_cus();
-    auto ksplit_for = [&](int M, int N, int K, int& kper) {
-        const int tiles = ((M + W_T - 1) / W_T) * ((N + W_T - 1) / W_T);
-        int ks = (2 * ncu + tiles - 1) / tiles;
-        const int kmax = (K + 511) / 512;                      // at least 512 of K per split
+    // K splits of a gradient GEMM: ~3 workgroups per CU over the whole launch (`nfam` families share it; one 128-KiB workgroup per CU at a
+    // time), at least 512 of K per split -- every split adds M x N fp32 atomics
+    auto ksplit_for = [&](int M, int N, int K, int nfam, int& kper) {
+        const int tiles = ((M + W_T - 1) / W_T) * ((N + W_T - 1) / W_T) * nfam;
+        int ks = (3 * ncu + tiles - 1) / tiles;
+        const int kmax = (K + 511) / 512;
         if (ks > kmax) ks = kmax;
         if (ks < 1) ks = 1;
         kper = ((K + ks - 1) / ks + W_KC - 1) / W_KC * W_KC;
@@ -315,9 +358,12 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
     };
     // one stash pair per family if the workspace holds four (then the four families share every launch), else family by family
     const bool batched = 4 * need(rows) <= stash_bytes;
+    int nfam = 0;
+    for (int q = 0; q < 4; ++q) nfam += b[q].n_oth > 0;
+    if (!batched || nfam < 1) nfam = 1;
     for (int lo = 0; lo < A; lo += (int)rows) {
         const int ns = (lo + (int)rows < A ? (int)rows : A - lo);
-        W16Batch bc{}, bct{}, bg1{}, bg2{};
+        W16Batch bc{}, bg1{}, bg2{};
         int k1s[4], k2s[4], ones[4] = {1, 1, 1, 1};
         for (int q = 0; q < 4; ++q) {
             const int J = b[q].n_oth;
@@ -327,16 +373,12 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
             W16Args a{};
             a.K = Dp; a.kper = (Dp + W_KC - 1) / W_KC * W_KC;
             a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.it0 = 1.f / tau0; a.it1 = 1.f / tau1; a.gs = gs8; a.fam = b[q].fam;
-            // C: rows = anchors of the block, lanes along the negatives
+            // ONE S pass writes both orientations: C [anchors of the block][pad8(J)] and C^T [J][pad8(ns)]
             a.A = Z + (size_t)(b[q].own_row + lo) * Dp; a.lda = Dp; a.M = ns;
             a.B = Z + (size_t)b[q].oth_row * Dp; a.ldb = Dp; a.N = J;
             a.cout = C; a.ldc = pad8(J);
+            a.cout2 = CT; a.ldc2 = pad8(ns);
             if (batched) bc.a[bc.n++] = a; else launch<W_COEF>(a, 1, s);
-            // C^T: rows = negatives, lanes along the anchors
-            a.A = Z + (size_t)b[q].oth_row * Dp; a.M = J;
-            a.B = Z + (size_t)(b[q].own_row + lo) * Dp; a.N = ns;
-            a.cout = CT; a.ldc = pad8(ns);
-            if (batched) bct.a[bct.n++] = a; else launch<W_COEF>(a, 1, s);
             // dZ[anchors] += alpha C Z[negatives]          (B operand: ZhT rows = columns d, k = negative)
             W16Args g{};
             g.k0 = a.k0; g.k1 = a.k1; g.it0 = a.it0; g.it1 = a.it1; g.gs = gs8; g.fam = b[q].fam;
@@ -344,19 +386,18 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
             g.B = ZT + b[q].oth_col; g.ldb = sc.ldt; g.N = Dp;
             g.K = J;
             g.out = dZ + (size_t)(b[q].own_row + lo) * Dp; g.ldo = Dp;
-            int ks = ksplit_for(g.M, g.N, g.K, g.kper);
+            int ks = ksplit_for(g.M, g.N, g.K, nfam, g.kper);
             if (batched) { k1s[bg1.n] = ks; bg1.a[bg1.n++] = g; } else launch<W_GEMM>(g, ks, s);
             // dZ[negatives] += alpha C^T Z[anchors of the block]
             g.A = CT; g.lda = pad8(ns); g.M = J;
             g.B = ZT + b[q].own_col + lo; g.N = Dp;
             g.K = ns;
             g.out = dZ + (size_t)b[q].oth_row * Dp;
-            ks = ksplit_for(g.M, g.N, g.K, g.kper);
+            ks = ksplit_for(g.M, g.N, g.K, nfam, g.kper);
             if (batched) { k2s[bg2.n] = ks; bg2.a[bg2.n++] = g; } else launch<W_GEMM>(g, ks, s);
         }
         if (batched && bc.n) {
             launch_batch<W_COEF>(bc, ones, s);
-            launch_batch<W_COEF>(bct, ones, s);
             launch_batch<W_GEMM>(bg1, k1s, s);
             launch_batch<W_GEMM>(bg2, k2s, s);
         }
