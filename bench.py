@@ -408,8 +408,8 @@ def roofline_objects(events, world):
                       'frac_useful': round((3.0 if grad else 1.0) * 2.0 * 100 * M * 2.0 * ns * (J1 + J2) / (avg_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4),
                       'frac_useful_is': 'S once + two gradient GEMMs over the M modality tables (sum D = 100 M; the joint table is derived, and the '
                                         'backward recomputes S in its second owner pass: 4 products executed for 3 useful)'})
-    for key, what, mult in (('wide16_grad', 'loss: negatives backward on fp16-input MFMA -- coefficient tiles in both orientations + both '
-                             'gradient GEMMs, every table', 2.0),
+    for key, what, mult in (('wide16_grad', 'loss: negatives backward on fp16-input MFMA -- one S pass writing the coefficient tile in both orientations '
+                             '+ both gradient GEMMs, every table', 2.0),
                             ('wide16_sums', 'loss: global sums on fp16-input MFMA, every table', 1.0)):
         evs = events.get(key, [])
         if not evs:
@@ -424,9 +424,10 @@ def roofline_objects(events, world):
         roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4),
                       'traffic': None, 'kernel': f'wide16_kernel ({what}; widths {sorted(set(widths))})', 'launch_groups_timed': len(evs),
                       'avg_launch_ms': round(step_ms, 4), 'step_ms': round(step_ms, 4), 'algorithmic_flops_per_launch': alg,
-                      'executed_flops_per_launch': alg * (2.0 if mult == 2.0 else 1.0),
-                      'note': 'one entry = the launches of ONE step over all tables (4 x 2 coefficient + 4 x 2 GEMM launches per table '
-                              'backward; 4 launches per table forward), HIP events around each table\'s group'})
+                      'executed_flops_per_launch': alg * (1.5 if mult == 2.0 else 1.0),
+                      'frac_executed': round(ach * (1.5 if mult == 2.0 else 1.0) / PEAK_F16_TFLOPS, 4),
+                      'note': 'one entry = the launches of ONE step over all tables (per table backward: 1 coefficient launch + 2 GEMM launches, '
+                              'the four sum families batched in each; forward: 1 launch), HIP events around each table\'s group'})
     # ---- the HBM-bound kernels SURVEY 8(d) names: fusion (2 x 4 T D M bytes per direction) and the GAT message passing (per layer and head-pair
     # launch: 256 x 4 B of features in and out per node; the 16 B/edge list only when the batch is not recognised as complete graphs --
     # then the attention kernels never read it).  `achieved` = algorithmic bytes / mean launch time; one object per kernel, step_ms = all

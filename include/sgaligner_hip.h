@@ -151,12 +151,18 @@ int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, con
 
 /* MFMA mode 'f16' (configs[4]: tables wider than 128 columns): the same two launches with fp16 INPUTS for the similarities of every table k
  * whose Zh[k] != NULL -- Zh[k] = the fp16 copy of Z[k]'s rows that sga_wide16_prepare writes (row pitch Dp[k] halfs); fp32 accumulate, the
- * epilogue unchanged.  Zh == NULL or Zh[k] == NULL: exact fp32 for that table.  1e-2 tolerance, like the mode's sweeps. */
+ * epilogue unchanged.  Zh == NULL or Zh[k] == NULL: exact fp32 for that table.  1e-2 tolerance, like the mode's sweeps.
+ * ws / ws_bytes (optional; sga_loss_anchor_f16_ws_bytes(NT, A, a_hi - a_lo) bytes): when given AND every table has its Zh[k], the 2 NT
+ * similarity blocks of the shard (X1 X2^T and X2 X1^T, [A][a_hi - a_lo] fp32 each) are formed first on the fp16 tile core of the mode's
+ * sweeps (csrc/wide16.hip: 256 x 256 tiles, LDS-DMA) and the kernels run their epilogue only -- same arithmetic, same results up to the
+ * fp32 summation order of the products.  ws == NULL: the one-kernel form. */
+size_t sga_loss_anchor_f16_ws_bytes(int NT, int A, int ns);
 int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
-                            float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream);
+                            float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* ws, size_t ws_bytes,
+                            void* stream);
 int sga_loss_anchor_bwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
                             float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
-                            double* gs, int a_lo, int a_hi, void* stream);
+                            double* gs, int a_lo, int a_hi, void* ws, size_t ws_bytes, void* stream);
 
 /* dZ[a_lo:a_hi,:] += M1^T Z[A:2A,:] ; dZ[A:2A,:] += M1 Z[a_lo:a_hi,:]  (M1 [A, a_hi-a_lo] from sga_loss_anchor_bwd; dZ zero-initialised) */
 int sga_loss_stash_grad(const float* M1, const float* Z, int A, int Dp, float* dZ, int a_lo, int a_hi, void* stream);
@@ -400,6 +406,13 @@ int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int J2, float t
 size_t sga_loss_neg_grad_f16_bytes(int A, int J1, int J2);
 int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
                           float* dZ, void* stash, size_t stash_bytes, void* stream);
+/* sga_loss_stash_grad for a wide table in the same mode (replaces the two fp32 GEMMs; the autograd of src/aligner/losses.py:6,50-57,81-94
+ * through S = X1 X2^T): dZ[A + j] += sum_i M1[j, i] Z[a_lo + i], dZ[a_lo + i] += sum_j M1[j, i] Z[A + j] with the coefficients as fp16 of
+ * 2^e M1 (2^e: the power of two that puts the block's largest magnitude into [2^13, 2^14), found by a max pass, undone exactly at the end),
+ * the rows from ZhT (sga_wide16_prepare), fp32 accumulate.  a_lo must be a multiple of 8.  ws: sga_loss_stash_grad_f16_bytes(A, a_hi - a_lo). */
+size_t sga_loss_stash_grad_f16_bytes(int A, int ns);
+int sga_loss_stash_grad_f16(const float* M1, const void* ZhT, int Dp, int A, int J1, int J2, float* dZ, int a_lo, int a_hi,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* ---- scalar head of OverallLoss -----------------------------------------------------------------------
  * replaces the one-element arithmetic of src/aligner/losses.py:114-152 + CustomMultiLossLayer.forward :28-34 on the raw terms

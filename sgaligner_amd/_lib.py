@@ -77,8 +77,11 @@ SIGNATURES = {
     'sga_loss_neg_grad_shard': (I, [P, I, I, I, I, F, F, P, P, I, I, P]),
     'sga_loss_anchor_fwd': (I, [P, P, I, I, P, F, F, F, P, I, I, P]),
     'sga_loss_anchor_bwd': (I, [P, P, I, I, P, F, F, F, P, P, P, I, I, P]),
-    'sga_loss_anchor_fwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, I, I, P]),
-    'sga_loss_anchor_bwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, P, P, I, I, P]),
+    'sga_loss_anchor_f16_ws_bytes': (c_size_t, [I, I, I]),
+    'sga_loss_anchor_fwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, I, I, P, c_size_t, P]),
+    'sga_loss_anchor_bwd_f16': (I, [P, P, P, I, I, P, F, F, F, P, P, P, I, I, P, c_size_t, P]),
+    'sga_loss_stash_grad_f16_bytes': (c_size_t, [I, I]),
+    'sga_loss_stash_grad_f16': (I, [P, P, I, I, I, I, P, I, I, P, c_size_t, P]),
     'sga_loss_multi_sums': (I, [P, I, I, P, I, I, I, F, F, P, I, I, P]),
     'sga_loss_multi_grad': (I, [P, I, I, P, I, I, I, F, F, P, P, P, I, I, P]),
     'sga_loss_centre_bytes': (c_size_t, []),

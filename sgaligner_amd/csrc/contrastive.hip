@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "loss_math.h"
+#include "wide16_api.h"
 
 // gemm.hip (include/sgaligner_hip.h): the stash gradient of the anchors x anchors backward runs on the GEMM kernels
 extern "C" int sga_gemm(int transA, int transB, int M, int N, int K, const void* A, long lda, int a_is_f64, const float* B,
@@ -1148,15 +1149,22 @@ struct AnchorArgs {
     const float* coef;             // bwd: upstream dL/d(out) in the same order
     float* M1[CT_MAXT];            // bwd: stash, M1[k][j*A + i] = dL/dS_k[i,j]
     double* gs;                    // bwd: [NT][8] dL/d(sums)
+    const float* SP[CT_MAXT];      // PRE: the similarity blocks formed beforehand (wide16.hip's tile core), SP[k][j * ldp + (i - i_lo)] = X1[i] . X2[j]
+    const float* SQ[CT_MAXT];      //      SQ[k][j * ldp + (i - i_lo)] = X2[i] . X1[j]
+    long ldp;
 };
 
-template <bool BWD>
+// PRE: epilogue only -- every table's two similarity blocks are read from memory in the accumulator layout (lanes along i: coalesced), no
+// K loop, no LDS tiles (mode 'f16' with all tables wide: the products run on the fp16 tile core at ~0.4 of the fp16 MFMA peak instead of
+// this kernel's single-buffered 128 x 64 staging).
+template <bool BWD, bool PRE = false>
 __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
     constexpr int NJT = 2, OT = 64;
-    __shared__ __attribute__((aligned(16))) float own1[128 * SGA_LDS_STRIDE];   // X1 rows of block I
-    __shared__ __attribute__((aligned(16))) float own2[128 * SGA_LDS_STRIDE];   // X2 rows of block I
-    __shared__ __attribute__((aligned(16))) float oth1[OT * SGA_LDS_STRIDE];    // X2 rows of block J  (for P)
-    __shared__ __attribute__((aligned(16))) float oth2[OT * SGA_LDS_STRIDE];    // X1 rows of block J  (for Q)
+    constexpr int LR = PRE ? 1 : 128, LO = PRE ? 1 : OT;
+    __shared__ __attribute__((aligned(16))) float own1[LR * SGA_LDS_STRIDE];    // X1 rows of block I
+    __shared__ __attribute__((aligned(16))) float own2[LR * SGA_LDS_STRIDE];    // X2 rows of block I
+    __shared__ __attribute__((aligned(16))) float oth1[LO * SGA_LDS_STRIDE];    // X2 rows of block J  (for P)
+    __shared__ __attribute__((aligned(16))) float oth2[LO * SGA_LDS_STRIDE];    // X1 rows of block J  (for Q)
     __shared__ float inv_s[CT_MAXT * 8];                                        // 1/(sum + 1e-9)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -1182,6 +1190,19 @@ __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
         zero_acc<NJT>(P);
         zero_acc<NJT>(Q);
         const _Float16* Zh = a.Zh[k];
+        if constexpr (PRE) {
+            __syncthreads();                                    // (inv_s)
+            const float* sp = a.SP[k] + (iv ? my_i - a.i_lo : 0);
+            const float* sq = a.SQ[k] + (iv ? my_i - a.i_lo : 0);
+#pragma unroll
+            for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = min(j0 + t * 32 + mfma32_row(r, h), A - 1);
+                    P[t][r] = sp[(size_t)j * a.ldp];
+                    Q[t][r] = sq[(size_t)j * a.ldp];
+                }
+        } else
         if (Zh) {                                               // uniform: fp16 inputs, 64 columns per chunk
             for (int k0 = 0; k0 < Dp; k0 += 64) {
                 __syncthreads();
@@ -2062,11 +2083,50 @@ static int fill_anchor(AnchorArgs& a, const float* const* Z, const int* Dp, int 
 
 extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
                                    float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream) {
-    return sga_loss_anchor_fwd_f16(Z, nullptr, Dp, NT, A, sums, alpha, tau_icl, tau_ial, out, a_lo, a_hi, stream);
+    return sga_loss_anchor_fwd_f16(Z, nullptr, Dp, NT, A, sums, alpha, tau_icl, tau_ial, out, a_lo, a_hi, nullptr, 0, stream);
+}
+
+// Mode 'f16', every table wide (Zh[k] set for all k) and a workspace given: the 2 NT similarity blocks of the anchor shard are formed on
+// wide16.hip's fp16 tile core (up to 8 per launch) and the epilogue-only form of the kernel reads them.
+static size_t anchor_ws_ldp(int ns) { return (size_t)(ns + 3) / 4 * 4; }
+extern "C" size_t sga_loss_anchor_f16_ws_bytes(int NT, int A, int ns) {
+    if (NT < 1 || A < 1 || ns < 1) return 256;
+    return (size_t)NT * 2 * A * anchor_ws_ldp(ns) * sizeof(float) + 256;
+}
+static int anchor_pre_blocks(AnchorArgs& a, const void* const* Zh, void* ws, size_t ws_bytes, hipStream_t s, bool& pre) {
+    pre = false;
+    if (!ws || !Zh) return SGA_OK;
+    for (int k = 0; k < a.NT; ++k) if (!Zh[k]) return SGA_OK;
+    const int ns = a.i_hi - a.i_lo, A = a.A;
+    if (ws_bytes < sga_loss_anchor_f16_ws_bytes(a.NT, A, ns)) {
+        sga_set_error("sga_loss_anchor (f16): workspace of %zu bytes, %zu needed", ws_bytes, sga_loss_anchor_f16_ws_bytes(a.NT, A, ns));
+        return SGA_ERR_WORKSPACE;
+    }
+    const size_t ldp = anchor_ws_ldp(ns);
+    float* w = static_cast<float*>(ws);
+    SgaW16Store e[8];
+    int n = 0;
+    for (int k = 0; k < a.NT; ++k) {
+        const _Float16* zh = static_cast<const _Float16*>(Zh[k]);
+        const long dp = a.Dp[k];
+        float* sp = w + (size_t)(2 * k) * A * ldp;
+        float* sq = w + (size_t)(2 * k + 1) * A * ldp;
+        a.SP[k] = sp; a.SQ[k] = sq;
+        e[n++] = SgaW16Store{zh + (size_t)A * dp, dp, A, zh + (size_t)a.i_lo * dp, dp, ns, (int)dp, sp, (long)ldp};          // X2[j] . X1[i]
+        e[n++] = SgaW16Store{zh, dp, A, zh + (size_t)(A + a.i_lo) * dp, dp, ns, (int)dp, sq, (long)ldp};                      // X1[j] . X2[i]
+        if (n == 8 || k == a.NT - 1) {
+            if (int rc = sga_wide16_store_batch(e, n, s)) return rc;
+            n = 0;
+        }
+    }
+    a.ldp = (long)ldp;
+    pre = true;
+    return SGA_OK;
 }
 
 extern "C" int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
-                                       float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* stream) {
+                                       float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* ws, size_t ws_bytes,
+                                       void* stream) {
     SGA_CHECK_ARG(Z && Dp && sums && out && A >= 0, "sga_loss_anchor_fwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = NT > 1 ? NT - 1 : 0;
@@ -2077,7 +2137,10 @@ extern "C" int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const*
     if (rc) return rc;
     a.out = out;
     for (int k = 0; k < NT; ++k) a.Zh[k] = Zh ? static_cast<const _Float16*>(Zh[k]) : nullptr;
-    hipLaunchKernelGGL(anchor_kernel<false>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    bool pre = false;
+    if (int rcp = anchor_pre_blocks(a, Zh, ws, ws_bytes, s, pre)) return rcp;
+    if (pre) hipLaunchKernelGGL((anchor_kernel<false, true>), dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(anchor_kernel<false>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(out, NT + 2 * M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_fwd");
     return SGA_OK;
@@ -2086,12 +2149,12 @@ extern "C" int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const*
 extern "C" int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, const double* sums,
                                    float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
                                    double* gs, int a_lo, int a_hi, void* stream) {
-    return sga_loss_anchor_bwd_f16(Z, nullptr, Dp, NT, A, sums, alpha, tau_icl, tau_ial, coef, M1, gs, a_lo, a_hi, stream);
+    return sga_loss_anchor_bwd_f16(Z, nullptr, Dp, NT, A, sums, alpha, tau_icl, tau_ial, coef, M1, gs, a_lo, a_hi, nullptr, 0, stream);
 }
 
 extern "C" int sga_loss_anchor_bwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
                                        float alpha, float tau_icl, float tau_ial, const float* coef, float* const* M1,
-                                       double* gs, int a_lo, int a_hi, void* stream) {
+                                       double* gs, int a_lo, int a_hi, void* ws, size_t ws_bytes, void* stream) {
     SGA_CHECK_ARG(Z && Dp && sums && coef && M1 && gs && A >= 0, "sga_loss_anchor_bwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc0 = zero_slots(gs, NT * 8, s, "sga_loss_anchor_bwd")) return rc0;
@@ -2102,7 +2165,10 @@ extern "C" int sga_loss_anchor_bwd_f16(const float* const* Z, const void* const*
     a.coef = coef; a.gs = gs;
     for (int k = 0; k < NT; ++k) { SGA_CHECK_ARG(M1[k], "sga_loss_anchor_bwd: null stash %d", k); a.M1[k] = M1[k]; }
     for (int k = 0; k < NT; ++k) a.Zh[k] = Zh ? static_cast<const _Float16*>(Zh[k]) : nullptr;
-    hipLaunchKernelGGL(anchor_kernel<true>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    bool pre = false;
+    if (int rcp = anchor_pre_blocks(a, Zh, ws, ws_bytes, s, pre)) return rcp;
+    if (pre) hipLaunchKernelGGL((anchor_kernel<true, true>), dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(anchor_kernel<true>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(gs, NT * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_bwd");
     return SGA_OK;

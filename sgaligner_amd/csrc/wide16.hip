@@ -10,13 +10,15 @@
 //   SUMS  exp2 of the S tile, masked, reduced to the fp64 per-wave slots;
 //   COEF  c_ij = (g0/tau0 exp(S/tau0) + g1/tau1 exp(S/tau1)) / alpha  written as fp16 (alpha = the coefficient's bound, so |c/alpha| <= 1:
 //         inside fp16's range whatever the loss scale; values below 6e-8 of the bound flush to zero);
-//   GEMM  out += alpha * acc  (fp32 atomics; split over K for occupancy).
+//   GEMM  out += alpha * acc  (fp32 atomics; split over K for occupancy);
+//   STORE out  = acc          (fp32; the anchors x anchors similarity blocks of contrastive.hip's epilogue-only kernels, wide16_api.h).
 // Operand layouts (sga_wide16_prepare): Zh [R][Dp] = fp16 copy of the packed normalised table (S operand), ZhT [Dp][ldt] = its
 // transpose with every segment (X1 | X2 | N1 | N2) starting at a multiple of 8 columns (the gradient GEMMs' B operand: k = packed row).
 // The gradient GEMMs need the coefficient tile in both orientations (anchor-major C for dZ[anchors] = C Z[neg], negative-major C^T for
 // dZ[neg] = C^T Z[anchors]); ONE S pass writes both: in the 32 x 32 accumulator layout a lane's registers 4 t .. 4 t + 3 are four consecutive
 // rows, i.e. one 8-byte store into C^T (until round 6 S was formed twice, once per orientation).
 #include "loss_math.h"
+#include "wide16_api.h"
 
 namespace {
 
@@ -28,7 +30,7 @@ constexpr int W_THREADS = 512, W_T = 256, W_KC = 64;
 constexpr int W_OP = W_T * W_KC * 2;        // bytes of one operand's K chunk in LDS: 256 rows x 128 B (32 KiB)
 constexpr int W_STAGE = 2 * W_OP;           // A rows | B rows
 constexpr int W_LDS = 2 * W_STAGE;          // two stages: 128 KiB, one workgroup (8 waves, two per SIMD) per CU
-constexpr int W_SUMS = 0, W_COEF = 1, W_GEMM = 2;
+constexpr int W_SUMS = 0, W_COEF = 1, W_GEMM = 2, W_STORE = 3;
 
 struct W16Args {
     const f16* A; long lda; int M;          // A operand rows [M][K]  (MFMA rows: r / lane>>5)
@@ -39,7 +41,8 @@ struct W16Args {
     double* sums;                           // SUMS out (slots)
     f16* cout; long ldc;                    // COEF out  C [M][ldc]; columns N .. ldc - 1 are written as zeros (the GEMMs read whole 8-half groups)
     f16* cout2; long ldc2;                  // COEF out  C^T [N][ldc2] (ldc2 = M padded to 8), same zero padding
-    float* out; long ldo;                   // GEMM out [M][ldo], atomically accumulated
+    float* out; long ldo;                   // GEMM out [M][ldo], atomically accumulated (STORE: plainly stored)
+    const float* alpha_dev;                 // GEMM: out += *alpha_dev * acc when set (a scale another kernel left in device memory), else the bound from gs
 };
 
 // 16 readable zero bytes: the source of every 8-half group that lies past the K range
@@ -68,12 +71,22 @@ __device__ __forceinline__ float coef_bound(const double* gs, int fam, float k0,
 // (rows 8 i .. 8 i + 7) fetches row 8 i + (l >> 3), group (l & 7) ^ swizzle(row).
 // Edges: rows past M / N re-read the last row (their results are masked in the epilogues); 8-half groups that START past the K range read
 // the zero block; a group that straddles K (GEMM mode: K = a packed row count) reads the operands' zero padding up to the next multiple of 8.
+// Tile order (XCD-aware): a launch's tile grid (gx column tiles x gy row tiles per z slice) is a 1-D grid of T8 = gx gy rounded up to 8
+// workgroups; the hardware deals consecutive workgroup ids to the 8 XCDs in turn, so XCD c = id % 8 gets the CONTIGUOUS range
+// [c T8 / 8, (c + 1) T8 / 8) of tile positions, and positions walk 8 row tiles down before they step to the next column tile: the ~32
+// workgroups an XCD runs at a time form an 8 x 4 patch that shares 12 operand panels through its L2 (a 256 x 256 x 64 tile step has 128
+// FLOP per operand byte: without that reuse 1 PFLOP/s would ask HBM for 8 TB/s).
 template <int MODE>
-__device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
+__device__ __forceinline__ void wide16_body(const W16Args& a, int bz, int gx, int gy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 2, wn = wave & 3;
-    const int m0 = blockIdx.y * W_T, n0 = blockIdx.x * W_T;
+    const int pos = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    const int grp = pos / (8 * gx), q = pos - grp * 8 * gx;
+    const int gm = min(8, gy - 8 * grp);                     // row tiles of this group (the last group may be shorter)
+    if (pos >= gx * gy) return;
+    const int tile_m = 8 * grp + q % gm, tile_n = q / gm;
+    const int m0 = tile_m * W_T, n0 = tile_n * W_T;
     if (m0 >= a.M || n0 >= a.N) return;                      // (batched launches: the grid is the largest family's)
     const int kb = bz * a.kper, ke = min(a.K, kb + a.kper);
     if (kb >= ke) return;
@@ -99,17 +112,17 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
     }
     const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)lds16) + (unsigned)wave * 8192u;
     const f16* zero = reinterpret_cast<const f16*>(g_w16_zero);
-    auto stage = [&](int buf, int k) {
+    auto stage = [&](int buf, int k, int q_lo, int q_hi) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) glds16(k + kg[q] < ke ? rp[q] + k : zero, lbase + (unsigned)(buf * W_STAGE + q * 1024));
+        for (int q = q_lo; q < q_hi; ++q) glds16(k + kg[q] < ke ? rp[q] + k : zero, lbase + (unsigned)(buf * W_STAGE + q * 1024));
     };
     const int swz = (l31 >> 1) & 7;
-    stage(0, kb);
+    stage(0, kb, 0, 8);
     int it = 0;
     for (int k = kb; k < ke; k += W_KC, ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of chunk `it` have landed ...
         __syncthreads();                                     // ... everybody's have, and everybody has read chunk it - 1: its buffer is free
-        if (k + W_KC < ke) stage((it + 1) & 1, k + W_KC);
+        const bool more = k + W_KC < ke;
         const unsigned char* sa = lds16 + (it & 1) * W_STAGE + (wm * 128 + l31) * 128;
         const unsigned char* sb = lds16 + (it & 1) * W_STAGE + W_OP + (wn * 64 + l31) * 128;
 #pragma unroll
@@ -120,6 +133,13 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
             for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f16x8*>(sa + i * 4096 + co);
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const f16x8*>(sb + j * 4096 + co);
+            // the next chunk's copies ride in the shadow of the first two steps' LDS reads, four each (all eight in a burst behind the
+            // barrier queue up at the CU's one address unit -- 16 cycles per 1-KiB copy, 64 per chunk -- before any wave reaches an MFMA)
+            if (kk < 2 && more) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage((it + 1) & 1, k + W_KC, 4 * kk, 4 * kk + 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -144,7 +164,7 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
                 }
         const double v0 = wave_sum_d((double)p0), v1 = wave_sum_d((double)p1);
         if (lane == 0) {
-            const int slot = (int)(((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) % SGA_SLOTS);
+            const int slot = (int)(((unsigned)blockIdx.x * 8u + (unsigned)wave) % SGA_SLOTS);
             atomicAdd(a.sums + 8 * (1 + slot) + a.fam * 2 + 0, v0);
             atomicAdd(a.sums + 8 * (1 + slot) + a.fam * 2 + 1, v1);
         }
@@ -175,8 +195,21 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
                     if (n < a.N && mq < a.ldc2) *reinterpret_cast<f16x4*>(a.cout2 + (size_t)n * a.ldc2 + mq) = v;
                 }
         }
+    } else if (MODE == W_STORE) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = nw + j * 32;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + mfma32_row(r, h);
+                    if (m < a.M) a.out[(size_t)m * a.ldo + n] = acc[i][j][r];
+                }
+        }
     } else {
-        const float alpha = coef_bound(a.gs, a.fam, a.k0, a.k1, a.it0, a.it1);
+        const float alpha = a.alpha_dev ? *a.alpha_dev : coef_bound(a.gs, a.fam, a.k0, a.k1, a.it0, a.it1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = nw + j * 32;
@@ -193,16 +226,16 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(W_THREADS, 1) void wide16_kernel(W16Args a) { wide16_body<MODE>(a, blockIdx.z); }
+__global__ __launch_bounds__(W_THREADS, 1) void wide16_kernel(W16Args a, int gx, int gy) { wide16_body<MODE>(a, blockIdx.z, gx, gy); }
 
-// The four sum families of a table in ONE launch (blockIdx.z = family * zper + K split): 16 launches of ~85 us per table and backward at
+// Up to eight products -- the four sum families of a table -- in ONE launch (blockIdx.z = product * zper + K split): 16 launches of ~85 us per table and backward at
 // configs[4] -- grids of a few hundred tiles each -- become 4.
-struct W16Batch { W16Args a[4]; int n, zper; };
+struct W16Batch { W16Args a[8]; int n, zper, gx, gy; };
 template <int MODE>
 __global__ __launch_bounds__(W_THREADS, 1) void wide16_batch_kernel(W16Batch b) {
     const int q = blockIdx.z / b.zper;
     if (q >= b.n) return;
-    wide16_body<MODE>(b.a[q], blockIdx.z - q * b.zper);
+    wide16_body<MODE>(b.a[q], blockIdx.z - q * b.zper, b.gx, b.gy);
 }
 
 // Z fp32 [R][Dp] -> Zh fp16 [R][Dp] and ZhT fp16 [Dp][ldt] (column of packed row r: r + shift of its segment)
@@ -241,10 +274,30 @@ inline SegCols seg_cols(int A, int J1, int J2) {
     return s;
 }
 
+// K splits of a gradient GEMM whose launch holds `tiles` output tiles (all products of the launch): one 128-KiB workgroup runs per CU at a
+// time, so the launch proceeds in rounds of `ncu` workgroups -- take the split count (at least 512 of K per split, at most 16) whose LAST
+// round is fullest among those that give >= 3 rounds (else the most rounds available); every split adds M x N fp32 atomics.
+inline int choose_ksplit(int tiles, int K, int ncu, int& kper) {
+    const int kmax = max(1, min(16, (K + 511) / 512));
+    int best = 1;
+    double best_eff = -1.0;
+    for (int ks = 1; ks <= kmax; ++ks) {
+        const long wgs = (long)tiles * ks;
+        const long rounds = (wgs + ncu - 1) / ncu;
+        double eff = (double)wgs / (double)(rounds * ncu);
+        if (rounds < 3) eff *= 0.25 * rounds;                 // few rounds: prologue / epilogue bubbles are not covered
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
+    }
+    kper = ((K + best - 1) / best + W_KC - 1) / W_KC * W_KC;
+    return (K + kper - 1) / kper;
+}
+
+inline int tiles8(int gx, int gy) { return (gx * gy + 7) / 8 * 8; }
 template <int MODE>
 void launch(const W16Args& a, int ksplit, hipStream_t s) {
+    const int gx = (a.N + W_T - 1) / W_T, gy = (a.M + W_T - 1) / W_T;
     hipFuncSetAttribute(reinterpret_cast<const void*>(wide16_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
-    hipLaunchKernelGGL(wide16_kernel<MODE>, dim3((a.N + W_T - 1) / W_T, (a.M + W_T - 1) / W_T, ksplit), dim3(W_THREADS), W_LDS, s, a);
+    hipLaunchKernelGGL(wide16_kernel<MODE>, dim3(tiles8(gx, gy), 1, ksplit), dim3(W_THREADS), W_LDS, s, a, gx, gy);
 }
 template <int MODE>
 void launch_batch(W16Batch& b, const int* ksplit, hipStream_t s) {
@@ -252,9 +305,9 @@ void launch_batch(W16Batch& b, const int* ksplit, hipStream_t s) {
     for (int q = 0; q < b.n; ++q) {
         gx = max(gx, (b.a[q].N + W_T - 1) / W_T); gy = max(gy, (b.a[q].M + W_T - 1) / W_T); kz = max(kz, ksplit[q]);
     }
-    b.zper = kz;
+    b.zper = kz; b.gx = gx; b.gy = gy;
     hipFuncSetAttribute(reinterpret_cast<const void*>(wide16_batch_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
-    hipLaunchKernelGGL(wide16_batch_kernel<MODE>, dim3(gx, gy, kz * b.n), dim3(W_THREADS), W_LDS, s, b);
+    hipLaunchKernelGGL(wide16_batch_kernel<MODE>, dim3(tiles8(gx, gy), 1, kz * b.n), dim3(W_THREADS), W_LDS, s, b);
 }
 
 }  // namespace
@@ -345,16 +398,8 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
     Blk b[4];
     four_blocks(b, A, J1, J2);
     const int ncu = sga_num_cus();
-    // K splits of a gradient GEMM: ~3 workgroups per CU over the whole launch (`nfam` families share it; one 128-KiB workgroup per CU at a
-    // time), at least 512 of K per split -- every split adds M x N fp32 atomics
     auto ksplit_for = [&](int M, int N, int K, int nfam, int& kper) {
-        const int tiles = ((M + W_T - 1) / W_T) * ((N + W_T - 1) / W_T) * nfam;
-        int ks = (3 * ncu + tiles - 1) / tiles;
-        const int kmax = (K + 511) / 512;
-        if (ks > kmax) ks = kmax;
-        if (ks < 1) ks = 1;
-        kper = ((K + ks - 1) / ks + W_KC - 1) / W_KC * W_KC;
-        return (K + kper - 1) / kper;
+        return choose_ksplit(((M + W_T - 1) / W_T) * ((N + W_T - 1) / W_T) * nfam, K, ncu, kper);
     };
     // one stash pair per family if the workspace holds four (then the four families share every launch), else family by family
     const bool batched = 4 * need(rows) <= stash_bytes;
@@ -403,5 +448,134 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
         }
     }
     SGA_CHECK_LAUNCH("sga_loss_neg_grad_f16");
+    return SGA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The tile core as a service (wide16_api.h): up to eight fp32 similarity blocks out = A B^T in one launch.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+int sga_wide16_store_batch(const SgaW16Store* e, int n, hipStream_t s) {
+    if (n < 0 || n > 8) { sga_set_error("sga_wide16_store_batch: %d products (at most 8)", n); return SGA_ERR_ARG; }
+    W16Batch b{};
+    int ones[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    for (int q = 0; q < n; ++q) {
+        if (e[q].M <= 0 || e[q].N <= 0 || e[q].K <= 0) continue;
+        if (!e[q].A || !e[q].B || !e[q].out || e[q].K % 8 || e[q].lda % 8 || e[q].ldb % 8) {
+            sga_set_error("sga_wide16_store_batch: product %d: null operand or K / row pitch not a multiple of 8", q);
+            return SGA_ERR_ARG;
+        }
+        W16Args a{};
+        a.A = static_cast<const f16*>(e[q].A); a.lda = e[q].lda; a.M = e[q].M;
+        a.B = static_cast<const f16*>(e[q].B); a.ldb = e[q].ldb; a.N = e[q].N;
+        a.K = e[q].K; a.kper = (e[q].K + W_KC - 1) / W_KC * W_KC;
+        a.out = e[q].out; a.ldo = e[q].ldo;
+        b.a[b.n++] = a;
+    }
+    if (b.n) launch_batch<W_STORE>(b, ones, s);
+    SGA_CHECK_LAUNCH("sga_wide16_store_batch");
+    return SGA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The two stash products of the anchors x anchors backward (sga_loss_stash_grad) on the same core, for a WIDE table in mode 'f16':
+//   dX2[j, :] += sum_i M1[j, i] X1[a_lo + i, :]        dX1[a_lo + i, :] += sum_j M1[j, i] X2[j, :]        M1 [A][ns] fp32 = (dL/dS)^T
+// (the autograd of losses.py:6,50-57,81-94 through S = X1 X2^T).  The coefficients enter the matrix cores as fp16 of 2^e M1, 2^e the power of
+// two that puts the block's largest magnitude into [2^13, 2^14) (found by a max pass; exact scaling, undone by the GEMM's alpha; what falls
+// below 2^-38 of the largest coefficient flushes to zero), in both orientations (M1h [A][pad8 ns], M1Th [ns][pad8 A], written by one
+// transposing pass); the B operands are the table's ZhT rows of sga_wide16_prepare.  fp32 accumulate, fp32 atomics into dZ.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void stash16_absmax_kernel(const float* __restrict__ M1, size_t n, unsigned* __restrict__ amax) {
+    __shared__ float wm[4];
+    float m = 0.f;
+    const size_t n4 = n / 4;                                 // (M1 is 16-byte aligned)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(M1)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(M1[n4 * 4 + threadIdx.x]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(amax, __float_as_uint(m));    // non-negative floats order like their bit patterns
+    }
+}
+// hdr: [0] max |M1| (bits), [1] alpha = 2^-e (for the GEMMs).  64 x 64 tiles of M1 (rows j, columns i).
+__global__ __launch_bounds__(256) void stash16_convert_kernel(const float* __restrict__ M1, int A, int ns, float* __restrict__ hdr,
+                                                              f16* __restrict__ Mh, int ldh, f16* __restrict__ MTh, int ldt2) {
+    __shared__ float tile[64][65];
+    const float amax = hdr[0];
+    int ex = 0;
+    if (amax > 0.f) (void)frexpf(amax, &ex);                      // amax = f 2^ex, f in [0.5, 1)
+    const float scale = amax > 0.f ? ldexpf(1.f, 14 - ex) : 1.f;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr[1] = amax > 0.f ? ldexpf(1.f, ex - 14) : 1.f;
+    const int j0 = blockIdx.y * 64, i0 = blockIdx.x * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = j0 + ty * 16 + q, i = i0 + tx;
+        const float v = (j < A && i < ns) ? M1[(size_t)j * ns + i] * scale : 0.f;
+        if (j < A && i < ldh) Mh[(size_t)j * ldh + i] = (f16)v;
+        tile[ty * 16 + q][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = i0 + ty * 16 + q, j = j0 + tx;
+        if (i < ns && j < ldt2) MTh[(size_t)i * ldt2 + j] = (f16)tile[tx][ty * 16 + q];
+    }
+}
+}  // namespace
+
+extern "C" size_t sga_loss_stash_grad_f16_bytes(int A, int ns) {
+    return 256 + sizeof(f16) * ((size_t)A * pad8(ns) + (size_t)ns * pad8(A)) + 256;
+}
+
+extern "C" int sga_loss_stash_grad_f16(const float* M1, const void* ZhT, int Dp, int A, int J1, int J2, float* dZ, int a_lo, int a_hi,
+                                       void* ws, size_t ws_bytes, void* stream) {
+    SGA_CHECK_ARG(A >= 0 && J1 >= 0 && J2 >= 0 && Dp >= 8 && Dp % 8 == 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi && a_lo % 8 == 0,
+                  "sga_loss_stash_grad_f16: bad sizes (Dp and a_lo must be multiples of 8)");
+    const int ns = a_hi - a_lo;
+    if (A == 0 || ns == 0) return SGA_OK;
+    SGA_CHECK_ARG(M1 && ZhT && dZ && ws && reinterpret_cast<uintptr_t>(M1) % 16 == 0, "sga_loss_stash_grad_f16: null or misaligned pointer");
+    SGA_CHECK_ARG(ws_bytes >= sga_loss_stash_grad_f16_bytes(A, ns), "sga_loss_stash_grad_f16: workspace of %zu bytes, %zu needed", ws_bytes,
+                  sga_loss_stash_grad_f16_bytes(A, ns));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* hdr = static_cast<float*>(ws);
+    f16* Mh = reinterpret_cast<f16*>(static_cast<unsigned char*>(ws) + 256);
+    const int ldh = pad8(ns), ldt2 = pad8(A);
+    f16* MTh = Mh + ((size_t)A * ldh + 127) / 128 * 128;
+    if (hipMemsetAsync(ws, 0, 16, s) != hipSuccess) { sga_set_error("sga_loss_stash_grad_f16: memset failed"); return SGA_ERR_HIP; }
+    const size_t n = (size_t)A * ns;
+    const int nb = (int)((n + 256 * 32 - 1) / (256 * 32));
+    hipLaunchKernelGGL(stash16_absmax_kernel, dim3(nb < 1024 ? (nb > 0 ? nb : 1) : 1024), dim3(256), 0, s, M1, n, reinterpret_cast<unsigned*>(ws));
+    hipLaunchKernelGGL(stash16_convert_kernel, dim3((ldh + 63) / 64, (ldt2 + 63) / 64), dim3(256), 0, s, M1, A, ns, hdr, Mh, ldh, MTh, ldt2);
+    const SegCols sc = seg_cols(A, J1, J2);
+    const f16* ZT = static_cast<const f16*>(ZhT);
+    const int ncu = sga_num_cus();
+    auto ksplit_for = [&](int M, int N, int K, int& kper) {
+        return choose_ksplit(((M + W_T - 1) / W_T) * ((N + W_T - 1) / W_T), K, ncu, kper);      // (the two products differ in shape: each on its own)
+    };
+    W16Batch b{};
+    int ks[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    W16Args g{};
+    g.alpha_dev = hdr + 1;
+    // dX2[j] += sum_i M1[j, i] X1[a_lo + i]          (B operand: ZhT rows = columns d, k = anchor a_lo + i of segment X1)
+    g.A = Mh; g.lda = ldh; g.M = A;
+    g.B = ZT + sc.x1 + a_lo; g.ldb = sc.ldt; g.N = Dp;
+    g.K = ns;
+    g.out = dZ + (size_t)A * Dp; g.ldo = Dp;
+    ks[0] = ksplit_for(g.M, g.N, g.K, g.kper);
+    b.a[b.n++] = g;
+    // dX1[a_lo + i] += sum_j M1[j, i] X2[j]
+    g.A = MTh; g.lda = ldt2; g.M = ns;
+    g.B = ZT + sc.x2; g.N = Dp;
+    g.K = A;
+    g.out = dZ + (size_t)a_lo * Dp;
+    ks[1] = ksplit_for(g.M, g.N, g.K, g.kper);
+    b.a[b.n++] = g;
+    launch_batch<W_GEMM>(b, ks, s);
+    SGA_CHECK_LAUNCH("sga_loss_stash_grad_f16");
     return SGA_OK;
 }

@@ -143,8 +143,21 @@ class ContrastiveTermsFn(torch.autograd.Function):
         dparr = (_ct.c_int * nt)(*dps)
         # (mode 'f16': the wide tables' anchors x anchors similarities take their fp16 copies as well -- fp16 inputs, fp32 accumulate)
         sums = _allreduce_sum(sums, reduce)
-        _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi, st),
-                   'sga_loss_anchor_fwd')
+        # (all tables wide: their 2 nt similarity blocks on the fp16 tile core first, then the epilogue-only kernel -- one anchor-row block at a time)
+        all16 = all(zh is not None for zh in zhs)
+        if all16 and a_hi > a_lo:
+            out.zero_()
+            part = torch.empty_like(out)
+            chunks = _anchor_chunks(a_lo, a_hi, s.A, 2 * nt)
+            ws = torch.empty((int(L.sga_loss_anchor_f16_ws_bytes(nt, s.A, max(hi - lo for lo, hi in chunks))),), device=dev, dtype=torch.uint8)
+            for lo, hi in chunks:
+                _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(part), lo, hi,
+                                                     _p(ws), ws.numel(), st), 'sga_loss_anchor_fwd')
+                out += part
+            del ws, part
+        else:
+            _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi,
+                                                 None, 0, st), 'sga_loss_anchor_fwd')
         out = _allreduce_sum(out[:nt + 2 * m].contiguous(), reduce)
         ctx.shard, ctx.reduce = (a_lo, a_hi), reduce
         ctx.s, ctx.alpha, ctx.dps, ctx.nt = s, float(alpha), dps, nt
@@ -172,19 +185,29 @@ class ContrastiveTermsFn(torch.autograd.Function):
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for dp in dps]
         gs = torch.zeros((nt, 8), device=dev, dtype=torch.float64)
         a_lo, a_hi = ctx.shard
-        chunks = _anchor_chunks(a_lo, a_hi, A, nt)
+        all16 = nt > 0 and all(zh is not None for zh in zhs)
+        chunks = _anchor_chunks(a_lo, a_hi, A, 3 * nt if all16 else nt)      # (all16: stash + the two similarity blocks per table)
         if chunks:
             cmax = max(hi - lo for lo, hi in chunks)
             m1 = [torch.empty((A * cmax,), device=dev, dtype=torch.float32) for _ in range(nt)]
             gsc = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
+            ws = ws16 = None
+            if all16:
+                ws = torch.empty((int(L.sga_loss_anchor_f16_ws_bytes(nt, A, cmax)),), device=dev, dtype=torch.uint8)
+                ws16 = torch.empty((int(L.sga_loss_stash_grad_f16_bytes(A, cmax)),), device=dev, dtype=torch.uint8)
             for lo, hi in chunks:          # bounded stash: one anchor-row block at a time
                 _lib.check(L.sga_loss_anchor_bwd_f16(_ptr_array(zs), _ptr_array(zhs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
-                                                     _ptr_array(m1), _p(gsc), lo, hi, st), 'sga_loss_anchor_bwd')
+                                                     _ptr_array(m1), _p(gsc), lo, hi, _p(ws) if all16 else None, ws.numel() if all16 else 0, st),
+                           'sga_loss_anchor_bwd')
                 gs += gsc[0]
                 for k in range(nt):
                     # dX1[i] = sum_j G[i,j] X2[j]  (M1 = G^T),  dX2[j] = sum_i G[i,j] X1[i]
-                    _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dps[k], _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
-            del m1
+                    if zhs[k] is not None and lo % 8 == 0:
+                        _lib.check(L.sga_loss_stash_grad_f16(_p(m1[k]), _p(zts[k]), dps[k], A, s.J1, s.J2, _p(dzs[k]), lo, hi, _p(ws16) if ws16 is not None else None,
+                                                             ws16.numel() if ws16 is not None else 0, st), 'sga_loss_stash_grad_f16')
+                    else:
+                        _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dps[k], _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
+            del m1, ws, ws16
         gs = _allreduce_sum(gs, ctx.reduce)                      # dL/d(global sums) needs every shard's anchors x anchors tiles
         grads = []
         for k in range(nt):
