@@ -428,6 +428,23 @@ def roofline_objects(events, world):
                       'frac_executed': round(ach * (1.5 if mult == 2.0 else 1.0) / PEAK_F16_TFLOPS, 4),
                       'note': 'one entry = the launches of ONE step over all tables (per table backward: 1 coefficient launch + 2 GEMM launches, '
                               'the four sum families batched in each; forward: 1 launch), HIP events around each table\'s group'})
+    for key, what, mult in (('wide16_aa_fwd', 'loss: anchors x anchors forward of the wide tables -- X1 X2^T and X2 X1^T blocks on the fp16 tile core + '
+                             'the epilogue-only kernel', 2.0),
+                            ('wide16_aa_bwd', 'loss: anchors x anchors backward of the wide tables -- the two similarity blocks again, the epilogue-only '
+                             'kernel, max + convert passes and both stash products on the fp16 tile core', 4.0)):
+        evs = events.get(key, [])
+        if not evs:
+            continue
+        n_steps = max(1, events.get('_steps', 0)) or 1
+        step_ms = sum(a_.elapsed_time(b_) for a_, b_, _ in evs) / n_steps
+        flops = sum(mult * 2.0 * dsum * A * A for _, _, (A, dsum) in evs) / n_steps        # products of [A, D] x [D, A] / [A, A] x [A, D] shape, all tables
+        ach = flops / (step_ms * 1e-3) / 1e12
+        roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4),
+                      'traffic': None, 'kernel': f'wide16_kernel + anchor_kernel<.., PRE> ({what})', 'launch_groups_timed': len(evs),
+                      'avg_launch_ms': round(step_ms, 4), 'step_ms': round(step_ms, 4), 'algorithmic_flops_per_launch': flops,
+                      'executed_flops_per_launch': flops,
+                      'note': 'one entry = every launch of ONE step (HIP events around the group); the epilogue kernels are VALU work on A^2 pairs '
+                              'per table, not matrix work: the fraction is that of the whole group'})
     # ---- the HBM-bound kernels SURVEY 8(d) names: fusion (2 x 4 T D M bytes per direction) and the GAT message passing (per layer and head-pair
     # launch: 256 x 4 B of features in and out per node; the 16 B/edge list only when the batch is not recognised as complete graphs --
     # then the attention kernels never read it).  `achieved` = algorithmic bytes / mean launch time; one object per kernel, step_ms = all

@@ -1159,7 +1159,7 @@ struct AnchorArgs {
 // this kernel's single-buffered 128 x 64 staging).
 template <bool BWD, bool PRE = false>
 __global__ __launch_bounds__(CT_THREADS) void anchor_kernel(AnchorArgs a) {
-    constexpr int NJT = 2, OT = 64;
+    constexpr int NJT = PRE ? 1 : 2, OT = 32 * NJT;         // (PRE: one 32-column tile per workgroup -- half the live registers of the epilogue)
     constexpr int LR = PRE ? 1 : 128, LO = PRE ? 1 : OT;
     __shared__ __attribute__((aligned(16))) float own1[LR * SGA_LDS_STRIDE];    // X1 rows of block I
     __shared__ __attribute__((aligned(16))) float own2[LR * SGA_LDS_STRIDE];    // X2 rows of block I
@@ -2139,7 +2139,7 @@ extern "C" int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const*
     for (int k = 0; k < NT; ++k) a.Zh[k] = Zh ? static_cast<const _Float16*>(Zh[k]) : nullptr;
     bool pre = false;
     if (int rcp = anchor_pre_blocks(a, Zh, ws, ws_bytes, s, pre)) return rcp;
-    if (pre) hipLaunchKernelGGL((anchor_kernel<false, true>), dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    if (pre) hipLaunchKernelGGL((anchor_kernel<false, true>), dim3((a_hi - a_lo + 127) / 128, (A + 31) / 32), dim3(CT_THREADS), 0, s, a);
     else hipLaunchKernelGGL(anchor_kernel<false>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(out, NT + 2 * M, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_fwd");
@@ -2167,7 +2167,7 @@ extern "C" int sga_loss_anchor_bwd_f16(const float* const* Z, const void* const*
     for (int k = 0; k < NT; ++k) a.Zh[k] = Zh ? static_cast<const _Float16*>(Zh[k]) : nullptr;
     bool pre = false;
     if (int rcp = anchor_pre_blocks(a, Zh, ws, ws_bytes, s, pre)) return rcp;
-    if (pre) hipLaunchKernelGGL((anchor_kernel<true, true>), dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
+    if (pre) hipLaunchKernelGGL((anchor_kernel<true, true>), dim3((a_hi - a_lo + 127) / 128, (A + 31) / 32), dim3(CT_THREADS), 0, s, a);
     else hipLaunchKernelGGL(anchor_kernel<true>, dim3((a_hi - a_lo + 127) / 128, (A + 63) / 64), dim3(CT_THREADS), 0, s, a);
     fold_slots(gs, NT * 8, s);
     SGA_CHECK_LAUNCH("sga_loss_anchor_bwd");

@@ -219,7 +219,11 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz, int gx, in
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mw + i * 32 + mfma32_row(r, h);
+#ifdef W16_DBG_NOATOMIC
+                    if (m < a.M) a.out[(size_t)m * a.ldo + n] = alpha * acc[i][j][r];       // (timing experiment: wrong results)
+#else
                     if (m < a.M) atomicAdd(a.out + (size_t)m * a.ldo + n, alpha * acc[i][j][r]);
+#endif
                 }
         }
     }

@@ -146,6 +146,10 @@ class ContrastiveTermsFn(torch.autograd.Function):
         # (all tables wide: their 2 nt similarity blocks on the fp16 tile core first, then the epilogue-only kernel -- one anchor-row block at a time)
         all16 = all(zh is not None for zh in zhs)
         if all16 and a_hi > a_lo:
+            eva = None
+            if _o.KERNEL_EVENTS is not None:
+                eva = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                eva[0].record()
             out.zero_()
             part = torch.empty_like(out)
             chunks = _anchor_chunks(a_lo, a_hi, s.A, 2 * nt)
@@ -155,6 +159,9 @@ class ContrastiveTermsFn(torch.autograd.Function):
                                                      _p(ws), ws.numel(), st), 'sga_loss_anchor_fwd')
                 out += part
             del ws, part
+            if eva is not None:
+                eva[1].record()
+                _o.KERNEL_EVENTS.setdefault('wide16_aa_fwd', []).append(eva + ((s.A, sum(dps)),))
         else:
             _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi,
                                                  None, 0, st), 'sga_loss_anchor_fwd')
@@ -191,7 +198,10 @@ class ContrastiveTermsFn(torch.autograd.Function):
             cmax = max(hi - lo for lo, hi in chunks)
             m1 = [torch.empty((A * cmax,), device=dev, dtype=torch.float32) for _ in range(nt)]
             gsc = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
-            ws = ws16 = None
+            ws = ws16 = evb = None
+            if all16 and _o.KERNEL_EVENTS is not None:
+                evb = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                evb[0].record()
             if all16:
                 ws = torch.empty((int(L.sga_loss_anchor_f16_ws_bytes(nt, A, cmax)),), device=dev, dtype=torch.uint8)
                 ws16 = torch.empty((int(L.sga_loss_stash_grad_f16_bytes(A, cmax)),), device=dev, dtype=torch.uint8)
@@ -208,6 +218,9 @@ class ContrastiveTermsFn(torch.autograd.Function):
                     else:
                         _lib.check(L.sga_loss_stash_grad(_p(m1[k]), _p(zs[k]), A, dps[k], _p(dzs[k]), lo, hi, st), 'sga_loss_stash_grad')
             del m1, ws, ws16
+            if evb is not None:
+                evb[1].record()
+                _o.KERNEL_EVENTS.setdefault('wide16_aa_bwd', []).append(evb + ((A, sum(dps)),))
         gs = _allreduce_sum(gs, ctx.reduce)                      # dL/d(global sums) needs every shard's anchors x anchors tiles
         grads = []
         for k in range(nt):

@@ -243,3 +243,76 @@ def test_simrank_f16_stream_table_converted_once():
     same = (k32[:, 0] == k16[:, 0]).cpu().numpy()
     assert same[gap > 5e-3].all()
     assert (r32 - r16).abs().float().mean().item() < 0.5
+
+
+@pytest.mark.parametrize('A,J,Dp,blk', [(300, 500, 264, None), (77, 130, 1024, None), (530, 600, 136, (256, 530))])
+def test_anchor_blocks_on_the_tile_core_equal_the_one_kernel_form(A, J, Dp, blk):
+    """sga_loss_anchor_fwd_f16 / _bwd_f16 with a workspace (similarity blocks formed by wide16.hip's tile core, epilogue-only kernel) against
+    the same calls without one (K loop inside the kernel): same fp16 inputs, fp32 accumulate -- equal up to the summation order of the
+    products; and sga_loss_stash_grad_f16 (coefficients as scaled fp16) against the fp32 stash GEMMs within the mode's tolerance."""
+    import ctypes as ct
+    from sgaligner_amd import _lib
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(A + Dp)
+    R = 2 * A + 2 * J
+    nt = 3
+    st = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ct.c_void_p(t.data_ptr())
+    zs, zhs, zts = [], [], []
+    for k in range(nt):
+        z = torch.nn.functional.normalize(torch.randn(R, Dp, device=dev) + 0.3 * k, dim=1).contiguous()
+        zh = torch.empty((R, Dp), device=dev, dtype=torch.float16)
+        zt = torch.empty((Dp, int(L.sga_wide16_ldt(A, J, J))), device=dev, dtype=torch.float16)
+        _lib.check(L.sga_wide16_prepare(p(z), Dp, A, J, J, p(zh), p(zt), st), 'prepare')
+        zs.append(z); zhs.append(zh); zts.append(zt)
+    za = (ct.c_void_p * nt)(*[t.data_ptr() for t in zs])
+    zha = (ct.c_void_p * nt)(*[t.data_ptr() for t in zhs])
+    dps = (ct.c_int * nt)(*([Dp] * nt))
+    lo, hi = blk if blk else (0, A)
+    ns = hi - lo
+    slots = 1 + L.sga_loss_slots()
+    sums = (torch.rand((nt, 8), device=dev, dtype=torch.float64) * 50 + 20) * J
+    m = nt - 1
+    ws = torch.empty((int(L.sga_loss_anchor_f16_ws_bytes(nt, A, ns)),), device=dev, dtype=torch.uint8)
+    outs = []
+    for w in (ws, None):
+        out = torch.empty((slots * (nt + 2 * m),), device=dev, dtype=torch.float64)
+        _lib.check(L.sga_loss_anchor_fwd_f16(za, zha, dps, nt, A, p(sums), 0.5, 0.1, 1.0, p(out), lo, hi, p(w) if w is not None else None,
+                                             w.numel() if w is not None else 0, st), 'anchor_fwd')
+        outs.append(out[:nt + 2 * m].clone())
+    assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-7), (outs[0], outs[1])
+    coef = torch.linspace(0.5, 1.5, nt + 2 * m, device=dev, dtype=torch.float32)
+    res = []
+    for w in (ws, None):
+        m1 = [torch.full((A * ns,), float('nan'), device=dev, dtype=torch.float32) for _ in range(nt)]
+        m1a = (ct.c_void_p * nt)(*[t.data_ptr() for t in m1])
+        gs = torch.empty((slots, nt, 8), device=dev, dtype=torch.float64)
+        _lib.check(L.sga_loss_anchor_bwd_f16(za, zha, dps, nt, A, p(sums), 0.5, 0.1, 1.0, p(coef), m1a, p(gs), lo, hi, p(w) if w is not None else None,
+                                             w.numel() if w is not None else 0, st), 'anchor_bwd')
+        res.append((m1, gs[0].clone()))
+    for k in range(nt):
+        a, b = res[0][0][k], res[1][0][k]
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-12, k
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-9 * float(res[1][1].abs().max()))
+    # the stash products: fp16 coefficients x fp16 rows against the fp32 GEMMs
+    m1 = res[1][0][0]
+    d32 = torch.zeros((R, Dp), device=dev, dtype=torch.float32)
+    d16 = torch.zeros((R, Dp), device=dev, dtype=torch.float32)
+    _lib.check(L.sga_loss_stash_grad(p(m1), p(zs[0]), A, Dp, p(d32), lo, hi, st), 'stash_grad')
+    ws16 = torch.empty((int(L.sga_loss_stash_grad_f16_bytes(A, ns)),), device=dev, dtype=torch.uint8)
+    _lib.check(L.sga_loss_stash_grad_f16(p(m1), p(zts[0]), Dp, A, J, J, p(d16), lo, hi, p(ws16), ws16.numel(), st), 'stash_grad_f16')
+    torch.cuda.synchronize()
+    assert torch.equal(d16[2 * A:], torch.zeros_like(d16[2 * A:]))                       # the negatives' rows are not touched
+    untouched = torch.ones(2 * A, dtype=torch.bool, device=dev)
+    untouched[lo:hi] = False
+    untouched[A:2 * A] = False
+    assert torch.equal(d16[:2 * A][untouched], torch.zeros_like(d16[:2 * A][untouched]))
+    err = (d16 - d32).abs().max().item() / d32.abs().max().item()
+    assert err < 2e-3, err                                                                # 2^-11 per operand, averaged over >= 77 terms
+    # scale independence: the power-of-two scaling is exact
+    d16b = torch.zeros_like(d16)
+    m1s = (m1 * 2.0 ** -40).contiguous()
+    _lib.check(L.sga_loss_stash_grad_f16(p(m1s), p(zts[0]), Dp, A, J, J, p(d16b), lo, hi, p(ws16), ws16.numel(), st), 'stash_grad_f16')
+    assert (d16b * 2.0 ** 40 - d16).abs().max().item() <= 2e-6 * d16.abs().max().item()     # (same bits up to the atomics' summation order)
