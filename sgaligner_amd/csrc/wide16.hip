@@ -278,19 +278,20 @@ inline SegCols seg_cols(int A, int J1, int J2) {
     return s;
 }
 
-// K splits of a gradient GEMM whose launch holds `tiles` output tiles (all products of the launch): one 128-KiB workgroup runs per CU at a
-// time, so the launch proceeds in rounds of `ncu` workgroups -- take the split count (at least 512 of K per split, at most 16) whose LAST
-// round is fullest among those that give >= 3 rounds (else the most rounds available); every split adds M x N fp32 atomics.
+// K splits of a gradient GEMM whose launch holds `tiles` output tiles (all products of the launch).  One 128-KiB workgroup runs per CU at a
+// time, so the launch proceeds in rounds of `ncu` workgroups, and a workgroup costs its K chunks plus a constant: prologue, and the fp32
+// atomics of its 256 x 256 tile, which the memory side executes as read-modify-writes of whole lines -- measured ~27 us per workgroup, the
+// time of ~20 K chunks (tools/bench_wide16.py with -DW16_DBG_NOATOMIC).  Take the split count that minimises rounds x (chunks + 26).
 inline int choose_ksplit(int tiles, int K, int ncu, int& kper) {
     const int kmax = max(1, min(16, (K + 511) / 512));
     int best = 1;
-    double best_eff = -1.0;
+    long best_cost = -1;
     for (int ks = 1; ks <= kmax; ++ks) {
         const long wgs = (long)tiles * ks;
         const long rounds = (wgs + ncu - 1) / ncu;
-        double eff = (double)wgs / (double)(rounds * ncu);
-        if (rounds < 3) eff *= 0.25 * rounds;                 // few rounds: prologue / epilogue bubbles are not covered
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
+        const long chunks = ((K + ks - 1) / ks + W_KC - 1) / W_KC;
+        const long cost = rounds * (chunks + 26);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ks; }
     }
     kper = ((K + best - 1) / best + W_KC - 1) / W_KC * W_KC;
     return (K + kper - 1) / kper;
