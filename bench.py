@@ -302,7 +302,7 @@ def pmc_traffic_bytes(kernel_tag, workload_key, source):
         return None
 
 
-def roofline_objects(events, world):
+def roofline_objects(events, world, workload=None):
     """The kernels that carry the step, each timed with HIP events on its launch stream (ops.KERNEL_EVENTS), sorted by their time per
     step: [0] is the line's `roofline`, the rest `roofline_other`.  All are bound by the exact-fp32 MFMA rate (157.3 TFLOP/s dense;
     on gfx950 fp32 MFMA and fp32 VALU share the SIMD's FMA datapath -- tools/micro/mfma_valu_overlap.hip -- so epilogue VALU work adds
@@ -421,8 +421,14 @@ def roofline_objects(events, world):
         alg = sum(mult * 2.0 * dp * 2.0 * A * (J1 + J2) for _, _, (A, J1, J2, dp) in evs) / n_steps
         step_ms = total_ms / n_steps
         ach = alg / (step_ms * 1e-3) / 1e12
+        # HBM-side bytes per step from the PMC passes of tools/pmc_traffic_c5.sh (per template; the GEMM template's row also holds the four
+        # stash-product launches of the A x A backward): only at the workload the passes ran on
+        traffic = None
+        if world == 1 and workload == 'c5:64x256x2048':      # configs[4] at 64 pairs: what tools/pmc_traffic_c5.sh ran
+            tk = [pmc_traffic_bytes(f'wide16_batch_kernel<{t}>', 'c5:64x256x2048 per step', 'wide16.hip') for t in ((1, 2) if mult == 2.0 else (0,))]
+            traffic = None if any(t is None for t in tk) else int(sum(tk))
         roofs.append({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4),
-                      'traffic': None, 'kernel': f'wide16_kernel ({what}; widths {sorted(set(widths))})', 'launch_groups_timed': len(evs),
+                      'traffic': traffic, 'kernel': f'wide16_kernel ({what}; widths {sorted(set(widths))})', 'launch_groups_timed': len(evs),
                       'avg_launch_ms': round(step_ms, 4), 'step_ms': round(step_ms, 4), 'algorithmic_flops_per_launch': alg,
                       'executed_flops_per_launch': alg * (1.5 if mult == 2.0 else 1.0),
                       'frac_executed': round(ach * (1.5 if mult == 2.0 else 1.0) / PEAK_F16_TFLOPS, 4),
@@ -584,7 +590,7 @@ def main():
     coll_events, sdist.COLLECTIVE_EVENTS = sdist.COLLECTIVE_EVENTS, None
     loss_val = _finite(loss_dict, 'headline step')
     peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
-    roofs = roofline_objects(events, world)
+    roofs = roofline_objects(events, world, workload=f'{cname}:{my_pairs}x{cfg["n_obj"]}x{cfg["n_pts"]}')
 
     # ---- extras, NOT the headline: the same steps in the other arithmetic modes (ops.set_mfma_mode), on the same batch and weights.
     #   extra_exact_f32: the sweeps on the fp32 MFMA (v_mfma_f32_16x16x4_f32, sweep16_kernel) -- the arithmetic every earlier round's headline

@@ -1,5 +1,5 @@
 """The fp16-input tile core of csrc/wide16.hip, call by call, at the configs[4] loss shape (A anchors, J1 = J2 negatives, Dp columns):
-  python tools/bench_wide16.py [A=3420] [J=16384] [Dp=1024]
+  python tools/bench_wide16.py [A=4864] [J=11520] [Dp=1024]
 times sga_loss_neg_sums_f16, sga_loss_neg_grad_f16, the anchors x anchors forward / backward with the similarity blocks formed on the core,
 and sga_loss_stash_grad_f16; prints TFLOP/s of the products each call executes against the 2.5 PFLOP/s dense fp16 peak."""
 import os, sys
@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as ct
 import torch
 from sgaligner_amd import _lib
-A = int(sys.argv[1]) if len(sys.argv) > 1 else 3420
-J = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+A = int(sys.argv[1]) if len(sys.argv) > 1 else 4864
+J = int(sys.argv[2]) if len(sys.argv) > 2 else 11520
 Dp = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 L = _lib.lib()
 dev = torch.device('cuda:0')
