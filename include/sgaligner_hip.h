@@ -152,10 +152,10 @@ int sga_loss_anchor_bwd(const float* const* Z, const int* Dp, int NT, int A, con
 /* MFMA mode 'f16' (configs[4]: tables wider than 128 columns): the same two launches with fp16 INPUTS for the similarities of every table k
  * whose Zh[k] != NULL -- Zh[k] = the fp16 copy of Z[k]'s rows that sga_wide16_prepare writes (row pitch Dp[k] halfs); fp32 accumulate, the
  * epilogue unchanged.  Zh == NULL or Zh[k] == NULL: exact fp32 for that table.  1e-2 tolerance, like the mode's sweeps.
- * ws / ws_bytes (optional; sga_loss_anchor_f16_ws_bytes(NT, A, a_hi - a_lo) bytes): when given AND every table has its Zh[k], the 2 NT
- * similarity blocks of the shard (X1 X2^T and X2 X1^T, [A][a_hi - a_lo] fp32 each) are formed first on the fp16 tile core of the mode's
- * sweeps (csrc/wide16.hip: 256 x 256 tiles, LDS-DMA) and the kernels run their epilogue only -- same arithmetic, same results up to the
- * fp32 summation order of the products.  ws == NULL: the one-kernel form. */
+ * ws / ws_bytes (optional; sga_loss_anchor_f16_ws_bytes(NT, A, a_hi - a_lo) bytes; the caller passes it for WIDE tables): the 2 NT
+ * similarity blocks of the shard (X1 X2^T and X2 X1^T, [A][a_hi - a_lo] fp32 each) are formed first -- tables with Zh[k] on the fp16 tile
+ * core of the mode's sweeps (csrc/wide16.hip: 256 x 256 tiles, LDS-DMA), the others by the exact-fp32 NT GEMM (sga_gemm) -- and the kernels
+ * run their epilogue only: same arithmetic, same results up to the fp32 summation order of the products.  ws == NULL: the one-kernel form. */
 size_t sga_loss_anchor_f16_ws_bytes(int NT, int A, int ns);
 int sga_loss_anchor_fwd_f16(const float* const* Z, const void* const* Zh, const int* Dp, int NT, int A, const double* sums,
                             float alpha, float tau_icl, float tau_ial, double* out, int a_lo, int a_hi, void* ws, size_t ws_bytes,

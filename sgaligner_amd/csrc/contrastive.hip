@@ -2086,8 +2086,9 @@ extern "C" int sga_loss_anchor_fwd(const float* const* Z, const int* Dp, int NT,
     return sga_loss_anchor_fwd_f16(Z, nullptr, Dp, NT, A, sums, alpha, tau_icl, tau_ial, out, a_lo, a_hi, nullptr, 0, stream);
 }
 
-// Mode 'f16', every table wide (Zh[k] set for all k) and a workspace given: the 2 NT similarity blocks of the anchor shard are formed on
-// wide16.hip's fp16 tile core (up to 8 per launch) and the epilogue-only form of the kernel reads them.
+// A workspace given (the caller's choice: wide tables): the 2 NT similarity blocks of the anchor shard are formed first -- tables with an
+// fp16 copy Zh[k] on wide16.hip's fp16 tile core (up to 8 blocks per launch), the others by the exact-fp32 NT GEMM of gemm.hip -- and the
+// epilogue-only form of the kernel reads them.
 static size_t anchor_ws_ldp(int ns) { return (size_t)(ns + 3) / 4 * 4; }
 extern "C" size_t sga_loss_anchor_f16_ws_bytes(int NT, int A, int ns) {
     if (NT < 1 || A < 1 || ns < 1) return 256;
@@ -2095,8 +2096,7 @@ extern "C" size_t sga_loss_anchor_f16_ws_bytes(int NT, int A, int ns) {
 }
 static int anchor_pre_blocks(AnchorArgs& a, const void* const* Zh, void* ws, size_t ws_bytes, hipStream_t s, bool& pre) {
     pre = false;
-    if (!ws || !Zh) return SGA_OK;
-    for (int k = 0; k < a.NT; ++k) if (!Zh[k]) return SGA_OK;
+    if (!ws) return SGA_OK;
     const int ns = a.i_hi - a.i_lo, A = a.A;
     if (ws_bytes < sga_loss_anchor_f16_ws_bytes(a.NT, A, ns)) {
         sga_set_error("sga_loss_anchor (f16): workspace of %zu bytes, %zu needed", ws_bytes, sga_loss_anchor_f16_ws_bytes(a.NT, A, ns));
@@ -2107,14 +2107,20 @@ static int anchor_pre_blocks(AnchorArgs& a, const void* const* Zh, void* ws, siz
     SgaW16Store e[8];
     int n = 0;
     for (int k = 0; k < a.NT; ++k) {
-        const _Float16* zh = static_cast<const _Float16*>(Zh[k]);
+        const _Float16* zh = Zh ? static_cast<const _Float16*>(Zh[k]) : nullptr;
         const long dp = a.Dp[k];
         float* sp = w + (size_t)(2 * k) * A * ldp;
         float* sq = w + (size_t)(2 * k + 1) * A * ldp;
         a.SP[k] = sp; a.SQ[k] = sq;
-        e[n++] = SgaW16Store{zh + (size_t)A * dp, dp, A, zh + (size_t)a.i_lo * dp, dp, ns, (int)dp, sp, (long)ldp};          // X2[j] . X1[i]
-        e[n++] = SgaW16Store{zh, dp, A, zh + (size_t)(A + a.i_lo) * dp, dp, ns, (int)dp, sq, (long)ldp};                      // X1[j] . X2[i]
-        if (n == 8 || k == a.NT - 1) {
+        if (zh) {
+            e[n++] = SgaW16Store{zh + (size_t)A * dp, dp, A, zh + (size_t)a.i_lo * dp, dp, ns, (int)dp, sp, (long)ldp};      // X2[j] . X1[i]
+            e[n++] = SgaW16Store{zh, dp, A, zh + (size_t)(A + a.i_lo) * dp, dp, ns, (int)dp, sq, (long)ldp};                  // X1[j] . X2[i]
+        } else {
+            const float* z = a.Z[k];
+            if (int rc = sga_gemm(0, 1, A, ns, (int)dp, z + (size_t)A * dp, dp, 0, z + (size_t)a.i_lo * dp, dp, sp, (long)ldp, nullptr, 0, s)) return rc;
+            if (int rc = sga_gemm(0, 1, A, ns, (int)dp, z, dp, 0, z + (size_t)(A + a.i_lo) * dp, dp, sq, (long)ldp, nullptr, 0, s)) return rc;
+        }
+        if (n == 8 || (k == a.NT - 1 && n > 0)) {
             if (int rc = sga_wide16_store_batch(e, n, s)) return rc;
             n = 0;
         }

@@ -144,7 +144,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
         # (mode 'f16': the wide tables' anchors x anchors similarities take their fp16 copies as well -- fp16 inputs, fp32 accumulate)
         sums = _allreduce_sum(sums, reduce)
         # (all tables wide: their 2 nt similarity blocks on the fp16 tile core first, then the epilogue-only kernel -- one anchor-row block at a time)
-        all16 = all(zh is not None for zh in zhs)
+        all16 = all(dp > 128 for dp in dps)          # every table wide: similarity blocks first (fp16 tile core / fp32 GEMM), epilogue-only kernel
         if all16 and a_hi > a_lo:
             eva = None
             if _o.KERNEL_EVENTS is not None:
@@ -161,7 +161,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
             del ws, part
             if eva is not None:
                 eva[1].record()
-                _o.KERNEL_EVENTS.setdefault('wide16_aa_fwd', []).append(eva + ((s.A, sum(dps)),))
+                if all(zh is not None for zh in zhs):
+                    _o.KERNEL_EVENTS.setdefault('wide16_aa_fwd', []).append(eva + ((s.A, sum(dps)),))
         else:
             _lib.check(L.sga_loss_anchor_fwd_f16(zarr, _ptr_array(zhs), dparr, nt, s.A, _p(sums), float(alpha), TAU_ICL, TAU_IAL, _p(out), a_lo, a_hi,
                                                  None, 0, st), 'sga_loss_anchor_fwd')
@@ -192,7 +193,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
         dzs = [torch.zeros((s.R, dp), device=dev, dtype=torch.float32) for dp in dps]
         gs = torch.zeros((nt, 8), device=dev, dtype=torch.float64)
         a_lo, a_hi = ctx.shard
-        all16 = nt > 0 and all(zh is not None for zh in zhs)
+        all16 = nt > 0 and all(dp > 128 for dp in dps)
         chunks = _anchor_chunks(a_lo, a_hi, A, 3 * nt if all16 else nt)      # (all16: stash + the two similarity blocks per table)
         if chunks:
             cmax = max(hi - lo for lo, hi in chunks)
@@ -204,7 +205,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
                 evb[0].record()
             if all16:
                 ws = torch.empty((int(L.sga_loss_anchor_f16_ws_bytes(nt, A, cmax)),), device=dev, dtype=torch.uint8)
-                ws16 = torch.empty((int(L.sga_loss_stash_grad_f16_bytes(A, cmax)),), device=dev, dtype=torch.uint8)
+                if any(zh is not None for zh in zhs):
+                    ws16 = torch.empty((int(L.sga_loss_stash_grad_f16_bytes(A, cmax)),), device=dev, dtype=torch.uint8)
             for lo, hi in chunks:          # bounded stash: one anchor-row block at a time
                 _lib.check(L.sga_loss_anchor_bwd_f16(_ptr_array(zs), _ptr_array(zhs), dparr, nt, A, _p(sums), ctx.alpha, TAU_ICL, TAU_IAL, _p(coef),
                                                      _ptr_array(m1), _p(gsc), lo, hi, _p(ws) if all16 else None, ws.numel() if all16 else 0, st),
@@ -220,7 +222,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
             del m1, ws, ws16
             if evb is not None:
                 evb[1].record()
-                _o.KERNEL_EVENTS.setdefault('wide16_aa_bwd', []).append(evb + ((A, sum(dps)),))
+                if all(zh is not None for zh in zhs):
+                    _o.KERNEL_EVENTS.setdefault('wide16_aa_bwd', []).append(evb + ((A, sum(dps)),))
         gs = _allreduce_sum(gs, ctx.reduce)                      # dL/d(global sums) needs every shard's anchors x anchors tiles
         grads = []
         for k in range(nt):
