@@ -235,6 +235,131 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
     }
 }
 
+// The same product with every fp32 operand split EXACTLY into three bf16 terms (x = h + m + l, 8 + 8 + 8 significand bits, fp32's exponent range:
+// no pre-scale, no range condition -- the arithmetic of the loss sweeps, sweep3.hip): a product is the six partial products
+// h h' | h m' + m h' | m m' + h l' + l h' on v_mfma_f32_32x32x16_bf16 into fp32 accumulators (the dropped three are <= 2^-23 of the
+// product: below the rounding of the fp32 accumulation that both this kernel and the fp32 MFMA perform), 6/16 of the fp32 MFMA's matrix
+// time.  The split happens ONCE per staged element, on its way from the prefetch registers to LDS (11 VALU per pair of values; an operand
+// element is then read by every wave / every column tile); LDS holds three bf16 planes per operand, [plane][row][32 k] with 80-byte rows
+// (64 + 16: the 16 rows a ds_read_b128 lane group touches land on 16 different 16-byte slots of the 256-byte bank row).
+// TWO accumulators per output: the h h' products and the five small ones apart -- the 16-bit MFMA aligns its products to the largest exponent
+// and chops what falls below toward minus infinity whatever the sign (tools/micro/mfma_round_probe.hip), and a BatchNorm batch sum over 10^5
+// rows of the output would collect that one-sided bias coherently; in their own accumulator nothing of the small products is chopped.
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float g_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int g_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int N3_RS = 80;                                // bytes per LDS row of a plane
+__device__ __forceinline__ void g_split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    const g_bf16x2 H = __builtin_convertvector(g_f32x2{v0, v1}, g_bf16x2);
+    const unsigned hu = __builtin_bit_cast(unsigned, H);
+    const float r0 = v0 - __builtin_bit_cast(float, hu << 16);
+    const float r1 = v1 - __builtin_bit_cast(float, hu & 0xffff0000u);
+    const g_bf16x2 Mi = __builtin_convertvector(g_f32x2{r0, r1}, g_bf16x2);
+    const unsigned mu = __builtin_bit_cast(unsigned, Mi);
+    const float s0 = r0 - __builtin_bit_cast(float, mu << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, mu & 0xffff0000u);
+    const g_bf16x2 Lo = __builtin_convertvector(g_f32x2{s0, s1}, g_bf16x2);
+    h = hu; m = mu; l = __builtin_bit_cast(unsigned, Lo);
+}
+template <int MT>
+__global__ __launch_bounds__(GM_THREADS, 2) void gemm_nt3_kernel(const float* __restrict__ A, long lda,
+                                                                 const float* __restrict__ B, long ldb,
+                                                                 float* __restrict__ C, long ldc,
+                                                                 const float* __restrict__ bias, int M, int N, int K,
+                                                                 int accumulate, int act, const float* __restrict__ resid,
+                                                                 long ldr, double* __restrict__ colstats) {
+    constexpr int NTA = MT / 32;
+    constexpr int APL = MT * N3_RS, BPL = 128 * N3_RS;  // bytes of one plane
+    __shared__ __attribute__((aligned(16))) unsigned char As3[3 * APL];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs3[3 * BPL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * MT, n0 = blockIdx.y * 128;
+    constexpr int V = SGA_KC / 4;                       // quads per tile row
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * GM_THREADS + tid, r = e / V, c = (e % V) * 4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool kin = k0 + c < K;                // K % 4 == 0: a quad is inside or outside as a whole
+            if (i < NTA) ra[i] = (m0 + r < M && kin) ? *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * lda + k0 + c) : z;
+            rb[i] = (n0 + r < N && kin) ? *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + r) * ldb + k0 + c) : z;
+        }
+    };
+    auto put3 = [&](unsigned char* base, int plane_bytes, int r, int c, const f32x4& v) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        g_split3_pair(v[0], v[1], h0, m0_, l0);
+        g_split3_pair(v[2], v[3], h1, m1, l1);
+        unsigned char* p = base + r * N3_RS + c * 2;
+        *reinterpret_cast<g_u32x2*>(p) = g_u32x2{h0, h1};
+        *reinterpret_cast<g_u32x2*>(p + plane_bytes) = g_u32x2{m0_, m1};
+        *reinterpret_cast<g_u32x2*>(p + 2 * plane_bytes) = g_u32x2{l0, l1};
+    };
+    f32x16 acc[NTA], accs[NTA];
+    zero_acc<NTA>(acc);
+    zero_acc<NTA>(accs);
+    gload(0);
+    const unsigned char* bp = Bs3 + (wave * 32 + l31) * N3_RS + h * 16;
+    const unsigned char* ap = As3 + l31 * N3_RS + h * 16;
+    for (int k0 = 0; k0 < K; k0 += SGA_KC) {
+        __syncthreads();                                // the previous chunk's operand reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * GM_THREADS + tid, r = e / V, c = (e % V) * 4;
+            if (i < NTA) put3(As3, APL, r, c, ra[i]);
+            put3(Bs3, BPL, r, c, rb[i]);
+        }
+        __syncthreads();
+        if (k0 + SGA_KC < K) gload(k0 + SGA_KC);       // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < SGA_KC / 16; ++kk) {
+            const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(bp + kk * 32);
+            const g_bf16x8 bm = *reinterpret_cast<const g_bf16x8*>(bp + BPL + kk * 32);
+            const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(bp + 2 * BPL + kk * 32);
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) {
+                const unsigned char* at = ap + t * 32 * N3_RS + kk * 32;
+                const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(at);
+                const g_bf16x8 am = *reinterpret_cast<const g_bf16x8*>(at + APL);
+                const g_bf16x8 al = *reinterpret_cast<const g_bf16x8*>(at + 2 * APL);
+                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accs[t], 0, 0, 0);
+                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accs[t], 0, 0, 0);
+                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, accs[t], 0, 0, 0);
+                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, accs[t], 0, 0, 0);
+                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, accs[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int n = n0 + wave * 32 + l31;
+    const bool nv = n < N;
+    if (!nv && !colstats) return;
+    const float bv = (bias && nv) ? bias[n] : 0.f;
+    float cs = 0.f, cq = 0.f;                           // column sum / sum of squares of what is written (colstats != null)
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + t * 32 + mfma32_row(r, h);
+            if (m < M && nv) {
+                float* p = C + (size_t)m * ldc + n;
+                float v = (acc[t][r] + accs[t][r]) + bv;
+                if (accumulate) v += *p;
+                if (act == 1) v = fmaxf(v, 0.f);
+                else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+                if (resid) v += resid[(size_t)m * ldr + n];
+                *p = v;
+                cs += v; cq = fmaf(v, v, cq);
+            }
+        }
+    }
+    if (colstats) {
+        cs += __shfl_xor(cs, 32, 64); cq += __shfl_xor(cq, 32, 64);
+        if (h == 0 && nv) { atomicAdd(colstats + n, (double)cs); atomicAdd(colstats + N + n, (double)cq); }
+    }
+}
+
 // C[M,N] += A^T B for A [K,M], B [K,N] both row-major (the weight-gradient shape dW = dY^T X with K = rows of the
 // batch): the row-major [32 k][128] chunks go to LDS as they are (f32x4 in, f32x4 out) and the MFMA operands are read
 // as ds_read_b32 with lane = output index (conflict free), K pair (2s, 2s+1) per step -- no transposed staging.
@@ -400,7 +525,17 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
                        const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
                        int act, const float* resid, long ldr, void* stream, double* colstats = nullptr) {
     SGA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sga_gemm: negative size");
-    
+    // the NT kernel's arithmetic: three exact bf16 planes (gemm_nt3_kernel; fp32-faithful, 6/16 of the fp32 MFMA's matrix time) from K = 256 on
+    // -- measured at 163 840 / 40 960 rows (tools/bench_gemm.py): K = 512 -> N = 1024 0.458 -> 0.306 ms, 1024 -> 512 0.407 -> 0.345, 512 -> 256
+    // 0.434 -> 0.331, 256 -> 100 0.128 -> 0.121; K = 128 layers are four chunks per tile (latency, not matrix time: 0.080 -> 0.078) and at K = 64 the
+    // kernel's 61 KiB of LDS planes cost more occupancy than the MFMAs save (0.054 -> 0.074) -- below 256 the fp32 MFMA kernel stays.  A function of K
+    // only, never of M: a batch walked in chunks of rows gets the same bits as the unchunked call.  -DSGA_GEMM_NT_FP32: fp32 MFMA everywhere
+    // (the A/B of tools/build_variant.sh).
+#ifdef SGA_GEMM_NT_FP32
+    const bool nt3 = false;
+#else
+    const bool nt3 = K >= 256;
+#endif
     SGA_CHECK_ARG(act >= 0 && act <= 2, "sga_gemm_ex: act=%d (0 none, 1 relu, 2 leaky-relu 0.2)", act);
     if (M == 0 || N == 0) return SGA_OK;                 // empty output (a zero-row shard): nothing to do, null pointers allowed
     SGA_CHECK_ARG(C && (K == 0 || (A && B)), "sga_gemm: null pointer");
@@ -463,11 +598,17 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
         // 1 024 slots run two rounds for 1.25 rounds of work; 2 560 half tiles run 2.5)
         const int slots = 4 * ncu, tiles = gx * gy, last = tiles % slots;
         if (tiles > slots && tiles < 3 * slots && last > 0 && last * 2 < slots) {
+            if (nt3) hipLaunchKernelGGL(gemm_nt3_kernel<64>, dim3((M + 63) / 64, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
+                                        bias, M, N, K, accumulate, act, resid, ldr, colstats);
+            else
             hipLaunchKernelGGL(gemm_nt_kernel<64>, dim3((M + 63) / 64, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
                                bias, M, N, K, accumulate, act, resid, ldr, colstats);
             SGA_CHECK_LAUNCH("sga_gemm");
             return SGA_OK;
         }
+        if (nt3) hipLaunchKernelGGL(gemm_nt3_kernel<128>, dim3(gx, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
+                                    bias, M, N, K, accumulate, act, resid, ldr, colstats);
+        else
         hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3(gx, gy), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc,
                            bias, M, N, K, accumulate, act, resid, ldr, colstats);
         SGA_CHECK_LAUNCH("sga_gemm");
