@@ -360,6 +360,43 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_nt3_kernel(const float* __
     }
 }
 
+// C[M,N] (+)= A^T B for A [K,M], B [K,N] with a NARROW B (N <= 8: the weight gradient of a layer that reads raw coordinates -- the first
+// Conv1d(3, .) of the PCT / PointNet encoders over 10^5 point rows: the MFMA kernels want N % 4 == 0, and the generic kernel walked it in
+// 620 K splits at 0.1 TB/s).  Memory-bound by A: a lane owns an output row m (A's column: coalesced 256-byte reads per k row), the N
+// values of B's row k are the same for every lane (scalar loads), the four waves of a workgroup take every fourth k row of the chunk, fold
+// through LDS, and one set of fp32 atomics per workgroup goes to C (zeroed by the host unless the caller accumulates).
+__global__ __launch_bounds__(GM_THREADS) void gemm_tn_narrow_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
+                                                                    float* __restrict__ C, long ldc, int M, int N, int K, int kchunk) {
+    __shared__ float red[3][8][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x * 64 + lane;
+    const int k0 = blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
+    const bool mv = m < M;
+    float acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+    for (int k = k0 + wave; k < k1; k += 4) {
+        const float a = mv ? A[(size_t)k * lda + m] : 0.f;
+        const float* br = B + (size_t)k * ldb;
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (n < N) acc[n] = fmaf(a, br[n], acc[n]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) red[wave - 1][n][lane] = acc[n];
+    }
+    __syncthreads();
+    if (wave == 0 && mv) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (n < N) {
+                const float v = acc[n] + red[0][n][lane] + red[1][n][lane] + red[2][n][lane];
+                if (v != 0.f) atomicAdd(C + (size_t)m * ldc + n, v);
+            }
+    }
+}
+
 // C[M,N] += A^T B for A [K,M], B [K,N] both row-major (the weight-gradient shape dW = dY^T X with K = rows of the
 // batch): the row-major [32 k][128] chunks go to LDS as they are (f32x4 in, f32x4 out) and the MFMA operands are read
 // as ds_read_b32 with lane = output index (conflict free), K pair (2s, 2s+1) per step -- no transposed staging.
@@ -540,6 +577,19 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     if (M == 0 || N == 0) return SGA_OK;                 // empty output (a zero-row shard): nothing to do, null pointers allowed
     SGA_CHECK_ARG(C && (K == 0 || (A && B)), "sga_gemm: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (transA && !transB && N <= 8 && K >= 64 && !a_is_f64 && !bias && act == 0 && !resid && !colstats) {
+        // narrow weight gradient (a function of the shape class only): memory-bound walk over A
+        if (!accumulate && hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess) { sga_set_error("sga_gemm: memset2d failed"); return SGA_ERR_HIP; }
+        const int gxn = (M + 63) / 64;
+        int chunks = (4 * sga_num_cus() + gxn - 1) / gxn;
+        if (chunks > (K + 31) / 32) chunks = (K + 31) / 32;              // at least 32 k rows per workgroup
+        if (chunks < 1) chunks = 1;
+        const int kchunk = (K + chunks - 1) / chunks;
+        hipLaunchKernelGGL(gemm_tn_narrow_kernel, dim3(gxn, (K + kchunk - 1) / kchunk), dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb,
+                           C, ldc, M, N, K, kchunk);
+        SGA_CHECK_LAUNCH("sga_gemm");
+        return SGA_OK;
+    }
     const int gx = (M + 127) / 128, gy = (N + 127) / 128;
     // split K when the output grid cannot fill the chip (weight-gradient shape)
     int splits = 1;
@@ -628,6 +678,9 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;
     }
+#ifdef SGA_GEMM_TRACE
+    fprintf(stderr, "[gemm generic] tA=%d tB=%d M=%d N=%d K=%d splits=%d f64=%d bias=%d acc=%d act=%d\n", transA, transB, M, N, K, splits, a_is_f64, bias != nullptr, accumulate, act);
+#endif
     if (a_is_f64)
         hipLaunchKernelGGL(gemm_kernel<double>, grid, dim3(GM_THREADS), 0, s, static_cast<const double*>(A), lda, transA, B, ldb,
                            transB, C, ldc, bias, M, N, K, accumulate, kper, use_atomic, 0, (int)b_al, act, resid, ldr);

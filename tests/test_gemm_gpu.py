@@ -11,7 +11,8 @@ def _check(c, ref, tol=2e-5):
     assert err < tol * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize('m,n,k', [(1000, 100, 256), (65, 33, 7), (128, 128, 32), (300, 104, 9728), (5000, 128, 3), (257, 260, 132)])
+@pytest.mark.parametrize('m,n,k', [(1000, 100, 256), (65, 33, 7), (128, 128, 32), (300, 104, 9728), (5000, 128, 3), (257, 260, 132), (128, 3, 40000), (70, 8, 333),
+                                   (2000, 512, 1024)])
 @pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False)])
 def test_gemm_variants_vs_fp64(m, n, k, ta, tb):
     from sgaligner_amd import ops
