@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-6 measurements in one GPU-box call:  tools/profile_round6.sh <tag>
-#   1. HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, counters only) at configs[2] and configs[1] -> profiles/r06_pmc_traffic.csv ON THE BOX, so that
+#   1. HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, counters only) at configs[2], configs[1] and configs[4] (the fp16 tile core) -> profiles/r06_pmc_traffic.csv ON THE BOX, so that
 #      the bench line of step 2 carries `traffic`; the file comes back as gpurun_out/<tag>_pmc_traffic.csv
 #   2. the default bench line with the driver's flags (the compact line on stdout + bench_extras.json)
 #   3. rocprofv3 kernel-trace stats at configs[2] (default arithmetic only) and configs[1]
@@ -13,6 +13,7 @@ mkdir -p gpurun_out
 rm -f gpurun_out/${tag}_pmc_traffic.csv
 bash tools/pmc_traffic.sh c3 gpurun_out/${tag}_pmc_traffic.csv --no-exact > gpurun_out/${tag}_pmc_c3.log 2>&1
 bash tools/pmc_traffic.sh c2 gpurun_out/${tag}_pmc_traffic.csv --no-exact > gpurun_out/${tag}_pmc_c2.log 2>&1
+bash tools/pmc_traffic_c5.sh gpurun_out/${tag}_pmc_traffic.csv > gpurun_out/${tag}_pmc_c5.log 2>&1
 cp gpurun_out/${tag}_pmc_traffic.csv profiles/r06_pmc_traffic.csv
 rm -rf gpurun_out/pmc_t_*
 timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_flags.json 2> gpurun_out/${tag}_bench_driver_flags.err
