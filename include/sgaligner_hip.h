@@ -402,10 +402,12 @@ int sga_loss_neg_grad_wide(const float* Z, int Dp, int A, int J1, int J2, float 
  * stash: caller-owned workspace of stash_bytes (sga_loss_neg_grad_f16_bytes() = the whole batch in one pass; less -> anchor-row blocks). */
 long sga_wide16_ldt(int A, int J1, int J2);
 int sga_wide16_prepare(const float* Z, int Dp, int A, int J1, int J2, void* Zh, void* ZhT, void* stream);
-int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, void* stream);
+/* [a_lo, a_hi): the anchor shard this process owns (0, A on one GPU; a_lo a multiple of 8 for the gradient) -- the shard's anchors against ALL
+ * negatives: partial sums8 (all-reduced by the caller), dZ complete for the shard's anchor rows and partial for the negatives' rows. */
+int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, int a_lo, int a_hi, void* stream);
 size_t sga_loss_neg_grad_f16_bytes(int A, int J1, int J2);
 int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, int A, int J1, int J2, float tau0, float tau1, const double* gs8,
-                          float* dZ, void* stash, size_t stash_bytes, void* stream);
+                          float* dZ, void* stash, size_t stash_bytes, int a_lo, int a_hi, void* stream);
 /* sga_loss_stash_grad for a wide table in the same mode (replaces the two fp32 GEMMs; the autograd of src/aligner/losses.py:6,50-57,81-94
  * through S = X1 X2^T): dZ[A + j] += sum_i M1[j, i] Z[a_lo + i], dZ[a_lo + i] += sum_j M1[j, i] Z[A + j] with the coefficients as fp16 of
  * 2^e M1 (2^e: the power of two that puts the block's largest magnitude into [2^13, 2^14), found by a max pass, undone exactly at the end),

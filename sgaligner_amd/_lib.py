@@ -27,9 +27,9 @@ SIGNATURES = {
     'sga_loss_neg_grad_wide': (I, [P, I, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
     'sga_wide16_ldt': (c_long, [I, I, I]),
     'sga_wide16_prepare': (I, [P, I, I, I, I, P, P, P]),
-    'sga_loss_neg_sums_f16': (I, [P, I, I, I, I, c_float, c_float, P, P]),
+    'sga_loss_neg_sums_f16': (I, [P, I, I, I, I, c_float, c_float, P, I, I, P]),
     'sga_loss_neg_grad_f16_bytes': (c_size_t, [I, I, I]),
-    'sga_loss_neg_grad_f16': (I, [P, P, I, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
+    'sga_loss_neg_grad_f16': (I, [P, P, I, I, I, I, c_float, c_float, P, P, P, c_size_t, I, I, P]),
     'sga_loss_head_fwd': (I, [P, I, P, P, I, c_double, c_double, c_double, c_double, P, P]),
     'sga_loss_head_bwd': (I, [P, P, I, P, P, I, c_double, c_double, c_double, c_double, P, P, P, P]),
     'sga_pointnet_fwd_ws': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, I, P]),

@@ -348,11 +348,13 @@ inline void four_blocks(Blk (&b)[4], int A, int J1, int J2) {
 }
 }  // namespace
 
-extern "C" int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, void* stream) {
-    SGA_CHECK_ARG(Zh && sums8 && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0 && tau0 > 0 && tau1 > 0, "sga_loss_neg_sums_f16: bad argument");
+extern "C" int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int J2, float tau0, float tau1, double* sums8, int a_lo, int a_hi,
+                                     void* stream) {
+    SGA_CHECK_ARG(Zh && sums8 && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0 && tau0 > 0 && tau1 > 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi,
+                  "sga_loss_neg_sums_f16: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = zero_slots(sums8, 8, s, "sga_loss_neg_sums_f16")) return rc;
-    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    if (a_hi == a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     Blk b[4];
     four_blocks(b, A, J1, J2);
     const f16* Z = static_cast<const f16*>(Zh);
@@ -361,7 +363,7 @@ extern "C" int sga_loss_neg_sums_f16(const void* Zh, int Dp, int A, int J1, int 
     for (int q = 0; q < 4; ++q) {
         if (b[q].n_own == 0 || b[q].n_oth == 0) continue;
         W16Args a{};
-        a.A = Z + (size_t)b[q].own_row * Dp; a.lda = Dp; a.M = b[q].n_own;
+        a.A = Z + (size_t)(b[q].own_row + a_lo) * Dp; a.lda = Dp; a.M = a_hi - a_lo;      // this process's anchor shard against all negatives
         a.B = Z + (size_t)b[q].oth_row * Dp; a.ldb = Dp; a.N = b[q].n_oth;
         a.K = Dp; a.kper = (Dp + W_KC - 1) / W_KC * W_KC;
         a.k0 = LOG2E / tau0; a.k1 = LOG2E / tau1; a.fam = b[q].fam; a.sums = sums8;
@@ -380,19 +382,20 @@ extern "C" size_t sga_loss_neg_grad_f16_bytes(int A, int J1, int J2) {
 }
 
 extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, int A, int J1, int J2, float tau0, float tau1,
-                                     const double* gs8, float* dZ, void* stash, size_t stash_bytes, void* stream) {
-    SGA_CHECK_ARG(Zh && ZhT && gs8 && dZ && stash && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0, "sga_loss_neg_grad_f16: bad argument");
+                                     const double* gs8, float* dZ, void* stash, size_t stash_bytes, int a_lo, int a_hi, void* stream) {
+    SGA_CHECK_ARG(Zh && ZhT && gs8 && dZ && stash && Dp % 8 == 0 && A >= 0 && J1 >= 0 && J2 >= 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi &&
+                  (a_lo % 8 == 0 || a_hi == a_lo), "sga_loss_neg_grad_f16: bad argument (a_lo must be a multiple of 8)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (A == 0 || (J1 == 0 && J2 == 0)) return SGA_OK;
+    if (a_hi == a_lo || (J1 == 0 && J2 == 0)) return SGA_OK;
     const int Jmax = J1 > J2 ? J1 : J2;
     // anchor rows per pass so that C + C^T of one block fit the workspace
     auto need = [&](size_t r) { return sizeof(f16) * (r * pad8(Jmax) + (size_t)Jmax * pad8((int)r)) + 256; };
-    size_t rows = A;
+    size_t rows = a_hi - a_lo;
     // prefer the largest block of which FOUR stash pairs fit (the four sum families then share every launch); only if not even 128 rows do,
     // fall back to the largest block with one pair (family-by-family launches)
     while (rows > 128 && 4 * need(rows) > stash_bytes) rows = (rows / 2 + 127) / 128 * 128;
     if (4 * need(rows) > stash_bytes) {
-        rows = A;
+        rows = a_hi - a_lo;
         while (rows > 128 && need(rows) > stash_bytes) rows = (rows / 2 + 127) / 128 * 128;
     }
     SGA_CHECK_ARG(need(rows) <= stash_bytes, "sga_loss_neg_grad_f16: workspace of %zu bytes holds fewer than %zu anchor rows for J = %d",
@@ -411,8 +414,8 @@ extern "C" int sga_loss_neg_grad_f16(const void* Zh, const void* ZhT, int Dp, in
     int nfam = 0;
     for (int q = 0; q < 4; ++q) nfam += b[q].n_oth > 0;
     if (!batched || nfam < 1) nfam = 1;
-    for (int lo = 0; lo < A; lo += (int)rows) {
-        const int ns = (lo + (int)rows < A ? (int)rows : A - lo);
+    for (int lo = a_lo; lo < a_hi; lo += (int)rows) {                 // (blocks of a multiple of 128 rows from a_lo: every `lo` stays a multiple of 8)
+        const int ns = (lo + (int)rows < a_hi ? (int)rows : a_hi - lo);
         W16Batch bc{}, bg1{}, bg2{};
         int k1s[4], k2s[4], ones[4] = {1, 1, 1, 1};
         for (int q = 0; q < 4; ++q) {
@@ -539,7 +542,7 @@ extern "C" size_t sga_loss_stash_grad_f16_bytes(int A, int ns) {
 
 extern "C" int sga_loss_stash_grad_f16(const float* M1, const void* ZhT, int Dp, int A, int J1, int J2, float* dZ, int a_lo, int a_hi,
                                        void* ws, size_t ws_bytes, void* stream) {
-    SGA_CHECK_ARG(A >= 0 && J1 >= 0 && J2 >= 0 && Dp >= 8 && Dp % 8 == 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi && a_lo % 8 == 0,
+    SGA_CHECK_ARG(A >= 0 && J1 >= 0 && J2 >= 0 && Dp >= 8 && Dp % 8 == 0 && a_lo >= 0 && a_hi <= A && a_lo <= a_hi && (a_lo % 8 == 0 || a_hi == a_lo),
                   "sga_loss_stash_grad_f16: bad sizes (Dp and a_lo must be multiples of 8)");
     const int ns = a_hi - a_lo;
     if (A == 0 || ns == 0) return SGA_OK;

@@ -118,8 +118,8 @@ class ContrastiveTermsFn(torch.autograd.Function):
             _lib.check(L.sga_loss_gather(_p(e), T, d, _p(s.idx), s.R, _p(z), dp, _p(nrm), st), 'sga_loss_gather')
             sk = torch.empty((slots * 8,), device=dev, dtype=torch.float64)
             zh = zt = None
-            if dp > 128 and not full:
-                raise RuntimeError('sgaligner_amd: anchor sharding of the general loss path is implemented for tables of at most 128 columns')
+            if dp > 128 and not full and a_lo % 8 and a_hi > a_lo:
+                raise RuntimeError('sgaligner_amd: an anchor shard of wide tables (more than 128 columns) must start at a multiple of 8 anchors')
             if dp > 128 and f16:
                 # opt-in fp16-input MFMA for wide tables (configs[4]): fp16 copies of the normalised table, once per step
                 ldt = int(L.sga_wide16_ldt(s.A, s.J1, s.J2))
@@ -130,7 +130,7 @@ class ContrastiveTermsFn(torch.autograd.Function):
                 if _o.KERNEL_EVENTS is not None:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                _lib.check(L.sga_loss_neg_sums_f16(_p(zh), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), st), 'sga_loss_neg_sums_f16')
+                _lib.check(L.sga_loss_neg_sums_f16(_p(zh), dp, s.A, s.J1, s.J2, TAU_ICL, TAU_IAL, _p(sk), a_lo, a_hi, st), 'sga_loss_neg_sums_f16')
                 if ev is not None:
                     ev[1].record()
                     _o.KERNEL_EVENTS.setdefault('wide16_sums', []).append(ev + ((s.A, s.J1, s.J2, dp),))
@@ -242,12 +242,12 @@ class ContrastiveTermsFn(torch.autograd.Function):
                     ev16 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev16[0].record()
                 _lib.check(L.sga_loss_neg_grad_f16(_p(zhs[k]), _p(zts[k]), dp, A, s.J1, s.J2, TAU_ICL, TAU_IAL, gs[k].data_ptr(), _p(dz),
-                                                   _p(stash), have, st), 'sga_loss_neg_grad_f16')
+                                                   _p(stash), have, a_lo, a_hi, st), 'sga_loss_neg_grad_f16')
                 if ev16 is not None:
                     ev16[1].record()
                     _o.KERNEL_EVENTS.setdefault('wide16_grad', []).append(ev16 + ((A, s.J1, s.J2, dp),))
                 del stash
-            elif dp > 128 and _o.WIDE_STASH:
+            elif dp > 128 and _o.WIDE_STASH and a_lo == 0 and a_hi == A:
                 # wide rows: S is the expensive part -> coefficient stash + GEMMs, S computed once (csrc/contrastive.hip, sweep_coef_kernel)
                 need = int(L.sga_loss_neg_grad_wide_floats(A, s.J1, s.J2))
                 have = max(min(need, _stash_bytes() // 4), 2 * (s.J1 + s.J2) * min(A, 32))

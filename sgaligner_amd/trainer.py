@@ -17,6 +17,8 @@ from .aligner.sg_aligner import MultiModalEncoder
 from .utils import alignment
 
 
+WIDE_SHARDED = True      # N > 1, tables outside the fused path: anchor-sharded general kernels (False: a replica of the whole loss per rank)
+
 class _ScaleGrad(torch.autograd.Function):
     """Identity whose backward multiplies the gradient by a constant (the replica fallback of AlignerSteps._global_loss)."""
 
@@ -114,7 +116,8 @@ class AlignerSteps:
         anchors against all negatives (partial scalars all-reduced inside ops.FusedContrastiveFn, so every rank holds the
         global loss value) and its share of dL/dE for all rows, summed over ranks in AllGatherRows.backward.
         M == 1 (ICL of the one table of <= 128 columns, the general per-table kernels): sharded by anchors the same way.
-        Anything else (wide tables, FUSED_JOINT off): a replica of the whole loss on every rank."""
+        Anything else (wide tables -- BASELINE configs[4] --, FUSED_JOINT off): the general per-table kernels, sharded by anchors as well
+        (balanced cuts on 32-anchor boundaries); WIDE_SHARDED = False: a replica of the whole loss on every rank (the round-5 form, a cross-check)."""
         world, rank = dist.get_world_size(), dist.get_rank()
         if layout is None:
             layout = sdist.layout_of(data_dict, self.device)                # [world, 4]: rows, |e1i|, |e1j|, |e2j|
@@ -129,11 +132,11 @@ class AlignerSteps:
             tabs = early.tables(mods)
         else:
             tabs = sdist.gather_tables({m: output_dict[m] for m in mods}, rows, reduce_grad=True)
-        if not fused and not (len(mods) == 1 and widths[0] <= 128):
-            # REPLICA fallback (tables the anchor-sharded kernels do not take: wider than 104 columns under a fused joint -- BASELINE
-            # configs[4], emb_dim 1024 -- or a single table wider than 128; or FUSED_JOINT switched off): every rank evaluates the whole loss on
-            # the gathered tables.  The table gradients are still summed over ranks by AllGatherRows.backward and the fusion weight's by the
-            # parameter all-reduce, and every rank now holds the FULL gradient, not a share: both enter through a 1 / world factor.
+        general_wide = not fused and not (len(mods) == 1 and widths[0] <= 128)
+        if general_wide and not WIDE_SHARDED:
+            # REPLICA of the whole loss on every rank (kept as a cross-check of the sharded form below: trainer.WIDE_SHARDED = False).  The table
+            # gradients are still summed over ranks by AllGatherRows.backward and the fusion weight's by the parameter all-reduce, and every rank
+            # holds the FULL gradient, not a share: both enter through a 1 / world factor.
             k = 1.0 / world
             gathered = {m: _ScaleGrad.apply(tabs[m], k) for m in mods}
             if len(mods) > 1:
@@ -141,6 +144,27 @@ class AlignerSteps:
                 joint = ops.fusion(_ScaleGrad.apply(fusion.weight, k), [gathered[m] for m in mods])     # sg_aligner.py:30-35 on the gathered rows
                 joint._sga_fusion = (fusion.weight, tuple(gathered[m] for m in mods))
                 gathered['joint'] = joint
+            return self.loss_func(gathered, gdd)
+
+        def _reduce(t):                                                   # fp64 partial sums / loss terms / dL/d(sums)
+            sdist._log('all_reduce', t, t)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if general_wide:
+            # Tables the fused kernels do not take (wider than 104 columns under a fused joint -- BASELINE configs[4], emb_dim 1024 --, a single table
+            # wider than 128, FUSED_JOINT off): the general per-table kernels, SHARDED BY ANCHORS like the fused path (round 6: the wide-table
+            # kernels take an anchor range) -- every rank forms the joint table from the gathered modality tables (sg_aligner.py:30-35), evaluates
+            # the global sums / loss terms of its anchor range against all rows (all-reduced) and its share of dL/dE for all rows (summed over ranks
+            # in AllGatherRows.backward; the fusion weight's share by the parameter all-reduce).  Any partition of [0, A) is valid since every
+            # rank holds all rows: balanced cuts on 32-anchor boundaries (the wide kernels want a_lo % 8 == 0).
+            gathered = dict(tabs)
+            if len(mods) > 1:
+                fusion = self.model.fusion
+                joint = ops.fusion(fusion.weight, [gathered[m] for m in mods])
+                joint._sga_fusion = (fusion.weight, tuple(gathered[m] for m in mods))
+                gathered['joint'] = joint
+            wcuts = [min(A, (A * r // world + 31) // 32 * 32) for r in range(world)] + [A]
+            gdd['_sga_shard'] = (wcuts[rank], wcuts[rank + 1])
+            gdd['_sga_reduce'] = _reduce
             return self.loss_func(gathered, gdd)
         gathered = dict(tabs)
         if fused:
@@ -154,9 +178,5 @@ class AlignerSteps:
         # walked symmetrically ACROSS ranks (ops._sym_jobs: every unordered pair once, the same number on every rank)
         cuts = [sum(anchors[:r]) for r in range(world + 1)]
         gdd['_sga_shard'] = (cuts[rank], cuts[rank + 1], cuts, rank)
-
-        def _reduce(t):                                                   # fp64 partial sums / loss terms / dL/d(sums)
-            sdist._log('all_reduce', t, t)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
         gdd['_sga_reduce'] = _reduce
         return self.loss_func(gathered, gdd)

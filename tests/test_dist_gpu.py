@@ -45,10 +45,22 @@ def _worker(rank, world, port, mods, n_pairs, cuts, out, nobj=14, ragged=True, e
         from sgaligner_amd import loss_ops as ops_mod          # (where FusedContrastiveFn looks _sym_jobs up)
         orig_jobs, ops_mod._sym_calls = ops_mod._sym_jobs, []
         ops_mod._sym_jobs = lambda c, r, nt: (ops_mod._sym_calls.append((len(c) - 1, r)), orig_jobs(c, r, nt))[1]
+        from sgaligner_amd import ops, trainer as trainer_mod
+        if os.environ.get('SGA_TEST_MFMA_MODE'):
+            ops.set_mfma_mode(os.environ['SGA_TEST_MFMA_MODE'])
+        if os.environ.get('SGA_TEST_WIDE_REPLICA') == '1':
+            trainer_mod.WIDE_SHARDED = False
+        shards = []
+        orig_terms = ops_mod.ContrastiveTermsFn.forward
         steps = AlignerSteps(mods, device=dev, seed=42, emb_dim=emb_dim)
+        orig_loss = steps.loss_func.forward
+        def spy(output_dict, data_dict):                        # (what anchor range the general path was handed)
+            shards.append(tuple(data_dict['_sga_shard'][:2]) if data_dict.get('_sga_shard') is not None else None)
+            return orig_loss(output_dict, data_dict)
+        steps.loss_func.forward = spy
         _, loss = steps.forward_backward(mine)
         torch.cuda.synchronize()
-        res = {'loss': float(loss['loss'].item()), 'sym_jobs': list(getattr(ops_mod, '_sym_calls', []))}
+        res = {'loss': float(loss['loss'].item()), 'sym_jobs': list(getattr(ops_mod, '_sym_calls', [])), 'shards': shards}
         for n, p in steps.model.named_parameters():
             if p.grad is not None:
                 res['g:' + n] = p.grad.detach().cpu()
@@ -96,18 +108,36 @@ def test_two_ranks_equal_single_process(mods, n_pairs, cuts):
                 a = next(layer.parameters()).grad.cpu()
                 assert (r['lv:' + tag] - a).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), (rank, tag)
 
+@pytest.mark.parametrize('how', ['sharded', 'f16', 'replica'])
 @pytest.mark.parametrize('mods', [['point', 'gat', 'rel'], ['point']])
-def test_two_ranks_wide_tables_replica_fallback_equals_single_process(mods):
-    """Tables the anchor-sharded kernels do not take (emb_dim 160: wider than the fused path's 104 columns and the general path's 128) run the
-    REPLICA fallback of AlignerSteps._global_loss under N > 1 -- BASELINE configs[4]'s 1024-d tables on 8 GPUs take this branch (round-5
-    advisor: it raised instead).  Same loss and parameter gradients as one process on the whole batch."""
+def test_two_ranks_wide_tables_equal_single_process(mods, how, monkeypatch):
+    """Tables the fused kernels do not take (emb_dim 160: wider than the fused path's 104 columns and the per-table path's 128 -- BASELINE
+    configs[4]'s 1024-d tables on 8 GPUs take this branch) under N > 1.  Round 6: the general per-table kernels SHARDED BY ANCHORS (balanced
+    cuts on 32-anchor boundaries; the wide-table kernels take an anchor range), in exact fp32 and in mode 'f16'; and the round-5 form -- a
+    REPLICA of the whole loss on every rank -- as a cross-check.  Same loss and parameter gradients as one process on the whole batch."""
+    if how == 'f16':
+        monkeypatch.setenv('SGA_TEST_MFMA_MODE', 'f16')
+    if how == 'replica':
+        monkeypatch.setenv('SGA_TEST_WIDE_REPLICA', '1')
     world, n_pairs, cuts = 2, 6, [0, 3, 6]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), mods, n_pairs, cuts, out, 14, True, 160), nprocs=world, join=True)
-    ref, loss = _single(mods, n_pairs, emb_dim=160)
+    mp.spawn(_worker, args=(world, _free_port(), mods, n_pairs, cuts, out, 40, True, 160), nprocs=world, join=True)     # (40 objects per scene: > 32 anchors)
+    from sgaligner_amd import ops
+    old_mode = ops.set_mfma_mode('f16') if how == 'f16' else None
+    try:
+        ref, loss = _single(mods, n_pairs, 40, emb_dim=160)
+    finally:
+        if old_mode is not None:
+            ops.set_mfma_mode(old_mode)
     for rank in range(world):
         r = out[rank]
+        if how == 'replica':
+            assert r['shards'] == [None], r['shards']
+        else:                                                   # a proper anchor range on a 32-anchor boundary, the two ranks' ranges adjacent
+            assert len(r['shards']) == 1 and r['shards'][0] is not None and r['shards'][0][0] % 32 == 0, r['shards']
+            assert out[0]['shards'][0][1] == out[1]['shards'][0][0] and out[0]['shards'][0][0] == 0
+            assert out[1]['shards'][0][1] > out[1]['shards'][0][0] > 0                  # both ranks own anchors
         assert abs(r['loss'] - loss['loss'].item()) <= 1e-5 * max(1.0, abs(loss['loss'].item())), (rank, r['loss'], loss['loss'].item())
         seen = 0
         for n, p in ref.model.named_parameters():

@@ -42,8 +42,8 @@ def timed(name, fn, flops, n=10):
     print(f'{name:52s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s executed = {flops / ms / 1e9 / 2500:.3f} of the fp16 peak')
 
 
-timed('sga_loss_neg_sums_f16 (S + exp sums)', lambda: _lib.check(L.sga_loss_neg_sums_f16(p(zh), Dp, A, J, J, 0.1, 1.0, p(sums), st), 'sums'), unit)
-timed('sga_loss_neg_grad_f16 (S -> C, C^T; two GEMMs)', lambda: _lib.check(L.sga_loss_neg_grad_f16(p(zh), p(zt), Dp, A, J, J, 0.1, 1.0, p(gs), p(dz), p(stash), need, st), 'grad'), 3 * unit)
+timed('sga_loss_neg_sums_f16 (S + exp sums)', lambda: _lib.check(L.sga_loss_neg_sums_f16(p(zh), Dp, A, J, J, 0.1, 1.0, p(sums), 0, A, st), 'sums'), unit)
+timed('sga_loss_neg_grad_f16 (S -> C, C^T; two GEMMs)', lambda: _lib.check(L.sga_loss_neg_grad_f16(p(zh), p(zt), Dp, A, J, J, 0.1, 1.0, p(gs), p(dz), p(stash), need, 0, A, st), 'grad'), 3 * unit)
 # anchors x anchors: one table + a joint of the same width (NT = 2)
 nt = 2
 zs = (ct.c_void_p * nt)(z.data_ptr(), z.data_ptr())
