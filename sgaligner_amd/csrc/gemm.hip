@@ -360,138 +360,6 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_nt3_kernel(const float* __
     }
 }
 
-// Short-K NT products over many rows (the per-point layers of the PCT encoder: 10^5 point rows through 128 x 128, 128 x 32, 64 x 64 ...
-// weights): with K <= 128 a 128-row tile is four K chunks -- the tiled kernels above spend such a tile in prologue / epilogue latency (0.43 of
-// the fp32 peak, 2.1 TB/s).  Here the WEIGHTS are resident: a persistent workgroup splits W [N, K] once into three bf16 planes in LDS
-// ([plane][n][K + 8]: 16 more bytes per row keep ds_read_b128 conflict-free) and its four waves then stream 32-row tiles of A on their own --
-// no barrier in the loop: a lane loads its row's K values straight from global memory in MFMA operand order (two float4 per 16-column step),
-// the next tile's loads in flight under this tile's MFMAs, splits them in registers (x = h + m + l exactly; 11 VALU per pair) and runs the
-// six bf16 MFMAs per product of gemm_nt3_kernel against B fragments read from the resident planes, in ONE accumulator chain per output with
-// the small partial products of all K steps ahead of the h h' ones.  Same epilogue (bias, activation, residual, accumulate, BatchNorm column statistics -- kept in registers over all of a wave's
-// tiles, one fp64 atomic pair per column and wave at the end).
-template <int NT, int KK>
-__global__ __launch_bounds__(GM_THREADS) void gemm_ntw_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
-                                                              float* __restrict__ C, long ldc, const float* __restrict__ bias, int M, int N,
-                                                              int accumulate, int act, const float* __restrict__ resid, long ldr,
-                                                              double* __restrict__ colstats) {
-    constexpr int K = 16 * KK, RS = 2 * K + 16, PL = 32 * NT * RS;        // bytes per plane row / per plane
-    extern __shared__ __attribute__((aligned(16))) unsigned char wpl[];    // [3][32 NT][RS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    // ---- W -> three planes (rows past N: zeros)
-    for (int e = tid; e < 32 * NT * (K / 4); e += GM_THREADS) {
-        const int r = e / (K / 4), c = (e % (K / 4)) * 4;
-        const f32x4 v = r < N ? *reinterpret_cast<const f32x4*>(B + (size_t)r * ldb + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned h0, m0_, l0, h1, m1, l1;
-        g_split3_pair(v[0], v[1], h0, m0_, l0);
-        g_split3_pair(v[2], v[3], h1, m1, l1);
-        unsigned char* p = wpl + r * RS + c * 2;
-        *reinterpret_cast<g_u32x2*>(p) = g_u32x2{h0, h1};
-        *reinterpret_cast<g_u32x2*>(p + PL) = g_u32x2{m0_, m1};
-        *reinterpret_cast<g_u32x2*>(p + 2 * PL) = g_u32x2{l0, l1};
-    }
-    __syncthreads();
-    const int ntiles = (M + 31) / 32, first = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
-    f32x4 an[KK][2];                                                        // the NEXT tile's row of A, in operand order
-    auto aload = [&](int tile) {
-        const float* ar = A + (size_t)min(tile * 32 + l31, M - 1) * lda + 8 * h;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            an[kk][0] = *reinterpret_cast<const f32x4*>(ar + 16 * kk);
-            an[kk][1] = *reinterpret_cast<const f32x4*>(ar + 16 * kk + 4);
-        }
-    };
-    float cs[NT], cq[NT], bv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { cs[t] = 0.f; cq[t] = 0.f; bv[t] = (bias && t * 32 + l31 < N) ? bias[t * 32 + l31] : 0.f; }
-    if (first < ntiles) aload(first);
-    const unsigned char* bp = wpl + l31 * RS + h * 16;
-    for (int tile = first; tile < ntiles; tile += stride) {
-        // this tile's row as three planes for every K step (the prefetch registers are free for the next tile's loads right after)
-        typedef unsigned g_u32x4 __attribute__((ext_vector_type(4)));
-        g_u32x4 ph[KK], pm[KK], pl[KK];
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            unsigned qh[4], qm[4], ql[4];
-            g_split3_pair(an[kk][0][0], an[kk][0][1], qh[0], qm[0], ql[0]);
-            g_split3_pair(an[kk][0][2], an[kk][0][3], qh[1], qm[1], ql[1]);
-            g_split3_pair(an[kk][1][0], an[kk][1][1], qh[2], qm[2], ql[2]);
-            g_split3_pair(an[kk][1][2], an[kk][1][3], qh[3], qm[3], ql[3]);
-            ph[kk] = g_u32x4{qh[0], qh[1], qh[2], qh[3]}; pm[kk] = g_u32x4{qm[0], qm[1], qm[2], qm[3]}; pl[kk] = g_u32x4{ql[0], ql[1], ql[2], ql[3]};
-        }
-        if (tile + stride < ntiles) aload(tile + stride);                   // in flight under this tile's MFMAs
-        // ONE accumulator chain per output, the small partial products of ALL K steps first, the h h' products last (as the S phase of
-        // sweep3_kernel): while the accumulator holds small terms only, the 16-bit MFMA's alignment chops nothing of them
-        f32x16 acc[NT];
-        zero_acc<NT>(acc);
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const g_bf16x8 ah = __builtin_bit_cast(g_bf16x8, ph[kk]), am = __builtin_bit_cast(g_bf16x8, pm[kk]), al = __builtin_bit_cast(g_bf16x8, pl[kk]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const unsigned char* bt = bp + t * 32 * RS + kk * 32;
-                const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(bt);
-                const g_bf16x8 bm = *reinterpret_cast<const g_bf16x8*>(bt + PL);
-                const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(bt + 2 * PL);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);                             // (keeps hipcc from hoisting every step's 12 fragment reads to the top: 384 registers)
-        }
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const g_bf16x8 ah = __builtin_bit_cast(g_bf16x8, ph[kk]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(bp + t * 32 * RS + kk * 32);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-            }
-            if (kk & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = t * 32 + l31;
-            if (n >= N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = tile * 32 + mfma32_row(r, h);
-                if (m < M) {
-                    float* p = C + (size_t)m * ldc + n;
-                    float v = acc[t][r] + bv[t];
-                    if (accumulate) v += *p;
-                    if (act == 1) v = fmaxf(v, 0.f);
-                    else if (act == 2) v = v > 0.f ? v : 0.2f * v;
-                    if (resid) v += resid[(size_t)m * ldr + n];
-                    *p = v;
-                    cs[t] += v; cq[t] = fmaf(v, v, cq[t]);
-                }
-            }
-        }
-    }
-    if (colstats) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = t * 32 + l31;
-            const float s0 = cs[t] + __shfl_xor(cs[t], 32, 64), q0 = cq[t] + __shfl_xor(cq[t], 32, 64);
-            if (h == 0 && n < N && (s0 != 0.f || q0 != 0.f)) { atomicAdd(colstats + n, (double)s0); atomicAdd(colstats + N + n, (double)q0); }
-        }
-    }
-}
-template <int NT, int KK>
-static void launch_ntw(const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, int M, int N, int accumulate, int act,
-                       const float* resid, long ldr, double* colstats, hipStream_t s) {
-    const int lds = 3 * 32 * NT * (2 * 16 * KK + 16);
-    const int tiles = (M + 31) / 32;
-    int wgs = (tiles + 3) / 4;
-    const int ncu = sga_num_cus();
-    if (wgs > ncu) wgs = ncu;
-    auto k = gemm_ntw_kernel<NT, KK>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3(wgs), dim3(GM_THREADS), lds, s, A, lda, B, ldb, C, ldc, bias, M, N, accumulate, act, resid, ldr, colstats);
-}
-
 // C[M,N] (+)= A^T B for A [K,M], B [K,N] with a NARROW B (N <= 8: the weight gradient of a layer that reads raw coordinates -- the first
 // Conv1d(3, .) of the PCT / PointNet encoders over 10^5 point rows: the MFMA kernels want N % 4 == 0, and the generic kernel walked it in
 // 620 K splits at 0.1 TB/s).  Memory-bound by A: a lane owns an output row m (A's column: coalesced 256-byte reads per k row), the N
@@ -701,9 +569,9 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     // only, never of M: a batch walked in chunks of rows gets the same bits as the unchunked call.  -DSGA_GEMM_NT_FP32: fp32 MFMA everywhere
     // (the A/B of tools/build_variant.sh).
 #ifdef SGA_GEMM_NT_FP32
-    const bool nt3 = false, ntw_on = false;
+    const bool nt3 = false;
 #else
-    const bool nt3 = K >= 256, ntw_on = true;
+    const bool nt3 = K >= 256;
 #endif
     SGA_CHECK_ARG(act >= 0 && act <= 2, "sga_gemm_ex: act=%d (0 none, 1 relu, 2 leaky-relu 0.2)", act);
     if (M == 0 || N == 0) return SGA_OK;                 // empty output (a zero-row shard): nothing to do, null pointers allowed
@@ -772,17 +640,6 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
     if (!a_is_f64 && !transA && !transB && a_al && b_al && K % 4 == 0 && N % 4 == 0 && !bias && act == 0 && !resid) {
         hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(GM_THREADS), 0, s, static_cast<const float*>(A), lda, B, ldb, C, ldc, M, N, K,
                            accumulate, kper, use_atomic);
-        SGA_CHECK_LAUNCH("sga_gemm");
-        return SGA_OK;
-    }
-    if (!a_is_f64 && !transA && transB && a_al && b_al && (K == 64 || K == 128) && N % 32 == 0 && N <= 128 && ntw_on) {
-        // weights-resident streaming kernel (a function of (N, K) only)
-        const float* Af = static_cast<const float*>(A);
-#define SGA_NTW(NT_, KK_) launch_ntw<NT_, KK_>(Af, lda, B, ldb, C, ldc, bias, M, N, accumulate, act, resid, ldr, colstats, s)
-        const int nt_ = N / 32;
-        if (K == 128) { if (nt_ == 1) SGA_NTW(1, 8); else if (nt_ == 2) SGA_NTW(2, 8); else if (nt_ == 3) SGA_NTW(3, 8); else SGA_NTW(4, 8); }
-        else { if (nt_ == 1) SGA_NTW(1, 4); else if (nt_ == 2) SGA_NTW(2, 4); else if (nt_ == 3) SGA_NTW(3, 4); else SGA_NTW(4, 4); }
-#undef SGA_NTW
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;
     }
