@@ -160,6 +160,45 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_small_kernel(const TA* __rest
     }
 }
 
+// Epilogue of one 32 x 32 accumulator tile: C[m_base + row(r, h)][n] = act(acc + bias (+ C)) (+ resid), column statistics on the side.
+// Addressing: ONE 64-bit row pointer per tile and lane, the sixteen rows of a lane (row(r, h) = (r & 3) + 8 (r >> 2) + 4 h) by 32-bit
+// offsets that are sums of a few multiples of ldc -- `C + (size_t)m * ldc + n` per element was two v_mul_lo_u32, a v_mad_u64_u32 and two more
+// 64-bit adds for every output (a K = 128 layer over 163 840 rows spent 38 of its 77 us there whatever its K: tools/bench_gemm.py with the
+// epilogue compiled out).  The optional C / residual loads of a tile are issued together; interior tiles carry no row masks.
+__device__ __forceinline__ void store_tile32(const f32x16& a, float bv, float* __restrict__ C, long ldc, int m_base, int h, int M, int n, bool nv,
+                                             int accumulate, int act, const float* __restrict__ resid, long ldr, float& cs, float& cq) {
+    if (!nv) return;
+    const bool full = m_base + 32 <= M;                   // uniform
+    float* cp = C + (size_t)(m_base + 4 * h) * ldc + n;
+    const int l1 = (int)ldc;                              // (a 32-row tile of a matrix whose row pitch fits 31 bits: checked by the launcher)
+    const float* rp = resid ? resid + (size_t)(m_base + 4 * h) * ldr + n : nullptr;
+    const int r1 = (int)ldr;
+    const float slope = act == 2 ? 0.2f : 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                         // four consecutive rows at a time (registers: the fp32 kernel keeps three workgroups per CU)
+        float old[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (full || m_base + 4 * h + 8 * q + e < M) old[e] = cp[(8 * q + e) * l1];
+        }
+        if (resid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (full || m_base + 4 * h + 8 * q + e < M) rs[e] = rp[(8 * q + e) * r1];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = (a[4 * q + e] + bv) + old[e];
+            const float neg = act == 1 ? 0.f : slope * v;
+            v = v > 0.f ? v : neg;
+            v += rs[e];
+            if (full || m_base + 4 * h + 8 * q + e < M) {
+                cp[(8 * q + e) * l1] = v;
+                cs += v; cq = fmaf(v, v, cq);
+            }
+        }
+    }
+}
+
 // C = act(A W^T + bias) (+ resid) for the common layout (A [M,K] and W [N,K] both k-contiguous, 16-byte aligned rows,
 // K % 4 == 0, no split-K): the next K chunk travels global -> registers while the MFMAs of the current one run, so a
 // workgroup does not alternate between "everybody loads" and "everybody multiplies" (the generic kernel above: 59
@@ -211,22 +250,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(const float* __rest
     const int h = lane >> 5;
     float cs = 0.f, cq = 0.f;                           // column sum / sum of squares of what is written (colstats != null)
 #pragma unroll
-    for (int t = 0; t < NTA; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + t * 32 + mfma32_row(r, h);
-            if (m < M && nv) {
-                float* p = C + (size_t)m * ldc + n;
-                float v = acc[t][r] + bv;
-                if (accumulate) v += *p;
-                if (act == 1) v = fmaxf(v, 0.f);
-                else if (act == 2) v = v > 0.f ? v : 0.2f * v;
-                if (resid) v += resid[(size_t)m * ldr + n];
-                *p = v;
-                cs += v; cq = fmaf(v, v, cq);
-            }
-        }
-    }
+    for (int t = 0; t < NTA; ++t) store_tile32(acc[t], bv, C, ldc, m0 + t * 32, h, M, n, nv, accumulate, act, resid, ldr, cs, cq);
     if (colstats) {
         // BatchNorm batch statistics of the output in the epilogue that produces it (pct.py: every conv is followed by a BatchNorm):
         // the two lane halves of a column fold, then one fp64 atomic pair per column and workgroup -- sums[0..N) = sum, [N..2N) = sum of squares
@@ -339,20 +363,10 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_nt3_kernel(const float* __
     float cs = 0.f, cq = 0.f;                           // column sum / sum of squares of what is written (colstats != null)
 #pragma unroll
     for (int t = 0; t < NTA; ++t) {
+        f32x16 sum;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + t * 32 + mfma32_row(r, h);
-            if (m < M && nv) {
-                float* p = C + (size_t)m * ldc + n;
-                float v = (acc[t][r] + accs[t][r]) + bv;
-                if (accumulate) v += *p;
-                if (act == 1) v = fmaxf(v, 0.f);
-                else if (act == 2) v = v > 0.f ? v : 0.2f * v;
-                if (resid) v += resid[(size_t)m * ldr + n];
-                *p = v;
-                cs += v; cq = fmaf(v, v, cq);
-            }
-        }
+        for (int r = 0; r < 16; ++r) sum[r] = acc[t][r] + accs[t][r];
+        store_tile32(sum, bv, C, ldc, m0 + t * 32, h, M, n, nv, accumulate, act, resid, ldr, cs, cq);
     }
     if (colstats) {
         cs += __shfl_xor(cs, 32, 64); cq += __shfl_xor(cq, 32, 64);
@@ -643,7 +657,7 @@ static int gemm_launch(int transA, int transB, int M, int N, int K, const void* 
         SGA_CHECK_LAUNCH("sga_gemm");
         return SGA_OK;
     }
-    if (!a_is_f64 && !transA && transB && splits == 1 && a_al && b_al && K % 4 == 0) {
+    if (!a_is_f64 && !transA && transB && splits == 1 && a_al && b_al && K % 4 == 0 && ldc < (1L << 26) && ldr < (1L << 26)) {
         // 64-row tiles when the 128-row grid ends in a mostly idle round (4 workgroups per CU: 163 840 rows x 128 columns = 1 280 tiles on
         // 1 024 slots run two rounds for 1.25 rounds of work; 2 560 half tiles run 2.5)
         const int slots = 4 * ncu, tiles = gx * gy, last = tiles % slots;
