@@ -177,6 +177,9 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz, int gx, in
         for (int j = 0; j < 2; ++j) {
             const int n = nw + j * 32;
             const float keep = n < a.N ? 1.f : 0.f;             // a row's padding up to ldc: zeros
+            f16* const cb = a.cout + (size_t)(mw + 4 * h) * a.ldc + n;
+            f16* const ctb = a.cout2 + (size_t)n * a.ldc2 + mw + 4 * h;
+            const int lc = (int)a.ldc;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -188,11 +191,12 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz, int gx, in
                         const float x = acc[i][j][4 * t + e];
                         v[e] = (f16)((mq + e < a.M ? keep : 0.f) * (c0 * fexp2(x * a.k0) + c1 * fexp2(x * a.k1)));
                     }
+                    // (one 64-bit pointer per (i, j) block and lane, rows by 32-bit offsets: a 64-bit multiply per element costs more than its store)
                     if (n < a.ldc) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (mq + e < a.M) a.cout[(size_t)(mq + e) * a.ldc + n] = v[e];
+                        for (int e = 0; e < 4; ++e) if (mq + e < a.M) cb[(i * 32 + 8 * t + e) * lc] = v[e];
                     }
-                    if (n < a.N && mq < a.ldc2) *reinterpret_cast<f16x4*>(a.cout2 + (size_t)n * a.ldc2 + mq) = v;
+                    if (n < a.N && mq < a.ldc2) *reinterpret_cast<f16x4*>(ctb + i * 32 + 8 * t) = v;
                 }
         }
     } else if (MODE == W_STORE) {
@@ -200,12 +204,14 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz, int gx, in
         for (int j = 0; j < 2; ++j) {
             const int n = nw + j * 32;
             if (n >= a.N) continue;
+            float* const ob = a.out + (size_t)(mw + 4 * h) * a.ldo + n;
+            const int lo_ = (int)a.ldo;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mw + i * 32 + mfma32_row(r, h);
-                    if (m < a.M) a.out[(size_t)m * a.ldo + n] = acc[i][j][r];
+                    const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (mw + 4 * h + ro < a.M) ob[ro * lo_] = acc[i][j][r];
                 }
         }
     } else {
@@ -214,15 +220,17 @@ __device__ __forceinline__ void wide16_body(const W16Args& a, int bz, int gx, in
         for (int j = 0; j < 2; ++j) {
             const int n = nw + j * 32;
             if (n >= a.N) continue;
+            float* const ob = a.out + (size_t)(mw + 4 * h) * a.ldo + n;
+            const int lo_ = (int)a.ldo;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mw + i * 32 + mfma32_row(r, h);
+                    const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
 #ifdef W16_DBG_NOATOMIC
-                    if (m < a.M) a.out[(size_t)m * a.ldo + n] = alpha * acc[i][j][r];       // (timing experiment: wrong results)
+                    if (mw + 4 * h + ro < a.M) ob[ro * lo_] = alpha * acc[i][j][r];       // (timing experiment: wrong results)
 #else
-                    if (m < a.M) atomicAdd(a.out + (size_t)m * a.ldo + n, alpha * acc[i][j][r]);
+                    if (mw + 4 * h + ro < a.M) atomicAdd(ob + ro * lo_, alpha * acc[i][j][r]);
 #endif
                 }
         }
@@ -298,9 +306,12 @@ inline int choose_ksplit(int tiles, int K, int ncu, int& kper) {
 }
 
 inline int tiles8(int gx, int gy) { return (gx * gy + 7) / 8 * 8; }
+// the epilogues address a 128-row block of C / out by 32-bit element offsets from one row pointer: pitch x 128 must stay below 2^31
+inline bool pitches_ok(const W16Args& a) { return a.ldc < (1L << 24) && a.ldc2 < (1L << 24) && a.ldo < (1L << 24); }
 template <int MODE>
 void launch(const W16Args& a, int ksplit, hipStream_t s) {
     const int gx = (a.N + W_T - 1) / W_T, gy = (a.M + W_T - 1) / W_T;
+    if (!pitches_ok(a)) { sga_set_error("wide16: a row pitch of 2^24 elements or more"); return; }
     hipFuncSetAttribute(reinterpret_cast<const void*>(wide16_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
     hipLaunchKernelGGL(wide16_kernel<MODE>, dim3(tiles8(gx, gy), 1, ksplit), dim3(W_THREADS), W_LDS, s, a, gx, gy);
 }
@@ -310,6 +321,7 @@ void launch_batch(W16Batch& b, const int* ksplit, hipStream_t s) {
     for (int q = 0; q < b.n; ++q) {
         gx = max(gx, (b.a[q].N + W_T - 1) / W_T); gy = max(gy, (b.a[q].M + W_T - 1) / W_T); kz = max(kz, ksplit[q]);
     }
+    for (int q = 0; q < b.n; ++q) if (!pitches_ok(b.a[q])) { sga_set_error("wide16: a row pitch of 2^24 elements or more"); return; }
     b.zper = kz; b.gx = gx; b.gy = gy;
     hipFuncSetAttribute(reinterpret_cast<const void*>(wide16_batch_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
     hipLaunchKernelGGL(wide16_batch_kernel<MODE>, dim3(tiles8(gx, gy), 1, kz * b.n), dim3(W_THREADS), W_LDS, s, b);
